@@ -1,0 +1,202 @@
+"""Pins the oracle (oracle/vaa_oracle.c and oracle/ref_port.py) to vectors the REFERENCE produced.
+
+The fixtures under tests/golden/ were recorded by tools/gen_golden.py, which imported and ran the
+reference's own functions on CPU (appply_random_transform.py, UADA.py, UADA_ddp.py, UPA.py, TMA.py,
+action_tokenizer.py) in the survey container. CPU only; runs anywhere.
+"""
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, GOLDEN
+from oracle import c_oracle, ref_port
+from roboticattack_amd import synthetic
+
+K1K2 = golden_files("k1k2_")
+assert len(K1K2) >= 10
+
+
+def _load_case(f):
+    d = np.load(f)
+    B = int(d["batch"])
+    imgs = synthetic.synth_images(int(d["img_seed"]), B, str(d["img_kind"]))
+    mm = 1 if str(d["fn"]) == "paste_patch_fix" else 0
+    g = synthetic.synth_upstream_grad(int(d["grad_seed"]), B)
+    return d, B, imgs, mm, g
+
+
+@pytest.mark.parametrize("f", K1K2, ids=[os.path.basename(f)[5:-4] for f in K1K2])
+def test_c_oracle_k1_bit_exact_and_k2(f):
+    d, B, imgs, mm, g = _load_case(f)
+    out, ob, keep = c_oracle.patch_apply_fwd(imgs, d["patch"], d["xy"], d["theta"], int(d["geometry"]), mm)
+    kb = np.unpackbits(d["keep_bits"], axis=-1)[:, :, : 224 * 224]
+    assert np.array_equal(kb, keep), "paste/warp mask indices must be bit-exact"
+    kv = out[:, 0:3].reshape(B, 3, -1)[keep.astype(bool)]
+    assert np.array_equal(kv, d["kept_vals"]), "kept (patch) pixels: fp32 values identical to the reference"
+    si = d["sample_idx"].astype(int)
+    assert np.array_equal(out[si[:, 0], si[:, 1], si[:, 2], si[:, 3]], d["samples"])
+    assert zlib.crc32(ob.view(np.int16).tobytes()) == int(d["bf16_crc32"]), "whole bf16 model input identical"
+    pg = c_oracle.patch_grad(g.view(torch.int16).numpy().view(np.uint16), d["patch"], d["xy"], d["theta"], int(d["geometry"]), mm)
+    ref = d["patch_grad"]
+    assert np.abs(pg - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("f", K1K2, ids=[os.path.basename(f)[5:-4] for f in K1K2])
+def test_torch_port_k1_k2(f):
+    d, B, imgs, mm, g = _load_case(f)
+    mode = "ne-100" if mm else "lt-20"
+    patch = torch.from_numpy(d["patch"])
+    out, keep = ref_port.apply_random_patch_batch(imgs, patch, d["xy"], d["theta"], bool(d["geometry"]), mode, return_keep=True)
+    kb = np.unpackbits(d["keep_bits"], axis=-1)[:, :, : 224 * 224]
+    assert np.array_equal(kb, keep.reshape(B, 3, -1).numpy().astype(np.uint8))
+    kv = out[:, 0:3][keep].numpy()
+    np.testing.assert_allclose(kv, d["kept_vals"], rtol=0, atol=1e-5)
+    pg = ref_port.patch_grad_via_autograd(imgs, patch, d["xy"], d["theta"], bool(d["geometry"]), g, mode).numpy()
+    assert np.abs(pg - d["patch_grad"]).max() <= 2e-6 * np.abs(d["patch_grad"]).max()
+
+
+def test_rng_stream_seed42():
+    """Draw order of a-2: randint(x), randint(y), rand, [uniform x3] per image (appply_random_transform.py:120-128)."""
+    d = np.load(os.path.join(GOLDEN, "rng_stream_seed42.npz"))
+    random.seed(42)
+    np.random.seed(42)
+    xy, th = ref_port.draw_params(len(d["xy"]), 50, 50, True)
+    assert np.array_equal(xy, d["xy"])
+    assert np.array_equal(th, d["theta"][:, :2, :])
+
+
+def test_labels_tokenizer():
+    d = np.load(os.path.join(GOLDEN, "labels_tokenizer.npz"))
+    assert int(d["begin_idx"]) == 31743
+    assert np.array_equal(ref_port.BIN_CENTERS, d["bin_centers"])
+    assert np.array_equal(ref_port.decode_token_ids_to_actions(d["tokens"]), d["decoded"])
+    lab = torch.from_numpy(d["labels_in"])
+    for tag, mi in (("0", [0]), ("012", [0, 1, 2]), ("6", [6]), ("all", list(range(7))), ("25", [2, 5])):
+        got = ref_port.mask_labels(lab.clone(), mi).numpy()
+        assert np.array_equal(got, d[f"uada_mask_{tag}"])
+        assert np.array_equal(got, d[f"ddp_mask_{tag}"])
+        assert np.array_equal(got, d[f"upa_mask_{tag}"])  # UPA.py:344-356 computes the same masking row by row
+
+
+def _rows(labels):
+    B, L = labels.shape
+    S = 256 + L
+    return [(b, S - L + k) for b in range(B) for k in range(L - 1) if labels[b, k + 1] != -100]
+
+
+def _check_grad(g_full, labels, d, pfx, rtol=2e-4):
+    rows = _rows(labels)
+    assert np.array_equal(np.array(rows, np.int32), d[f"{pfx}_rows"])
+    rb = np.array([r[0] for r in rows])
+    rp = np.array([r[1] for r in rows])
+    gr = g_full[rb, rp]
+    scale = max(np.abs(d[f"{pfx}_g_action"]).max(), np.abs(d[f"{pfx}_g_cols"]).max(), 1e-30)
+    assert np.abs(gr[:, 31744:32000] - d[f"{pfx}_g_action"]).max() <= rtol * scale
+    assert np.abs(gr[:, d[f"{pfx}_cols"]] - d[f"{pfx}_g_cols"]).max() <= rtol * scale
+    # nothing outside the labelled rows
+    assert abs(np.abs(g_full).sum() - float(d[f"{pfx}_l1_total"])) <= 1e-3 * float(d[f"{pfx}_l1_total"]) + 1e-12
+    assert abs(np.abs(gr).sum() - np.abs(g_full).sum()) <= 1e-6 * np.abs(g_full).sum() + 1e-12
+
+
+@pytest.mark.parametrize("tag", ["m0", "m012", "m6", "mall"])
+def test_k3_uada(tag):
+    d = np.load(os.path.join(GOLDEN, f"k3_uada_{tag}.npz"))
+    B, S, seed = int(d["B"]), int(d["S"]), int(d["seed"])
+    labels = torch.from_numpy(d["labels"])
+    masked = ref_port.mask_labels(labels.clone(), list(d["maskidx"]))
+    assert np.array_equal(masked.numpy(), d["masked"])
+    logits = synthetic.synth_logits(seed + 1000, B, S, 32064)
+    # torch port
+    lg = logits.clone().requires_grad_(True)
+    mse, uad = ref_port.uada_weighted_loss(lg, masked, 5.0)
+    ce = ref_port.hf_ce(lg, masked)
+    total = mse + 1 / ce
+    assert abs(mse.item() - float(d["mse"])) < 1e-5 and abs(ce.item() - float(d["ce"])) < 1e-5
+    assert abs(float(uad) - float(d["uad"])) < 1e-6 and abs(total.item() - float(d["total"])) < 1e-5
+    # C oracle, mode UADA and UADA_DDP
+    sc, g = c_oracle.loss(logits.numpy(), masked.numpy(), c_oracle.MODE_UADA, w=5.0)
+    assert abs(sc[0] - float(d["total"])) < 2e-5 and abs(sc[1] - float(d["ce"])) < 2e-5 and abs(sc[2] - float(d["mse"])) < 2e-5
+    _check_grad(g, d["masked"], d, "uada")
+    pred, gt = c_oracle.action_argmax(logits.numpy(), masked.numpy())
+    assert abs(float(ref_port.cal_uad(torch.from_numpy(pred), torch.from_numpy(gt))) - float(d["uad"])) < 1e-6
+    sc2, g2 = c_oracle.loss(logits.numpy(), masked.numpy(), c_oracle.MODE_UADA_DDP, w=float(d["ddp_w"]))
+    assert abs(sc2[0] - float(d["ddp_mse"])) < 2e-5
+    _check_grad(g2, d["masked"], d, "ddp")
+    mse2, uad2 = ref_port.uada_weighted_loss(logits, masked, float(d["ddp_w"]))
+    assert abs(mse2.item() - float(d["ddp_mse"])) < 1e-5 and abs(float(uad2) - float(d["ddp_uad"])) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_k3_upa(tag):
+    d = np.load(os.path.join(GOLDEN, f"k3_upa_{tag}.npz"))
+    B, S, seed = int(d["B"]), int(d["S"]), int(d["seed"])
+    labels = torch.from_numpy(d["labels"])
+    logits = synthetic.synth_logits(seed + 1000, B, S, 32064)
+    tot, ang, dist = ref_port.upa_weighted_loss(logits, labels, float(d["alpha"]), float(d["belta"]))
+    assert abs(tot.item() - float(d["total"])) < 1e-5 and abs(ang.item() - float(d["angle"])) < 1e-5
+    assert abs(dist.item() - float(d["dist"])) < 1e-5
+    sc, g = c_oracle.loss(logits.numpy(), d["labels"], c_oracle.MODE_UPA, alpha=float(d["alpha"]), beta=float(d["belta"]))
+    assert abs(sc[0] - float(d["total"])) < 2e-5 and abs(sc[3] - float(d["angle"])) < 2e-5 and abs(sc[4] - float(d["dist"])) < 2e-5
+    _check_grad(g, d["labels"], d, "upa")
+
+
+@pytest.mark.parametrize("tag", ["t0", "t012"])
+def test_k3_tma(tag):
+    d = np.load(os.path.join(GOLDEN, f"k3_tma_{tag}.npz"))
+    B, S, seed = int(d["B"]), int(d["S"]), int(d["seed"])
+    labels = torch.from_numpy(d["labels"])
+    newl = ref_port.tma_target_labels(labels, torch.from_numpy(d["target_tokens"]))
+    assert np.array_equal(newl.numpy(), d["newlabels"])
+    logits = synthetic.synth_logits(seed + 1000, B, S, 32064)
+    assert abs(ref_port.hf_ce(logits, newl).item() - float(d["ce"])) < 1e-5
+    sc, g = c_oracle.loss(logits.numpy(), d["newlabels"], c_oracle.MODE_CE, scale=1.0)
+    assert abs(sc[0] - float(d["ce"])) < 2e-5
+    _check_grad(g, d["newlabels"], d, "tma")
+
+
+def test_cosine_schedule():
+    d = np.load(os.path.join(GOLDEN, "sched.npz"))
+    for tag, warm, total in (("w20_t2000", 20, 2000), ("w200_t10000", 200, 10000), ("w2_t4", 2, 4)):
+        got = np.array([ref_port.cosine_lambda(s, warm, total) for s in range(len(d[tag]))])
+        np.testing.assert_allclose(got, d[tag], rtol=0, atol=1e-15)
+
+
+def test_adamw_restatement_self_consistency():
+    """HF AdamW is third-party and absent here ("parity unpinned"): check the restatement against its defining
+    formula in float64 and against torch.optim.Adam with eps moved outside the bias correction."""
+    rs = np.random.RandomState(0)
+    p0 = rs.rand(300).astype(np.float32)
+    p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = ref_port.HFAdamW([p], lr=1e-2)
+    m = np.zeros(300)
+    v = np.zeros(300)
+    pp = p0.astype(np.float64)
+    pc, mc, vc = p0.copy(), np.zeros(300, np.float32), np.zeros(300, np.float32)
+    for t in range(1, 8):
+        g = (rs.randn(300) * 10.0 ** rs.uniform(-6, -1, 300)).astype(np.float32)
+        p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        p.data = p.data.clamp(0, 1)
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g.astype(np.float64) ** 2
+        pp = np.clip(pp - 1e-2 * np.sqrt(1 - 0.999**t) / (1 - 0.9**t) * m / (np.sqrt(v) + 1e-6), 0, 1)
+        c_oracle.patch_update(pc, g, mc, vc, 0, 1e-2, t)
+        assert np.abs(p.detach().numpy() - pp).max() < 2e-6
+        assert np.abs(pc - pp).max() < 2e-6
+    # PGD sign step + L1 clip in the C oracle
+    g = rs.randn(300).astype(np.float32)
+    pc2 = p0.copy()
+    c_oracle.patch_update(pc2, g, mc, vc, 1, 0.05, 1)
+    np.testing.assert_allclose(pc2, ref_port.pgd_step(torch.from_numpy(p0), torch.from_numpy(g), 0.05).numpy(), atol=1e-7)
+    gt = torch.from_numpy(g.copy())
+    tot = ref_port.l1_clip_(gt, 1e-3)
+    torch_g = torch.from_numpy(g.copy()).requires_grad_(False)
+    pt = torch.nn.Parameter(torch.zeros(300))
+    pt.grad = torch_g.clone()
+    torch.nn.utils.clip_grad_norm_([pt], max_norm=1e-3, norm_type=1)
+    np.testing.assert_allclose(gt.numpy(), pt.grad.numpy(), rtol=1e-6)
+    assert abs(tot.item() - np.abs(g).sum()) < 1e-3
