@@ -1,0 +1,128 @@
+/*
+ * vaa.h — C-ABI of libvaa_hip.so: the MI355X (gfx950) replacement for the UADA/UPA/TMA inner attack loop's
+ * patch operators of William-wAng618/roboticAttack.
+ *
+ * The reference is pure Python and has no FFI; the seams this library replaces are the Python operator calls
+ * listed per entry point below (file:line under the reference tree). INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add to call them.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only. Every pointer marked `dev` is a DEVICE pointer owned by the
+ *     caller (e.g. a PyTorch-ROCm tensor's data_ptr()); `host` pointers are ordinary host memory read during
+ *     the call. Nothing is allocated or freed by the library; scratch comes from the caller via *_ws_bytes().
+ *   - Every function returns VAA_OK (0) or a negative VAA_E_* code; vaa_last_error() returns a thread-local
+ *     message for the last failure on the calling thread.
+ *   - Kernels are enqueued on the caller's `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and the call returns without synchronising. Re-entrant per stream; no global mutable state.
+ *   - Images are 224x224 (the reference hard-codes this size: UADA.py:60, modeling_prismatic.py:120).
+ */
+#ifndef VAA_H_
+#define VAA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAA_OK 0
+#define VAA_E_INVALID (-1)     /* bad argument (null pointer, size out of range, unknown mode) */
+#define VAA_E_UNSUPPORTED (-2) /* valid request the kernels do not cover (e.g. patch larger than 224) */
+#define VAA_E_LAUNCH (-3)      /* HIP runtime reported an error at launch */
+#define VAA_E_WORKSPACE (-4)   /* workspace missing or too small */
+#define VAA_E_NODEVICE (-5)    /* no gfx950 device visible */
+
+#define VAA_IMG 224
+
+/* paste-mask rule */
+#define VAA_MASK_LT_M20 0 /* keep patch where !(canvas < -20)  : apply_random_patch_batch, appply_random_transform.py:131 */
+#define VAA_MASK_NE_M100 1 /* keep patch where canvas != -100   : paste_patch_fix / random_paste_patch, :153 :179 */
+
+/* loss modes (K3) */
+#define VAA_LOSS_UADA 0     /* w^2*mean((r-t)^2) + 1/CE                       UADA.py:145-148,381-406 */
+#define VAA_LOSS_UADA_DDP 1 /* w^2*mean((r-t)^2)                              UADA_ddp.py:99-124,203-206 */
+#define VAA_LOSS_UPA 2      /* alpha*mean(cos+1) + beta/(mean||e-l|| + 1e-3)  UPA.py:367-387 */
+#define VAA_LOSS_CE 3       /* scale*CE (TMA target CE, UPA guide / -CE)      TMA.py:148, UPA.py:143-150 */
+
+/* logits element type */
+#define VAA_DTYPE_F32 0
+#define VAA_DTYPE_BF16 1
+
+/* logits layout */
+#define VAA_LAYOUT_FULL 0 /* [B,S,V], S = 256 + L: row (b, S-L+k) predicts labels[b,k+1] (HF shift; UADA.py:385) */
+#define VAA_LAYOUT_ROWS 1 /* [R,V]: only the labelled rows, in (b,k) row-major order of labels[b,k+1] != -100 */
+
+/* optimiser modes (K4) */
+#define VAA_OPT_ADAMW_HF 0 /* transformers==4.40.1 AdamW.step (eps outside bias correction) + clamp(0,1)  UADA.py:155-156 */
+#define VAA_OPT_PGD_SIGN 1 /* p = clamp(p - lr*sign(g), 0, 1)                                            TMA.py:171-175 */
+
+const char* vaa_last_error(void);
+int vaa_version(void);
+/* VAA_OK when a gfx950 device is visible to the HIP runtime, else VAA_E_NODEVICE. */
+int vaa_device_check(void);
+
+/*
+ * K1 — replaces RandomPatchTransform.apply_random_patch_batch (appply_random_transform.py:104-136) followed by the
+ * caller's `.to(torch.bfloat16)` (UADA.py:142), and paste_patch_fix (:160-188) with mask_mode=VAA_MASK_NE_M100,
+ * geometry=0. The random draws (:120-128) stay on the host so the RNG streams match; their results come in as xy/theta.
+ *   img_u8   dev  [B,224,224,3] uint8 HWC (what PIL/ToTensor sees, :108)
+ *   patch    dev  [3,ph,pw] float32
+ *   xy       dev  [B,2] int32 (x,y) paste position (:123-125)
+ *   theta    dev  [B,6] float32 row-major 2x3 affine (rows 0-1 of combined_transform_matrix(), :88-96); ignored if !geometry
+ *   mean6/std6 host [6] float32: channels 0-2 -> first normalisation, 3-5 -> second (UADA.py:56-57)
+ *   out_bf16 dev  [B,6,224,224] bfloat16 bits: the model's pixel_values
+ *   keep_bits dev [B,3,224*224/8] uint8 or NULL: bit (p&7) of byte p>>3 is 1 where channel c of pixel p=i*224+j
+ *             shows the patch (the `torch.where` mask, :131); consumed by vaa_patch_grad_gather
+ */
+int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, const int32_t* xy, const float* theta, int B, int ph,
+                        int pw, int geometry, int mask_mode, const float* mean6, const float* std6, uint16_t* out_bf16,
+                        uint8_t* keep_bits, void* stream);
+
+/*
+ * K2 — replaces the autograd backward of K1 to the patch (implicit in `.backward()`, UADA.py:148): bf16->f32 cast,
+ * /std of both normalisations summed, where-mask, grid_sample-backward scatter, slice, sum over the batch.
+ *   gout_bf16 dev [B,6,224,224] bfloat16 bits: dL/d pixel_values from the model
+ *   patch, xy, theta, geometry, mask_mode: as given to K1 for the same step
+ *   keep_bits dev: K1's mask output, or NULL to recompute the mask from `patch`
+ *   std6     host [6]
+ *   gpatch   dev  [3,ph,pw] float32, overwritten with dL/d patch (sum over the B images)
+ *   ws       dev  scratch of at least vaa_patch_grad_ws_bytes(B,ph,pw) bytes (contents undefined on entry and exit)
+ */
+size_t vaa_patch_grad_ws_bytes(int B, int ph, int pw);
+int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* patch, const int32_t* xy, const float* theta,
+                          const uint8_t* keep_bits, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
+                          float* gpatch, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * K3 — replaces HF Llama's `.loss` (via modeling_prismatic.py:404-415) + OpenVLAAttacker.weighted_loss
+ * (UADA.py:381-406, UADA_ddp.py:99-124, UPA.py:367-387) and their autograd backward to the logits.
+ *   logits   dev  f32|bf16, layout FULL [B,S,V] or ROWS [R,V]
+ *   labels   dev  [B,L] int64, already masked by the caller (mask_labels, UADA.py:371-379)
+ *   params   host [4] float32: {w (MSE weight: 5 or --MSE_weights), alpha, beta, scale (1/accumulate_steps)}
+ *   scalars  dev  [8] float32 out: {total, CE, w^2*MSE, aux0 (UPA angle), aux1 (UPA dist), #CE rows, #action rows, UAD}
+ *   pred_tokens dev [B*(L-1)] int32 or NULL: argmax action token (31744 + argmax of the 256-slice, UADA.py:395) per
+ *             labelled row in (b,k) order (rows whose label is <= 2 get -1)
+ *   glogits  dev or NULL: d total / d logits in the logits' dtype and layout. FULL: only labelled rows are written
+ *             (zero the buffer once; rows never change while labels keep their shape). ROWS: every row is written.
+ *   ws       dev scratch >= vaa_loss_ws_bytes(B,L)
+ */
+size_t vaa_loss_ws_bytes(int B, int L);
+int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const int64_t* labels, int B, int S, int L, int V, int mode,
+                     const float* params, float* scalars, int32_t* pred_tokens, void* glogits, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/*
+ * K4 — replaces transformers.AdamW.step + `patch.data.clamp(0,1)` + zero_grad (UADA.py:155-157; UADA_ddp.py:208-209),
+ * optional `clip_grad_norm_([patch], l1_clip, norm_type=1)` (UPA.py:157) and the PGD sign step (TMA.py:171-175).
+ *   patch,m,v dev [n] float32 in place; g dev [n] float32 (sum over ranks when grad_scale = 1/world, DDP mean)
+ *   step     1-based Adam step count t; lr already multiplied by the cosine schedule (UADA.py:109-115,162-164)
+ *   stats    dev [2] float32 out or NULL: {sum|g*grad_scale|, mean(g*grad_scale)} (the logged TRAIN_patch_gradient)
+ */
+int vaa_patch_update(float* patch, const float* g, float* m, float* v, int n, int mode, float lr, float beta1, float beta2,
+                     float eps, int step, float l1_clip, float grad_scale, float* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAA_H_ */

@@ -1,0 +1,92 @@
+"""ctypes loader for libvaa_hip.so (C-ABI declared in include/vaa.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvaa_hip.so")
+
+# mirrors include/vaa.h
+VAA_OK = 0
+MASK_LT_M20, MASK_NE_M100 = 0, 1
+LOSS_UADA, LOSS_UADA_DDP, LOSS_UPA, LOSS_CE = 0, 1, 2, 3
+DTYPE_F32, DTYPE_BF16 = 0, 1
+LAYOUT_FULL, LAYOUT_ROWS = 0, 1
+OPT_ADAMW_HF, OPT_PGD_SIGN = 0, 1
+
+EXPORTS = (
+    "vaa_last_error",
+    "vaa_version",
+    "vaa_device_check",
+    "vaa_patch_apply_fwd",
+    "vaa_patch_grad_ws_bytes",
+    "vaa_patch_grad_gather",
+    "vaa_loss_ws_bytes",
+    "vaa_loss_fwd_bwd",
+    "vaa_patch_update",
+)
+
+
+class VaaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    import subprocess
+
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    out = subprocess.run(["bash", script], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise VaaError(f"building libvaa_hip.so failed:\n{out.stdout}\n{out.stderr}")
+    if verbose:
+        print(out.stdout.strip())
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VaaError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or roboticattack_amd/csrc/build.sh"
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.vaa_last_error.restype = C.c_char_p
+    L.vaa_last_error.argtypes = []
+    L.vaa_version.restype = i32
+    L.vaa_device_check.restype = i32
+    L.vaa_patch_apply_fwd.restype = i32
+    L.vaa_patch_apply_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, vp]
+    L.vaa_patch_grad_ws_bytes.restype = sz
+    L.vaa_patch_grad_ws_bytes.argtypes = [i32, i32, i32]
+    L.vaa_patch_grad_gather.restype = i32
+    L.vaa_patch_grad_gather.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, sz, vp]
+    L.vaa_loss_ws_bytes.restype = sz
+    L.vaa_loss_ws_bytes.argtypes = [i32, i32]
+    L.vaa_loss_fwd_bwd.restype = i32
+    L.vaa_loss_fwd_bwd.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, vp, vp, sz, vp]
+    L.vaa_patch_update.restype = i32
+    L.vaa_patch_update.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != VAA_OK:
+        msg = lib().vaa_last_error().decode("utf-8", "replace")
+        raise VaaError(f"{what} failed with code {rc}: {msg}")
+
+
+def f32x(vals):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])

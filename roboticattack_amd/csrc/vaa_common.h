@@ -1,0 +1,124 @@
+// vaa_common.h — shared device helpers for the gfx950 kernels behind include/vaa.h.
+//
+// Numerics contract (re-verified against the reference in tests/golden):
+// this translation unit is compiled with -ffp-contract=off; every fused multiply-add below is
+// explicit so the warp coordinates, bilinear weights and the `canvas < -20` mask reproduce the
+// reference's PyTorch-CPU path (F.affine_grid + F.grid_sample, appply_random_transform.py:93-102)
+// bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vaa.h"
+
+#define VAA_NPIX (VAA_IMG * VAA_IMG)
+
+namespace vaa {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+struct Norm6 {
+    float mean[6];
+    float stdv[6];
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
+// torch `.to(torch.bfloat16)`: round-to-nearest-even; NaN stays NaN.
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x0040u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+// F.affine_grid(align_corners=False) base coordinate of pixel index i along a 224-long axis:
+// torch.linspace(-1, 1, 224)[i] * 223 / 224, with linspace's two-sided evaluation (one FMA each side).
+__device__ __forceinline__ float base_coord(int i) {
+    const float step = 2.0f / 223.0f;
+    float lin = (i < VAA_IMG / 2) ? __builtin_fmaf((float)i, step, -1.0f)
+                                  : __builtin_fmaf(-(float)(VAA_IMG - 1 - i), step, 1.0f);
+    return (lin * 223.0f) / 224.0f;
+}
+
+struct Samp {
+    int x0, y0;            // floor of the clamped source position (north-west corner)
+    float nw, ne, sw, se;  // bilinear corner weights
+};
+
+// bx/by: base coords of output column j / row i; th: row-major 2x3 affine.
+// grid = base @ theta^T as torch's CPU GEMM evaluates it (product, one FMA, plain add), then
+// grid_sample's unnormalise contracted into one FMA, clamp to the border, floor, weights.
+__device__ __forceinline__ Samp sample_pos(float bx, float by, const float* th) {
+    Samp s;
+    float gx = __builtin_fmaf(by, th[1], bx * th[0]) + th[2];
+    float gy = __builtin_fmaf(by, th[4], bx * th[3]) + th[5];
+    float ix = __builtin_fmaf(gx + 1.0f, 112.0f, -0.5f);
+    float iy = __builtin_fmaf(gy + 1.0f, 112.0f, -0.5f);
+    ix = fminf(223.0f, fmaxf(ix, 0.0f));
+    iy = fminf(223.0f, fmaxf(iy, 0.0f));
+    float xw = floorf(ix), yn = floorf(iy);
+    float w = ix - xw, e = 1.0f - w, n = iy - yn, so = 1.0f - n;
+    s.x0 = (int)xw;
+    s.y0 = (int)yn;
+    s.nw = so * e;
+    s.ne = so * w;
+    s.sw = n * e;
+    s.se = n * w;
+    return s;
+}
+
+// canvas = -100 everywhere with the patch pasted at (px,py) (appply_random_transform.py:111,125);
+// corners beyond the frame contribute 0 (grid_sample's bounds mask).
+__device__ __forceinline__ float canvas_at(const float* __restrict__ patch_c, int ph, int pw, int px, int py, int xx, int yy) {
+    if (xx >= VAA_IMG || yy >= VAA_IMG) return 0.0f;
+    int u = xx - px, v = yy - py;
+    if ((unsigned)u < (unsigned)pw && (unsigned)v < (unsigned)ph) return patch_c[v * pw + u];
+    return -100.0f;
+}
+
+__device__ __forceinline__ float sample_canvas(const float* __restrict__ patch_c, int ph, int pw, int px, int py, const Samp& s) {
+    float vnw = canvas_at(patch_c, ph, pw, px, py, s.x0, s.y0);
+    float vne = canvas_at(patch_c, ph, pw, px, py, s.x0 + 1, s.y0);
+    float vsw = canvas_at(patch_c, ph, pw, px, py, s.x0, s.y0 + 1);
+    float vse = canvas_at(patch_c, ph, pw, px, py, s.x0 + 1, s.y0 + 1);
+    return __builtin_fmaf(vse, s.se, __builtin_fmaf(vsw, s.sw, __builtin_fmaf(vne, s.ne, vnw * s.nw)));
+}
+
+__device__ __forceinline__ bool keep_rule(float cv, int mask_mode) {
+    return mask_mode == VAA_MASK_LT_M20 ? !(cv < -20.0f) : (cv != -100.0f);
+}
+
+// Pixel-space view of the same affine map (used only to BOUND the footprint, never for values):
+//   ix ~= a00*j + a01*i + c0,  iy ~= a10*j + a11*i + c1.
+struct PixAffine {
+    float a00, a01, c0, a10, a11, c1;
+};
+
+__device__ __forceinline__ PixAffine pix_affine(const float* th) {
+    PixAffine p;
+    p.a00 = th[0];
+    p.a01 = th[1];
+    p.c0 = 112.0f * (th[2] + 1.0f) - 0.5f - 111.5f * (th[0] + th[1]);
+    p.a10 = th[3];
+    p.a11 = th[4];
+    p.c1 = 112.0f * (th[5] + 1.0f) - 0.5f - 111.5f * (th[3] + th[4]);
+    return p;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace vaa

@@ -1,0 +1,94 @@
+// vaa_update.hip — K4: fused pixel update of the patch: [DDP 1/world scale] -> [L1 grad-norm clip] ->
+// HF-AdamW or PGD-sign step -> clamp to [0,1], plus the logged gradient statistics. One workgroup:
+// the patch has 7,500 (50x50) to ~58,000 (139x139) elements, so the op is launch-latency bound and the
+// L1 norm needs a grid-wide reduction anyway.
+//
+// Replaces (UADA.py:154-157, UADA_ddp.py:207-209): `patch.grad.mean().item()`, `optimizer.step()`
+// (transformers==4.40.1 AdamW [3p]: m=b1*m+(1-b1)g; v=b2*v+(1-b2)g^2; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps),
+// eps NOT bias corrected), `patch.data.clamp(0,1)`, `zero_grad()`; UPA.py:157 clip_grad_norm_(L1, 1e-3);
+// TMA.py:171-175 PGD sign step.
+#include <math.h>
+
+#include "vaa_common.h"
+
+namespace vaa {
+
+struct UpdArgs {
+    float* patch;
+    const float* g;
+    float* m;
+    float* v;
+    float* stats;
+    int n, mode;
+    float lr, b1, b2, eps, step_size, one_m_b1, one_m_b2, l1_clip, grad_scale;
+};
+
+__global__ __launch_bounds__(1024) void patch_update_kernel(UpdArgs a) {
+    __shared__ double sh_abs[16], sh_sum[16];
+    __shared__ float coef_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double sa = 0.0, ss = 0.0;
+    for (int i = tid; i < a.n; i += 1024) {
+        const float g = a.g[i] * a.grad_scale;
+        sa += fabs((double)g);
+        ss += (double)g;
+    }
+    sa = wave_sum(sa);
+    ss = wave_sum(ss);
+    if (lane == 0) { sh_abs[wv] = sa; sh_sum[wv] = ss; }
+    __syncthreads();
+    if (tid == 0) {
+        double ta = 0.0, ts = 0.0;
+        for (int q = 0; q < 16; ++q) { ta += sh_abs[q]; ts += sh_sum[q]; }
+        float coef = 1.0f;
+        if (a.l1_clip > 0.0f) {  // torch clip_grad_norm_: coef = clamp(max_norm / (total_norm + 1e-6), max=1)
+            const float c = a.l1_clip / ((float)ta + 1e-6f);
+            coef = c < 1.0f ? c : 1.0f;
+        }
+        coef_sh = coef;
+        if (a.stats) { a.stats[0] = (float)ta; a.stats[1] = (float)(ts / a.n); }
+    }
+    __syncthreads();
+    const float coef = coef_sh;
+    for (int i = tid; i < a.n; i += 1024) {
+        const float g = a.g[i] * a.grad_scale * coef;
+        float p = a.patch[i];
+        if (a.mode == VAA_OPT_ADAMW_HF) {
+            const float m = __builtin_fmaf(g, a.one_m_b1, a.m[i] * a.b1);   // exp_avg.mul_(b1).add_(g, alpha=1-b1)
+            const float v = a.v[i] * a.b2 + (a.one_m_b2 * g) * g;           // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
+            a.m[i] = m;
+            a.v[i] = v;
+            const float denom = sqrtf(v) + a.eps;                          // v.sqrt().add_(eps)
+            p = p + ((-a.step_size) * m) / denom;                          // p.addcdiv_(m, denom, value=-step_size)
+        } else {
+            const float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+            p = p - a.lr * sg;
+        }
+        a.patch[i] = fminf(1.0f, fmaxf(0.0f, p));                          // patch.data.clamp(0, 1)
+    }
+}
+
+}  // namespace vaa
+
+extern "C" int vaa_patch_update(float* patch, const float* g, float* m, float* v, int n, int mode, float lr, float beta1,
+                                float beta2, float eps, int step, float l1_clip, float grad_scale, float* stats, void* stream) {
+    using namespace vaa;
+    if (!patch || !g || (mode == VAA_OPT_ADAMW_HF && (!m || !v))) {
+        set_error("vaa_patch_update: null pointer argument");
+        return VAA_E_INVALID;
+    }
+    if (n <= 0 || (mode != VAA_OPT_ADAMW_HF && mode != VAA_OPT_PGD_SIGN) || (mode == VAA_OPT_ADAMW_HF && step < 1)) {
+        set_error("vaa_patch_update: bad sizes/mode (n=%d mode=%d step=%d)", n, mode, step);
+        return VAA_E_INVALID;
+    }
+    UpdArgs a;
+    a.patch = patch; a.g = g; a.m = m; a.v = v; a.stats = stats; a.n = n; a.mode = mode;
+    a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.l1_clip = l1_clip; a.grad_scale = grad_scale;
+    // python-side doubles of the reference optimiser, narrowed to f32 exactly where torch narrows them
+    const double b1 = (double)beta1, b2 = (double)beta2;
+    a.one_m_b1 = (float)(1.0 - b1);
+    a.one_m_b2 = (float)(1.0 - b2);
+    a.step_size = (mode == VAA_OPT_ADAMW_HF) ? (float)((double)lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step))) : 0.0f;
+    hipLaunchKernelGGL(patch_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    return check_launch("vaa_patch_update");
+}

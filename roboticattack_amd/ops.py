@@ -1,0 +1,192 @@
+"""PyTorch-ROCm front end of the C-ABI (include/vaa.h): device memory, streams and autograd plumbing only.
+
+Every function here enqueues hand-written HIP kernels from libvaa_hip.so on torch's current stream and
+returns without synchronising. No function has a CPU path; tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import (  # noqa: F401  (re-exported)
+    LAYOUT_FULL,
+    LAYOUT_ROWS,
+    LOSS_CE,
+    LOSS_UADA,
+    LOSS_UADA_DDP,
+    LOSS_UPA,
+    MASK_LT_M20,
+    MASK_NE_M100,
+    OPT_ADAMW_HF,
+    OPT_PGD_SIGN,
+)
+from .constants import IMG, MEAN6, STD6
+
+_MEAN = _lib.f32x(MEAN6)
+_STD = _lib.f32x(STD6)
+_ws_cache: dict = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, dtype, name: str, shape=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.VaaError(f"{name}: expected a tensor on a ROCm device (there is no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.VaaError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.VaaError(f"{name}: expected a contiguous tensor")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise _lib.VaaError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), "ws")
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def device_check() -> None:
+    _lib.check(_lib.lib().vaa_device_check(), "vaa_device_check")
+
+
+# ------------------------------------------------------------------------------------------------------
+# K1 / K2
+# ------------------------------------------------------------------------------------------------------
+def patch_apply_fwd(img_u8, patch, xy, theta, geometry: bool, mask_mode: int = MASK_LT_M20, want_keep: bool = True):
+    """K1. img_u8 [B,224,224,3] u8, patch [3,ph,pw] f32, xy [B,2] i32, theta [B,6] f32 -> (bf16 [B,6,224,224], keep bits)."""
+    B = img_u8.shape[0]
+    _need(img_u8, torch.uint8, "img_u8", (B, IMG, IMG, 3))
+    _need(patch, torch.float32, "patch")
+    _need(xy, torch.int32, "xy", (B, 2))
+    if geometry:
+        _need(theta, torch.float32, "theta", (B, 6))
+    ph, pw = int(patch.shape[1]), int(patch.shape[2])
+    out = torch.empty((B, 6, IMG, IMG), dtype=torch.bfloat16, device=img_u8.device)
+    keep = torch.empty((B, 3, IMG * IMG // 8), dtype=torch.uint8, device=img_u8.device) if want_keep else None
+    rc = _lib.lib().vaa_patch_apply_fwd(
+        img_u8.data_ptr(), patch.data_ptr(), xy.data_ptr(), theta.data_ptr() if geometry else None, B, ph, pw,
+        int(bool(geometry)), int(mask_mode), _MEAN, _STD, out.data_ptr(), keep.data_ptr() if want_keep else None, _stream())
+    _lib.check(rc, "vaa_patch_apply_fwd")
+    return out, keep
+
+
+def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20):
+    """K2. gout_bf16 [B,6,224,224] bf16 -> dL/d patch [3,ph,pw] f32 (sum over the batch)."""
+    B = gout_bf16.shape[0]
+    _need(gout_bf16, torch.bfloat16, "gout_bf16", (B, 6, IMG, IMG))
+    _need(patch, torch.float32, "patch")
+    _need(xy, torch.int32, "xy", (B, 2))
+    if geometry:
+        _need(theta, torch.float32, "theta", (B, 6))
+    if keep_bits is not None:
+        _need(keep_bits, torch.uint8, "keep_bits", (B, 3, IMG * IMG // 8))
+    ph, pw = int(patch.shape[1]), int(patch.shape[2])
+    L = _lib.lib()
+    nbytes = L.vaa_patch_grad_ws_bytes(B, ph, pw)
+    ws = _workspace(patch.device, nbytes)
+    gpatch = torch.empty_like(patch)
+    rc = L.vaa_patch_grad_gather(
+        gout_bf16.data_ptr(), patch.data_ptr(), xy.data_ptr(), theta.data_ptr() if geometry else None,
+        keep_bits.data_ptr() if keep_bits is not None else None, B, ph, pw, int(bool(geometry)), int(mask_mode), _STD,
+        gpatch.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "vaa_patch_grad_gather")
+    return gpatch
+
+
+class PatchApply(torch.autograd.Function):
+    """Differentiable (w.r.t. `patch`) K1: PyTorch-ROCm autograd hands the model's bf16 pixel gradient to K2."""
+
+    @staticmethod
+    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode):
+        out, keep = patch_apply_fwd(img_u8, patch.detach(), xy, theta, geometry, mask_mode, want_keep=True)
+        ctx.save_for_backward(patch.detach(), xy, theta if geometry else xy, keep)
+        ctx.geometry, ctx.mask_mode = bool(geometry), int(mask_mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        patch, xy, theta, keep = ctx.saved_tensors
+        g = patch_grad_gather(gout.contiguous(), patch, xy, theta if ctx.geometry else None, keep, ctx.geometry, ctx.mask_mode)
+        return g, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# K3
+# ------------------------------------------------------------------------------------------------------
+def loss_fwd_bwd(logits, labels, mode: int, w: float = 5.0, alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0,
+                 layout: int = LAYOUT_FULL, want_grad: bool = True, want_pred: bool = True, glogits=None):
+    """K3. Returns (scalars f32[8] on device, pred_tokens i32 [B,L-1] or None, glogits or None).
+
+    scalars = [total, CE, w^2*MSE, UPA angle, UPA dist, #CE rows, #action rows, UAD]."""
+    if logits.dtype == torch.float32:
+        dt = _lib.DTYPE_F32
+    elif logits.dtype == torch.bfloat16:
+        dt = _lib.DTYPE_BF16
+    else:
+        raise _lib.VaaError(f"logits: unsupported dtype {logits.dtype}")
+    _need(logits, logits.dtype, "logits")
+    _need(labels, torch.int64, "labels")
+    B, Lt = int(labels.shape[0]), int(labels.shape[1])
+    if layout == LAYOUT_FULL:
+        if logits.dim() != 3 or logits.shape[0] != B:
+            raise _lib.VaaError(f"logits: FULL layout expects [B,S,V], got {tuple(logits.shape)}")
+        S, V = int(logits.shape[1]), int(logits.shape[2])
+    else:
+        if logits.dim() != 2:
+            raise _lib.VaaError(f"logits: ROWS layout expects [R,V], got {tuple(logits.shape)}")
+        S, V = 0, int(logits.shape[1])
+    L = _lib.lib()
+    ws = _workspace(logits.device, L.vaa_loss_ws_bytes(B, Lt))
+    scalars = torch.empty(8, dtype=torch.float32, device=logits.device)
+    pred = torch.empty((B, Lt - 1), dtype=torch.int32, device=logits.device) if want_pred else None
+    if want_grad and glogits is None:
+        glogits = torch.zeros_like(logits) if layout == LAYOUT_FULL else torch.empty_like(logits)
+    rc = L.vaa_loss_fwd_bwd(
+        logits.data_ptr(), dt, int(layout), labels.data_ptr(), B, S, Lt, V, int(mode), _lib.f32x([w, alpha, beta, scale]),
+        scalars.data_ptr(), pred.data_ptr() if want_pred else None, glogits.data_ptr() if want_grad else None,
+        ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "vaa_loss_fwd_bwd")
+    return scalars, pred, (glogits if want_grad else None)
+
+
+class DiscrepancyLoss(torch.autograd.Function):
+    """total = loss(logits, labels) with d total/d logits produced by the same fused launch sequence."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, mode, w, alpha, beta, scale, layout):
+        scalars, pred, g = loss_fwd_bwd(logits.detach(), labels, mode, w, alpha, beta, scale, layout, want_grad=True)
+        ctx.save_for_backward(g)
+        ctx.mark_non_differentiable(scalars, pred)
+        return scalars[0].clone(), scalars, pred
+
+    @staticmethod
+    def backward(ctx, gtotal, _gs, _gp):
+        (g,) = ctx.saved_tensors
+        return g * gtotal.to(g.dtype), None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# K4
+# ------------------------------------------------------------------------------------------------------
+def patch_update(patch, grad, m, v, mode: int, lr: float, step: int, beta1: float = 0.9, beta2: float = 0.999,
+                 eps: float = 1e-6, l1_clip: float = 0.0, grad_scale: float = 1.0, want_stats: bool = True):
+    """K4 (in place on patch/m/v). Returns stats f32[2] = [sum|g|, mean g] (device) or None."""
+    _need(patch, torch.float32, "patch")
+    _need(grad, torch.float32, "grad", patch.shape)
+    if mode == OPT_ADAMW_HF:
+        _need(m, torch.float32, "m", patch.shape)
+        _need(v, torch.float32, "v", patch.shape)
+    stats = torch.empty(2, dtype=torch.float32, device=patch.device) if want_stats else None
+    rc = _lib.lib().vaa_patch_update(
+        patch.data_ptr(), grad.data_ptr(), m.data_ptr() if m is not None else None, v.data_ptr() if v is not None else None,
+        patch.numel(), int(mode), float(lr), float(beta1), float(beta2), float(eps), int(step), float(l1_clip),
+        float(grad_scale), stats.data_ptr() if want_stats else None, _stream())
+    _lib.check(rc, "vaa_patch_update")
+    return stats

@@ -1,0 +1,53 @@
+"""CPU-only: the C-ABI library builds for gfx950, loads, and exports every symbol include/vaa.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from roboticattack_amd import _lib
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "vaa.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(vaa_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(L, name), f"libvaa_hip.so does not export {name}"
+    assert _lib.lib().vaa_version() >= 100
+
+
+def test_sizes_and_argument_errors_without_gpu():
+    """Pure host-side entry points and argument validation (no kernel is launched)."""
+    L = _lib.lib()
+    assert L.vaa_patch_grad_ws_bytes(64, 50, 50) == 64 * 3 * 50 * 50 * 4
+    assert L.vaa_patch_grad_ws_bytes(4096, 50, 50) == 512 * 3 * 50 * 50 * 4
+    assert L.vaa_patch_grad_ws_bytes(0, 50, 50) == 0
+    assert L.vaa_loss_ws_bytes(64, 45) == 64 * 44 * 32
+    rc = L.vaa_patch_apply_fwd(None, None, None, None, 1, 50, 50, 1, 0, _lib.f32x([0] * 6), _lib.f32x([1] * 6), None, None, None)
+    assert rc == -1 and b"null pointer" in L.vaa_last_error()
+    rc = L.vaa_patch_update(None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-6, 1, 0.0, 1.0, None, None)
+    assert rc == -1
+    with pytest.raises(_lib.VaaError):
+        _lib.check(rc, "vaa_patch_update")
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+
+    from roboticattack_amd import ops
+
+    with pytest.raises(_lib.VaaError, match="no CPU fallback"):
+        ops.patch_apply_fwd(torch.zeros(1, 224, 224, 3, dtype=torch.uint8), torch.zeros(3, 50, 50), torch.zeros(1, 2, dtype=torch.int32),
+                            torch.zeros(1, 6), True)

@@ -1,0 +1,376 @@
+"""GPU parity tests: every call goes through the C-ABI (libvaa_hip.so) and is compared with
+  (1) the golden vectors the REFERENCE produced (tests/golden, made by tools/gen_golden.py), and
+  (2) the plain-C oracle on the same seeded inputs (oracle/vaa_oracle.c, itself pinned to the golden vectors).
+Bars: paste/warp mask indices and the whole bf16 model input bit-exact; fp32 gradients/losses to the stated tolerance.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_files
+from oracle import c_oracle, ref_port
+from roboticattack_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+K1K2 = golden_files("k1k2_")
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from roboticattack_amd import ops as _ops
+
+    _ops.device_check()
+    return _ops
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def _bits(t_bf16):
+    return t_bf16.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def _keep_unpack(keep_bits):  # [B,3,6272] u8, bit p&7 of byte p>>3  ->  [B,3,50176] 0/1
+    k = keep_bits.cpu().numpy()
+    return np.unpackbits(k, axis=-1, bitorder="little")
+
+
+def _run_k1(ops, imgs, patch, xy, theta, geometry, mm):
+    out, keep = ops.patch_apply_fwd(_t(imgs), _t(patch), _t(xy, torch.int32), _t(theta.reshape(-1, 6)), bool(geometry), mm)
+    torch.cuda.synchronize()
+    return out, keep
+
+
+@pytest.mark.parametrize("f", K1K2, ids=[os.path.basename(f)[5:-4] for f in K1K2])
+def test_k1_k2_vs_reference_golden(ops, f):
+    d = np.load(f)
+    B, geo = int(d["batch"]), int(d["geometry"])
+    mm = 1 if str(d["fn"]) == "paste_patch_fix" else 0
+    imgs = synthetic.synth_images(int(d["img_seed"]), B, str(d["img_kind"]))
+    out, keep = _run_k1(ops, imgs, d["patch"], d["xy"], d["theta"], geo, mm)
+    # mask indices: bit-exact against the reference's torch.where condition
+    ref_keep = np.unpackbits(d["keep_bits"], axis=-1)[:, :, : 224 * 224]
+    assert np.array_equal(_keep_unpack(keep), ref_keep)
+    # the whole bf16 model input equals the reference's (CRC over all B*6*224*224 values)
+    assert zlib.crc32(_bits(out).view(np.int16).tobytes()) == int(d["bf16_crc32"])
+    # K2 against the reference's autograd patch gradient, with and without the stored mask
+    g = synthetic.synth_upstream_grad(int(d["grad_seed"]), B).to(DEV)
+    args = (_t(d["patch"]), _t(d["xy"], torch.int32), _t(d["theta"].reshape(-1, 6)))
+    ref = d["patch_grad"]
+    tol = 2e-6 * np.abs(ref).max()  # fp32 summation-order level (reference accumulates in fp32)
+    g1 = ops.patch_grad_gather(g, *args, keep, bool(geo), mm).cpu().numpy()
+    g2 = ops.patch_grad_gather(g, *args, None, bool(geo), mm).cpu().numpy()
+    assert np.abs(g1 - ref).max() <= tol
+    assert np.array_equal(g1, g2), "stored-mask and recomputed-mask paths must agree exactly"
+
+
+def _random_case(rs, B, ph, pw, edge_frac=0.3, identity_frac=0.2):
+    xy = np.stack([rs.randint(0, 224 - pw + 1, B), rs.randint(0, 224 - ph + 1, B)], 1).astype(np.int32)
+    for b in range(B):
+        if rs.rand() < edge_frac:
+            xy[b, 0] = rs.choice([0, 224 - pw])
+        if rs.rand() < edge_frac:
+            xy[b, 1] = rs.choice([0, 224 - ph])
+    theta = np.zeros((B, 2, 3), np.float32)
+    for b in range(B):
+        if rs.rand() < identity_frac:
+            m = np.eye(3, dtype=np.float32)
+        else:
+            m = np.dot(ref_port.shear_matrix(rs.uniform(-0.2, 0.2), rs.uniform(-0.2, 0.2)), ref_port.rotation_matrix(rs.uniform(-30, 30)))
+        theta[b] = m[:2]
+    return xy, theta
+
+
+@pytest.mark.parametrize("ph,pw,B,geo", [(50, 50, 16, 1), (50, 50, 8, 0), (22, 22, 8, 1), (37, 61, 6, 1), (100, 100, 6, 1),
+                                         (139, 139, 3, 1), (61, 61, 5, 1), (1, 1, 4, 1), (224, 224, 2, 1)])
+def test_k1_k2_random_sweep_vs_oracle(ops, ph, pw, B, geo):
+    rs = np.random.RandomState(ph * 1000 + pw * 10 + B + geo)
+    imgs = synthetic.synth_images(ph + pw + B, B, "noise")
+    patch = rs.rand(3, ph, pw).astype(np.float32)
+    xy, theta = _random_case(rs, B, ph, pw)
+    out, keep = _run_k1(ops, imgs, patch, xy, theta, geo, 0)
+    o_f32, o_bf16, o_keep = c_oracle.patch_apply_fwd(imgs, patch, xy, theta, geo, 0)
+    assert np.array_equal(_keep_unpack(keep), o_keep)
+    assert np.array_equal(_bits(out), o_bf16)
+    g = synthetic.synth_upstream_grad(5 + B, B)
+    og = c_oracle.patch_grad(_bits(g), patch, xy, theta, geo, 0)
+    try:
+        gg = ops.patch_grad_gather(g.to(DEV), _t(patch), _t(xy, torch.int32), _t(theta.reshape(-1, 6)), keep, bool(geo), 0).cpu().numpy()
+    except Exception as e:  # the only legal refusal: a patch whose accumulator tile exceeds the LDS
+        assert ph * pw * 4 > 150 * 1024, e
+        return
+    assert np.abs(gg - og).max() <= 3e-6 * max(np.abs(og).max(), 1e-30)
+
+
+def test_k1_general_affine_with_translation(ops):
+    """The C-ABI takes any 2x3 theta (the reference only draws rotation+shear): scale, translation, near-singular."""
+    rs = np.random.RandomState(77)
+    B = 6
+    imgs = synthetic.synth_images(9, B, "smooth")
+    patch = rs.rand(3, 50, 50).astype(np.float32)
+    xy = np.array([[10, 20], [0, 0], [174, 174], [100, 3], [60, 60], [5, 150]], np.int32)
+    theta = np.array([[[1.3, 0.1, 0.2], [-0.2, 0.8, -0.1]], [[0.5, 0, 0.5], [0, 0.5, 0.5]], [[2.0, 0, -0.9], [0, 2.0, -0.9]],
+                      [[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]], [[1e-7, 1.0, 0.0], [1.0, 1e-7, 0.0]], [[1, 0, 3.0], [0, 1, 3.0]]], np.float32)
+    out, keep = _run_k1(ops, imgs, patch, xy, theta, 1, 0)
+    _, o_bf16, o_keep = c_oracle.patch_apply_fwd(imgs, patch, xy, theta, 1, 0)
+    assert np.array_equal(_keep_unpack(keep), o_keep)
+    assert np.array_equal(_bits(out), o_bf16)
+    g = synthetic.synth_upstream_grad(3, B)
+    og = c_oracle.patch_grad(_bits(g), patch, xy, theta, 1, 0)
+    gg = ops.patch_grad_gather(g.to(DEV), _t(patch), _t(xy, torch.int32), _t(theta.reshape(-1, 6)), keep, True, 0).cpu().numpy()
+    assert np.abs(gg - og).max() <= 3e-6 * np.abs(og).max()
+
+
+def test_k2_full_size_properties_bs64(ops):
+    """BASELINE size (bs=64, 3x50x50): linearity in the upstream gradient, bitwise repeatability, sum over sub-batches."""
+    B = 64
+    rs = np.random.RandomState(64)
+    imgs = _t(synthetic.synth_images(640, B, "noise"))
+    patch = _t(rs.rand(3, 50, 50).astype(np.float32))
+    xy_n, th_n = _random_case(rs, B, 50, 50)
+    xy, th = _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6))
+    out, keep = ops.patch_apply_fwd(imgs, patch, xy, th, True, 0)
+    g1 = synthetic.synth_upstream_grad(1, B).to(DEV)
+    g2 = synthetic.synth_upstream_grad(2, B).to(DEV)
+    a = ops.patch_grad_gather(g1, patch, xy, th, keep, True, 0)
+    b = ops.patch_grad_gather(g2, patch, xy, th, keep, True, 0)
+    for _ in range(3):  # fp64 LDS accumulation + fixed-order partial sums -> run-to-run identical bits
+        assert torch.equal(a, ops.patch_grad_gather(g1, patch, xy, th, keep, True, 0))
+    # linearity: bf16(2*g) is exact, so K2(2 g1) == 2 K2(g1) bitwise; K2 of a sum within fp32 rounding
+    assert torch.equal(ops.patch_grad_gather((g1.float() * 2).to(torch.bfloat16), patch, xy, th, keep, True, 0), a * 2)
+    gs = (g1.float() + g2.float())
+    exact = gs.to(torch.bfloat16).float().equal(gs)
+    s = ops.patch_grad_gather(gs.to(torch.bfloat16), patch, xy, th, keep, True, 0)
+    if exact:
+        assert (s - (a + b)).abs().max() <= 1e-6 * (a.abs().max() + b.abs().max())
+    # batch additivity: halves sum to the whole
+    h1 = ops.patch_grad_gather(g1[:32].contiguous(), patch, xy[:32].contiguous(), th[:32].contiguous(), keep[:32].contiguous(), True, 0)
+    h2 = ops.patch_grad_gather(g1[32:].contiguous(), patch, xy[32:].contiguous(), th[32:].contiguous(), keep[32:].contiguous(), True, 0)
+    assert (h1 + h2 - a).abs().max() <= 1e-6 * a.abs().max()
+    # and the oracle on the same 64 images
+    og = c_oracle.patch_grad(_bits(g1), patch.cpu().numpy(), xy_n, th_n, 1, 0)
+    assert np.abs(a.cpu().numpy() - og).max() <= 3e-6 * np.abs(og).max()
+    _, o_bf16, _ = c_oracle.patch_apply_fwd(imgs.cpu().numpy(), patch.cpu().numpy(), xy_n, th_n, 1, 0)
+    assert np.array_equal(_bits(out), o_bf16)
+
+
+def test_k1_k2_empty_and_large_batch(ops):
+    patch = _t(np.random.RandomState(0).rand(3, 50, 50).astype(np.float32))
+    e_out, e_keep = ops.patch_apply_fwd(torch.empty((0, 224, 224, 3), dtype=torch.uint8, device=DEV), patch,
+                                        torch.empty((0, 2), dtype=torch.int32, device=DEV), torch.empty((0, 6), device=DEV), True, 0)
+    assert e_out.shape == (0, 6, 224, 224)
+    gz = ops.patch_grad_gather(torch.empty((0, 6, 224, 224), dtype=torch.bfloat16, device=DEV), patch,
+                               torch.empty((0, 2), dtype=torch.int32, device=DEV), torch.empty((0, 6), device=DEV), None, True, 0)
+    assert torch.count_nonzero(gz) == 0
+    # more images than persistent workgroups (B > 512): every image must still be accumulated exactly once
+    B = 700
+    rs = np.random.RandomState(700)
+    xy_n, th_n = _random_case(rs, B, 50, 50)
+    xy, th = _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6))
+    imgs = torch.zeros((B, 224, 224, 3), dtype=torch.uint8, device=DEV)
+    _, keep = ops.patch_apply_fwd(imgs, patch, xy, th, True, 0)
+    g = torch.ones((B, 6, 224, 224), dtype=torch.bfloat16, device=DEV)
+    whole = ops.patch_grad_gather(g, patch, xy, th, keep, True, 0)
+    parts = sum(ops.patch_grad_gather(g[s:e].contiguous(), patch, xy[s:e].contiguous(), th[s:e].contiguous(), keep[s:e].contiguous(), True, 0)
+                for s, e in ((0, 300), (300, 700)))
+    assert (whole - parts).abs().max() <= 1e-6 * whole.abs().max()
+
+
+def test_patch_apply_autograd_function(ops):
+    """PyTorch-ROCm autograd drives K2 through PatchApply.backward exactly like the attack loop does."""
+    d = np.load(os.path.join(GOLDEN, "k1k2_geo50_rand.npz"))
+    B = int(d["batch"])
+    imgs = _t(synthetic.synth_images(int(d["img_seed"]), B, str(d["img_kind"])))
+    patch = _t(d["patch"]).requires_grad_(True)
+    out = ops.PatchApply.apply(patch, imgs, _t(d["xy"], torch.int32), _t(d["theta"].reshape(-1, 6)), True, 0)
+    assert out.dtype == torch.bfloat16 and out.requires_grad
+    g = synthetic.synth_upstream_grad(int(d["grad_seed"]), B).to(DEV)
+    out.backward(gradient=g)
+    assert np.abs(patch.grad.cpu().numpy() - d["patch_grad"]).max() <= 2e-6 * np.abs(d["patch_grad"]).max()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# K3
+# ----------------------------------------------------------------------------------------------------------
+def _rows(labels):
+    B, L = labels.shape
+    S = 256 + L
+    return [(b, S - L + k) for b in range(B) for k in range(L - 1) if labels[b, k + 1] != -100]
+
+
+def _check_rows(g_full, labels, d, pfx, rtol):
+    rows = _rows(labels)
+    rb, rp = np.array([r[0] for r in rows]), np.array([r[1] for r in rows])
+    gr = g_full[rb, rp]
+    scale = max(np.abs(d[f"{pfx}_g_action"]).max(), np.abs(d[f"{pfx}_g_cols"]).max())
+    assert np.abs(gr[:, 31744:32000] - d[f"{pfx}_g_action"]).max() <= rtol * scale
+    assert np.abs(gr[:, d[f"{pfx}_cols"]] - d[f"{pfx}_g_cols"]).max() <= rtol * scale
+    assert abs(np.abs(g_full).sum() - np.abs(gr).sum()) <= 1e-6 * np.abs(gr).sum() + 1e-12  # unlabelled rows untouched (zero)
+    return gr
+
+
+@pytest.mark.parametrize("tag", ["m0", "m012", "m6", "mall"])
+def test_k3_uada_vs_reference_golden(ops, tag):
+    d = np.load(os.path.join(GOLDEN, f"k3_uada_{tag}.npz"))
+    B, S, seed = int(d["B"]), int(d["S"]), int(d["seed"])
+    logits = synthetic.synth_logits(seed + 1000, B, S, 32064).to(DEV)
+    labels = _t(d["masked"])
+    sc, pred, g = ops.loss_fwd_bwd(logits, labels, ops.LOSS_UADA, w=5.0)
+    sc = sc.cpu().numpy()
+    assert abs(sc[0] - float(d["total"])) < 3e-5 and abs(sc[1] - float(d["ce"])) < 3e-5 and abs(sc[2] - float(d["mse"])) < 3e-5
+    assert abs(sc[7] - float(d["uad"])) < 1e-6
+    gr = _check_rows(g.cpu().numpy(), d["masked"], d, "uada", 2e-4)
+    # DDP mode (no 1/CE term) with --MSE_weights
+    sc2, _, g2 = ops.loss_fwd_bwd(logits, labels, ops.LOSS_UADA_DDP, w=float(d["ddp_w"]))
+    assert abs(sc2.cpu().numpy()[0] - float(d["ddp_mse"])) < 3e-5
+    _check_rows(g2.cpu().numpy(), d["masked"], d, "ddp", 2e-4)
+    # ROWS layout on the compacted labelled rows gives the same numbers
+    rows = _rows(d["masked"])
+    compact = logits[torch.tensor([r[0] for r in rows]), torch.tensor([r[1] for r in rows])].contiguous()
+    sc3, pred3, g3 = ops.loss_fwd_bwd(compact, labels, ops.LOSS_UADA, w=5.0, layout=ops.LAYOUT_ROWS)
+    assert torch.equal(sc3, sc_t(sc, DEV)) or np.allclose(sc3.cpu().numpy(), sc, rtol=0, atol=1e-6)
+    assert np.allclose(g3.cpu().numpy(), gr, rtol=0, atol=1e-9)
+    assert torch.equal(pred, pred3)
+    # argmax tokens equal the oracle's
+    op, _ = c_oracle.action_argmax(logits.cpu().numpy(), d["masked"])
+    assert np.array_equal(pred.cpu().numpy()[pred.cpu().numpy() >= 0], op)
+    # bf16 logits: same loss to bf16-level tolerance, gradient in bf16
+    lb = logits.to(torch.bfloat16)
+    scb, _, gb = ops.loss_fwd_bwd(lb, labels, ops.LOSS_UADA, w=5.0)
+    so, go = c_oracle.loss(lb.float().cpu().numpy(), d["masked"], c_oracle.MODE_UADA, w=5.0)
+    assert np.allclose(scb.cpu().numpy()[:3], so[:3], rtol=1e-5, atol=1e-5)
+    assert gb.dtype == torch.bfloat16
+    assert np.abs(gb.float().cpu().numpy() - go).max() <= 1e-2 * np.abs(go).max()
+
+
+def sc_t(sc, dev):
+    return torch.from_numpy(np.asarray(sc)).to(dev)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_k3_upa_vs_reference_golden(ops, tag):
+    d = np.load(os.path.join(GOLDEN, f"k3_upa_{tag}.npz"))
+    B, S, seed = int(d["B"]), int(d["S"]), int(d["seed"])
+    logits = synthetic.synth_logits(seed + 1000, B, S, 32064).to(DEV)
+    sc, _, g = ops.loss_fwd_bwd(logits, _t(d["labels"]), ops.LOSS_UPA, alpha=float(d["alpha"]), beta=float(d["belta"]))
+    sc = sc.cpu().numpy()
+    assert abs(sc[0] - float(d["total"])) < 3e-5 and abs(sc[3] - float(d["angle"])) < 3e-5 and abs(sc[4] - float(d["dist"])) < 3e-5
+    _check_rows(g.cpu().numpy(), d["labels"], d, "upa", 2e-4)
+
+
+@pytest.mark.parametrize("tag", ["t0", "t012"])
+def test_k3_tma_vs_reference_golden(ops, tag):
+    d = np.load(os.path.join(GOLDEN, f"k3_tma_{tag}.npz"))
+    B, S, seed = int(d["B"]), int(d["S"]), int(d["seed"])
+    logits = synthetic.synth_logits(seed + 1000, B, S, 32064).to(DEV)
+    sc, _, g = ops.loss_fwd_bwd(logits, _t(d["newlabels"]), ops.LOSS_CE, scale=1.0)
+    assert abs(sc.cpu().numpy()[0] - float(d["ce"])) < 3e-5
+    _check_rows(g.cpu().numpy(), d["newlabels"], d, "tma", 2e-4)
+    sc2, _, g2 = ops.loss_fwd_bwd(logits, _t(d["newlabels"]), ops.LOSS_CE, scale=0.25)  # accumulate_steps = 4
+    assert abs(sc2.cpu().numpy()[0] - 0.25 * float(d["ce"])) < 1e-5
+    assert np.allclose(g2.cpu().numpy(), 0.25 * g.cpu().numpy(), rtol=1e-6, atol=1e-12)
+
+
+def test_k3_bs64_vs_oracle(ops):
+    """BASELINE size: B=64, maskidx=[0] -> 128 labelled rows of 32064 logits."""
+    B = 64
+    _, labels, _ = synthetic.synth_text_batch(4242, B)
+    masked = ref_port.mask_labels(labels.clone(), [0])
+    L = labels.shape[1]
+    S = 256 + L
+    rs = np.random.RandomState(1)
+    logits = torch.zeros((B, S, 32064), dtype=torch.float32)
+    rows = _rows(masked.numpy())
+    for (b, p) in rows:
+        logits[b, p] = torch.from_numpy((rs.standard_normal(32064) * 2).astype(np.float32))
+    sc, pred, g = ops.loss_fwd_bwd(logits.to(DEV), masked.to(DEV), ops.LOSS_UADA, w=5.0)
+    so, go = c_oracle.loss(logits.numpy(), masked.numpy(), c_oracle.MODE_UADA, w=5.0)
+    assert np.allclose(sc.cpu().numpy()[:7], so[:7], rtol=2e-5, atol=2e-5)
+    assert np.abs(g.cpu().numpy() - go).max() <= 2e-4 * np.abs(go).max()
+    dsc = DiscrepancyCheck(ops, logits.to(DEV), masked.to(DEV))
+    assert abs(dsc - so[0]) < 3e-5
+
+
+def DiscrepancyCheck(ops, logits, labels):
+    lg = logits.clone().requires_grad_(True)
+    total, scalars, pred = ops.DiscrepancyLoss.apply(lg, labels, ops.LOSS_UADA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
+    (total * 2.0).backward()
+    _, _, g = ops.loss_fwd_bwd(logits, labels, ops.LOSS_UADA, w=5.0)
+    assert torch.allclose(lg.grad, 2.0 * g)
+    return float(total)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# K4
+# ----------------------------------------------------------------------------------------------------------
+def test_k4_adamw_pgd_clip_vs_oracle(ops):
+    rs = np.random.RandomState(4)
+    n_shape = (3, 50, 50)
+    p0 = rs.rand(*n_shape).astype(np.float32)
+    p = _t(p0)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    pc, mc, vc = p0.copy().ravel(), np.zeros(7500, np.float32), np.zeros(7500, np.float32)
+    pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = ref_port.HFAdamW([pt], lr=1e-3)
+    for t in range(1, 7):
+        lr = 1e-3 * ref_port.cosine_lambda(t, 2, 10)
+        g = (rs.randn(*n_shape) * 10.0 ** rs.uniform(-7, -1, n_shape)).astype(np.float32)
+        st = ops.patch_update(p, _t(g), m, v, ops.OPT_ADAMW_HF, lr, t)
+        l1 = c_oracle.patch_update(pc, g.ravel(), mc, vc, 0, lr, t)
+        opt.param_groups[0]["lr"] = lr
+        pt.grad = torch.from_numpy(g.copy())
+        opt.step()
+        pt.data = pt.data.clamp(0, 1)
+        assert np.abs(p.cpu().numpy().ravel() - pc).max() < 1e-6
+        assert np.abs(p.cpu().numpy() - pt.detach().numpy()).max() < 1e-6
+        s = st.cpu().numpy()
+        assert abs(s[0] - l1) <= 1e-5 * l1 and abs(s[1] - g.mean()) <= 1e-6 * abs(g).mean() + 1e-9
+    assert p.min() >= 0 and p.max() <= 1
+    # DDP: sum of ranks' gradients with grad_scale = 1/world == mean gradient
+    pa, pb = _t(p0), _t(p0)
+    ma, va, mb, vb = (torch.zeros_like(pa) for _ in range(4))
+    g = rs.randn(*n_shape).astype(np.float32)
+    ops.patch_update(pa, _t(g * 4), ma, va, ops.OPT_ADAMW_HF, 1e-3, 1, grad_scale=0.25)
+    ops.patch_update(pb, _t(g), mb, vb, ops.OPT_ADAMW_HF, 1e-3, 1)
+    assert torch.equal(pa, pb)
+    # UPA: L1 grad-norm clip 1e-3 before the step (UPA.py:157)
+    pq, mq, vq = _t(p0), torch.zeros_like(pa), torch.zeros_like(pa)
+    ops.patch_update(pq, _t(g), mq, vq, ops.OPT_ADAMW_HF, 2e-3, 1, l1_clip=1e-3)
+    pcq, mcq, vcq = p0.copy().ravel(), np.zeros(7500, np.float32), np.zeros(7500, np.float32)
+    c_oracle.patch_update(pcq, g.ravel(), mcq, vcq, 0, 2e-3, 1, l1_clip=1e-3)
+    assert np.abs(pq.cpu().numpy().ravel() - pcq).max() < 1e-6
+    # PGD sign step (TMA.py:171-175)
+    pg = _t(p0)
+    ops.patch_update(pg, _t(g), None, None, ops.OPT_PGD_SIGN, 0.05, 1)
+    assert np.allclose(pg.cpu().numpy(), ref_port.pgd_step(torch.from_numpy(p0), torch.from_numpy(g), 0.05).numpy(), atol=1e-7)
+
+
+def test_capi_error_paths_on_gpu(ops):
+    from roboticattack_amd import _lib
+
+    L = _lib.lib()
+    p = torch.zeros((3, 50, 50), device=DEV)
+    g = torch.zeros((2, 6, 224, 224), dtype=torch.bfloat16, device=DEV)
+    xy = torch.zeros((2, 2), dtype=torch.int32, device=DEV)
+    th = torch.zeros((2, 6), device=DEV)
+    out = torch.zeros((3, 50, 50), device=DEV)
+    ws = torch.zeros(16, dtype=torch.uint8, device=DEV)
+    rc = L.vaa_patch_grad_gather(g.data_ptr(), p.data_ptr(), xy.data_ptr(), th.data_ptr(), None, 2, 50, 50, 1, 0, _lib.f32x([1] * 6),
+                                 out.data_ptr(), ws.data_ptr(), 16, None)
+    assert rc == -4 and b"workspace" in L.vaa_last_error()
+    rc = L.vaa_patch_apply_fwd(g.data_ptr(), p.data_ptr(), xy.data_ptr(), th.data_ptr(), 2, 300, 50, 1, 0, _lib.f32x([0] * 6),
+                               _lib.f32x([1] * 6), g.data_ptr(), None, None)
+    assert rc == -2
+    rc = L.vaa_loss_fwd_bwd(g.data_ptr(), 7, 0, xy.data_ptr(), 2, 300, 40, 32064, 0, _lib.f32x([5, 0, 0, 1]), out.data_ptr(), None, None,
+                            ws.data_ptr(), 16, None)
+    assert rc == -1
