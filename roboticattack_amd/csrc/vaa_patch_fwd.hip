@@ -147,6 +147,7 @@ extern "C" int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, co
                                    int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
                                    uint16_t* out_bf16, uint8_t* keep_bits, void* stream) {
     using namespace vaa;
+    if (B == 0) return VAA_OK;  // empty batch: nothing to read or write (pointers may be null)
     if (!img_u8 || !patch || !xy || !out_bf16 || !mean6 || !std6 || (geometry && !theta)) {
         set_error("vaa_patch_apply_fwd: null pointer argument");
         return VAA_E_INVALID;
@@ -159,7 +160,6 @@ extern "C" int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, co
         set_error("vaa_patch_apply_fwd: patch %dx%d larger than the %dx%d frame", ph, pw, VAA_IMG, VAA_IMG);
         return VAA_E_UNSUPPORTED;
     }
-    if (B == 0) return VAA_OK;
     FwdArgs a;
     a.img = img_u8; a.patch = patch; a.xy = xy; a.theta = theta; a.out = out_bf16; a.keep = keep_bits;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;

@@ -186,6 +186,11 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
                                      const uint8_t* keep_bits, int B, int ph, int pw, int geometry, int mask_mode,
                                      const float* std6, float* gpatch, void* ws, size_t ws_bytes, void* stream) {
     using namespace vaa;
+    if (B == 0 && gpatch && ph > 0 && pw > 0) {  // empty batch: the sum over no images is zero
+        if (hipMemsetAsync(gpatch, 0, (size_t)3 * ph * pw * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return check_launch("vaa_patch_grad_gather(memset)");
+        return VAA_OK;
+    }
     if (!gout_bf16 || !xy || !std6 || !gpatch || (geometry && !theta) || (!keep_bits && !patch)) {
         set_error("vaa_patch_grad_gather: null pointer argument");
         return VAA_E_INVALID;
@@ -200,10 +205,6 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     }
     const int n = 3 * ph * pw;
     hipStream_t st = (hipStream_t)stream;
-    if (B == 0) {
-        if (hipMemsetAsync(gpatch, 0, (size_t)n * sizeof(float), st) != hipSuccess) return check_launch("vaa_patch_grad_gather(memset)");
-        return VAA_OK;
-    }
     if (!ws || ws_bytes < vaa_patch_grad_ws_bytes(B, ph, pw)) {
         set_error("vaa_patch_grad_gather: workspace %zu B < required %zu B", ws_bytes, vaa_patch_grad_ws_bytes(B, ph, pw));
         return VAA_E_WORKSPACE;
