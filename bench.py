@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py — attack-steps/sec of the UADA inner loop (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one inner-loop iteration of UADA_wrapper_ddp (UADA_ddp.py:189-209):
+    host RNG draws -> K1 paste/warp (HIP) -> OpenVLA-7B-shaped bf16 forward + activation backward (PyTorch-ROCm)
+    -> K3 loss fwd+bwd on the labelled rows (HIP) -> K2 patch-grad gather (HIP) -> [RCCL all-reduce, 30 KB] -> K4 AdamW+clamp (HIP)
+Workload: bs=64 PER RANK (reference semantics, UADA_ddp.py:158 -> weak scaling), 3x50x50 patch, geometry=True, maskidx=[0],
+synthetic BridgeData-shaped frames resident in HBM as u8, random-init weights of the OpenVLA-7B architecture.
+Prints ONE JSON line on rank 0. `roofline` is the slowest hand-written kernel inside the timed region (HIP events on the
+launch stream); `roofline_kernels`/`k2_sweep` carry every kernel and the K2 batch sweep; `cpu_baseline` is the reference's
+PyTorch-CPU op sequence for the same replaced ops (oracle/ref_port.py) timed on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bs", type=int, default=64, help="per-rank batch (UADA_ddp.py:158)")
+    ap.add_argument("--patch", type=str, default="3,50,50")
+    ap.add_argument("--model", type=str, default="openvla-7b", choices=["openvla-7b", "tiny", "surrogate"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-suite", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def build_model(kind, dev):
+    from roboticattack_amd.openvla_model import build_openvla, openvla_7b_cfg, tiny_cfg
+
+    if kind == "openvla-7b":
+        return build_openvla(openvla_7b_cfg(), device=dev, dtype=torch.bfloat16, seed=0), "OpenVLA-7B shape (DINOv2-L/14 + SigLIP-so400m/14 + Llama-2-7B), random init"
+    if kind == "tiny":
+        return build_openvla(tiny_cfg(), device=dev, dtype=torch.float32, seed=0), "tiny topology-equal model"
+    from roboticattack_amd.surrogate import SurrogateVLA
+
+    return SurrogateVLA(seed=0).to(dev), "fp32 surrogate"
+
+
+def cpu_baseline(bs, patch_shape, iters):
+    """The reference's CPU path for the replaced ops at the same shapes: per-image PyTorch op chain + autograd (K1,K2),
+    HF-style CE + weighted_loss on fp32 logits [B,S,32064] + backward (K3), HF AdamW + clamp (K4). Bounded sample."""
+    from oracle import ref_port
+    from roboticattack_amd import synthetic
+    from roboticattack_amd.benchmarks import random_params
+
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    imgs = synthetic.synth_images(1234, bs, "noise")
+    patch = torch.nn.Parameter(torch.rand(*patch_shape))
+    opt = ref_port.HFAdamW([patch], lr=1e-3)
+    xy, th = random_params(bs, patch_shape[1], patch_shape[2], 42)
+    th = th.reshape(bs, 2, 3)
+    gout = synthetic.synth_upstream_grad(7, bs)
+    _, labels, _ = synthetic.synth_text_batch(4242, bs)
+    labels = ref_port.mask_labels(labels, [0])
+    S = 256 + labels.shape[1]
+    logits = torch.randn(bs, S, 32064)
+    t12, t3 = [], []
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        ref_port.cpu_patch_step(imgs, patch, opt, xy, th, True, gout)
+        t1 = time.perf_counter()
+        lg = logits.detach().requires_grad_(True)
+        mse, _ = ref_port.uada_weighted_loss(lg, labels, 5.0)
+        ce = ref_port.hf_ce(lg, labels)  # the model's `.loss` is always computed by HF when labels are passed (UADA_ddp.py:196-201)
+        (mse + 0.0 * ce).backward()
+        t2 = time.perf_counter()
+        if it > 0:
+            t12.append(t1 - t0)
+            t3.append(t2 - t1)
+    k124, k3 = float(np.min(t12)), float(np.min(t3))
+    return {
+        "value": 1.0 / (k124 + k3), "unit": "patch-path steps/s on host CPU (K1+K2+K3+K4 only, model excluded)", "cores": ncores,
+        "kind": "port",
+        "sample": f"oracle/ref_port.py (PyTorch-CPU restatement of the reference op sequence), bs={bs}, patch {patch_shape}, geometry=True, "
+                  f"fp32 logits [{bs},{S},32064]; min of {iters} timed iterations after 1 warm-up",
+        "ms_K1_K2_K4": k124 * 1e3, "ms_K3": k3 * 1e3,
+    }
+
+
+def main():
+    args = parse()
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1 here)", file=sys.stderr)
+        sys.exit(2)
+    import torch.distributed as dist
+
+    from roboticattack_amd import dist as vdist
+    from roboticattack_amd import ops, synthetic
+    from roboticattack_amd.benchmarks import HBM_PEAK_GBS, algo_bytes, k2_sweep, kernel_suite
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.optim import PatchOptimizer
+    from roboticattack_amd.transform import RandomPatchTransform
+
+    ops.device_check()
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        vdist.init_process_group("nccl", device=dev)
+    random.seed(42)
+    np.random.seed(42)
+    torch.manual_seed(42)  # UADA_wrapper_ddp.py:53: every rank seeds 42
+
+    patch_shape = [int(v) for v in args.patch.split(",")]
+    B = args.bs
+    model, model_desc = build_model(args.model, dev)
+    use_rows = hasattr(model, "forward_rows")
+    tr = RandomPatchTransform(dev, False)
+    mean = [torch.tensor([0.484375, 0.455078125, 0.40625]), torch.tensor([0.5, 0.5, 0.5])]
+    std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
+
+    batch = synthetic.synth_batch(1234 + rank, B, "noise", as_pil=False)
+    img = tr.stage_images(torch.from_numpy(batch["pixel_values"]))
+    input_ids = batch["input_ids"].to(dev)
+    attn = batch["attention_mask"].to(dev)
+    labels = mask_labels(batch["labels"].clone(), [0]).to(dev)
+    if rank == 0:
+        patch = torch.rand(patch_shape).to(dev)
+    else:
+        patch = torch.empty(patch_shape).to(dev)
+    vdist.broadcast_patch(patch)
+    patch.requires_grad_(True)
+    opt = PatchOptimizer(patch, 1e-3, "adamW")
+    sync = vdist.PatchGradSync(patch.numel(), 4, dev)
+    inv_world = 1.0 / world
+    scal = torch.zeros(8, device=dev)
+
+    def step():
+        opt.zero_grad()
+        pix = tr.apply_random_patch_batch(img, patch, mean, std, geometry=True)  # host RNG draws + K1
+        if use_rows:
+            logits = model.forward_rows(input_ids, pix, labels)
+            total, scalars, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
+        else:
+            out = model(input_ids=input_ids, attention_mask=attn, pixel_values=pix, labels=None)
+            total, scalars, _ = ops.DiscrepancyLoss.apply(out.logits.contiguous(), labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
+        total.backward()  # ... -> K2
+        g_sum, _ = sync.allreduce(patch.grad, torch.stack([scalars[1], scalars[2], scalars[7], patch.grad.mean()]))
+        opt.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4
+        scal.copy_(scalars)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.TIMER = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
+    finite = bool(torch.isfinite(scal).all())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- per-kernel durations inside the timed region (events on the launch stream) ----
+    R = int((labels[:, 1:] != -100).sum())
+    per = {}
+    for name, s, e, info in timer:
+        per.setdefault(name, []).append(s.elapsed_time(e) * 1e-3)
+    kern = {}
+    esz = 2 if use_rows and args.model == "openvla-7b" else 4
+    for name, ts in per.items():
+        key = name[:2]
+        nb = algo_bytes(key, B, patch_shape[1], patch_shape[2], rows=R, esize=esz)
+        mean = float(np.mean(ts))
+        kern[name] = {"launches": len(ts), "mean_us": mean * 1e6, "algo_bytes": nb, "achieved_GBs": nb / mean / 1e9,
+                      "frac": nb / mean / 1e9 / HBM_PEAK_GBS}
+    dom = max(kern, key=lambda k: kern[k]["mean_us"]) if kern else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if dom and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+    roofline = None
+    if dom:
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": kern[dom]["frac"], "traffic": traffic, "mean_us": kern[dom]["mean_us"], "algo_bytes": kern[dom]["algo_bytes"],
+                    "note": "event-bracketed launch sequence on the launching stream inside the timed region (includes launch gaps of multi-kernel ops)"}
+
+    extra = {}
+    if not args.no_kernel_suite:
+        del model
+        torch.cuda.empty_cache()
+        extra["roofline_kernels_standalone"] = kernel_suite(B, patch_shape[1], patch_shape[2], device=str(dev))
+        extra["k2_sweep"] = k2_sweep(device=str(dev))
+        ks = extra["roofline_kernels_standalone"]
+        gpu_ops_s = sum(v["mean_us"] for v in ks.values()) * 1e-6
+        extra["gpu_patch_path_steps_per_s"] = 1.0 / gpu_ops_s
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(B, patch_shape, args.cpu_iters)
+
+    line = {
+        "metric": "attack-steps/sec (bs=64, 3x50x50 patch, OpenVLA-7B)", "value": world * args.steps / dt,
+        "unit": "attack-steps/s (one unit = one bs-64 inner step on one rank; whole job = ranks x synchronous steps)",
+        "sync_steps_per_s": args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"UADA_wrapper_ddp inner step: bs={B} per rank (global {B * world}), patch {args.patch}, geometry=True, maskidx=[0], "
+                               f"{model_desc}; frames resident in HBM as u8",
+                   "global_batch": B * world, "images_per_s": B * world * args.steps / dt, "parallelism": f"dp{world}",
+                   "labelled_rows_per_rank": R, "lm_head": "labelled rows only" if use_rows else "full logits"},
+        "roofline": roofline, "roofline_kernels": kern, "cpu_baseline": cpu,
+        "peak_mem_GiB": peak_mem, "loss_finite": finite,
+    }
+    line.update(extra)
+    print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+"""Shared machinery of the UADA / UPA / TMA attack loops (the hot inner step and the validation/checkpoint side).
+
+One inner step = K1 (paste/warp, HIP) -> model forward/backward (PyTorch-ROCm) -> K3 (loss fwd+bwd, HIP) ->
+K2 (patch-grad gather, HIP, inside autograd backward) -> [RCCL all-reduce of the 30 KB patch gradient] -> K4 (update, HIP).
+Nothing in the step synchronises with the host: the loss scalars of all innerLoop steps of an outer iteration are kept
+in a device buffer and read back once (the reference calls `.item()` 4-5 times per inner step, UADA.py:149-154).
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..action_tokenizer import ActionTokenizer
+from ..constants import MEAN0, MEAN1, STD0, STD1
+from ..transform import RandomPatchTransform
+
+try:  # optional, exactly like a reference run with --wandb_project false
+    import wandb  # type: ignore
+except Exception:  # pragma: no cover
+    wandb = None
+
+
+def wandb_enabled(args) -> bool:
+    return wandb is not None and args is not None and getattr(args, "wandb_project", "false") != "false"
+
+
+class AttackBase:
+    """State every OpenVLAAttacker variant shares (UADA.py:34-74, UPA.py:31-71, TMA.py:29-64)."""
+
+    val_batches = 1000  # UADA.py:202; subclasses override (UPA/TMA: 100)
+
+    def __init__(self, vla, processor=None, save_dir: str = "", optimizer: str = "pgd", resize_patch: bool = False):
+        self.vla = vla.eval()
+        self.processor = processor
+        tok = getattr(processor, "tokenizer", None)
+        self.action_tokenizer = ActionTokenizer(tok)
+        self.base_tokenizer = tok
+        self.predict_stop_token = True
+        self.pad_token_id = 32000
+        self.model_max_length = 2048
+        self.loss_buffer = []
+        self.save_dir = save_dir
+        self.device = torch.device(getattr(vla, "device", "cuda"))
+        self.randomPatchTransform = RandomPatchTransform(self.device, resize_patch)
+        self.mean = [torch.tensor(MEAN0), torch.tensor(MEAN1)]
+        self.std = [torch.tensor(STD0), torch.tensor(STD1)]
+        self.optimizer = optimizer
+        self.use_rows = hasattr(vla, "forward_rows")  # LM head on labelled rows only (no [B,S,32064] logits)
+        self.n_img_tokens = vla.vision_backbone.featurizer.patch_embed.num_patches
+
+    # ---- the model + loss leg of a step ----
+    def model_loss(self, input_ids, attention_mask, pix, labels, mode, w=5.0, alpha=0.8, beta=0.2, scale=1.0, need_grad=True):
+        """Returns (total [autograd scalar or None], scalars f32[8] device, pred i32 [B,L-1] device)."""
+        if self.use_rows:
+            logits = self.vla.forward_rows(input_ids, pix, labels)
+            layout = ops.LAYOUT_ROWS
+        else:
+            out = self.vla(input_ids=input_ids, attention_mask=attention_mask, pixel_values=pix, labels=None)
+            logits = out.logits
+            layout = ops.LAYOUT_FULL
+        if need_grad:
+            return ops.DiscrepancyLoss.apply(logits.contiguous(), labels, mode, w, alpha, beta, scale, layout)
+        scalars, pred, _ = ops.loss_fwd_bwd(logits.detach().contiguous(), labels, mode, w, alpha, beta, scale, layout, want_grad=False)
+        return None, scalars, pred
+
+    # ---- metrics (host, once per outer iteration) ----
+    def decode_pred_gt(self, pred: torch.Tensor, labels: torch.Tensor):
+        """Continuous predicted / ground-truth actions of the action rows, (b,k) order (UADA.py:165-175)."""
+        p = pred.detach().cpu().numpy()
+        gt = labels[:, 1:].detach().cpu().numpy()
+        m = gt > self.action_tokenizer.action_token_begin_idx
+        return (torch.tensor(self.action_tokenizer.decode_token_ids_to_actions(p[m])),
+                torch.tensor(self.action_tokenizer.decode_token_ids_to_actions(gt[m])))
+
+    def calculate_relative_distance(self, pred, gt, maskidx, relative_distance):
+        """UADA.py:354-369."""
+        pred = pred.clone().view(pred.shape[0] // len(maskidx), len(maskidx))
+        gt = gt.clone().view(gt.shape[0] // len(maskidx), len(maskidx))
+        for i1 in range(pred.shape[0]):
+            for i2 in range(pred.shape[1]):
+                anchor = gt[i1, i2]
+                max_boundary = max(1 - anchor, anchor - (-1))
+                relative_distance[f"{str(maskidx[i2])}"].append((abs(pred[i1, i2] - anchor) / max_boundary).item())
+        return relative_distance
+
+    def filter_train(self, data):
+        """UADA.py:308-339 — optional gripper filtering; keeps the reference's thresholds."""
+        import random
+
+        pixel_values = data["pixel_values"]
+        labels = data["labels"].to(self.device)
+        attention_mask = data["attention_mask"].to(self.device)
+        input_ids = data["input_ids"].to(self.device)
+        masked = labels[labels > self.action_tokenizer.action_token_begin_idx]
+        masked = masked.view(masked.shape[0] // 7, 7)
+        one_index = [i for i in range(masked.shape[0]) if masked[i, 6] == 31744]
+        chosen = None
+        if 1 < len(one_index) < 8:
+            chosen = one_index
+        elif len(one_index) > 8:
+            chosen = random.sample(one_index, k=8)
+        if chosen is not None:
+            labels, attention_mask, input_ids = labels[chosen, :], attention_mask[chosen, :], input_ids[chosen, :]
+            pixel_values = [pixel_values[i] for i in chosen]
+        return labels, attention_mask, input_ids, pixel_values
+
+    # ---- outputs (a-12) ----
+    def save_patch(self, patch: torch.Tensor, sub: str) -> str:
+        """`torch.save(patch.detach().cpu(), <save_dir>/<sub>/patch.pt)` — plain fp32 [3,ph,pw] CPU tensor (UADA.py:257-275)."""
+        d = os.path.join(self.save_dir, sub)
+        os.makedirs(d, exist_ok=True)
+        torch.save(patch.detach().float().cpu().contiguous().clone(), os.path.join(d, "patch.pt"))
+        return d
+
+    def save_val_images(self, modified_images: torch.Tensor, d: str):
+        """De-normalised first-3-channel frames as PNG (UADA.py:260-268): ToPILImage == mul(255).byte()."""
+        from PIL import Image
+
+        path = os.path.join(d, "val_related_data")
+        os.makedirs(path, exist_ok=True)
+        imgs = self.randomPatchTransform.denormalize(modified_images[:, 0:3].detach().float().cpu(), self.mean[0], self.std[0])
+        pil = []
+        for o in range(imgs.shape[0]):
+            arr = imgs[o].mul(255).byte().permute(1, 2, 0).numpy()
+            im = Image.fromarray(arr)
+            im.save(os.path.join(path, f"{o}.png"))
+            pil.append(im)
+        return path, pil
+
+    def plot_loss(self):
+        """UADA.py:76-91 (seaborn theme dropped; the curve is identical)."""
+        try:
+            import matplotlib
+
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+
+            plt.plot(list(range(len(self.loss_buffer))), self.loss_buffer, label="Target Loss")
+            plt.title("Loss Plot")
+            plt.xlabel("Iters")
+            plt.ylabel("Loss")
+            plt.legend(loc="best")
+            plt.savefig("%s/loss_curve.png" % (self.save_dir))
+            plt.clf()
+        except Exception:  # plotting is best effort
+            pass
+        torch.save(self.loss_buffer, "%s/loss" % (self.save_dir))
+
+    def dump_lists(self, names):
+        for n in names:
+            with open(os.path.join(self.save_dir, f"{n}.pkl"), "wb") as f:
+                pickle.dump(getattr(self, n), f)
+
+
+def to_dev(batch, device):
+    """labels/attention_mask/input_ids .to(device) (UADA.py:125-127); `.to` on a same-device tensor aliases, and
+    mask_labels mutates in place, so labels are cloned to keep the loader's copy intact."""
+    return (batch["pixel_values"], batch["labels"].to(device).clone(), batch["attention_mask"].to(device),
+            batch["input_ids"].to(device))
+
+
+def next_or_restart(iterator, loader):
+    try:
+        return next(iterator), iterator
+    except StopIteration:
+        iterator = iter(loader)
+        return next(iterator), iterator

@@ -1,0 +1,191 @@
+"""UADA, data-parallel over the GPUs of one node. Mirrors VLAAttacker/white_patch/UADA_ddp.py:36-344.
+
+One process per GPU under torchrun (RANK / WORLD_SIZE / LOCAL_RANK), `torch.distributed` backend "nccl" (= RCCL over
+xGMI). Same constructor arguments and `_attack_entry(rank, params, world)` / `attack(rank, world)` entry points as the
+reference. What differs by design:
+  * K1/K2 run on the GPU (the reference binds the transform to the CPU while the model is still there, Appendix A-D9);
+  * no DistributedDataParallel wrapper around 7.5 B frozen parameters: the single trainable tensor is synchronised by
+    one fused all-reduce per inner step (`dist.PatchGradSync`) and DDP's mean is folded into K4's grad_scale;
+  * every rank seeds Python/NumPy with 42 (UADA_wrapper_ddp.py:53), so transform parameters per local index are
+    identical across ranks, exactly like the reference.
+`bs` is the PER-RANK batch (UADA_ddp.py:158); data are sharded by rank (tf.data shard in the reference, :157-160).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .. import dist as vdist
+from .. import ops
+from ..labels import mask_labels as _mask_labels
+from ..optim import CosineWarmupSchedule, PatchOptimizer
+from .engine import AttackBase, to_dev, wandb, wandb_enabled
+
+
+def default_model_factory(vla_path: str, device):
+    """`vla_path` forms: "random:openvla-7b" / "random:tiny" (random init), "surrogate[:seed]", or a local HF checkpoint dir."""
+    from ..openvla_model import build_openvla, load_hf_openvla, openvla_7b_cfg, tiny_cfg
+
+    if vla_path.startswith("surrogate"):
+        from ..surrogate import SurrogateVLA
+
+        seed = int(vla_path.split(":")[1]) if ":" in vla_path else 0
+        return SurrogateVLA(seed=seed).to(device)
+    if vla_path.startswith("random:"):
+        cfg = tiny_cfg() if vla_path.endswith("tiny") else openvla_7b_cfg()
+        dtype = torch.float32 if vla_path.endswith("tiny") else torch.bfloat16
+        return build_openvla(cfg, device=device, dtype=dtype)
+    if os.path.isdir(vla_path):
+        return load_hf_openvla(build_openvla(openvla_7b_cfg(), device=device), vla_path)
+    raise FileNotFoundError(
+        f"no local OpenVLA checkpoint at {vla_path!r} (this image has no network); use 'random:openvla-7b' for shape-exact runs")
+
+
+def default_dataset_factory(dataset_name: str, bs: int, rank: int, world: int):
+    """Synthetic BridgeData-shaped loaders, sharded by rank through the seed (stands in for RLDSDataset.shard)."""
+    from ..synthetic import SyntheticLoader
+
+    return (SyntheticLoader(bs, seed=1234 + 1000003 * rank, kind="noise"), SyntheticLoader(bs, seed=99991 + 1000003 * rank, kind="noise"))
+
+
+class OpenVLAAttacker(AttackBase):
+    val_batches = 100  # UADA_ddp.py:240
+    val_every = 200  # UADA_ddp.py:233
+
+    def __init__(self, vla_path, dataset_name, save_dir="", resize_patch=False, patch_size=[3, 50, 50], lr=0.01, bs=1, warmup=20,
+                 num_iter=10000, maskidx=[], innerLoop=1, geometry=True, use_wandb=True, MSE_weights=1,
+                 model_factory=None, dataset_factory=None, device=None):
+        rank, world, local = vdist.env_rank_world()
+        if device is None:
+            device = torch.device(f"cuda:{local}") if torch.cuda.is_available() else torch.device("cpu")
+        self._rank, self._world = rank, world
+        vla = (model_factory or default_model_factory)(vla_path, device)
+        super().__init__(vla, None, save_dir, "adamW", resize_patch)
+        self.device = torch.device(device)
+        self.train_loader, self.val_loader = (dataset_factory or default_dataset_factory)(dataset_name, bs, rank, world)
+        self.MSE_Distance_best = 1000000
+        self.bs, self.lr, self.warmup, self.num_iter = bs, lr, warmup, num_iter
+        self.maskidx, self.innerLoop, self.geometry = maskidx, innerLoop, geometry
+        self.use_wandb = bool(use_wandb) and use_wandb != "false"  # Appendix A-D14
+        self.patch_size = patch_size
+        self.val_CE_loss, self.val_MSE_Distance, self.val_UAD = [], [], []
+        self.MSE_weights = MSE_weights
+
+    def setup(self, rank, world_size):
+        vdist.init_process_group(device=self.device if self.device.type == "cuda" else None)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+
+    def cleanup(self):
+        import torch.distributed as dist
+
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+    def mask_labels(self, labels, maskidx):
+        return _mask_labels(labels, maskidx)
+
+    def attack(self, rank, world_size):
+        self.setup(rank, world_size)
+        dev = self.device
+        if rank == 0:
+            patch = torch.rand(self.patch_size).to(dev)  # UADA_ddp.py:140-141
+        else:
+            patch = torch.empty(self.patch_size).to(dev)
+        vdist.broadcast_patch(patch, src=0)  # C1
+        patch.requires_grad_(True)
+        self.patch = patch
+        optimizer = PatchOptimizer(patch, self.lr, "adamW")
+        scheduler = CosineWarmupSchedule(optimizer, self.warmup, int(self.num_iter), 0.5)
+        sync = vdist.PatchGradSync(patch.numel(), 4, dev)
+        inv_world = 1.0 / world_size
+        log_max_grad = 0.0
+
+        for i, data in enumerate(self.train_loader):
+            if i == self.num_iter:
+                break
+            pixel_values, labels, attention_mask, input_ids = to_dev(data, dev)
+            labels = self.mask_labels(labels, self.maskidx)
+            local_stats = None
+            for inner_loop in range(self.innerLoop):
+                optimizer.zero_grad()
+                pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
+                                                                          geometry=self.geometry)
+                total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, ops.LOSS_UADA_DDP, w=float(self.MSE_weights))
+                total.backward()  # K2 inside
+                local_stats = (patch.grad.mean(), scalars)
+                # C3 + C4 in one message: [grad | CE, MSE, UAD, mean-grad]
+                g_sum, s_sum = sync.allreduce(patch.grad, torch.stack([scalars[1], scalars[2], scalars[7], patch.grad.mean()]))
+                optimizer.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4, DDP mean folded in
+            scheduler.step()
+            s = (s_sum * inv_world).cpu().numpy()
+            log_patch_grad = vdist.allreduce_scalar(float(local_stats[0].item()), "MAX", dev)  # UADA_ddp.py:216-217
+            train_logdata = {"TRAIN_attack_loss(CE)": float(s[0]), "TRAIN_patch_gradient": log_patch_grad,
+                             "TRAIN_LR": optimizer.param_groups[0]["lr"], "TRAIN_attack_loss (MSE_Distance)": float(s[1]),
+                             "TRAIN_UAD": float(s[2])}
+            self.last_train_log = train_logdata
+            if rank == 0 and self.use_wandb and wandb is not None:
+                wandb.log(train_logdata, step=i)
+            if i % self.val_every == 0:
+                self.validate(i, patch, rank)
+        self.cleanup()
+        return patch
+
+    def validate(self, i, patch, rank):
+        """UADA_ddp.py:233-324: 100 local val batches, 3 scalar all-reduces (C5), rank 0 writes the files."""
+        avg_CE = avg_MSE = avg_UAD = 0.0
+        modified_images = None
+        with torch.no_grad():
+            for j, data in enumerate(self.val_loader):
+                if j == self.val_batches:
+                    break
+                pixel_values, labels, attention_mask, input_ids = to_dev(data, self.device)
+                modified_images = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch.detach(), mean=self.mean,
+                                                                                      std=self.std, geometry=self.geometry)
+                labels = self.mask_labels(labels, self.maskidx)
+                _, scalars, _ = self.model_loss(input_ids, attention_mask, modified_images, labels, ops.LOSS_UADA_DDP,
+                                                w=float(self.MSE_weights), need_grad=False)
+                s = scalars.cpu().numpy()
+                avg_MSE += float(s[2])
+                avg_UAD += float(s[7])
+                avg_CE += float(s[1])
+        avg_MSE /= self.val_batches
+        avg_UAD /= self.val_batches
+        avg_CE /= self.val_batches
+        g_MSE = vdist.allreduce_scalar(avg_MSE, "AVG", self.device)
+        g_UAD = vdist.allreduce_scalar(avg_UAD, "AVG", self.device)
+        g_CE = vdist.allreduce_scalar(avg_CE, "AVG", self.device)
+        self.last_val_log = {"VAL_MSE_Distance": g_MSE, "VAL_UAD": g_UAD}
+        if rank == 0:
+            if g_MSE < self.MSE_Distance_best:
+                self.MSE_Distance_best = g_MSE
+                d = self.save_patch(patch, f"{str(i)}")
+                _, pil = self.save_val_images(modified_images, d)
+                if self.use_wandb and wandb is not None:
+                    wandb.log(self.last_val_log, step=i)
+                    wandb.log({"AdvImg": [wandb.Image(p) for p in pil]})
+            d = self.save_patch(patch, "last")
+            os.makedirs(os.path.join(d, "val_related_data"), exist_ok=True)
+            self.val_CE_loss.append(g_CE)
+            self.val_MSE_Distance.append(g_MSE)
+            self.val_UAD.append(g_UAD)
+
+    @classmethod
+    def run(cls, **instance_params):
+        """UADA_ddp.py:326-336 spawns one process per visible GPU; torchrun is the supported launcher here."""
+        import torch.multiprocessing as mp
+
+        world_size = max(torch.cuda.device_count(), 1)
+        mp.spawn(cls._spawn_entry, args=(instance_params, world_size), nprocs=world_size)
+
+    @staticmethod
+    def _spawn_entry(rank, instance_params, world_size):
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size))
+        OpenVLAAttacker._attack_entry(rank, instance_params, world_size)
+
+    @staticmethod
+    def _attack_entry(rank, instance_params, world_size):
+        """UADA_ddp.py:338-344."""
+        instance = OpenVLAAttacker(**instance_params)
+        return instance.attack(rank, world_size)

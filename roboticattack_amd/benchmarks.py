@@ -1,0 +1,121 @@
+"""Kernel-level measurement helpers shared by bench.py and tools/kbench.py (HIP events on the launching stream).
+
+Algorithmic bytes per launch (restated in DESIGN.md):
+  K1 fwd   : B*(150,528 [u8 frame] + 602,112 [bf16 6-ch output]) + 12*ph*pw [patch]
+  K2 gather: strict  = B*3*ph*pw*(2*2 [bf16 upstream grad, channels c and c+3, ~ph*pw kept pixels/|det|~1]) + 12*ph*pw
+             i.e. ~ B*12*ph*pw + 12*ph*pw  (B*30,000 + 30,000 at 50x50);  full-frame figure B*602,112 reported separately
+  K3 loss  : 2 * R' * V * e   (one read + one write of the labelled rows; e = bytes per logit)
+  K4 update: 7*4*n  (patch, g, m, v read; patch, m, v written)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops, synthetic
+from .labels import mask_labels
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
+
+
+def algo_bytes(kernel: str, B: int, ph: int = 50, pw: int = 50, rows: int = 0, V: int = 32064, esize: int = 2) -> float:
+    n = 3 * ph * pw
+    if kernel == "K1":
+        return B * (150528 + 602112) + 4 * n
+    if kernel == "K2":
+        return B * 4 * n + 4 * n
+    if kernel == "K2_fullframe":
+        return B * 602112 + 4 * n
+    if kernel == "K3":
+        return 2.0 * rows * V * esize
+    if kernel == "K4":
+        return 7 * 4 * n
+    raise KeyError(kernel)
+
+
+def random_params(B, ph, pw, seed=0):
+    """Host draws in the reference's order (appply_random_transform.py:120-128) -> device tensors."""
+    import random
+
+    from .transform import RandomPatchTransform
+
+    st_r, st_n = random.getstate(), np.random.get_state()
+    random.seed(seed)
+    np.random.seed(seed)
+    t = RandomPatchTransform("cpu")
+    xy, th = t._draw(B, ph, pw, True)
+    random.setstate(st_r)
+    np.random.set_state(st_n)
+    return xy, th
+
+
+def _time(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    t = np.array([s.elapsed_time(e) for s, e in evs]) * 1e-3
+    return float(t.mean()), float(np.median(t)), float(t.min())
+
+
+def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), logits_dtype=torch.bfloat16):
+    """Times K1..K4 standalone on BASELINE-shaped synthetic inputs already resident in HBM. Returns dict per kernel."""
+    dev = torch.device(device)
+    img = torch.from_numpy(synthetic.synth_images(1234, B, "noise")).to(dev)
+    patch = torch.rand(3, ph, pw, device=dev)
+    xy_n, th_n = random_params(B, ph, pw, 42)
+    xy, th = torch.from_numpy(xy_n).to(dev), torch.from_numpy(th_n).to(dev)
+    out, keep = ops.patch_apply_fwd(img, patch, xy, th, True)
+    g = synthetic.synth_upstream_grad(7, min(B, 64)).to(dev)
+    if B > g.shape[0]:
+        g = g.repeat((B + g.shape[0] - 1) // g.shape[0], 1, 1, 1)[:B].contiguous()
+    _, labels, _ = synthetic.synth_text_batch(4242, B)
+    labels = mask_labels(labels, list(maskidx)).to(dev)
+    R = int((labels[:, 1:] != -100).sum())
+    logits = (torch.randn(R, 32064, device=dev) * 2).to(logits_dtype)
+    glog = torch.empty_like(logits)
+    m, v = torch.zeros_like(patch), torch.zeros_like(patch)
+    gp = torch.randn_like(patch) * 1e-3
+    res = {}
+
+    def rec(name, key, fn, nbytes, **extra):
+        mean, med, mn = _time(fn, iters)
+        res[name] = dict(mean_us=mean * 1e6, median_us=med * 1e6, min_us=mn * 1e6, algo_bytes=nbytes,
+                         achieved_GBs=nbytes / mean / 1e9, frac_of_8TBs=nbytes / mean / 1e9 / HBM_PEAK_GBS, **extra)
+
+    rec("K1_patch_apply_fwd", "K1", lambda: ops.patch_apply_fwd(img, patch, xy, th, True), algo_bytes("K1", B, ph, pw), B=B)
+    rec("K2_patch_grad_gather", "K2", lambda: ops.patch_grad_gather(g, patch, xy, th, keep, True), algo_bytes("K2", B, ph, pw), B=B,
+        fullframe_bytes=algo_bytes("K2_fullframe", B, ph, pw))
+    rec("K3_loss_fwd_bwd", "K3",
+        lambda: ops.loss_fwd_bwd(logits, labels, ops.LOSS_UADA_DDP, w=5.0, layout=ops.LAYOUT_ROWS, glogits=glog),
+        algo_bytes("K3", B, rows=R, esize=logits.element_size()), rows=R)
+    rec("K4_patch_update", "K4", lambda: ops.patch_update(patch, gp, m, v, ops.OPT_ADAMW_HF, 1e-3, 1), algo_bytes("K4", B, ph, pw))
+    return res
+
+
+def k2_sweep(batches=(64, 256, 1024, 4096), ph=50, pw=50, iters=20, device="cuda:0"):
+    """The north-star roofline target of K2 is evaluated on a batch sweep (one launch = B images; §8d)."""
+    dev = torch.device(device)
+    out = []
+    patch = torch.rand(3, ph, pw, device=dev)
+    g64 = synthetic.synth_upstream_grad(7, 64).to(dev)
+    for B in batches:
+        xy_n, th_n = random_params(B, ph, pw, 42)
+        xy, th = torch.from_numpy(xy_n).to(dev), torch.from_numpy(th_n).to(dev)
+        img = torch.zeros((B, 224, 224, 3), dtype=torch.uint8, device=dev)
+        _, keep = ops.patch_apply_fwd(img, patch, xy, th, True)
+        del img
+        g = g64.repeat((B + 63) // 64, 1, 1, 1)[:B].contiguous()
+        mean, med, mn = _time(lambda: ops.patch_grad_gather(g, patch, xy, th, keep, True), iters)
+        nb = algo_bytes("K2", B, ph, pw)
+        out.append(dict(B=B, mean_us=mean * 1e6, min_us=mn * 1e6, algo_bytes=nb, achieved_GBs=nb / mean / 1e9,
+                        frac_of_8TBs=nb / mean / 1e9 / HBM_PEAK_GBS, fullframe_GBs=algo_bytes("K2_fullframe", B, ph, pw) / mean / 1e9))
+        del g, keep
+    return out

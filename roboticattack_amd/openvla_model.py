@@ -1,0 +1,280 @@
+"""OpenVLA-7B-shaped model in plain PyTorch-ROCm (plumbing around the hot path, NOT a hand-written kernel target).
+
+The reference keeps the model as stock PyTorch/HF/timm (prismatic/extern/hf/modeling_prismatic.py:63-447);
+neither timm nor the OpenVLA weights exist in this image, so the repo carries the architecture itself:
+
+  vision  : DINOv2 ViT-L/14-reg4 @224 (1024-d, 24 blocks, LayerScale, cls + 4 register tokens) and
+            SigLIP so400m/14 @224 (1152-d, 27 blocks); each returns the patch tokens of its SECOND-TO-LAST block
+            (`get_intermediate_layers(n={len(blocks)-2})`, modeling_prismatic.py:85-87, 99-101), concatenated on the
+            feature axis -> [B,256,2176]; the 6-channel input is split 3+3 (modeling_prismatic.py:120).
+  project : fused-backbone MLP 2176 -> 8704 -> 4096 -> 4096 with GELU (modeling_prismatic.py:139-156).
+  llm     : Llama-2-7B (32 layers, 4096-d, 32 heads, SwiGLU 11008, RoPE, RMSNorm 1e-6... HF default 1e-5 for Llama-2),
+            vocab padded to 32064 (configuration_prismatic.py:86); image tokens inserted after BOS (:383-385).
+
+All weights are frozen (Appendix A-D12: freezing does not change the patch gradient), so autograd stores no GEMM
+inputs and computes activation gradients only. Instead of materialising fp32 logits [B,S,32064] (2.4 GB at B=64) the
+LM head runs on the labelled rows only (`forward_rows`), which is exactly the set of rows the reference's losses read.
+Random-init throughput runs use `init="random"`; a local HF checkpoint directory can be mapped in with `load_hf_openvla`.
+"""
+from __future__ import annotations
+
+import math
+import types
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .constants import IGNORE_INDEX, MODEL_VOCAB, N_IMG_TOKENS
+
+
+@dataclass
+class VitCfg:
+    dim: int
+    depth: int
+    heads: int
+    mlp: int
+    n_prefix: int  # cls + register tokens
+    cls_pos: bool  # cls token carries a position embedding (DINOv2); register tokens never do
+    layerscale: bool
+
+
+@dataclass
+class OpenVLACfg:
+    dino: VitCfg
+    siglip: VitCfg
+    llm_dim: int = 4096
+    llm_layers: int = 32
+    llm_heads: int = 32
+    llm_mlp: int = 11008
+    vocab: int = MODEL_VOCAB
+    rms_eps: float = 1e-6
+    rope_theta: float = 10000.0
+
+
+def openvla_7b_cfg() -> OpenVLACfg:
+    return OpenVLACfg(
+        dino=VitCfg(1024, 24, 16, 4096, 5, True, True),
+        siglip=VitCfg(1152, 27, 16, 4304, 0, False, False),
+    )
+
+
+def tiny_cfg() -> OpenVLACfg:
+    """Same topology, toy widths: CPU-runnable plumbing tests."""
+    return OpenVLACfg(
+        dino=VitCfg(32, 3, 2, 64, 5, True, True),
+        siglip=VitCfg(48, 3, 2, 80, 0, False, False),
+        llm_dim=64, llm_layers=2, llm_heads=4, llm_mlp=128,
+    )
+
+
+class VitBlock(nn.Module):
+    def __init__(self, c: VitCfg):
+        super().__init__()
+        self.heads = c.heads
+        self.norm1 = nn.LayerNorm(c.dim, eps=1e-6)
+        self.qkv = nn.Linear(c.dim, 3 * c.dim)
+        self.proj = nn.Linear(c.dim, c.dim)
+        self.norm2 = nn.LayerNorm(c.dim, eps=1e-6)
+        self.fc1 = nn.Linear(c.dim, c.mlp)
+        self.fc2 = nn.Linear(c.mlp, c.dim)
+        self.ls1 = nn.Parameter(torch.ones(c.dim)) if c.layerscale else None
+        self.ls2 = nn.Parameter(torch.ones(c.dim)) if c.layerscale else None
+
+    def forward(self, x):
+        B, T, D = x.shape
+        qkv = self.qkv(self.norm1(x)).view(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, T, D)
+        a = self.proj(a)
+        x = x + (a * self.ls1 if self.ls1 is not None else a)
+        h = self.fc2(F.gelu(self.fc1(self.norm2(x))))
+        return x + (h * self.ls2 if self.ls2 is not None else h)
+
+
+class Vit(nn.Module):
+    """timm VisionTransformer restricted to what `get_intermediate_layers(n={depth-2})` evaluates."""
+
+    def __init__(self, c: VitCfg):
+        super().__init__()
+        self.c = c
+        self.patch_embed = nn.Conv2d(3, c.dim, kernel_size=14, stride=14)
+        self.pos_embed = nn.Parameter(torch.zeros(1, N_IMG_TOKENS + (1 if c.cls_pos else 0), c.dim))
+        self.prefix = nn.Parameter(torch.zeros(1, c.n_prefix, c.dim)) if c.n_prefix else None
+        self.blocks = nn.ModuleList([VitBlock(c) for _ in range(c.depth - 1)])  # the last block is never evaluated
+
+    def forward(self, img):
+        x = self.patch_embed(img).flatten(2).transpose(1, 2)  # [B,256,D]
+        if self.prefix is not None:
+            B = x.shape[0]
+            cls = self.prefix[:, :1].expand(B, -1, -1)
+            reg = self.prefix[:, 1:].expand(B, -1, -1)
+            x = torch.cat([cls, x], dim=1) + self.pos_embed  # timm: pos-embed over [cls, patches], then registers
+            x = torch.cat([x[:, :1], reg, x[:, 1:]], dim=1)
+        else:
+            x = x + self.pos_embed
+        for blk in self.blocks:
+            x = blk(x)
+        return x[:, self.c.n_prefix :]
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.eps = eps
+
+    def forward(self, x):
+        return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
+
+
+def _rope(q, k, cos, sin):
+    def rot(x):
+        x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2 :]
+        return torch.cat((-x2, x1), dim=-1)
+
+    return q * cos + rot(q) * sin, k * cos + rot(k) * sin
+
+
+class LlamaLayer(nn.Module):
+    def __init__(self, c: OpenVLACfg):
+        super().__init__()
+        d = c.llm_dim
+        self.heads = c.llm_heads
+        self.input_layernorm = RMSNorm(d, c.rms_eps)
+        self.q_proj = nn.Linear(d, d, bias=False)
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d, bias=False)
+        self.o_proj = nn.Linear(d, d, bias=False)
+        self.post_attention_layernorm = RMSNorm(d, c.rms_eps)
+        self.gate_proj = nn.Linear(d, c.llm_mlp, bias=False)
+        self.up_proj = nn.Linear(d, c.llm_mlp, bias=False)
+        self.down_proj = nn.Linear(c.llm_mlp, d, bias=False)
+
+    def forward(self, x, cos, sin):
+        B, T, D = x.shape
+        h = self.input_layernorm(x)
+        hd = D // self.heads
+        q = self.q_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+        k = self.k_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+        v = self.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+        q, k = _rope(q, k, cos, sin)
+        a = F.scaled_dot_product_attention(q, k, v, is_causal=True)  # right padding + causal == HF's mask on real tokens
+        x = x + self.o_proj(a.transpose(1, 2).reshape(B, T, D))
+        h = self.post_attention_layernorm(x)
+        return x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
+
+
+class OpenVLAShaped(nn.Module):
+    def __init__(self, cfg: OpenVLACfg | None = None):
+        super().__init__()
+        self.cfg = c = cfg or openvla_7b_cfg()
+        self.featurizer = Vit(c.dino)
+        self.fused_featurizer = Vit(c.siglip)
+        vd = c.dino.dim + c.siglip.dim
+        self.fc1 = nn.Linear(vd, 4 * vd)
+        self.fc2 = nn.Linear(4 * vd, c.llm_dim)
+        self.fc3 = nn.Linear(c.llm_dim, c.llm_dim)
+        self.embed_tokens = nn.Embedding(c.vocab, c.llm_dim)
+        self.layers = nn.ModuleList([LlamaLayer(c) for _ in range(c.llm_layers)])
+        self.norm = RMSNorm(c.llm_dim, c.rms_eps)
+        self.lm_head = nn.Linear(c.llm_dim, c.vocab, bias=False)
+        # the attack loops read vla.vision_backbone.featurizer.patch_embed.num_patches (UADA.py:166)
+        self.vision_backbone = types.SimpleNamespace(
+            featurizer=types.SimpleNamespace(patch_embed=types.SimpleNamespace(num_patches=N_IMG_TOKENS)))
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    @property
+    def device(self):
+        return self.embed_tokens.weight.device
+
+    @torch.no_grad()
+    def init_random(self, seed: int = 0, std: float = 0.02):
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, std, generator=g)
+            elif name.endswith("bias"):
+                p.zero_()
+            elif "ls1" in name or "ls2" in name:
+                p.fill_(1.0)
+        return self
+
+    def hidden_states(self, input_ids, pixel_values):
+        """[B, 1+256+(L-1), D] final-norm hidden states of the multimodal sequence (modeling_prismatic.py:366-415)."""
+        img, img_fused = torch.split(pixel_values, [3, 3], dim=1)
+        feats = torch.cat([self.featurizer(img), self.fused_featurizer(img_fused)], dim=2)
+        proj = self.fc3(F.gelu(self.fc2(F.gelu(self.fc1(feats)))))
+        emb = self.embed_tokens(input_ids)
+        x = torch.cat([emb[:, :1], proj.to(emb.dtype), emb[:, 1:]], dim=1)
+        T = x.shape[1]
+        hd = self.cfg.llm_dim // self.cfg.llm_heads
+        inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, device=x.device, dtype=torch.float32) / hd))
+        ang = torch.outer(torch.arange(T, device=x.device, dtype=torch.float32), inv)
+        ang = torch.cat([ang, ang], dim=-1)
+        cos, sin = ang.cos().to(x.dtype)[None, None], ang.sin().to(x.dtype)[None, None]
+        for layer in self.layers:
+            x = layer(x, cos, sin)
+        return self.norm(x)
+
+    def forward_rows(self, input_ids, pixel_values, labels):
+        """Logits [R,V] of the labelled rows only, in (b,k) row-major order of labels[b,k+1] != -100 (VAA_LAYOUT_ROWS):
+        row (b,k) is model position S-L+k = 256+k, the position whose next-token target is labels[b,k+1]."""
+        h = self.hidden_states(input_ids, pixel_values)
+        sel = labels[:, 1:] != IGNORE_INDEX  # [B, L-1]
+        rows = h[:, N_IMG_TOKENS:-1][sel]  # [R, D]; h[:, 256+k] for k in [0, L-1)
+        return self.lm_head(rows)
+
+    def forward(self, input_ids, attention_mask=None, pixel_values=None, labels=None, **_):
+        """Drop-in contract of PrismaticForConditionalGeneration.forward: full fp32 logits and HF's mean CE."""
+        from .surrogate import hf_causal_ce
+
+        logits = self.lm_head(self.hidden_states(input_ids, pixel_values)).float()
+        loss = hf_causal_ce(logits, labels) if labels is not None else None
+        return types.SimpleNamespace(loss=loss, logits=logits)
+
+
+def build_openvla(cfg: OpenVLACfg | None = None, device="cuda", dtype=torch.bfloat16, seed: int = 0) -> OpenVLAShaped:
+    """Random-init OpenVLA-7B-shaped model created directly on `device` in `dtype` (15 GB in bf16)."""
+    with torch.device(device):
+        m = OpenVLAShaped(cfg)
+    m = m.to(dtype)
+    m.init_random(seed)
+    return m.eval()
+
+
+def load_hf_openvla(model: OpenVLAShaped, ckpt_dir: str) -> OpenVLAShaped:
+    """Map a local HF `openvla/openvla-7b` safetensors checkpoint onto this module tree (names follow
+    modeling_prismatic.py: vision_backbone.{featurizer,fused_featurizer}.*, projector.fc{1,2,3}, language_model.model.*).
+    Untested in this image (no weights, no network)."""
+    import glob
+    import os
+
+    from safetensors.torch import load_file
+
+    sd = {}
+    for f in sorted(glob.glob(os.path.join(ckpt_dir, "*.safetensors"))):
+        sd.update(load_file(f))
+    own = dict(model.named_parameters())
+    ren = {}
+    for k, v in sd.items():
+        n = k
+        n = n.replace("vision_backbone.featurizer.", "featurizer.").replace("vision_backbone.fused_featurizer.", "fused_featurizer.")
+        n = n.replace("projector.", "").replace("language_model.model.", "").replace("language_model.lm_head.", "lm_head.")
+        n = n.replace(".attn.qkv.", ".qkv.").replace(".attn.proj.", ".proj.").replace(".mlp.fc1.", ".fc1.").replace(".mlp.fc2.", ".fc2.")
+        n = n.replace(".ls1.scale_factor", ".ls1").replace(".ls2.scale_factor", ".ls2").replace(".ls1.gamma", ".ls1").replace(".ls2.gamma", ".ls2")
+        n = n.replace("patch_embed.proj.", "patch_embed.").replace(".self_attn.", ".").replace(".mlp.", ".")
+        ren[n] = v
+    missing = []
+    with torch.no_grad():
+        for name, p in own.items():
+            if name == "featurizer.prefix":
+                p.copy_(torch.cat([ren["featurizer.cls_token"], ren["featurizer.reg_token"]], dim=1))
+            elif name in ren and ren[name].shape == p.shape:
+                p.copy_(ren[name])
+            else:
+                missing.append(name)
+    if missing:
+        raise RuntimeError(f"load_hf_openvla: {len(missing)} parameters not found, e.g. {missing[:5]}")
+    return model

@@ -26,6 +26,28 @@ _MEAN = _lib.f32x(MEAN6)
 _STD = _lib.f32x(STD6)
 _ws_cache: dict = {}
 
+# Optional kernel timing (bench.py): when TIMER is a list, every hand-written kernel launch sequence is bracketed by
+# torch.cuda.Event pairs recorded on the launching (= torch current) stream; entries are (name, start, end, info).
+TIMER = None
+
+
+class _timed:
+    def __init__(self, name, **info):
+        self.name, self.info = name, info
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMER is not None:
+            self.e.record()
+            TIMER.append((self.name, self.s, self.e, self.info))
+        return False
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -59,7 +81,8 @@ def device_check() -> None:
 # ------------------------------------------------------------------------------------------------------
 # K1 / K2
 # ------------------------------------------------------------------------------------------------------
-def patch_apply_fwd(img_u8, patch, xy, theta, geometry: bool, mask_mode: int = MASK_LT_M20, want_keep: bool = True):
+def patch_apply_fwd(img_u8, patch, xy, theta, geometry: bool, mask_mode: int = MASK_LT_M20, want_keep: bool = True,
+                    mean6=None, std6=None):
     """K1. img_u8 [B,224,224,3] u8, patch [3,ph,pw] f32, xy [B,2] i32, theta [B,6] f32 -> (bf16 [B,6,224,224], keep bits)."""
     B = img_u8.shape[0]
     _need(img_u8, torch.uint8, "img_u8", (B, IMG, IMG, 3))
@@ -70,14 +93,17 @@ def patch_apply_fwd(img_u8, patch, xy, theta, geometry: bool, mask_mode: int = M
     ph, pw = int(patch.shape[1]), int(patch.shape[2])
     out = torch.empty((B, 6, IMG, IMG), dtype=torch.bfloat16, device=img_u8.device)
     keep = torch.empty((B, 3, IMG * IMG // 8), dtype=torch.uint8, device=img_u8.device) if want_keep else None
-    rc = _lib.lib().vaa_patch_apply_fwd(
-        img_u8.data_ptr(), patch.data_ptr(), xy.data_ptr(), theta.data_ptr() if geometry else None, B, ph, pw,
-        int(bool(geometry)), int(mask_mode), _MEAN, _STD, out.data_ptr(), keep.data_ptr() if want_keep else None, _stream())
+    mean_c = _MEAN if mean6 is None else _lib.f32x(mean6)
+    std_c = _STD if std6 is None else _lib.f32x(std6)
+    with _timed("K1_patch_apply_fwd", B=B, ph=ph, pw=pw):
+        rc = _lib.lib().vaa_patch_apply_fwd(
+            img_u8.data_ptr(), patch.data_ptr(), xy.data_ptr(), theta.data_ptr() if geometry else None, B, ph, pw,
+            int(bool(geometry)), int(mask_mode), mean_c, std_c, out.data_ptr(), keep.data_ptr() if want_keep else None, _stream())
     _lib.check(rc, "vaa_patch_apply_fwd")
     return out, keep
 
 
-def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20):
+def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None):
     """K2. gout_bf16 [B,6,224,224] bf16 -> dL/d patch [3,ph,pw] f32 (sum over the batch)."""
     B = gout_bf16.shape[0]
     _need(gout_bf16, torch.bfloat16, "gout_bf16", (B, 6, IMG, IMG))
@@ -92,10 +118,12 @@ def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, ma
     nbytes = L.vaa_patch_grad_ws_bytes(B, ph, pw)
     ws = _workspace(patch.device, nbytes)
     gpatch = torch.empty_like(patch)
-    rc = L.vaa_patch_grad_gather(
-        gout_bf16.data_ptr(), patch.data_ptr(), xy.data_ptr(), theta.data_ptr() if geometry else None,
-        keep_bits.data_ptr() if keep_bits is not None else None, B, ph, pw, int(bool(geometry)), int(mask_mode), _STD,
-        gpatch.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    std_c = _STD if std6 is None else _lib.f32x(std6)
+    with _timed("K2_patch_grad_gather", B=B, ph=ph, pw=pw):
+        rc = L.vaa_patch_grad_gather(
+            gout_bf16.data_ptr(), patch.data_ptr(), xy.data_ptr(), theta.data_ptr() if geometry else None,
+            keep_bits.data_ptr() if keep_bits is not None else None, B, ph, pw, int(bool(geometry)), int(mask_mode), std_c,
+            gpatch.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "vaa_patch_grad_gather")
     return gpatch
 
@@ -104,17 +132,19 @@ class PatchApply(torch.autograd.Function):
     """Differentiable (w.r.t. `patch`) K1: PyTorch-ROCm autograd hands the model's bf16 pixel gradient to K2."""
 
     @staticmethod
-    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode):
-        out, keep = patch_apply_fwd(img_u8, patch.detach(), xy, theta, geometry, mask_mode, want_keep=True)
-        ctx.save_for_backward(patch.detach(), xy, theta if geometry else xy, keep)
-        ctx.geometry, ctx.mask_mode = bool(geometry), int(mask_mode)
+    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode, mean6=None, std6=None):
+        p = patch.detach().contiguous()
+        out, keep = patch_apply_fwd(img_u8, p, xy, theta, geometry, mask_mode, want_keep=True, mean6=mean6, std6=std6)
+        ctx.save_for_backward(p, xy, theta if geometry else xy, keep)
+        ctx.geometry, ctx.mask_mode, ctx.std6 = bool(geometry), int(mask_mode), std6
         return out
 
     @staticmethod
     def backward(ctx, gout):
         patch, xy, theta, keep = ctx.saved_tensors
-        g = patch_grad_gather(gout.contiguous(), patch, xy, theta if ctx.geometry else None, keep, ctx.geometry, ctx.mask_mode)
-        return g, None, None, None, None, None
+        g = patch_grad_gather(gout.to(torch.bfloat16).contiguous(), patch, xy, theta if ctx.geometry else None, keep,
+                              ctx.geometry, ctx.mask_mode, std6=ctx.std6)
+        return g, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -148,10 +178,11 @@ def loss_fwd_bwd(logits, labels, mode: int, w: float = 5.0, alpha: float = 0.8, 
     pred = torch.empty((B, Lt - 1), dtype=torch.int32, device=logits.device) if want_pred else None
     if want_grad and glogits is None:
         glogits = torch.zeros_like(logits) if layout == LAYOUT_FULL else torch.empty_like(logits)
-    rc = L.vaa_loss_fwd_bwd(
-        logits.data_ptr(), dt, int(layout), labels.data_ptr(), B, S, Lt, V, int(mode), _lib.f32x([w, alpha, beta, scale]),
-        scalars.data_ptr(), pred.data_ptr() if want_pred else None, glogits.data_ptr() if want_grad else None,
-        ws.data_ptr(), ws.numel(), _stream())
+    with _timed("K3_loss_fwd_bwd", B=B, L=Lt, V=V, dtype=str(logits.dtype), rows=(int(logits.shape[0]) if layout == LAYOUT_ROWS else -1)):
+        rc = L.vaa_loss_fwd_bwd(
+            logits.data_ptr(), dt, int(layout), labels.data_ptr(), B, S, Lt, V, int(mode), _lib.f32x([w, alpha, beta, scale]),
+            scalars.data_ptr(), pred.data_ptr() if want_pred else None, glogits.data_ptr() if want_grad else None,
+            ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "vaa_loss_fwd_bwd")
     return scalars, pred, (glogits if want_grad else None)
 
@@ -184,9 +215,10 @@ def patch_update(patch, grad, m, v, mode: int, lr: float, step: int, beta1: floa
         _need(m, torch.float32, "m", patch.shape)
         _need(v, torch.float32, "v", patch.shape)
     stats = torch.empty(2, dtype=torch.float32, device=patch.device) if want_stats else None
-    rc = _lib.lib().vaa_patch_update(
-        patch.data_ptr(), grad.data_ptr(), m.data_ptr() if m is not None else None, v.data_ptr() if v is not None else None,
-        patch.numel(), int(mode), float(lr), float(beta1), float(beta2), float(eps), int(step), float(l1_clip),
-        float(grad_scale), stats.data_ptr() if want_stats else None, _stream())
+    with _timed("K4_patch_update", n=int(patch.numel())):
+        rc = _lib.lib().vaa_patch_update(
+            patch.data_ptr(), grad.data_ptr(), m.data_ptr() if m is not None else None, v.data_ptr() if v is not None else None,
+            patch.numel(), int(mode), float(lr), float(beta1), float(beta2), float(eps), int(step), float(l1_clip),
+            float(grad_scale), stats.data_ptr() if want_stats else None, _stream())
     _lib.check(rc, "vaa_patch_update")
     return stats

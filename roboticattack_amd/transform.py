@@ -1,0 +1,171 @@
+"""RandomPatchTransform — host-side mirror of VLAAttacker/white_patch/appply_random_transform.py:8-197.
+
+Same class name, method names, argument meaning and RNG draw order as the reference; the per-image PyTorch op
+chain is replaced by ONE fused HIP launch per batch (K1, `ops.PatchApply`) whose backward is K2. The random
+draws stay in Python (`random`, `numpy.random`) so that seeded runs consume the generators exactly like the
+reference does; only their results (x, y, 2x3 theta) travel to the device.
+
+Differences a caller can observe (all documented in DESIGN.md):
+  * the returned tensor is already bfloat16 (every reference call site casts `.to(torch.bfloat16)` immediately:
+    UADA.py:142, UADA_ddp.py:199, UPA.py:142, TMA.py:145); pass out_dtype=torch.float32 to get the fp32 view.
+  * images may be a list of PIL images / HWC uint8 arrays (staged to the device once and cached while the same
+    list object is passed again, i.e. for all innerLoop steps of an outer iteration) or a uint8 device tensor.
+  * Appendix A defects: D1 (IndentationError) n/a; D2 (resize_patch UnboundLocalError) resolved as "scale the BASE
+    patch per image"; D3 (`colorjitter=` kwarg) accepted and ignored.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .constants import IMG, MAX_ANGLE_DEG, MAX_SHEAR, P_IDENTITY
+
+
+def _six(mean, std):
+    m = [float(v) for t in mean for v in (t.tolist() if hasattr(t, "tolist") else t)]
+    s = [float(v) for t in std for v in (t.tolist() if hasattr(t, "tolist") else t)]
+    if len(m) != 6 or len(s) != 6:
+        raise ValueError("mean/std must be two 3-vectors each (DINOv2 stats, SigLIP stats)")
+    return m, s
+
+
+class RandomPatchTransform:
+    def __init__(self, device, resize_patch: bool = False):
+        self.device = torch.device(device)
+        self.angle = MAX_ANGLE_DEG  # appply_random_transform.py:11
+        self.shx = MAX_SHEAR  # :12
+        self.shy = MAX_SHEAR  # :13
+        self.resize_patch = resize_patch
+        self._staged_key = None
+        self._staged = None
+        self.last_params = None  # (xy, theta) of the most recent call, host numpy (tests / logging)
+
+    # ---- small tensor helpers kept for API compatibility (:16-24) ----
+    def normalize(self, images, mean, std):
+        return (images - mean[None, :, None, None]) / std[None, :, None, None]
+
+    def denormalize(self, images, mean, std):
+        return images * std[None, :, None, None] + mean[None, :, None, None]
+
+    # ---- geometry (:26-41, :80-91) ----
+    def rotation_matrix(self, theta):
+        t = np.deg2rad(theta)
+        c, s = np.cos(t), np.sin(t)
+        return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float32)
+
+    def shear_matrix(self, shx, shy):
+        return np.array([[1, shx, 0], [shy, 1, 0], [0, 0, 1]], dtype=np.float32)
+
+    def combined_transform_matrix(self):
+        """p=0.2 identity, else S(shx,shy) @ R(angle) with angle~U(-30,30) deg, shear~U(-0.2,0.2); float32 3x3 tensor."""
+        if np.random.rand() < P_IDENTITY:
+            return torch.tensor(np.eye(3, dtype=np.float32))
+        angle = np.random.uniform(-self.angle, self.angle)
+        shx = np.random.uniform(-self.shx, self.shx)
+        shy = np.random.uniform(-self.shy, self.shy)
+        return torch.tensor(np.dot(self.shear_matrix(shx, shy), self.rotation_matrix(angle)))
+
+    # ---- staging ----
+    def stage_images(self, images) -> torch.Tensor:
+        """uint8 [B,224,224,3] on the device. The reference re-runs ToTensor + H2D for every image on every inner step
+        (:108); the frames do not change during an outer iteration, so they are staged once."""
+        if isinstance(images, torch.Tensor):
+            t = images
+            if t.dtype != torch.uint8 or t.dim() != 4 or tuple(t.shape[1:]) != (IMG, IMG, 3):
+                raise ValueError("image tensor must be uint8 [B,224,224,3] (HWC)")
+            return t.to(self.device).contiguous()
+        key = (id(images), len(images))
+        if self._staged_key == key and self._staged is not None:
+            return self._staged
+        arr = np.stack([np.asarray(im, dtype=np.uint8) for im in images])
+        if arr.shape[1:] != (IMG, IMG, 3):
+            raise ValueError(f"images must be 224x224 RGB, got {arr.shape[1:]}")
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device, non_blocking=True)
+        self._staged_key, self._staged = key, t
+        return t
+
+    def _draw(self, batch, ph, pw, geometry):
+        """RNG draw order per image (:120-128): randint(x), randint(y), then (geometry) rand [, uniform x3]."""
+        xy = np.empty((batch, 2), np.int32)
+        theta = np.empty((batch, 6), np.float32)
+        for b in range(batch):
+            xy[b, 0] = random.randint(0, IMG - pw)
+            xy[b, 1] = random.randint(0, IMG - ph)
+            m = self.combined_transform_matrix().numpy() if geometry else np.eye(3, dtype=np.float32)
+            theta[b] = m[:2].reshape(6)
+        return xy, theta
+
+    def _to_dev(self, xy, theta):
+        self.last_params = (xy, theta)
+        return torch.from_numpy(xy).to(self.device, non_blocking=True), torch.from_numpy(theta).to(self.device, non_blocking=True)
+
+    # ---- the operators ----
+    def apply_random_patch_batch(self, images, patch, mean, std, geometry, colorjitter=False, out_dtype=torch.bfloat16):
+        """Paste `patch` at a random position of every image, optionally warp it by a random rotation+shear, composite
+        where the warped canvas is >= -20, normalise twice and stack to 6 channels (:104-136). Differentiable w.r.t. patch."""
+        mean6, std6 = _six(mean, std)
+        img = self.stage_images(images)
+        B = img.shape[0]
+        if self.resize_patch:
+            return self._apply_resized(img, patch, mean6, std6, geometry, out_dtype)
+        ph, pw = int(patch.shape[1]), int(patch.shape[2])
+        xy, theta = self._to_dev(*self._draw(B, ph, pw, geometry))
+        out = ops.PatchApply.apply(patch, img, xy, theta, bool(geometry), ops.MASK_LT_M20, mean6, std6)
+        return out if out_dtype == torch.bfloat16 else out.to(out_dtype)
+
+    def _apply_resized(self, img, patch, mean6, std6, geometry, out_dtype):
+        """resize_patch=True (:113-116, Appendix A-D2): per image s~U(0.61,1.39) drawn BEFORE the position; the base
+        patch is resized (bilinear, antialias) to (int(ph*s), int(pw*s)). One launch per image (sizes differ)."""
+        outs, xs, ts = [], [], []
+        ph0, pw0 = int(patch.shape[1]), int(patch.shape[2])
+        for b in range(img.shape[0]):
+            scale = random.uniform(0.61, 1.39)
+            h, w = max(1, int(ph0 * scale)), max(1, int(pw0 * scale))
+            p = F.interpolate(patch[None], size=(h, w), mode="bilinear", antialias=True, align_corners=False)[0].contiguous()
+            xy, theta = self._draw(1, h, w, geometry)
+            xs.append(xy)
+            ts.append(theta)
+            outs.append(ops.PatchApply.apply(p, img[b : b + 1], torch.from_numpy(xy).to(self.device),
+                                             torch.from_numpy(theta).to(self.device), bool(geometry), ops.MASK_LT_M20, mean6, std6))
+        self.last_params = (np.concatenate(xs), np.concatenate(ts))
+        out = torch.cat(outs, dim=0)
+        return out if out_dtype == torch.bfloat16 else out.to(out_dtype)
+
+    def _paste(self, images, patch, mean, std, out_dtype):
+        mean6, std6 = _six(mean, std)
+        img = self.stage_images(images)
+        ph, pw = int(patch.shape[1]), int(patch.shape[2])
+        xy, theta = self._to_dev(*self._draw(img.shape[0], ph, pw, False))
+        out = ops.PatchApply.apply(patch, img, xy, theta, False, ops.MASK_NE_M100, mean6, std6)
+        return (out if out_dtype == torch.bfloat16 else out.to(out_dtype)), xy
+
+    def random_paste_patch(self, images, patch, mean, std, out_dtype=torch.bfloat16):
+        """:138-158 — paste without warp, mask rule `canvas != -100`."""
+        return self._paste(images, patch, mean, std, out_dtype)[0]
+
+    def paste_patch_fix(self, images, patch, mean, std, inference=False, out_dtype=torch.bfloat16):
+        """:160-188 — identical to random_paste_patch; with inference=True also returns the per-image canvases."""
+        out, xy = self._paste(images, patch, mean, std, out_dtype)
+        if not inference:
+            return out
+        ph, pw = int(patch.shape[1]), int(patch.shape[2])
+        canvases = []
+        for b, (x, y) in enumerate(self.last_params[0]):
+            c = torch.ones(3, IMG, IMG, device=self.device) * -100
+            c[:, y : y + ph, x : x + pw] = patch.detach()
+            canvases.append(c)
+        return out, canvases
+
+    def im_process(self, images, mean, std, out_dtype=torch.bfloat16):
+        """:190-197 — normalise the clean frames only (K1 with a 1x1 sentinel patch that is never kept)."""
+        mean6, std6 = _six(mean, std)
+        img = self.stage_images(images)
+        B = img.shape[0]
+        sentinel = torch.full((3, 1, 1), -100.0, device=self.device)
+        xy = torch.zeros((B, 2), dtype=torch.int32, device=self.device)
+        out, _ = ops.patch_apply_fwd(img, sentinel, xy, None, False, ops.MASK_LT_M20, want_keep=False, mean6=mean6, std6=std6)
+        return out if out_dtype == torch.bfloat16 else out.to(out_dtype)
