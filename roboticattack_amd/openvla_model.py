@@ -98,13 +98,18 @@ class Vit(nn.Module):
     def __init__(self, c: VitCfg):
         super().__init__()
         self.c = c
+        # timm's PatchEmbed is Conv2d(3, dim, 14, stride=14); kernel == stride, so it is exactly a GEMM over 588-pixel
+        # tiles. Stored in conv layout (checkpoint compatible), evaluated as unfold + linear: hipBLASLt instead of
+        # MIOpen (whose bf16 backward-data path for this shape goes through a slow find pass).
         self.patch_embed = nn.Conv2d(3, c.dim, kernel_size=14, stride=14)
         self.pos_embed = nn.Parameter(torch.zeros(1, N_IMG_TOKENS + (1 if c.cls_pos else 0), c.dim))
         self.prefix = nn.Parameter(torch.zeros(1, c.n_prefix, c.dim)) if c.n_prefix else None
         self.blocks = nn.ModuleList([VitBlock(c) for _ in range(c.depth - 1)])  # the last block is never evaluated
 
     def forward(self, img):
-        x = self.patch_embed(img).flatten(2).transpose(1, 2)  # [B,256,D]
+        B0 = img.shape[0]
+        tiles = img.reshape(B0, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(B0, 256, 588)
+        x = F.linear(tiles, self.patch_embed.weight.reshape(self.c.dim, 588), self.patch_embed.bias)  # [B,256,D]
         if self.prefix is not None:
             B = x.shape[0]
             cls = self.prefix[:, :1].expand(B, -1, -1)
