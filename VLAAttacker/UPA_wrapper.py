@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""UPA wrapper CLI — drop-in for the reference's VLAAttacker/UPA_wrapper.py (flags :90-112)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from roboticattack_amd import cli  # noqa: E402
+from white_patch.UPA import OpenVLAAttacker  # noqa: E402
+
+
+def main(args):
+    exp_id = cli.new_exp_id()
+    cli.vla_path_for(args.dataset)
+    cli.set_seed(42)
+    target = "".join(str(i) for i in args.maskidx)
+    name = (f"{args.dataset}_UPA_lr{format(args.lr, '.0e')}_iter{args.iter}_warmup{args.warmup}_target{target}"
+            f"_inner_loop{args.innerLoop}_patch_size{args.patch_size}_seed42-{exp_id}")
+    cli.maybe_wandb_init(args, name)
+    print(f"exp_id:{exp_id}")
+    path = f"{args.server}/run/white_patch_attack/{exp_id}"
+    device = torch.device(f"cuda:{args.device}" if torch.cuda.is_available() else "cpu")
+    vla, _ = cli.resolve_model(args, device)
+    os.makedirs(path, exist_ok=True)
+    train_dataloader, val_dataloader = cli.synthetic_loaders(args.bs)
+    attacker = OpenVLAAttacker(vla, None, path, optimizer="adamW", resize_patch=args.resize_patch, alpha=args.alpha, belta=args.belta)
+    attacker.patchattack_unconstrained(train_dataloader, val_dataloader, num_iter=args.iter, target_action=np.zeros(7),
+                                       patch_size=args.patch_size, lr=args.lr, accumulate_steps=args.accumulate, maskidx=args.maskidx,
+                                       warmup=args.warmup, filterGripTrainTo1=args.filterGripTrainTo1, geometry=args.geometry,
+                                       innerLoop=args.innerLoop, reverse_direction=args.reverse_direction, args=args)
+    print("Attack done!")
+
+
+def arg_parser(argv=None):
+    parser = argparse.ArgumentParser()
+    cli.add_common(parser, lr=2e-3, maskidx="0,1,2", iters=10000, warmup=200, inner=100, device_default=1,
+                   tags=["debug target-direction alpha0beta1"])
+    parser.add_argument("--server", default="xxx", type=str, help="Prefix of the server path")
+    parser.add_argument("--filterGripTrainTo1", type=cli.str2bool, nargs="?", default=False,
+                        help="Remove the gripper 0 traning samples during the attack of target at grip to 0")
+    parser.add_argument("--reverse_direction", type=cli.str2bool, default=True)
+    parser.add_argument("--alpha", type=float, default=0.8)
+    parser.add_argument("--belta", type=float, default=0.2)
+    return parser.parse_args(argv)
+
+
+if __name__ == "__main__":
+    args = arg_parser()
+    print(f"Paramters:\n maskidx:{args.maskidx}\n lr:{args.lr} \n server:{args.server} \n device:{args.device} \ntags:{args.tags}")
+    main(args)

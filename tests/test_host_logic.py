@@ -1,0 +1,138 @@
+"""CPU-only tests of the PRODUCT host code (roboticattack_amd/*) against the reference's golden vectors:
+RNG draw order, label masking, tokenizer, LR schedule, CLI surface, patch.pt format, synthetic batch contract."""
+import json
+import os
+import random
+import runpy
+import zipfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from roboticattack_amd import synthetic
+from roboticattack_amd.action_tokenizer import ActionTokenizer
+from roboticattack_amd.labels import mask_labels, tma_target_labels, tma_target_tokens
+from roboticattack_amd.optim import cosine_with_warmup_lambda
+from roboticattack_amd.transform import RandomPatchTransform
+
+
+def test_transform_rng_draw_order_seed42():
+    d = np.load(os.path.join(GOLDEN, "rng_stream_seed42.npz"))
+    random.seed(42)
+    np.random.seed(42)
+    t = RandomPatchTransform("cpu")
+    xy, th = t._draw(len(d["xy"]), 50, 50, True)
+    assert np.array_equal(xy, d["xy"])
+    assert np.array_equal(th.reshape(-1, 2, 3), d["theta"][:, :2, :])
+    # geometry=False consumes only the two randint draws per image
+    random.seed(42)
+    np.random.seed(42)
+    st = np.random.get_state()[1].copy()
+    xy2, th2 = t._draw(4, 50, 50, False)
+    assert np.array_equal(xy2, d["xy"][:4]) and np.array_equal(np.random.get_state()[1], st)
+    assert np.array_equal(th2, np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32), (4, 1)))
+
+
+def test_labels_and_tokenizer_vs_reference():
+    d = np.load(os.path.join(GOLDEN, "labels_tokenizer.npz"))
+    lab = torch.from_numpy(d["labels_in"])
+    for tag, mi in (("0", [0]), ("012", [0, 1, 2]), ("6", [6]), ("all", list(range(7))), ("25", [2, 5])):
+        assert np.array_equal(mask_labels(lab.clone(), mi).numpy(), d[f"uada_mask_{tag}"])
+    at = ActionTokenizer()
+    assert at.action_token_begin_idx == int(d["begin_idx"]) == 31743
+    assert np.array_equal(at.bin_centers, d["bin_centers"])
+    assert np.array_equal(at.decode_token_ids_to_actions(d["tokens"]), d["decoded"])
+    with pytest.raises(RuntimeError):
+        mask_labels(torch.full((2, 10), -100, dtype=torch.int64), [0])  # the reference's view(-1, 7) would raise too
+    for tag in ("t0", "t012"):
+        t = np.load(os.path.join(GOLDEN, f"k3_tma_{tag}.npz"))
+        tt = tma_target_tokens(np.ones(7) * float(t["target_action"]), list(t["maskidx"]))
+        assert np.array_equal(tt.numpy(), t["target_tokens"])
+        assert np.array_equal(tma_target_labels(torch.from_numpy(t["labels"]), tt).numpy(), t["newlabels"])
+
+
+def test_relative_distance_metric():
+    from roboticattack_amd.attack.engine import AttackBase
+
+    d = np.load(os.path.join(GOLDEN, "labels_tokenizer.npz"))
+    rd = AttackBase.calculate_relative_distance(None, torch.from_numpy(d["rd_pred"]), torch.from_numpy(d["rd_gt"]), [0, 3], {"0": [], "3": []})
+    np.testing.assert_allclose(rd["0"], d["rd_0"], rtol=1e-12)
+    np.testing.assert_allclose(rd["3"], d["rd_3"], rtol=1e-12)
+
+
+def test_cosine_schedule_vs_transformers_golden():
+    d = np.load(os.path.join(GOLDEN, "sched.npz"))
+    for tag, warm, total in (("w20_t2000", 20, 2000), ("w200_t10000", 200, 10000), ("w2_t4", 2, 4)):
+        got = np.array([cosine_with_warmup_lambda(s, warm, total) for s in range(len(d[tag]))])
+        np.testing.assert_allclose(got, d[tag], rtol=0, atol=1e-15)
+    assert cosine_with_warmup_lambda(0, 20, 2000) == 0.0  # lr = 0 during the whole first outer iteration
+
+
+def test_cli_surface_matches_reference_defaults():
+    want = {
+        "UADA_wrapper": dict(maskidx=[0], lr=1e-3, device=1, iter=2000, accumulate=1, bs=8, warmup=20, geometry=True, patch_size=[3, 50, 50],
+                             innerLoop=50, dataset="bridge_orig", resize_patch=False, filterGripTrainTo1=False),
+        "UADA_wrapper_ddp": dict(maskidx=[0], lr=1e-3, iter=2000, MSE_weights=5, bs=8, warmup=20, innerLoop=50, geometry=True),
+        "TMA_wrapper": dict(maskidx=[0], lr=2e-3, device=0, iter=2000, warmup=20, innerLoop=50, targetAction=0, server="xxx"),
+        "UPA_wrapper": dict(maskidx=[0, 1, 2], lr=2e-3, device=1, iter=10000, warmup=200, innerLoop=100, alpha=0.8, belta=0.2,
+                            reverse_direction=True),
+    }
+    for w, exp in want.items():
+        mod = runpy.run_path(os.path.join(ROOT, "VLAAttacker", f"{w}.py"), run_name="not_main")
+        a = mod["arg_parser"]([])
+        for k, v in exp.items():
+            assert getattr(a, k) == v, (w, k, getattr(a, k), v)
+    a = runpy.run_path(os.path.join(ROOT, "VLAAttacker", "UADA_wrapper_ddp.py"), run_name="x")["arg_parser"](
+        ["--maskidx", "0,1,2", "--geometry", "false", "--patch_size", "3,100,100", "--wandb_project", "false"])
+    assert a.maskidx == [0, 1, 2] and a.geometry is False and a.patch_size == [3, 100, 100] and not hasattr(a, "device")
+
+
+def test_patch_pt_format_matches_released_patch(tmp_path):
+    """a-12: `torch.save(patch.detach().cpu())` -> fp32 contiguous [3,ph,pw], same zip entries/sizes as a released file."""
+    from roboticattack_amd.attack.engine import AttackBase
+
+    meta = json.load(open(os.path.join(GOLDEN, "released_patch_meta.json")))
+    rel = torch.load(os.path.join(GOLDEN, "released_patch_T-dof1.pt"), map_location="cpu")
+    assert str(rel.dtype) == meta["dtype"] and list(rel.shape) == meta["shape"] and 0.0 <= float(rel.min()) and float(rel.max()) <= 1.0
+    obj = AttackBase.__new__(AttackBase)
+    obj.save_dir = str(tmp_path)
+    p = torch.rand(3, 50, 50, requires_grad=True)
+    d = AttackBase.save_patch(obj, p, "last")
+    f = os.path.join(d, "patch.pt")
+    back = torch.load(f, map_location="cpu")
+    assert back.dtype == torch.float32 and tuple(back.shape) == (3, 50, 50) and not back.requires_grad and torch.equal(back, p.detach())
+    with zipfile.ZipFile(f) as z:
+        ours = {os.path.basename(i.filename) if "/data/" not in i.filename else "data/0": i.file_size for i in z.infolist()}
+    theirs = {os.path.basename(n) if "/data/" not in n else "data/0": s for n, s in meta["entries"]}
+    assert ours["data/0"] == theirs["data/0"] == 30000
+    assert {"data.pkl", "byteorder", "version"} <= set(ours) and {"data.pkl", "byteorder", "version"} <= set(theirs)
+
+
+def test_synthetic_batch_contract():
+    b = synthetic.synth_batch(3, 5)
+    assert len(b["pixel_values"]) == 5 and b["pixel_values"][0].size == (224, 224) and b["pixel_values"][0].mode == "RGB"
+    ids, lab, att = b["input_ids"], b["labels"], b["attention_mask"]
+    assert ids.dtype == lab.dtype == torch.int64 and att.dtype == torch.bool and ids.shape == lab.shape == att.shape
+    assert bool((ids[:, 0] == 1).all()) and bool(((ids == 32000) == ~att).all())
+    for r in range(5):
+        real = lab[r][lab[r] != -100]
+        assert len(real) == 8 and real[-1] == 2 and bool(((real[:7] >= 31744) & (real[:7] <= 31999)).all())
+    assert np.array_equal(synthetic.synth_images(9, 2), synthetic.synth_images(9, 2))
+
+
+def test_tiny_model_rows_equal_full_logits():
+    from roboticattack_amd.openvla_model import OpenVLAShaped, tiny_cfg
+
+    m = OpenVLAShaped(tiny_cfg()).init_random(0).eval()
+    ids, labels, attn = synthetic.synth_text_batch(1, 3, 18, 24)
+    labels = mask_labels(labels, [0, 2])
+    pix = torch.randn(3, 6, 224, 224)
+    out = m(ids, attn, pix, labels)
+    rows = m.forward_rows(ids, pix, labels)
+    L = labels.shape[1]
+    sel = [(b, 256 + k) for b in range(3) for k in range(L - 1) if labels[b, k + 1] != -100]
+    full = torch.stack([out.logits[b, p] for b, p in sel])
+    assert torch.allclose(full, rows, atol=1e-5) and out.logits.shape == (3, 256 + L, 32064)
+    assert all(not p.requires_grad for p in m.parameters())
