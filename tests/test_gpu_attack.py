@@ -76,38 +76,76 @@ def test_uada_trajectory_vs_reference_loop(tmp_path):
         assert os.path.exists(os.path.join(str(tmp_path), f)), f
 
 
+def _objective(att, patch, batch, mode, geometry, labels_fn, reps=6, **kw):
+    """Mean objective of `patch` over a FIXED set of placements (re-seeded), no grad."""
+    import random
+
+    from roboticattack_amd.attack.engine import to_dev
+
+    random.seed(123)
+    np.random.seed(123)
+    pixel_values, labels, attention_mask, input_ids = to_dev(batch, att.device)
+    labels = labels_fn(labels)
+    tot = 0.0
+    with torch.no_grad():
+        for _ in range(reps):
+            if geometry is None:
+                pix = att.randomPatchTransform.paste_patch_fix(pixel_values, patch, mean=att.mean, std=att.std)
+            else:
+                pix = att.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=att.mean, std=att.std, geometry=geometry)
+            _, sc, _ = att.model_loss(input_ids, attention_mask, pix, labels, mode, need_grad=False, **kw)
+            tot += float(sc[0])
+    return tot / reps
+
+
 @pytest.mark.parametrize("which", ["tma_geo", "tma_fix", "tma_pgd", "upa", "upa_ce"])
 def test_tma_upa_loops_run_and_improve(tmp_path, which):
-    """TMA / UPA loops on the surrogate: objective goes the right way, outputs are written, patch stays in [0,1]."""
+    """TMA / UPA loops on the surrogate: the optimised patch scores better than the initial one on a fixed set of
+    placements, outputs are written, the patch stays in [0,1]."""
     import types
 
+    from roboticattack_amd import ops
+    from roboticattack_amd.labels import tma_target_labels, tma_target_tokens
     from roboticattack_amd.surrogate import SurrogateVLA
 
     vla = SurrogateVLA(seed=5).to(DEV)
     args = types.SimpleNamespace(wandb_project="false")
     _seed()
-    train = _Fresh([7000] * 12, 2)  # same batch every outer iteration -> the loss must fall
+    n_it = 16
+    train = _Fresh([7000] * n_it, 4)  # same batch every outer iteration
     val = _Fresh([7100], 2)
+    batch = synthetic.synth_batch(7000, 4, "smooth")
+    torch.manual_seed(42)
+    init = torch.rand([3, 50, 50]).to(DEV)  # what the loops draw first after the seed
     if which.startswith("tma"):
         from roboticattack_amd.attack.tma import OpenVLAAttacker
 
         att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="pgd" if which == "tma_pgd" else "adamW")
         att.val_batches = 2
-        att.patchattack_unconstrained(train, val, num_iter=12, target_action=np.zeros(7), patch_size=[3, 50, 50],
-                                      alpha=0.02 if which == "tma_pgd" else 0.05, accumulate_steps=1, maskidx=[0, 1], warmup=1,
-                                      geometry=(which == "tma_geo"), innerLoop=4, args=args)
-        assert att.train_CE_loss[-1] < att.train_CE_loss[1] - 0.05, att.train_CE_loss
+        geo = which == "tma_geo"
+        att.patchattack_unconstrained(train, val, num_iter=n_it, target_action=np.zeros(7), patch_size=[3, 50, 50],
+                                      alpha=0.01 if which == "tma_pgd" else 0.03, accumulate_steps=1, maskidx=[0, 1], warmup=1,
+                                      geometry=geo, innerLoop=5, args=args)
+        tgt = tma_target_tokens(np.zeros(7), [0, 1]).to(DEV)
+        f = lambda p: _objective(att, p, batch, ops.LOSS_CE, True if geo else None, lambda l: tma_target_labels(l, tgt))  # noqa: E731
         assert os.path.exists(os.path.join(str(tmp_path), "last", "val_related_data", "continuous_actions_pred.pt"))
+        assert len(att.train_CE_loss) == n_it and len(att.val_CE_loss) == 1
     else:
         from roboticattack_amd.attack.upa import OpenVLAAttacker
 
         att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="adamW", alpha=0.8, belta=0.2)
         att.val_batches = 2
-        att.patchattack_unconstrained(train, val, num_iter=12, patch_size=[3, 50, 50], lr=0.05, accumulate_steps=1, maskidx=[0, 1, 2],
-                                      warmup=1, geometry=True, innerLoop=4, reverse_direction=(which == "upa"), args=args)
-        assert att.train_CE_loss[-1] < att.train_CE_loss[1], att.train_CE_loss
+        rev = which == "upa"
+        att.patchattack_unconstrained(train, val, num_iter=n_it, patch_size=[3, 50, 50], lr=0.03, accumulate_steps=1, maskidx=[0, 1, 2],
+                                      warmup=1, geometry=True, innerLoop=5, reverse_direction=rev, args=args)
+        if rev:
+            f = lambda p: _objective(att, p, batch, ops.LOSS_UPA, True, lambda l: l, alpha=0.8, beta=0.2)  # noqa: E731
+        else:
+            f = lambda p: _objective(att, p, batch, ops.LOSS_CE, True, lambda l: att.mask_labels(l, [0, 1, 2]), scale=-1.0)  # noqa: E731
     p = att.patch.detach()
+    assert f(p) < f(init), (f(p), f(init))
     assert float(p.min()) >= 0.0 and float(p.max()) <= 1.0 and bool(torch.isfinite(p).all())
+    assert (p - init).abs().max() > 0.05
     assert os.path.exists(os.path.join(str(tmp_path), "last", "patch.pt"))
 
 
