@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvaa_hip.so")
+LIB_PATH = os.environ.get("VAA_LIB_PATH") or os.path.join(_HERE, "libvaa_hip.so")  # override = A/B experiments only
 
 # mirrors include/vaa.h
 VAA_OK = 0

@@ -45,33 +45,48 @@ __device__ __forceinline__ void solve_interval(float a, float base, float lo, fl
     }
 }
 
+constexpr int kGradThreads = 1024;  // 16 waves: two workgroups per CU with the 60 KB fp64 tile
+constexpr int kImgsPerPass = 8;      // images whose row tables are built together (one barrier set per pass)
+
+// Schedule: image b is owned by workgroup-row (b % gx); each workgroup-row is `split` workgroups that share the image's
+// footprint slots. Small batches use split > 1 to fill the chip.
+//
+// Footprint walk without any per-pixel search: the footprint rows [rmin, rmax] of an image are cut into 32-column
+// segments; one half-wave owns one (row, segment) slot at a time, so a lane needs ONE LDS read (packed {jlo,len} of its
+// row) to know its pixel. Slots are dealt round-robin to the half-waves of the workgroup-row.
 template <typename ACC, int NCH>
-__global__ __launch_bounds__(256) void patch_grad_scatter_kernel(GradArgs a) {
+__global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradArgs a, int gx, int split) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     ACC* acc = reinterpret_cast<ACC*>(smem_raw);  // [NCH][ph][pw]
     __shared__ float bgrid[VAA_IMG];
-    __shared__ int row_start[VAA_IMG + 1];
-    __shared__ short row_jlo[VAA_IMG];
+    __shared__ uint32_t row_word[kImgsPerPass][VAA_IMG];  // (jlo << 16) | len
+    __shared__ int row_min[kImgsPerPass], row_max[kImgsPerPass], len_max[kImgsPerPass];
 
     const int tid = threadIdx.x;
     const int plane = a.ph * a.pw;
     const int c_base = (NCH == 1) ? blockIdx.y : 0;
-    for (int e = tid; e < NCH * plane; e += 256) acc[e] = (ACC)0;
+    const int wg_row = blockIdx.x / split, chunk = blockIdx.x - wg_row * split;
+    const int hw = (chunk * kGradThreads + tid) >> 5, nhw = split * (kGradThreads >> 5), hl = tid & 31;
+    for (int e = tid; e < NCH * plane; e += kGradThreads) acc[e] = (ACC)0;
     if (tid < VAA_IMG) bgrid[tid] = base_coord(tid);
-    __syncthreads();
 
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
-        float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
-        if (a.geometry) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) th[q] = a.theta[6 * b + q];
-        }
-        // ---- per-row column bounds of the footprint (conservative) ----
-        if (tid < VAA_IMG) {
-            const int i = tid;
+
+    for (int b0 = wg_row; b0 < a.B; b0 += gx * kImgsPerPass) {
+        int nimg = (a.B - b0 + gx - 1) / gx;  // images of this pass: b0, b0+gx, ...
+        nimg = nimg < kImgsPerPass ? nimg : kImgsPerPass;
+        __syncthreads();  // previous pass done with the tables (also orders the initial zero-fill)
+        if (tid < kImgsPerPass) { row_min[tid] = VAA_IMG; row_max[tid] = -1; len_max[tid] = 0; }
+        __syncthreads();
+        // ---- per-row column bounds of each footprint (conservative) ----
+        for (int r = tid; r < nimg * VAA_IMG; r += kGradThreads) {
+            const int q = r / VAA_IMG, i = r - q * VAA_IMG;
+            const int b = b0 + q * gx;
+            const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
             int jlo = 0, jhi = -1;
             if (a.geometry) {
+                float th[6];
+#pragma unroll
+                for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
                 const PixAffine pa = pix_affine(th);
                 // source x must fall in [px-1, px+pw) (corner x0 or x0+1 on the patch); a side that lies on the
                 // frame edge also receives every clamped out-of-frame sample (padding_mode='border').
@@ -90,96 +105,138 @@ __global__ __launch_bounds__(256) void patch_grad_scatter_kernel(GradArgs a) {
                 jlo = px;
                 jhi = px + a.pw - 1;
             }
-            row_jlo[i] = (short)jlo;
-            row_start[i + 1] = max(0, jhi - jlo + 1);
+            const int len = max(0, jhi - jlo + 1);
+            row_word[q][i] = ((uint32_t)jlo << 16) | (uint32_t)len;
+            if (len > 0) {
+                atomicMin(&row_min[q], i);
+                atomicMax(&row_max[q], i);
+                atomicMax(&len_max[q], len);
+            }
         }
         __syncthreads();
-        if (tid < 64) {  // exclusive scan of 224 row lengths: 56 lanes x 4 rows
-            int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-            if (tid < 56) { l0 = row_start[4 * tid + 1]; l1 = row_start[4 * tid + 2]; l2 = row_start[4 * tid + 3]; l3 = row_start[4 * tid + 4]; }
-            int s = l0 + l1 + l2 + l3, incl = s;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int t = __shfl_up(incl, o, 64);
-                if (tid >= o) incl += t;
-            }
-            const int excl = incl - s;
-            if (tid < 56) {
-                row_start[4 * tid + 1] = excl + l0;
-                row_start[4 * tid + 2] = excl + l0 + l1;
-                row_start[4 * tid + 3] = excl + l0 + l1 + l2;
-                row_start[4 * tid + 4] = excl + s;
-            }
-            if (tid == 0) row_start[0] = 0;
-        }
-        __syncthreads();
-        const int T = row_start[VAA_IMG];
 
-        const uint16_t* gb = a.g + (size_t)b * 6 * VAA_NPIX;
-        for (int t = tid; t < T; t += 256) {
-            int lo = 0, hi = VAA_IMG;  // last row whose start <= t
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int mid = (lo + hi) >> 1;
-                if (row_start[mid] <= t) lo = mid; else hi = mid;
-            }
-            const int i = lo;
-            const int j = row_jlo[i] + (t - row_start[i]);
-            Samp s;
+        for (int q = 0; q < nimg; ++q) {
+            const int rmin = row_min[q], nrows = row_max[q] - rmin + 1;
+            if (nrows <= 0) continue;
+            const int nseg = (len_max[q] + 31) >> 5;                   // <= 7
+            const uint32_t inv_nseg = (65536u + nseg - 1) / nseg;      // exact floor(s/nseg) for s < 9362
+            const int nslots = nrows * nseg;
+            const int b = b0 + q * gx;
+            const int px = a.xy[2 * b], py = a.xy[2 * b + 1];          // workgroup-uniform -> scalar loads
+            float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
             if (a.geometry) {
-                s = sample_pos(bgrid[j], bgrid[i], th);
-            } else {
-                s.x0 = j; s.y0 = i; s.nw = 1.0f; s.ne = 0.0f; s.sw = 0.0f; s.se = 0.0f;
-            }
-            const int u0 = s.x0 - px, v0 = s.y0 - py;
-            if (u0 < -1 || u0 >= a.pw || v0 < -1 || v0 >= a.ph) continue;
-            const bool uin0 = u0 >= 0, uin1 = (u0 + 1 < a.pw) && (s.x0 + 1 < VAA_IMG);
-            const bool vin0 = v0 >= 0, vin1 = (v0 + 1 < a.ph) && (s.y0 + 1 < VAA_IMG);
-            const int pix = i * VAA_IMG + j;
 #pragma unroll
-            for (int cc = 0; cc < NCH; ++cc) {
-                const int c = c_base + cc;
-                bool kept;
-                if (a.keep) {
-                    kept = (a.keep[((size_t)(b * 3 + c) * VAA_NPIX + pix) >> 3] >> (pix & 7)) & 1;
+                for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
+            }
+            const uint16_t* gimg = a.g + (size_t)b * 6 * VAA_NPIX;
+            const uint8_t* kimg = a.keep ? a.keep + (size_t)b * 3 * (VAA_NPIX / 8) : nullptr;
+            for (int sidx = hw; sidx < nslots; sidx += nhw) {
+                const int r = (int)(((uint32_t)sidx * inv_nseg) >> 16);
+                const int k = sidx - r * nseg;
+                const int i = rmin + r;
+                const uint32_t w = row_word[q][i];
+                const int off = (k << 5) + hl;
+                if (off >= (int)(w & 0xffffu)) continue;
+                const int j = (int)(w >> 16) + off;
+                Samp s;
+                if (a.geometry) {
+                    s = sample_pos(bgrid[j], bgrid[i], th);
                 } else {
-                    const float cv = a.geometry ? sample_canvas(a.patch + c * plane, a.ph, a.pw, px, py, s)
-                                                : canvas_at(a.patch + c * plane, a.ph, a.pw, px, py, j, i);
-                    kept = keep_rule(cv, a.mask_mode);
+                    s.x0 = j; s.y0 = i; s.nw = 1.0f; s.ne = 0.0f; s.sw = 0.0f; s.se = 0.0f;
                 }
-                if (!kept) continue;
-                const float G = bf16_bits_to_f32(gb[(size_t)c * VAA_NPIX + pix]) / a.std6[c] +
-                                bf16_bits_to_f32(gb[(size_t)(c + 3) * VAA_NPIX + pix]) / a.std6[c + 3];
-                ACC* t0 = acc + cc * plane + v0 * a.pw + u0;
-                if (vin0 && uin0) atomicAdd(t0, (ACC)G * (ACC)s.nw);
-                if (vin0 && uin1) atomicAdd(t0 + 1, (ACC)G * (ACC)s.ne);
-                if (vin1 && uin0) atomicAdd(t0 + a.pw, (ACC)G * (ACC)s.sw);
-                if (vin1 && uin1) atomicAdd(t0 + a.pw + 1, (ACC)G * (ACC)s.se);
+                const int u0 = s.x0 - px, v0 = s.y0 - py;
+                if (u0 < -1 || u0 >= a.pw || v0 < -1 || v0 >= a.ph) continue;
+                const bool uin0 = u0 >= 0, uin1 = (u0 + 1 < a.pw) && (s.x0 + 1 < VAA_IMG);
+                const bool vin0 = v0 >= 0, vin1 = (v0 + 1 < a.ph) && (s.y0 + 1 < VAA_IMG);
+                const int pix = i * VAA_IMG + j;
+                const uint16_t* gb = gimg + pix;
+                // issue every load of this pixel before the first use
+                uint32_t kbyte[NCH], g0[NCH], g1[NCH];
+#pragma unroll
+                for (int cc = 0; cc < NCH; ++cc) {
+                    const int c = c_base + cc;
+#ifndef VAA_EXP_NOLOAD
+                    kbyte[cc] = kimg ? kimg[(size_t)c * (VAA_NPIX / 8) + (pix >> 3)] : 0u;
+                    g0[cc] = gb[(size_t)c * VAA_NPIX];
+                    g1[cc] = gb[(size_t)(c + 3) * VAA_NPIX];
+#else
+                    kbyte[cc] = 0xffu; g0[cc] = 0x3f80u + (pix & 3); g1[cc] = 0x3f80u + c;
+#endif
+                }
+#pragma unroll
+                for (int cc = 0; cc < NCH; ++cc) {
+                    const int c = c_base + cc;
+                    bool kept;
+                    if (kimg) {
+                        kept = (kbyte[cc] >> (pix & 7)) & 1u;
+                    } else {
+                        const float cv = a.geometry ? sample_canvas(a.patch + c * plane, a.ph, a.pw, px, py, s)
+                                                    : canvas_at(a.patch + c * plane, a.ph, a.pw, px, py, j, i);
+                        kept = keep_rule(cv, a.mask_mode);
+                    }
+                    if (!kept) continue;
+                    // d/d(im) of (im-mean)/std for both normalisations (true divisions, as autograd does), fp32 products
+                    // exactly like the reference's scatter; only the ACCUMULATION is fp64 (order-independent sum).
+                    const float G = bf16_bits_to_f32(g0[cc]) / a.std6[c] + bf16_bits_to_f32(g1[cc]) / a.std6[c + 3];
+                    ACC* t0 = acc + cc * plane + v0 * a.pw + u0;
+#ifndef VAA_EXP_NOATOMIC
+                    if (vin0 && uin0) atomicAdd(t0, (ACC)(G * s.nw));
+                    if (vin0 && uin1) atomicAdd(t0 + 1, (ACC)(G * s.ne));
+                    if (vin1 && uin0) atomicAdd(t0 + a.pw, (ACC)(G * s.sw));
+                    if (vin1 && uin1) atomicAdd(t0 + a.pw + 1, (ACC)(G * s.se));
+#else
+                    if (G * (s.nw + s.ne + s.sw + s.se) == 123.456f) atomicAdd(t0, (ACC)G);
+#endif
+                }
             }
         }
-        __syncthreads();  // row tables are rebuilt for the next image
     }
+    __syncthreads();
     float* dst = a.partial + ((size_t)blockIdx.x * 3 + c_base) * plane;
-    for (int e = tid; e < NCH * plane; e += 256) dst[e] = (float)acc[e];
+    for (int e = tid; e < NCH * plane; e += kGradThreads) dst[e] = (float)acc[e];
 }
 
-// gpatch[e] = sum_s partial[s][e] in fixed order (fp64 running sum), e over 3*ph*pw.
-__global__ __launch_bounds__(256) void patch_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gpatch,
-                                                                 int n, int nparts) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)partial[(size_t)p * n + e];
-    gpatch[e] = (float)s;
+// gpatch[e] = sum_p partial[p][e] in a fixed two-level order (16 interleaved slices, then slice 0..15), fp64.
+// Workgroup = 64 elements x 16 slices.
+__global__ __launch_bounds__(1024) void patch_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gpatch,
+                                                                  int n, int nparts) {
+    __shared__ double sl[16][64];
+    const int el = threadIdx.x & 63, s = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    double acc = 0.0;
+    if (e < n) {
+#pragma unroll 8
+        for (int p = s; p < nparts; p += 16) acc += (double)partial[(size_t)p * n + e];
+    }
+    sl[s][el] = acc;
+    __syncthreads();
+    if (s == 0 && e < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sl[q][el];
+        gpatch[e] = (float)t;
+    }
 }
 
-static int grad_grid(int B) { return B < 512 ? B : 512; }
+struct GradSched {
+    int gx, split;
+};
+
+static GradSched grad_sched(int B) {
+    GradSched g;
+    g.gx = B < 512 ? B : 512;
+    g.split = 1;
+    if (B <= 128) g.split = 4;
+    else if (B <= 256) g.split = 2;
+    return g;
+}
 
 }  // namespace vaa
 
 extern "C" size_t vaa_patch_grad_ws_bytes(int B, int ph, int pw) {
     if (B <= 0 || ph <= 0 || pw <= 0) return 0;
-    return (size_t)vaa::grad_grid(B) * 3 * (size_t)ph * pw * sizeof(float);
+    const vaa::GradSched g = vaa::grad_sched(B);
+    return (size_t)g.gx * g.split * 3 * (size_t)ph * pw * sizeof(float);
 }
 
 extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* patch, const int32_t* xy, const float* theta,
@@ -213,22 +270,23 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.std6[q] = std6[q];
-    const int G = grad_grid(B);
+    const GradSched gs = grad_sched(B);
+    const int G = gs.gx * gs.split;  // workgroups (x) == partial tiles
     const size_t plane = (size_t)ph * pw;
-    const size_t lds_budget = 150 * 1024;  // 160 KiB per CU minus the static tables
+    const size_t lds_budget = 144 * 1024;  // 160 KiB per CU minus the static row tables (~13 KB)
     hipError_t e = hipSuccess;
     if (3 * plane * sizeof(double) <= 64 * 1024) {  // e.g. 50x50: 60,000 B, two workgroups per CU
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 3>), dim3(G), dim3(256), 3 * plane * sizeof(double), st, a);
+        hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 3>), dim3(G), dim3(kGradThreads), 3 * plane * sizeof(double), st, a, gs.gx, gs.split);
     } else if (plane * sizeof(double) <= lds_budget) {  // up to ~138x138: one channel per workgroup
         const size_t bytes = plane * sizeof(double);
         if (bytes > 64 * 1024)
             e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 1>), dim3(G, 3), dim3(256), bytes, st, a);
+        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 1>), dim3(G, 3), dim3(kGradThreads), bytes, st, a, gs.gx, gs.split);
     } else if (plane * sizeof(float) <= lds_budget) {  // up to ~195x195: fp32 accumulation
         const size_t bytes = plane * sizeof(float);
         if (bytes > 64 * 1024)
             e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<float, 1>), dim3(G, 3), dim3(256), bytes, st, a);
+        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<float, 1>), dim3(G, 3), dim3(kGradThreads), bytes, st, a, gs.gx, gs.split);
     } else {
         set_error("vaa_patch_grad_gather: patch %dx%d does not fit the LDS accumulator", ph, pw);
         return VAA_E_UNSUPPORTED;
@@ -239,6 +297,6 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     }
     int rc = check_launch("vaa_patch_grad_gather(scatter)");
     if (rc != VAA_OK) return rc;
-    hipLaunchKernelGGL(patch_grad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)ws, gpatch, n, G);
+    hipLaunchKernelGGL(patch_grad_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, (const float*)ws, gpatch, n, G);
     return check_launch("vaa_patch_grad_gather(reduce)");
 }
