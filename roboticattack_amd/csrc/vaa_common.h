@@ -72,14 +72,16 @@ __device__ __forceinline__ Samp sample_pos(float bx, float by, const float* th) 
 
 // canvas = -100 everywhere with the patch pasted at (px,py) (appply_random_transform.py:111,125);
 // corners beyond the frame contribute 0 (grid_sample's bounds mask).
-__device__ __forceinline__ float canvas_at(const float* __restrict__ patch_c, int ph, int pw, int px, int py, int xx, int yy) {
+template <typename P>
+__device__ __forceinline__ float canvas_at(P patch_c, int ph, int pw, int px, int py, int xx, int yy) {
     if (xx >= VAA_IMG || yy >= VAA_IMG) return 0.0f;
     int u = xx - px, v = yy - py;
     if ((unsigned)u < (unsigned)pw && (unsigned)v < (unsigned)ph) return patch_c[v * pw + u];
     return -100.0f;
 }
 
-__device__ __forceinline__ float sample_canvas(const float* __restrict__ patch_c, int ph, int pw, int px, int py, const Samp& s) {
+template <typename P>
+__device__ __forceinline__ float sample_canvas(P patch_c, int ph, int pw, int px, int py, const Samp& s) {
     float vnw = canvas_at(patch_c, ph, pw, px, py, s.x0, s.y0);
     float vne = canvas_at(patch_c, ph, pw, px, py, s.x0 + 1, s.y0);
     float vsw = canvas_at(patch_c, ph, pw, px, py, s.x0, s.y0 + 1);
@@ -106,6 +108,18 @@ __device__ __forceinline__ PixAffine pix_affine(const float* th) {
     p.a11 = th[4];
     p.c1 = 112.0f * (th[5] + 1.0f) - 0.5f - 111.5f * (th[3] + th[4]);
     return p;
+}
+
+// j-interval of row i whose (approximate, unclamped) source coordinate a*j + base lies in [lo, hi)
+__device__ __forceinline__ void solve_interval(float a, float base, float lo, float hi, float& jl, float& jh) {
+    if (fabsf(a) > 1e-6f) {
+        float t0 = (lo - base) / a, t1 = (hi - base) / a;
+        jl = fmaxf(jl, fminf(t0, t1));
+        jh = fminf(jh, fmaxf(t0, t1));
+    } else if (!(base >= lo - 1.0f && base < hi + 1.0f)) {
+        jl = 1e30f;
+        jh = -1e30f;
+    }
 }
 
 template <typename T>

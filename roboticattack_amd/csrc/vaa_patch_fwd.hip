@@ -29,114 +29,218 @@ struct FwdArgs {
     Norm6 nrm;
 };
 
-constexpr int kGroupsPerRow = VAA_IMG / 8;                // 28
-constexpr int kGroupsPerImg = VAA_IMG * kGroupsPerRow;    // 6272
+struct FwdLut {
+    uint32_t v[3][256];  // packed {bf16 norm0(x/255), bf16 norm1(x/255)} per channel and byte value x, built on the host
+};
 
-__device__ __forceinline__ uint32_t norm_pack(float v, const Norm6& n, int c) {
-    float o0 = (v - n.mean[c]) / n.stdv[c];
-    float o1 = (v - n.mean[c + 3]) / n.stdv[c + 3];
-    return f32_to_bf16_bits(o0) | (f32_to_bf16_bits(o1) << 16);
+constexpr int kPix = 16;                                  // pixels per item: 48 B in (3 x 16 B), 2 x 16 B out per plane
+constexpr int kItemsPerRow = VAA_IMG / kPix;              // 14
+constexpr int kItemsPerImg = VAA_IMG * kItemsPerRow;      // 3136
+constexpr int kFwdThreads = 256;
+constexpr int kMaxRows = 20;                              // rows one workgroup's 256 items can touch (256/14 + 2)
+
+// Host and device share the arithmetic of the camera-pixel LUT: IEEE fp32 true divisions, RNE bf16 cast
+// (host code of this file is compiled with -ffp-contract=off as well).
+__host__ __device__ inline uint32_t bf16_rne(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x0040u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
 }
 
-__global__ __launch_bounds__(256) void patch_apply_fwd_kernel(FwdArgs a) {
-    __shared__ uint32_t lut[3][256];
-    __shared__ float bgrid[VAA_IMG];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 768; e += 256) {
-        int c = e >> 8, v = e & 255;
-        float im = (float)v / 255.0f;  // torchvision ToTensor (appply_random_transform.py:108)
-        lut[c][v] = norm_pack(im, a.nrm, c);
-    }
-    if (tid < VAA_IMG) bgrid[tid] = base_coord(tid);
-    __syncthreads();
+__host__ __device__ inline uint32_t norm_pack(float v, const Norm6& n, int c) {
+    float o0 = (v - n.mean[c]) / n.stdv[c];
+    float o1 = (v - n.mean[c + 3]) / n.stdv[c + 3];
+    return bf16_rne(o0) | (bf16_rne(o1) << 16);
+}
 
-    const long total = (long)a.B * kGroupsPerImg;
-    const int plane = a.ph * a.pw;
-    for (long gid = (long)blockIdx.x * 256 + tid; gid < total; gid += (long)gridDim.x * 256) {
-        const int b = (int)(gid / kGroupsPerImg);
-        const int rem = (int)(gid - (long)b * kGroupsPerImg);
-        const int i = rem / kGroupsPerRow;
-        const int j0 = (rem - i * kGroupsPerRow) * 8;
-
-        const uint2* src = reinterpret_cast<const uint2*>(a.img + ((size_t)(b * VAA_IMG + i) * VAA_IMG + j0) * 3);
-        uint2 w0 = src[0], w1 = src[1], w2 = src[2];
-        const uint32_t d[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
-
-        uint32_t L[3][8];  // packed {bf16 plane c, bf16 plane c+3} per pixel
+// Conservative ITEM bounds of output row i of image b: items [it_lo, it_hi] (16-pixel groups) may contain a pixel whose
+// source point touches the patch; it_hi < it_lo when the row is clear. Both kernel roles call this same function, which
+// is what makes their ownership of items disjoint and complete.
+__device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it_lo, int& it_hi) {
+    const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
+    int jlo = 0, jhi = -1;
+    if (a.geometry) {
+        float th[6];
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
+        for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
+        const PixAffine pa = pix_affine(th);
+        const float xlo = (px == 0) ? -1e30f : (float)(px - 1);
+        const float xhi = (px + a.pw == VAA_IMG) ? 1e30f : (float)(px + a.pw);
+        const float ylo = (py == 0) ? -1e30f : (float)(py - 1);
+        const float yhi = (py + a.ph == VAA_IMG) ? 1e30f : (float)(py + a.ph);
+        float jl = -1e30f, jh = 1e30f;
+        solve_interval(pa.a00, pa.a01 * (float)i + pa.c0, xlo, xhi, jl, jh);
+        solve_interval(pa.a10, pa.a11 * (float)i + pa.c1, ylo, yhi, jl, jh);
+        if (jl <= jh) {
+            jlo = (int)fmaxf(0.0f, floorf(jl) - 1.0f);
+            jhi = (int)fminf((float)(VAA_IMG - 1), ceilf(jh) + 1.0f);
+        }
+    } else if (i >= py && i < py + a.ph) {
+        jlo = px;
+        jhi = px + a.pw - 1;
+    }
+    it_lo = jlo >> 4;
+    it_hi = (jhi < jlo) ? -1 : (jhi >> 4);
+}
+
+// One launch, two workgroup roles:
+//   blockIdx.x >= n_fp : BACKGROUND — 256 items of 16 pixels, pure streaming through the LUT; items that may show the
+//                        patch are skipped entirely (not written).
+//   blockIdx.x <  n_fp : FOOTPRINT  — owns exactly the skipped items of one image (a 1/fsplit share of them), one LANE per
+//                        pixel: LUT value, exact warp sample, mask, normalise, 2-byte stores; keep bits by wave ballot.
+// The two roles never write the same byte, so no ordering between workgroups is needed.
+__global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdArgs a, const FwdLut hl, int n_fp, int fsplit) {
+    __shared__ uint32_t lut[3 * 256];
+    __shared__ float bgrid[VAA_IMG];
+    __shared__ uint32_t row_word[VAA_IMG];  // footprint role: (it_lo << 8) | n_items per row; background: first kMaxRows rows
+    __shared__ int red_min, red_max, red_n;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = tid; e < 768; e += kFwdThreads) lut[e] = (&hl.v[0][0])[e];
+
+    if ((int)blockIdx.x >= n_fp) {  // footprint workgroups come FIRST in dispatch order: their latency chain overlaps the stream
+        // ------------------------------------------------------------------ background role
+        const long item0 = (long)((int)blockIdx.x - n_fp) * kFwdThreads;
+        const long total = (long)a.B * kItemsPerImg;
+        const long grow0 = item0 / kItemsPerRow;  // first global row (b*224 + i) this workgroup touches
+        if (tid < kMaxRows) {
+            const long gr = grow0 + tid;
+            int lo = 0, hi = -1;
+            if (gr < (long)a.B * VAA_IMG) row_items(a, (int)(gr / VAA_IMG), (int)(gr % VAA_IMG), lo, hi);
+            row_word[tid] = ((uint32_t)(lo & 0xff) << 8) | (uint32_t)((hi - lo + 1) & 0xff);
+        }
+        __syncthreads();
+        const long item = item0 + tid;
+        if (item >= total) return;
+        const long grow = item / kItemsPerRow;
+        const int it = (int)(item - grow * kItemsPerRow);
+        const uint32_t w = row_word[(int)(grow - grow0)];
+        const int lo = (int)(w >> 8), n = (int)(w & 0xffu);
+        if (it >= lo && it < lo + n) return;  // owned by the footprint role
+        const int j0 = it * kPix;
+        const int b = (int)(grow / VAA_IMG), i = (int)(grow - (long)b * VAA_IMG);
+
+        const uint4* src = reinterpret_cast<const uint4*>(a.img + ((size_t)grow * VAA_IMG + j0) * 3);
+        const uint4 w0 = src[0], w1 = src[1], w2 = src[2];
+        const uint32_t d[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+        uint32_t L[3][kPix];  // packed {bf16 plane c, bf16 plane c+3} per pixel
+#pragma unroll
+        for (int p = 0; p < kPix; ++p)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int k = p * 3 + c;
-                L[c][p] = lut[c][(d[k >> 2] >> (8 * (k & 3))) & 0xffu];
+                L[c][p] = lut[c * 256 + ((d[k >> 2] >> (8 * (k & 3))) & 0xffu)];
             }
-
-        const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
-        uint32_t kb[3] = {0u, 0u, 0u};
-        if (a.geometry) {
-            float th[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) th[q] = a.theta[6 * b + q];
-            const float by = bgrid[i];
-            // conservative reject: clamped source coords of the two end pixels bound those of the 6 in between
-            Samp sa = sample_pos(bgrid[j0], by, th), sb = sample_pos(bgrid[j0 + 7], by, th);
-            const int xmin = min(sa.x0, sb.x0), xmax = max(sa.x0, sb.x0) + 1;
-            const int ymin = min(sa.y0, sb.y0), ymax = max(sa.y0, sb.y0) + 1;
-            const bool maybe = !(xmax < px - 1 || xmin > px + a.pw || ymax < py - 1 || ymin > py + a.ph);
-            if (maybe) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    Samp s = (p == 0) ? sa : ((p == 7) ? sb : sample_pos(bgrid[j0 + p], by, th));
-                    const int u0 = s.x0 - px, v0 = s.y0 - py;
-                    if (u0 < -1 || u0 >= a.pw || v0 < -1 || v0 >= a.ph) continue;  // all four corners off the patch
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float cv = sample_canvas(a.patch + c * plane, a.ph, a.pw, px, py, s);
-                        if (keep_rule(cv, a.mask_mode)) {
-                            L[c][p] = norm_pack(cv, a.nrm, c);
-                            kb[c] |= 1u << p;
-                        }
-                    }
-                }
-            }
-        } else {
-            const int v = i - py;
-            if ((unsigned)v < (unsigned)a.ph && j0 + 7 >= px && j0 < px + a.pw) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const int u = j0 + p - px;
-                    if ((unsigned)u >= (unsigned)a.pw) continue;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float cv = a.patch[c * plane + v * a.pw + u];
-                        if (keep_rule(cv, a.mask_mode)) {
-                            L[c][p] = norm_pack(cv, a.nrm, c);
-                            kb[c] |= 1u << p;
-                        }
-                    }
-                }
-            }
-        }
-
         const size_t obase = ((size_t)b * 6 * VAA_IMG + i) * VAA_IMG + j0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            uint4 lo, hi;
-            lo.x = (L[c][0] & 0xffffu) | (L[c][1] << 16);
-            lo.y = (L[c][2] & 0xffffu) | (L[c][3] << 16);
-            lo.z = (L[c][4] & 0xffffu) | (L[c][5] << 16);
-            lo.w = (L[c][6] & 0xffffu) | (L[c][7] << 16);
-            hi.x = (L[c][0] >> 16) | (L[c][1] & 0xffff0000u);
-            hi.y = (L[c][2] >> 16) | (L[c][3] & 0xffff0000u);
-            hi.z = (L[c][4] >> 16) | (L[c][5] & 0xffff0000u);
-            hi.w = (L[c][6] >> 16) | (L[c][7] & 0xffff0000u);
-            *reinterpret_cast<uint4*>(a.out + obase + (size_t)c * VAA_NPIX) = lo;
-            *reinterpret_cast<uint4*>(a.out + obase + (size_t)(c + 3) * VAA_NPIX) = hi;
+            uint32_t lo4[8], hi4[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                lo4[q] = __builtin_amdgcn_perm(L[c][2 * q + 1], L[c][2 * q], 0x05040100u);
+                hi4[q] = __builtin_amdgcn_perm(L[c][2 * q + 1], L[c][2 * q], 0x07060302u);
+            }
+            uint4* o0 = reinterpret_cast<uint4*>(a.out + obase + (size_t)c * VAA_NPIX);
+            uint4* o1 = reinterpret_cast<uint4*>(a.out + obase + (size_t)(c + 3) * VAA_NPIX);
+            o0[0] = make_uint4(lo4[0], lo4[1], lo4[2], lo4[3]);
+            o0[1] = make_uint4(lo4[4], lo4[5], lo4[6], lo4[7]);
+            o1[0] = make_uint4(hi4[0], hi4[1], hi4[2], hi4[3]);
+            o1[1] = make_uint4(hi4[4], hi4[5], hi4[6], hi4[7]);
         }
         if (a.keep) {
             const size_t kbase = ((size_t)b * 3 * VAA_NPIX + (size_t)i * VAA_IMG + j0) >> 3;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) a.keep[kbase + (size_t)c * (VAA_NPIX / 8)] = (uint8_t)kb[c];
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<uint16_t*>(a.keep + kbase + (size_t)c * (VAA_NPIX / 8)) = (uint16_t)0;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- footprint role
+#ifdef VAA_EXP_FPNONE
+    return;
+#endif
+    const int fid = (int)blockIdx.x;
+    const int b = fid / fsplit, chunk = fid - b * fsplit;
+    if (tid == 0) { red_min = VAA_IMG; red_max = -1; red_n = 0; }
+    if (tid < VAA_IMG) bgrid[tid] = base_coord(tid);
+    __syncthreads();
+    if (tid < VAA_IMG) {
+        int lo, hi;
+        row_items(a, b, tid, lo, hi);
+        const int n = hi - lo + 1;
+        row_word[tid] = ((uint32_t)(lo & 0xff) << 8) | (uint32_t)(n > 0 ? n : 0);
+        if (n > 0) { atomicMin(&red_min, tid); atomicMax(&red_max, tid); atomicMax(&red_n, n); }
+    }
+    __syncthreads();
+    const int rmin = red_min, nrows = red_max - rmin + 1;
+    if (nrows <= 0) return;
+#ifdef VAA_EXP_FPSETUP
+    return;
+#endif
+    const int nseg = (red_n + 1) >> 1;                             // half-wave = 32 pixels = 2 items per slot
+    const uint32_t inv_nseg = (65536u + nseg - 1) / nseg;
+    const int nslots = nrows * nseg;
+    const int hw = (chunk * kFwdThreads + tid) >> 5, nhw = fsplit * (kFwdThreads >> 5), hlane = tid & 31;
+    const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
+    const int plane = a.ph * a.pw;
+    float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    if (a.geometry) {
+#pragma unroll
+        for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
+    }
+    for (int sidx = hw; sidx < nslots; sidx += nhw) {  // trip count is uniform within a wave (both half-waves iterate alike or idle)
+        const int r = (int)(((uint32_t)sidx * inv_nseg) >> 16);
+        const int k = sidx - r * nseg;
+        const int i = rmin + r;
+        const uint32_t w = row_word[i];
+        const int off = (k << 5) + hlane;
+        const bool active = (off >> 4) < (int)(w & 0xffu);
+        const int j = ((int)(w >> 8) << 4) + off;
+        uint32_t L[3] = {0u, 0u, 0u};
+        bool kept[3] = {false, false, false};
+        if (active) {
+            const uint8_t* sp = a.img + ((size_t)(b * VAA_IMG + i) * VAA_IMG + j) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) L[c] = lut[c * 256 + sp[c]];
+            if (a.geometry) {
+                const Samp s = sample_pos(bgrid[j], bgrid[i], th);
+                const int u0 = s.x0 - px, v0 = s.y0 - py;
+                if (!(u0 < -1 || u0 >= a.pw || v0 < -1 || v0 >= a.ph)) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float cv = sample_canvas(a.patch + c * plane, a.ph, a.pw, px, py, s);
+                        if (keep_rule(cv, a.mask_mode)) { L[c] = norm_pack(cv, a.nrm, c); kept[c] = true; }
+                    }
+                }
+            } else {
+                const int u = j - px, v = i - py;
+                if ((unsigned)u < (unsigned)a.pw && (unsigned)v < (unsigned)a.ph) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float cv = a.patch[c * plane + v * a.pw + u];
+                        if (keep_rule(cv, a.mask_mode)) { L[c] = norm_pack(cv, a.nrm, c); kept[c] = true; }
+                    }
+                }
+            }
+            const size_t o = ((size_t)b * 6 * VAA_IMG + i) * VAA_IMG + j;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a.out[o + (size_t)c * VAA_NPIX] = (uint16_t)(L[c] & 0xffffu);
+                a.out[o + (size_t)(c + 3) * VAA_NPIX] = (uint16_t)(L[c] >> 16);
+            }
+        }
+        if (a.keep) {  // 16 consecutive lanes = one item = one 16-bit word of the keep mask
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned long long m = __ballot(kept[c]);
+                if (active && (hlane & 15) == 0) {
+                    const uint32_t bits = (uint32_t)(m >> (tid & 48)) & 0xffffu;
+                    const size_t kbase = ((size_t)b * 3 * VAA_NPIX + (size_t)i * VAA_IMG + j) >> 3;
+                    *reinterpret_cast<uint16_t*>(a.keep + kbase + (size_t)c * (VAA_NPIX / 8)) = (uint16_t)bits;
+                }
+            }
         }
     }
 }
@@ -164,10 +268,15 @@ extern "C" int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, co
     a.img = img_u8; a.patch = patch; a.xy = xy; a.theta = theta; a.out = out_bf16; a.keep = keep_bits;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) { a.nrm.mean[q] = mean6[q]; a.nrm.stdv[q] = std6[q]; }
-    const long total = (long)B * kGroupsPerImg;
-    long blocks = (total + 511) / 512;  // two 8-pixel groups per thread amortise the per-workgroup LUT build
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(patch_apply_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    FwdLut hl;
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) hl.v[c][v] = norm_pack((float)v / 255.0f, a.nrm, c);  // ToTensor (:108) + 2x normalise
+    const long total = (long)B * kItemsPerImg;
+    const long n_bg = (total + kFwdThreads - 1) / kFwdThreads;
+    int fsplit = 16;  // footprint workgroups per image: ~6,400 pixel-lanes per 50x50 footprint -> 2 slot rounds each
+    while (fsplit > 1 && (long)B * fsplit > 2048) fsplit >>= 1;
+    const long n_fp = (long)B * fsplit;
+    hipLaunchKernelGGL(patch_apply_fwd_kernel, dim3((unsigned)(n_fp + n_bg)), dim3(kFwdThreads), 0, (hipStream_t)stream, a, hl,
+                       (int)n_fp, fsplit);
     return check_launch("vaa_patch_apply_fwd");
 }

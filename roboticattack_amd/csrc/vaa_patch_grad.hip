@@ -33,18 +33,6 @@ struct GradArgs {
     float std6[6];
 };
 
-// j-interval of row i whose (approximate, unclamped) source coordinate a*j + base lies in [lo, hi)
-__device__ __forceinline__ void solve_interval(float a, float base, float lo, float hi, float& jl, float& jh) {
-    if (fabsf(a) > 1e-6f) {
-        float t0 = (lo - base) / a, t1 = (hi - base) / a;
-        jl = fmaxf(jl, fminf(t0, t1));
-        jh = fminf(jh, fmaxf(t0, t1));
-    } else if (!(base >= lo - 1.0f && base < hi + 1.0f)) {
-        jl = 1e30f;
-        jh = -1e30f;
-    }
-}
-
 constexpr int kGradThreads = 1024;  // 16 waves: two workgroups per CU with the 60 KB fp64 tile
 constexpr int kImgsPerPass = 8;      // images whose row tables are built together (one barrier set per pass)
 
