@@ -6,11 +6,10 @@
 // softmax/CE over every one of the B*S rows; only B*(n_mask+1) rows carry loss, so these kernels touch
 // exactly those rows: one streaming read for the statistics, one read + one write for the gradient.
 //
-//   stats    : grid = B*(L-1) positions, unlabelled positions exit at once; 1024 threads stream one row
-//              (16-byte loads), block-reduce max / sum-exp, wave 0 does the 256-wide action slice.
-//   finalize : one workgroup folds the per-row statistics into the scalars and per-row gradient coefficients
-//              (needs global means: 1/CE, UPA's mean norm) in fixed order -> deterministic.
-//   grad     : same grid as stats; g = kCE*(softmax - onehot) + kE*p_a*((a+1) - E) on the action slice.
+//   stats : grid = B*(L-1) positions, unlabelled positions exit at once; 1024 threads stream one row (16-byte loads) into
+//           registers, block-reduce max / sum-exp; the 256 action logits sit in one wave's registers -> soft-argmax by shuffles.
+//   grad  : same grid; every labelled row folds the per-row statistics into the global scalars it needs (1/CE, UPA means;
+//           fixed order -> deterministic), then writes g = kCE*(softmax - onehot) + kE*p_a*((a+1) - E).
 #include "vaa_common.h"
 
 namespace vaa {
@@ -19,15 +18,15 @@ constexpr int kA0 = 31744;   // first action token (UADA.py:384)
 constexpr int kNA = 256;     // action bins
 constexpr int kRowThreads = 1024;
 
-struct RowStat {  // per position p = b*(L-1)+k
-    float lse;      // logsumexp over all V classes
-    float zlab;     // logit of the label
-    float alse;     // logsumexp over the 256 action classes
-    float E;        // sum_a softmax_a * (a+1), in [1,256]
-    int pred;       // 31744 + argmax over the action slice
-    int rowidx;     // compact row index (ROWS layout) or -1
-    float kce;      // d total / d z contribution weight of (softmax - onehot)
-    float kE;       // d total / d E
+struct RowStat {  // one per LABELLED row, stored compactly at its row-major rank `rowidx` among labelled positions
+    float lse;   // logsumexp over all V classes
+    float zlab;  // logit of the label
+    float alse;  // logsumexp over the 256 action classes
+    float E;     // sum_a softmax_a * (a+1), in [1,256]
+    int pred;    // 31744 + argmax over the action slice
+    int pos;     // position p = b*(L-1)+k
+    int lab;     // the label (token id)
+    int ord;     // rank of this position among its sample's labelled positions (0 = first)
 };
 
 struct LossArgs {
@@ -41,6 +40,8 @@ struct LossArgs {
     float w, alpha, beta, scale;
 };
 
+constexpr int kLabLds = 24576;  // label matrices up to this many entries (48 KB as int16) are staged in LDS once per workgroup
+
 __device__ __forceinline__ size_t row_offset(const LossArgs& a, int b, int k, int rowidx) {
     return a.layout == VAA_LAYOUT_FULL ? ((size_t)b * a.S + (a.S - a.L + k)) * a.V : (size_t)rowidx * a.V;
 }
@@ -50,14 +51,12 @@ struct Vec;
 template <>
 struct Vec<float> {
     static constexpr int N = 4;
-    typedef float4 raw;
     __device__ static void load(const float* p, float* v) {
         float4 r = *reinterpret_cast<const float4*>(p);
         v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
     }
     __device__ static void store(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
     __device__ static float get(const float* p) { return *p; }
-    __device__ static void put(float* p, float v) { *p = v; }
 };
 template <>
 struct Vec<uint16_t> {  // bf16 bits
@@ -77,60 +76,119 @@ struct Vec<uint16_t> {  // bf16 bits
         *reinterpret_cast<uint4*>(p) = r;
     }
     __device__ static float get(const uint16_t* p) { return bf16_bits_to_f32(*p); }
-    __device__ static void put(uint16_t* p, float v) { *p = (uint16_t)f32_to_bf16_bits(v); }
 };
 
-// ---- index: compact row numbers in (b,k) row-major order of labelled positions (ROWS layout) ----
-__global__ __launch_bounds__(1024) void loss_index_kernel(const int64_t* __restrict__ labels, RowStat* st, int B, int L) {
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < B; b0 += 1024) {
-        const int b = b0 + tid;
-        int cnt = 0;
-        if (b < B)
-            for (int k = 0; k + 1 < L; ++k) cnt += labels[(size_t)b * L + k + 1] != -100;
-        int incl = cnt;
+__device__ __forceinline__ double bin_center(int tok) {  // ActionTokenizer.decode_token_ids_to_actions (action_tokenizer.py:49-68)
+    int d = 32000 - tok - 1;
+    d = d < 0 ? 0 : (d > 254 ? 254 : d);
+    return -1.0 + (2.0 * d + 1.0) / 255.0;
+}
+
+// block-wide sums of NV doubles at once (fixed order: lanes by xor-shuffle, then waves 0..15) -> deterministic
+template <int NV, int NT = kRowThreads>
+__device__ __forceinline__ void block_sums(double (&v)[NV], double (*sh)[NV]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wsum[wv] = incl;
-        __syncthreads();
-        int base = carry;
-        for (int q = 0; q < wv; ++q) base += wsum[q];
-        int r = base + incl - cnt;
-        if (b < B)
-            for (int k = 0; k + 1 < L; ++k) {
-                const bool lab = labels[(size_t)b * L + k + 1] != -100;
-                st[(size_t)b * (L - 1) + k].rowidx = lab ? r : -1;
-                r += lab;
-            }
-        __syncthreads();
-        if (tid == 1023) carry = base + incl;
-        __syncthreads();
+    for (int q = 0; q < NV; ++q) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) sh[wv][q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double t = 0.0;
+        for (int w = 0; w < NT / 64; ++w) t += sh[w][q];
+        v[q] = t;
     }
 }
 
-// ---- stats ----
-template <typename T>
-__global__ __launch_bounds__(kRowThreads) void loss_stats_kernel(LossArgs a) {
-    const int p = blockIdx.x, b = p / (a.L - 1), k = p - b * (a.L - 1);
-    const int64_t lab = a.labels[(size_t)b * a.L + k + 1];
-    if (lab == -100) return;
-    RowStat* st = a.st + p;
-    const T* z = reinterpret_cast<const T*>(a.logits) + row_offset(a, b, k, st->rowidx);
-    constexpr int N = Vec<T>::N;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nvec = a.V / N;  // V = 32064 is a multiple of 8
-    __shared__ float red[16];
-    __shared__ float bmax;
+// Label access: the whole [B,L] matrix staged in LDS as int16 (token ids < 32768, -100 stays -100) when it fits, else global.
+struct Labels {
+    const int64_t* g;
+    const int16_t* l;  // nullptr -> read from global
+    __device__ __forceinline__ int at(int idx) const { return l ? (int)l[idx] : (int)g[idx]; }
+};
 
-    // one streaming pass: this thread's elements stay in registers (8 x 16-byte vectors cover V = 32064 in f32)
-    constexpr int MAXV = 32 / N;  // 8 f32 or 4 bf16 vectors per thread = 32 logits x 1024 threads >= 32064
+template <int NT = kRowThreads>
+__device__ __forceinline__ Labels stage_labels(const LossArgs& a, int16_t* lds) {
+    Labels lb;
+    lb.g = a.labels;
+    lb.l = nullptr;
+    const int n = a.B * a.L;
+    if (n <= kLabLds) {
+        for (int e = threadIdx.x; e < n; e += NT) lds[e] = (int16_t)a.labels[e];
+        lb.l = lds;
+        __syncthreads();
+    }
+    return lb;
+}
+
+// Locates the jj-th labelled position of sample b (row (b,k) predicts labels[b,k+1]); returns k or -1 and its rank.
+// Every wave evaluates this redundantly with ballots (no barrier); the result is workgroup-uniform.
+__device__ __forceinline__ int nth_labelled(const Labels& lb, int b, int L, int jj) {
+    const int lane = threadIdx.x & 63;
+    for (int c0 = 0; c0 < L - 1; c0 += 64) {
+        const int k = c0 + lane;
+        const bool lab = (k < L - 1) && (lb.at(b * L + k + 1) != -100);
+        unsigned long long m = __ballot(lab);
+        const int cnt = __popcll(m);
+        if (jj < cnt) {
+            for (int z = 0; z < jj; ++z) m &= m - 1;  // drop the jj lowest set bits
+            return c0 + __ffsll((long long)m) - 1;
+        }
+        jj -= cnt;
+    }
+    return -1;
+}
+
+// counts of labelled positions: before flat label index `upto` (row-major rank) and in total
+template <int NT = kRowThreads>
+__device__ __forceinline__ void count_labelled(const Labels& lb, int B, int L, int upto, int& before, int& total, int (*shi)[2]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int cb = 0, ct = 0;
+    for (int e = threadIdx.x; e < B * L; e += NT) {
+        const int col = e % L;
+        const int is = (col != 0 && lb.at(e) != -100) ? 1 : 0;
+        ct += is;
+        cb += (e < upto) ? is : 0;
+    }
+    cb = wave_sum(cb);
+    ct = wave_sum(ct);
+    __syncthreads();
+    if (lane == 0) { shi[wv][0] = cb; shi[wv][1] = ct; }
+    __syncthreads();
+    before = 0;
+    total = 0;
+    for (int q = 0; q < NT / 64; ++q) { before += shi[q][0]; total += shi[q][1]; }
+}
+
+// ---- kernel A: per labelled row: compact rank, logsumexp, label logit, action-slice soft-argmax / argmax ----
+template <typename T>
+__global__ __launch_bounds__(kRowThreads) void loss_stats_kernel(LossArgs a, int J) {
+    // workgroup (j, b) owns the j-th, (j+J)-th, ... labelled position of sample b (usually exactly one row, or none);
+    // sample index fastest: consecutive blocks (dealt round-robin to the 8 XCDs) are all active.
+    const int j = blockIdx.x / a.B, b = blockIdx.x - j * a.B;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int16_t lab16[kLabLds];
+    __shared__ float red[16];
+    __shared__ int shi[16][2];
+    __shared__ float bmax;
+    const Labels lb = stage_labels(a, lab16);
+  for (int jj = j;; jj += J) {
+    const int k = nth_labelled(lb, b, a.L, jj);
+    if (k < 0) return;
+    const int lab = lb.at(b * a.L + k + 1);
+    int rowidx, total;
+    count_labelled(lb, a.B, a.L, b * a.L + k + 1, rowidx, total, shi);
+
+    const T* z = reinterpret_cast<const T*>(a.logits) + row_offset(a, b, k, rowidx);
+    constexpr int N = Vec<T>::N;
+    const int nvec = a.V / N;  // V = 32064 is a multiple of 8
+
+    // one streaming pass: this thread's elements stay in registers (8 f32 or 4 bf16 16-byte vectors = 32 logits)
+    constexpr int MAXV = 32 / N;
     float v[MAXV][N];
     float m = -INFINITY;
 #pragma unroll
@@ -145,14 +203,14 @@ __global__ __launch_bounds__(kRowThreads) void loss_stats_kernel(LossArgs a) {
 #pragma unroll
         for (int e = 0; e < N; ++e) m = fmaxf(m, v[c][e]);
     }
-    // generic tail for V larger than MAXV*N*1024 (not the case for OpenVLA): re-read from L2
-    for (int q = tid + MAXV * kRowThreads; q < nvec; q += kRowThreads) {
+    for (int q = tid + MAXV * kRowThreads; q < nvec; q += kRowThreads) {  // generic tail for larger vocabularies (re-read from L2)
         float t[N];
         Vec<T>::load(z + (size_t)q * N, t);
 #pragma unroll
         for (int e = 0; e < N; ++e) m = fmaxf(m, t[e]);
     }
     m = wave_max(m);
+    __syncthreads();
     if (lane == 0) red[wv] = m;
     __syncthreads();
     if (tid == 0) {
@@ -176,193 +234,222 @@ __global__ __launch_bounds__(kRowThreads) void loss_stats_kernel(LossArgs a) {
     s = wave_sum(s);
     __syncthreads();
     if (lane == 0) red[wv] = s;
-    __syncthreads();
 
-    if (wv == 0) {  // action slice: 256 classes, 4 per lane
-        float x[4];
+    // the 256 action logits sit in registers of ONE wave: vector index q0 = 31744/N lives at c = q0/1024, tid = q0%1024
+    constexpr int q0 = kA0 / N, cs = q0 / kRowThreads, t0 = q0 % kRowThreads, nthr = kNA / N;
+    static_assert(t0 % 64 == 0 && nthr <= 64 && cs < MAXV, "action slice must map onto one wave");
+    float alse = 0.0f, E = 0.0f;
+    int pred = 0;
+    if (wv == t0 / 64) {
+        const bool own = lane < nthr;
+        float x[N];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = Vec<T>::get(z + kA0 + lane * 4 + e);
-        float am = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        for (int e = 0; e < N; ++e) x[e] = own ? v[cs][e] : -INFINITY;
+        float am = x[0];
         int ai = 0;
 #pragma unroll
-        for (int e = 1; e < 4; ++e) if (x[e] > x[ai]) ai = e;
+        for (int e = 1; e < N; ++e) if (x[e] > x[ai]) ai = e;
         float bestv = x[ai];
-        int besti = lane * 4 + ai;
+        int besti = lane * N + ai;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {  // argmax with lowest-index tie break (torch.argmax on CPU)
-            float ov = __shfl_xor(bestv, o, 64);
-            int oi = __shfl_xor(besti, o, 64);
+        for (int e = 1; e < N; ++e) am = fmaxf(am, x[e]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {  // argmax with lowest-index tie break (torch.argmax)
+            const float ov = __shfl_xor(bestv, o, 64);
+            const int oi = __shfl_xor(besti, o, 64);
             if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
         }
         am = wave_max(am);
         float es = 0.0f, ew = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float ex = expf(x[e] - am);
+        for (int e = 0; e < N; ++e) {
+            const float ex = expf(x[e] - am);
             es += ex;
-            ew += ex * (float)(lane * 4 + e + 1);
+            ew += ex * (float)(lane * N + e + 1);
         }
         es = wave_sum(es);
         ew = wave_sum(ew);
-        if (lane == 0) {
-            float tot = 0.0f;
-            for (int q = 0; q < kRowThreads / 64; ++q) tot += red[q];
-            st->lse = M + logf(tot);
-            st->zlab = Vec<T>::get(z + lab);
-            st->alse = am + logf(es);
-            st->E = ew / es;
-            st->pred = kA0 + besti;
-        }
+        alse = am + logf(es);
+        E = ew / es;
+        pred = kA0 + besti;
     }
-}
-
-// ---- finalize: scalars + per-row gradient coefficients (single workgroup, fixed-order reductions) ----
-__device__ double block_sum(double v, double* sh) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    v = wave_sum(v);
     __syncthreads();
-    if (lane == 0) sh[wv] = v;
-    __syncthreads();
-    double t = 0.0;
-    for (int q = 0; q < 16; ++q) t += sh[q];
-    return t;
+    if (tid == t0) {  // first lane of the slice wave
+        float tot = 0.0f;
+        for (int q = 0; q < kRowThreads / 64; ++q) tot += red[q];
+        RowStat r;
+        r.lse = M + logf(tot);
+        r.zlab = Vec<T>::get(z + lab);
+        r.alse = alse;
+        r.E = E;
+        r.pred = pred;
+        r.pos = b * (a.L - 1) + k;
+        r.lab = lab;
+        r.ord = jj;
+        a.st[rowidx] = r;
+    }
+  }
 }
 
-__device__ __forceinline__ double bin_center(int tok) {  // ActionTokenizer.decode_token_ids_to_actions (action_tokenizer.py:49-68)
-    int d = 32000 - tok - 1;
-    d = d < 0 ? 0 : (d > 254 ? 254 : d);
-    return -1.0 + (2.0 * d + 1.0) / 255.0;
-}
+// UPA per-sample terms from the E / label of a sample's first three labelled rows (UPA.py:375-384)
+struct Upa3 {
+    double e[3], l[3];
+    __device__ void set(int q, const RowStat& s) { e[q] = ((double)s.E - 1.0) / 255.0; l[q] = ((double)(s.lab - 31743) - 1.0) / 255.0; }
+    __device__ void terms(double& cosp1, double& nd) const {
+        const double dot = e[0] * l[0] + e[1] * l[1] + e[2] * l[2];
+        const double ne = e[0] * e[0] + e[1] * e[1] + e[2] * e[2], nl = l[0] * l[0] + l[1] * l[1] + l[2] * l[2];
+        const double d0 = e[0] - l[0], d1 = e[1] - l[1], d2 = e[2] - l[2];
+        cosp1 = dot / (fmax(sqrt(ne), 1e-8) * fmax(sqrt(nl), 1e-8)) + 1.0;  // F.cosine_similarity + 1 (UPA.py:382-383)
+        nd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    }
+    __device__ double dE(int q, double alpha, double beta, double aux1, int B) const {  // d total / d e[q]
+        const double dot = e[0] * l[0] + e[1] * l[1] + e[2] * l[2];
+        const double ne = e[0] * e[0] + e[1] * e[1] + e[2] * e[2], nl = l[0] * l[0] + l[1] * l[1] + l[2] * l[2];
+        const double d0 = e[0] - l[0], d1 = e[1] - l[1], d2 = e[2] - l[2];
+        const double sne = fmax(sqrt(ne), 1e-8), snl = fmax(sqrt(nl), 1e-8), nd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        const double eq = q == 0 ? e[0] : (q == 1 ? e[1] : e[2]), lq = q == 0 ? l[0] : (q == 1 ? l[1] : l[2]);
+        const double dcos = lq / (sne * snl) - dot * eq / (sne * sne * sne * snl);
+        const double dn = nd > 0 ? (eq - lq) / nd : 0.0;
+        return alpha * dcos / B - beta * aux1 * aux1 * dn / B;
+    }
+};
 
-__global__ __launch_bounds__(1024) void loss_finalize_kernel(LossArgs a) {
-    __shared__ double sh[16];
+// ---- kernel B: every labelled row folds the compact per-row statistics into the global scalars it needs (fixed order ->
+//      deterministic and identical in all workgroups), then writes its gradient row; rank-0's workgroup (or workgroup 0
+//      when nothing is labelled) publishes the scalars and the predicted tokens. ----
+constexpr int kGradT = 512;  // 64 logits per thread stay in registers (256-VGPR budget), fp64 reductions do not spill
+
+template <typename T>
+__global__ __launch_bounds__(kGradT) void loss_grad_kernel(LossArgs a, int J) {
+    const int j = blockIdx.x / a.B, b = blockIdx.x - j * a.B;
     const int tid = threadIdx.x;
-    const int P = a.B * (a.L - 1);
-    double ce = 0.0, mse = 0.0, uad = 0.0, nrow = 0.0, nact = 0.0;
-    for (int p = tid; p < P; p += 1024) {
-        const int b = p / (a.L - 1), k = p - b * (a.L - 1);
-        const int64_t lab = a.labels[(size_t)b * a.L + k + 1];
-        if (a.pred_tokens) a.pred_tokens[p] = (lab > 2) ? a.st[p].pred : -1;
-        if (lab == -100) continue;
-        const RowStat s = a.st[p];
-        nrow += 1.0;
-        ce += (double)s.lse - (double)s.zlab;
-        if (lab > 2) {
-            nact += 1.0;
-            const double r = (double)s.E / 256.0, t = (lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10: 1/256 -> 0)
-            mse += (r - t) * (r - t);
-            const double ag = bin_center((int)lab), ap = bin_center(s.pred);  // cal_UAD, UADA.py:408-418
-            uad += fabs(ap - ag) / (ag > 0 ? fabs(ag + 1.0) : fabs(ag - 1.0));
+    __shared__ int16_t lab16[kLabLds];
+    __shared__ int shi[kGradT / 64][2];
+    __shared__ double sh[kGradT / 64][7];
+    const Labels lb = stage_labels<kGradT>(a, lab16);
+  for (int jj = j;; jj += J) {
+    const int k = nth_labelled(lb, b, a.L, jj);
+    if (k < 0 && !(blockIdx.x == 0 && jj == j)) return;  // workgroup 0 always runs once: it publishes zeros when nothing is labelled
+    const int lab = k < 0 ? -100 : lb.at(b * a.L + k + 1);
+    int rowidx, R;
+    count_labelled<kGradT>(lb, a.B, a.L, k < 0 ? 0 : b * a.L + k + 1, rowidx, R, shi);
+
+    // this row's logits: issue the loads now, use them after the reductions (addresses do not depend on the statistics)
+    constexpr int N = Vec<T>::N;
+    constexpr int MAXV = 64 / N;
+    const int nvec = a.V / N;
+    const size_t off = k < 0 ? 0 : row_offset(a, b, k, rowidx);
+    const T* z = reinterpret_cast<const T*>(a.logits) + off;
+    const bool want_row = (k >= 0) && a.glogits && (a.mode != VAA_LOSS_UADA_DDP && a.mode != VAA_LOSS_UPA);  // CE term needs every logit
+
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // ce, mse, uad, nrow, nact, upa sum(cos+1), upa sum ||e'-l'||
+    for (int r = tid; r < R; r += kGradT) {
+        const RowStat s = a.st[r];
+        acc[3] += 1.0;
+        acc[0] += (double)s.lse - (double)s.zlab;
+        if (s.lab > 2) {
+            acc[4] += 1.0;
+            const double rr = (double)s.E / 256.0, t = (s.lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10: 1/256 -> 0)
+            acc[1] += (rr - t) * (rr - t);
+            const double ag = bin_center(s.lab), ap = bin_center(s.pred);  // cal_UAD, UADA.py:408-418
+            acc[2] += fabs(ap - ag) / (ag > 0 ? fabs(ag + 1.0) : fabs(ag - 1.0));
+        }
+        if (a.mode == VAA_LOSS_UPA && s.ord == 0 && r + 2 < R) {  // first three labelled rows of a sample are consecutive ranks
+            Upa3 u;
+            u.set(0, s); u.set(1, a.st[r + 1]); u.set(2, a.st[r + 2]);
+            double c1, nd;
+            u.terms(c1, nd);
+            acc[5] += c1;
+            acc[6] += nd;
         }
     }
-    ce = block_sum(ce, sh); mse = block_sum(mse, sh); uad = block_sum(uad, sh);
-    nrow = block_sum(nrow, sh); nact = block_sum(nact, sh);
-    const double CE = nrow > 0 ? ce / nrow : 0.0;
-    const double MSE = nact > 0 ? (double)a.w * a.w * mse / nact : 0.0;
-    const double UAD = nact > 0 ? uad / nact : 0.0;
+    block_sums<7, kGradT>(acc, sh);
+    const double nrow = acc[3], nact = acc[4];
+    const double CE = nrow > 0 ? acc[0] / nrow : 0.0;
+    const double MSE = nact > 0 ? (double)a.w * a.w * acc[1] / nact : 0.0;
+    const double UAD = nact > 0 ? acc[2] / nact : 0.0;
 
     double total = 0.0, aux0 = 0.0, aux1 = 0.0;
+    float kce = 0.0f, kE = 0.0f;
+    RowStat me;
+    me.lse = me.alse = me.E = 0.0f; me.ord = 0;
+    if (k >= 0) me = a.st[rowidx];
     if (a.mode == VAA_LOSS_UPA) {
-        // per sample: first three labelled positions = x,y,z tokens (UPA.py:375-380)
-        double ang = 0.0, nsum = 0.0;
-        for (int b = tid; b < a.B; b += 1024) {
-            double e3[3] = {0, 0, 0}, l3[3] = {0, 0, 0};
-            int cnt = 0;
-            for (int k = 0; k + 1 < a.L && cnt < 3; ++k) {
-                const int64_t lab = a.labels[(size_t)b * a.L + k + 1];
-                if (lab == -100) continue;
-                e3[cnt] = ((double)a.st[(size_t)b * (a.L - 1) + k].E - 1.0) / 255.0;
-                l3[cnt] = ((double)(lab - 31743) - 1.0) / 255.0;
-                ++cnt;
-            }
-            double dot = 0, ne = 0, nl = 0, d2 = 0;
-            for (int q = 0; q < 3; ++q) { dot += e3[q] * l3[q]; ne += e3[q] * e3[q]; nl += l3[q] * l3[q]; d2 += (e3[q] - l3[q]) * (e3[q] - l3[q]); }
-            ang += dot / (fmax(sqrt(ne), 1e-8) * fmax(sqrt(nl), 1e-8)) + 1.0;  // F.cosine_similarity + 1 (UPA.py:382-383)
-            nsum += sqrt(d2);
-        }
-        ang = block_sum(ang, sh);
-        nsum = block_sum(nsum, sh);
-        aux0 = ang / a.B;
-        const double mean_norm = nsum / a.B;
-        aux1 = 1.0 / (mean_norm + 1e-3);  // UPA.py:384
+        aux0 = acc[5] / a.B;
+        aux1 = 1.0 / (acc[6] / a.B + 1e-3);  // UPA.py:384
         total = (double)a.alpha * aux0 + (double)a.beta * aux1;
-        for (int b = tid; b < a.B; b += 1024) {
-            double e3[3] = {0, 0, 0}, l3[3] = {0, 0, 0};
-            int kk[3] = {-1, -1, -1}, cnt = 0;
-            for (int k = 0; k + 1 < a.L; ++k) {
-                const int64_t lab = a.labels[(size_t)b * a.L + k + 1];
-                if (lab == -100) continue;
-                RowStat* s = a.st + (size_t)b * (a.L - 1) + k;
-                s->kce = 0.0f;
-                s->kE = 0.0f;
-                if (cnt < 3) { e3[cnt] = ((double)s->E - 1.0) / 255.0; l3[cnt] = ((double)(lab - 31743) - 1.0) / 255.0; kk[cnt] = k; ++cnt; }
-            }
-            double dot = 0, ne = 0, nl = 0, d2 = 0;
-            for (int q = 0; q < 3; ++q) { dot += e3[q] * l3[q]; ne += e3[q] * e3[q]; nl += l3[q] * l3[q]; d2 += (e3[q] - l3[q]) * (e3[q] - l3[q]); }
-            const double sne = fmax(sqrt(ne), 1e-8), snl = fmax(sqrt(nl), 1e-8), nd = sqrt(d2);
-            for (int q = 0; q < cnt; ++q) {
-                const double dcos = l3[q] / (sne * snl) - dot * e3[q] / (sne * sne * sne * snl);
-                const double dn = nd > 0 ? (e3[q] - l3[q]) / nd : 0.0;
-                const double dde = (double)a.alpha * dcos / a.B - (double)a.beta * aux1 * aux1 * dn / a.B;
-                a.st[(size_t)b * (a.L - 1) + kk[q]].kE = (float)(dde / 255.0);
-            }
+        if (k >= 0 && me.ord < 3 && rowidx - me.ord + 2 < R) {
+            Upa3 u;
+            u.set(0, a.st[rowidx - me.ord]); u.set(1, a.st[rowidx - me.ord + 1]); u.set(2, a.st[rowidx - me.ord + 2]);
+            kE = (float)(u.dE(me.ord, (double)a.alpha, (double)a.beta, aux1, a.B) / 255.0);
         }
     } else {
         double dce = 0.0;
         if (a.mode == VAA_LOSS_UADA) { total = MSE + 1.0 / CE; dce = -1.0 / (CE * CE); }  // UADA.py:147
         else if (a.mode == VAA_LOSS_UADA_DDP) { total = MSE; }                            // UADA_ddp.py:203-206
         else { total = (double)a.scale * CE; dce = (double)a.scale; }                     // TMA.py:148
-        const float kce = nrow > 0 ? (float)(dce / nrow) : 0.0f;
-        const bool has_mse = a.mode != VAA_LOSS_CE;
-        for (int p = tid; p < P; p += 1024) {
-            const int b = p / (a.L - 1), k = p - b * (a.L - 1);
-            const int64_t lab = a.labels[(size_t)b * a.L + k + 1];
-            if (lab == -100) continue;
-            RowStat* s = a.st + p;
-            s->kce = kce;
-            float kE = 0.0f;
-            if (has_mse && lab > 2) {
-                const double r = (double)s->E / 256.0, t = (lab > 31872) ? 0.0 : 1.0;
-                kE = (float)((double)a.w * a.w * 2.0 * (r - t) / nact / 256.0);
-            }
-            s->kE = kE;
+        kce = nrow > 0 ? (float)(dce / nrow) : 0.0f;
+        if (a.mode != VAA_LOSS_CE && lab > 2) {
+            const double rr = (double)me.E / 256.0, t = (lab > 31872) ? 0.0 : 1.0;
+            kE = (float)((double)a.w * a.w * 2.0 * (rr - t) / nact / 256.0);
         }
     }
-    if (tid == 0) {
+
+    // publication: scalars by the rank-0 row (or by workgroup 0 when nothing is labelled); predicted tokens likewise
+    const bool first = (k >= 0) ? (rowidx == 0) : (R == 0);
+    if (first && tid == 0) {
         a.scalars[0] = (float)total; a.scalars[1] = (float)CE; a.scalars[2] = (float)MSE; a.scalars[3] = (float)aux0;
         a.scalars[4] = (float)aux1; a.scalars[5] = (float)nrow; a.scalars[6] = (float)nact; a.scalars[7] = (float)UAD;
     }
-}
+    if (first && a.pred_tokens) {
+        const int P = a.B * (a.L - 1);
+        for (int q = tid; q < P; q += kGradT) a.pred_tokens[q] = -1;
+        __syncthreads();
+        for (int r = tid; r < R; r += kGradT) {
+            const RowStat s = a.st[r];
+            if (s.lab > 2) a.pred_tokens[s.pos] = s.pred;
+        }
+    }
+    if (k < 0) return;
+    if (!a.glogits) continue;
 
-// ---- grad ----
-template <typename T>
-__global__ __launch_bounds__(kRowThreads) void loss_grad_kernel(LossArgs a) {
-    const int p = blockIdx.x, b = p / (a.L - 1), k = p - b * (a.L - 1);
-    const int64_t lab = a.labels[(size_t)b * a.L + k + 1];
-    if (lab == -100) return;
-    const RowStat s = a.st[p];
-    const size_t off = row_offset(a, b, k, s.rowidx);
-    const T* z = reinterpret_cast<const T*>(a.logits) + off;
     T* g = reinterpret_cast<T*>(a.glogits) + off;
-    constexpr int N = Vec<T>::N;
-    const int nvec = a.V / N;
-    for (int q = threadIdx.x; q < nvec; q += kRowThreads) {
-        float x[N], o[N];
+    float x[MAXV][N];
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {  // all of this thread's loads first, then the math
+        const int q = tid + c * kGradT;
         const int v0 = q * N;
         const bool in_slice = (v0 >= kA0 && v0 < kA0 + kNA);
-        if (s.kce != 0.0f || (in_slice && s.kE != 0.0f)) Vec<T>::load(z + (size_t)v0, x);
+        if (q < nvec && (want_row || (in_slice && kE != 0.0f))) Vec<T>::load(z + (size_t)v0, x[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int q = tid + c * kGradT;
+        if (q >= nvec) continue;
+        const int v0 = q * N;
+        const bool in_slice = (v0 >= kA0 && v0 < kA0 + kNA);
+        float o[N];
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             float gv = 0.0f;
-            if (s.kce != 0.0f) gv = s.kce * (expf(x[e] - s.lse) - ((v0 + e) == lab ? 1.0f : 0.0f));
-            if (in_slice && s.kE != 0.0f) {
-                const float pa = expf(x[e] - s.alse);
-                gv += s.kE * pa * ((float)(v0 + e - kA0 + 1) - s.E);
+            if (kce != 0.0f) gv = kce * (expf(x[c][e] - me.lse) - ((v0 + e) == lab ? 1.0f : 0.0f));
+            if (in_slice && kE != 0.0f) {
+                const float pa = expf(x[c][e] - me.alse);
+                gv += kE * pa * ((float)(v0 + e - kA0 + 1) - me.E);
             }
             o[e] = gv;
         }
         Vec<T>::store(g + (size_t)v0, o);
     }
+    for (int q = tid + MAXV * kGradT; q < nvec; q += kGradT) {  // generic tail for larger vocabularies
+        float t[N], o[N];
+        const int v0 = q * N;
+        if (kce != 0.0f) Vec<T>::load(z + (size_t)v0, t);
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] = kce != 0.0f ? kce * (expf(t[e] - me.lse) - ((v0 + e) == lab ? 1.0f : 0.0f)) : 0.0f;
+        Vec<T>::store(g + (size_t)v0, o);
+    }
+  }
 }
 
 }  // namespace vaa
@@ -398,23 +485,14 @@ extern "C" int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const
     a.logits = logits; a.labels = labels; a.st = (RowStat*)ws; a.glogits = glogits; a.scalars = scalars; a.pred_tokens = pred_tokens;
     a.B = B; a.S = S; a.L = L; a.V = V; a.mode = mode; a.layout = layout;
     a.w = params[0]; a.alpha = params[1]; a.beta = params[2]; a.scale = params[3];
-    const int P = B * (L - 1);
-    if (layout == VAA_LAYOUT_ROWS) {
-        hipLaunchKernelGGL(loss_index_kernel, dim3(1), dim3(1024), 0, st, labels, a.st, B, L);
-        int rc = check_launch("vaa_loss_fwd_bwd(index)");
-        if (rc != VAA_OK) return rc;
-    }
-    if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(loss_stats_kernel<float>, dim3(P), dim3(kRowThreads), 0, st, a);
-    else hipLaunchKernelGGL(loss_stats_kernel<uint16_t>, dim3(P), dim3(kRowThreads), 0, st, a);
+    const int J = (L - 1) < 8 ? (L - 1) : 8;  // workgroups per sample; the attacks label at most 8 positions per sample
+    const unsigned G = (unsigned)B * (unsigned)J;
+    if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(loss_stats_kernel<float>, dim3(G), dim3(kRowThreads), 0, st, a, J);
+    else hipLaunchKernelGGL(loss_stats_kernel<uint16_t>, dim3(G), dim3(kRowThreads), 0, st, a, J);
     int rc = check_launch("vaa_loss_fwd_bwd(stats)");
     if (rc != VAA_OK) return rc;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, a);
-    rc = check_launch("vaa_loss_fwd_bwd(finalize)");
-    if (rc != VAA_OK) return rc;
-    if (glogits) {
-        if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(P), dim3(kRowThreads), 0, st, a);
-        else hipLaunchKernelGGL(loss_grad_kernel<uint16_t>, dim3(P), dim3(kRowThreads), 0, st, a);
-        rc = check_launch("vaa_loss_fwd_bwd(grad)");
-    }
+    if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(G), dim3(kGradT), 0, st, a, J);
+    else hipLaunchKernelGGL(loss_grad_kernel<uint16_t>, dim3(G), dim3(kGradT), 0, st, a, J);
+    rc = check_launch("vaa_loss_fwd_bwd(grad)");
     return rc;
 }

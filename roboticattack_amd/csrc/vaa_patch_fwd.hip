@@ -158,9 +158,6 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
     }
 
     // ---------------------------------------------------------------------- footprint role
-#ifdef VAA_EXP_FPNONE
-    return;
-#endif
     const int fid = (int)blockIdx.x;
     const int b = fid / fsplit, chunk = fid - b * fsplit;
     if (tid == 0) { red_min = VAA_IMG; red_max = -1; red_n = 0; }
@@ -176,9 +173,6 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
     __syncthreads();
     const int rmin = red_min, nrows = red_max - rmin + 1;
     if (nrows <= 0) return;
-#ifdef VAA_EXP_FPSETUP
-    return;
-#endif
     const int nseg = (red_n + 1) >> 1;                             // half-wave = 32 pixels = 2 items per slot
     const uint32_t inv_nseg = (65536u + nseg - 1) / nseg;
     const int nslots = nrows * nseg;

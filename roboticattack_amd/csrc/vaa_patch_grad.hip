@@ -143,13 +143,9 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
 #pragma unroll
                 for (int cc = 0; cc < NCH; ++cc) {
                     const int c = c_base + cc;
-#ifndef VAA_EXP_NOLOAD
                     kbyte[cc] = kimg ? kimg[(size_t)c * (VAA_NPIX / 8) + (pix >> 3)] : 0u;
                     g0[cc] = gb[(size_t)c * VAA_NPIX];
                     g1[cc] = gb[(size_t)(c + 3) * VAA_NPIX];
-#else
-                    kbyte[cc] = 0xffu; g0[cc] = 0x3f80u + (pix & 3); g1[cc] = 0x3f80u + c;
-#endif
                 }
 #pragma unroll
                 for (int cc = 0; cc < NCH; ++cc) {
@@ -167,14 +163,10 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
                     // exactly like the reference's scatter; only the ACCUMULATION is fp64 (order-independent sum).
                     const float G = bf16_bits_to_f32(g0[cc]) / a.std6[c] + bf16_bits_to_f32(g1[cc]) / a.std6[c + 3];
                     ACC* t0 = acc + cc * plane + v0 * a.pw + u0;
-#ifndef VAA_EXP_NOATOMIC
                     if (vin0 && uin0) atomicAdd(t0, (ACC)(G * s.nw));
                     if (vin0 && uin1) atomicAdd(t0 + 1, (ACC)(G * s.ne));
                     if (vin1 && uin0) atomicAdd(t0 + a.pw, (ACC)(G * s.sw));
                     if (vin1 && uin1) atomicAdd(t0 + a.pw + 1, (ACC)(G * s.se));
-#else
-                    if (G * (s.nw + s.ne + s.sw + s.se) == 123.456f) atomicAdd(t0, (ACC)G);
-#endif
                 }
             }
         }
