@@ -177,12 +177,13 @@ def main():
     sync = vdist.PatchGradSync(patch.numel(), 4, dev)
     inv_world = 1.0 / world
     scal = torch.zeros(8, device=dev)
+    row_index = model.label_row_index(labels) if use_rows else None  # once per outer iteration, as the attack loops do
 
     def step():
         opt.zero_grad()
         pix = tr.apply_random_patch_batch(img, patch, mean, std, geometry=True)  # host RNG draws + K1
         if use_rows:
-            logits = model.forward_rows(input_ids, pix, labels)
+            logits = model.forward_rows(input_ids, pix, labels, row_index)
             total, scalars, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
         else:
             out = model(input_ids=input_ids, attention_mask=attn, pixel_values=pix, labels=None)

@@ -56,7 +56,11 @@ class AttackBase:
     def model_loss(self, input_ids, attention_mask, pix, labels, mode, w=5.0, alpha=0.8, beta=0.2, scale=1.0, need_grad=True):
         """Returns (total [autograd scalar or None], scalars f32[8] device, pred i32 [B,L-1] device)."""
         if self.use_rows:
-            logits = self.vla.forward_rows(input_ids, pix, labels)
+            # labels are fixed during an outer iteration: the row index (one host sync) is cached per tensor OBJECT; the
+            # cache holds a reference, so identity cannot be recycled by the allocator, and in-place edits bump _version
+            if getattr(self, "_row_ref", None) is not labels or self._row_ver != labels._version:
+                self._row_ref, self._row_ver, self._row_index = labels, labels._version, self.vla.label_row_index(labels)
+            logits = self.vla.forward_rows(input_ids, pix, labels, self._row_index)
             layout = ops.LAYOUT_ROWS
         else:
             out = self.vla(input_ids=input_ids, attention_mask=attention_mask, pixel_values=pix, labels=None)

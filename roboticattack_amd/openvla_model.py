@@ -223,12 +223,23 @@ class OpenVLAShaped(nn.Module):
             x = layer(x, cos, sin)
         return self.norm(x)
 
-    def forward_rows(self, input_ids, pixel_values, labels):
+    @staticmethod
+    def label_row_index(labels):
+        """Flat indices (into the [B*S] hidden rows, S = 256 + L) of the labelled rows in (b,k) row-major order of
+        labels[b,k+1] != -100. Costs one host sync (nonzero); the attack loops compute it once per outer iteration."""
+        B, L = labels.shape
+        S = N_IMG_TOKENS + L
+        bk = (labels[:, 1:] != IGNORE_INDEX).nonzero(as_tuple=False)  # [R,2] sorted row-major
+        return bk[:, 0] * S + N_IMG_TOKENS + bk[:, 1]
+
+    def forward_rows(self, input_ids, pixel_values, labels, row_index=None):
         """Logits [R,V] of the labelled rows only, in (b,k) row-major order of labels[b,k+1] != -100 (VAA_LAYOUT_ROWS):
-        row (b,k) is model position S-L+k = 256+k, the position whose next-token target is labels[b,k+1]."""
+        row (b,k) is model position S-L+k = 256+k, the position whose next-token target is labels[b,k+1].
+        Pass `row_index=label_row_index(labels)` to keep the step free of host synchronisation."""
         h = self.hidden_states(input_ids, pixel_values)
-        sel = labels[:, 1:] != IGNORE_INDEX  # [B, L-1]
-        rows = h[:, N_IMG_TOKENS:-1][sel]  # [R, D]; h[:, 256+k] for k in [0, L-1)
+        if row_index is None:
+            row_index = self.label_row_index(labels)
+        rows = h.reshape(-1, h.shape[-1]).index_select(0, row_index)  # [R, D]
         return self.lm_head(rows)
 
     def forward(self, input_ids, attention_mask=None, pixel_values=None, labels=None, **_):
