@@ -18,12 +18,21 @@ def main():
     ap.add_argument("--bs", type=int, default=64)
     ap.add_argument("--patch", type=str, default="50,50")
     ap.add_argument("--sweep", action="store_true")
-    ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--calib", action="store_true", help="also run a 512 MiB device copy (PMC calibration kernel)")
     args = ap.parse_args()
     from roboticattack_amd import benchmarks, ops
 
     ops.device_check()
     ph, pw = [int(v) for v in args.patch.split(",")]
+    if args.calib:
+        import torch
+
+        src = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device="cuda").normal_()
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        del src, dst
     res = {"suite": benchmarks.kernel_suite(args.bs, ph, pw, iters=args.iters)}
     if args.sweep:
         res["k2_sweep"] = benchmarks.k2_sweep(ph=ph, pw=pw, iters=max(5, args.iters // 2))
