@@ -149,6 +149,64 @@ def test_tma_upa_loops_run_and_improve(tmp_path, which):
     assert os.path.exists(os.path.join(str(tmp_path), "last", "patch.pt"))
 
 
+@pytest.mark.parametrize("tag", ["tma_adamw", "tma_pgd", "upa"])
+def test_tma_upa_trajectories_vs_reference_loops(tmp_path, tag):
+    """Replays runs of the REFERENCE's own TMA.patchattack_unconstrained (AdamW and PGD, paste_patch_fix path) and
+    UPA.patchattack_unconstrained (reverse_direction loss, L1 grad clip) made by tools/gen_golden.py:gen_trajectory_tma_upa."""
+    import types
+
+    from roboticattack_amd.surrogate import SurrogateVLA
+
+    d = np.load(os.path.join(GOLDEN, f"traj_{tag}.npz"))
+    n_it, inner, bs = int(d["num_iter"]), int(d["inner"]), int(d["bs"])
+    vla = SurrogateVLA(seed=int(d["model_seed"])).to(DEV)
+    args = types.SimpleNamespace(wandb_project="false")
+    train = _Fresh([int(d["train_seed0"]) + i for i in range(n_it)], bs)
+    val = _Fresh([int(d["val_seed"])], 1)
+    snaps = []
+    _seed()
+    if tag.startswith("tma"):
+        from roboticattack_amd.attack.tma import OpenVLAAttacker
+        from roboticattack_amd.optim import PatchOptimizer
+
+        att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer=str(d["optimizer"]))
+        run = lambda: att.patchattack_unconstrained(  # noqa: E731
+            train, val, num_iter=n_it, target_action=float(d["target_action"]) * np.ones(7), patch_size=[3, 50, 50], alpha=float(d["lr"]),
+            accumulate_steps=1, maskidx=list(d["maskidx"]), warmup=int(d["warmup"]), geometry=False, colorjitter=False, innerLoop=inner, args=args)
+    else:
+        from roboticattack_amd.attack.upa import OpenVLAAttacker
+        from roboticattack_amd.optim import PatchOptimizer
+
+        att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="adamW", alpha=float(d["alpha"]), belta=float(d["belta"]))
+        run = lambda: att.patchattack_unconstrained(  # noqa: E731
+            train, val, num_iter=n_it, patch_size=[3, 50, 50], lr=float(d["lr"]), accumulate_steps=1, maskidx=list(d["maskidx"]),
+            warmup=int(d["warmup"]), geometry=True, innerLoop=inner, guide=False, reverse_direction=True, args=args)
+    att.val_batches = 2
+    orig_step = PatchOptimizer.step
+
+    def rec(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        snaps.append(self.patch.detach().cpu().numpy().copy())
+        return r
+
+    PatchOptimizer.step = rec
+    try:
+        run()
+    finally:
+        PatchOptimizer.step = orig_step
+    np.testing.assert_allclose(att.train_CE_loss, d["train_ce"], rtol=3e-4)
+    last = torch.load(os.path.join(str(tmp_path), "last", "patch.pt")).numpy()
+    if "patches" in d:
+        ref = d["patches"]
+        assert len(snaps) == len(ref)
+        err = [float(np.abs(a - b).max()) for a, b in zip(snaps, ref)]
+        assert max(err) <= 1e-4, err
+        assert np.abs(last - d["last_saved"]).max() <= 1e-4
+    else:  # PGD: a sign flip on a ~zero gradient moves a pixel by 2*lr; allow a handful, everything else must agree
+        bad = np.abs(last - d["last_saved"]) > 1e-4
+        assert bad.sum() <= 5, int(bad.sum())
+
+
 def test_resize_patch_and_misc_transform_ops():
     from roboticattack_amd.transform import RandomPatchTransform
 

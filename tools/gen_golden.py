@@ -462,9 +462,92 @@ def gen_trajectory():
           "ce", att.train_CE_loss[:3], "files", sorted(os.listdir(save_dir)))
 
 
+# ------------------------------------------------------------------------------------------------
+# TMA / UPA trajectories through the reference's own loops (tiny surrogate model)
+# ------------------------------------------------------------------------------------------------
+class _TokWithText(ref_import.FakeTokenizer):
+    """TMA.py:93 round-trips the target through text: tokenizer(action_tokenizer(a)).input_ids[2:]. The fake keeps the ids:
+    decode() returns them, __call__() prepends the two tokens ([BOS, '_']) the Llama tokenizer would add."""
+
+    def decode(self, ids):
+        return list(int(i) for i in ids)
+
+    def __call__(self, ids, **_):
+        return types.SimpleNamespace(input_ids=[1, 29871] + list(ids))
+
+
+def _fresh_loader(seeds, b):
+    class _Fresh:
+        def __iter__(self):
+            for s_ in seeds:
+                yield synthetic.synth_batch(s_, b, "smooth")
+
+    return _Fresh()
+
+
+def _run_ref_loop(mod, make_attacker, run, tag, extra):
+    import transformers
+
+    from oracle.ref_port import HFAdamW
+    from roboticattack_amd.surrogate import SurrogateVLA
+
+    transformers.AdamW = HFAdamW
+    mod.transformers.AdamW = HFAdamW
+    mod.tqdm = lambda x, *a, **k: x
+    mod.range = lambda *a: __builtins__.range(2) if a == (100,) else __builtins__.range(*a)  # shrink the 100-batch validation
+    save_dir = f"/tmp/vaa_golden_{tag}"
+    shutil.rmtree(save_dir, ignore_errors=True)
+    os.makedirs(save_dir)
+    vla = SurrogateVLA(seed=4)
+    processor = types.SimpleNamespace(tokenizer=_TokWithText(), image_processor=types.SimpleNamespace(apply_transform=None))
+    att = make_attacker(vla, processor, save_dir)
+    snaps = []
+    orig_step = HFAdamW.step
+
+    def rec_step(self, closure=None):
+        orig_step(self)
+        snaps.append(self.param_groups[0]["params"][0].detach().clone().clamp(0, 1).numpy())
+
+    HFAdamW.step = rec_step
+    random.seed(42)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    try:
+        run(att, types.SimpleNamespace(wandb_project="false"))
+    finally:
+        HFAdamW.step = orig_step
+    last = torch.load(os.path.join(save_dir, "last", "patch.pt")).numpy()
+    d = dict(last_saved=last, model_seed=4, train_ce=np.array(att.train_CE_loss, np.float64), **extra)
+    if snaps:
+        d["patches"] = np.stack(snaps).astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, f"traj_{tag}.npz"), **d)
+    print(f"traj_{tag}: steps={len(snaps)} train_ce={att.train_CE_loss} files={sorted(os.listdir(save_dir))}")
+
+
+def gen_trajectory_tma_upa():
+    TMA, UPA = ref.TMA, ref.UPA
+    n_it, inner, bs = 3, 2, 2
+    common = dict(num_iter=n_it, inner=inner, bs=bs, train_seed0=8000, val_seed=8100)
+    for tag, opt, lr in (("tma_adamw", "adamW", 2e-2), ("tma_pgd", "pgd", 4e-3)):
+        _run_ref_loop(
+            TMA, lambda v, p, s_, opt=opt: TMA.OpenVLAAttacker(v, p, s_, optimizer=opt, resize_patch=False),
+            lambda att, args, lr=lr: att.patchattack_unconstrained(
+                _fresh_loader([8000 + i for i in range(n_it)], bs), _fresh_loader([8100], 1), num_iter=n_it, target_action=0.25 * np.ones(7),
+                patch_size=[3, 50, 50], alpha=lr, accumulate_steps=1, maskidx=[0, 1], warmup=1, filterGripTrainTo1=False,
+                geometry=False, colorjitter=False, innerLoop=inner, args=args),
+            tag, dict(lr=lr, warmup=1, maskidx=np.array([0, 1]), target_action=0.25, optimizer=opt, **common))
+    _run_ref_loop(
+        UPA, lambda v, p, s_: UPA.OpenVLAAttacker(v, p, s_, optimizer="adamW", resize_patch=False, alpha=0.8, belta=0.2),
+        lambda att, args: att.patchattack_unconstrained(
+            _fresh_loader([8000 + i for i in range(n_it)], bs), _fresh_loader([8100], 1), num_iter=n_it, patch_size=[3, 50, 50], lr=2e-2,
+            accumulate_steps=1, maskidx=[0, 1, 2], warmup=1, filterGripTrainTo1=False, geometry=True, innerLoop=inner, guide=False,
+            reverse_direction=True, args=args),
+        "upa", dict(lr=2e-2, warmup=1, maskidx=np.array([0, 1, 2]), alpha=0.8, belta=0.2, **common))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1k2", "rng", "labels", "k3", "sched", "fmt", "traj"]
+    which = sys.argv[1:] or ["k1k2", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2"]
     fns = dict(k1k2=gen_k1k2, rng=gen_rng_stream, labels=gen_labels_tokenizer, k3=gen_k3, sched=gen_sched, fmt=gen_patch_format,
-               traj=gen_trajectory)
+               traj=gen_trajectory, traj2=gen_trajectory_tma_upa)
     for w in which:
         fns[w]()
