@@ -236,14 +236,18 @@ def main():
                       "frac": nb / mean / 1e9 / HBM_PEAK_GBS}
     dom = max(kern, key=lambda k: kern[k]["mean_us"]) if kern else None
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if dom and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")  # rocprofv3 --pmc passes of tools/pmc_traffic.py (same kernels, same shapes)
+    tr_ops = json.load(open(tpath)).get("ops", {}) if os.path.exists(tpath) else {}
+    if dom:
+        traffic = tr_ops.get(dom, {}).get("hbm_bytes_per_launch")
+    for name in kern:
+        kern[name]["traffic"] = tr_ops.get(name, {}).get("hbm_bytes_per_launch")
     roofline = None
     if dom:
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kern[dom]["frac"], "traffic": traffic, "mean_us": kern[dom]["mean_us"], "algo_bytes": kern[dom]["algo_bytes"],
-                    "note": "event-bracketed launch sequence on the launching stream inside the timed region (includes launch gaps of multi-kernel ops)"}
+                    "note": "event-bracketed launch sequence on the launching stream inside the timed region (includes launch gaps of multi-kernel ops); "
+                            "traffic = HBM-side bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/traffic_r01.json, calibrated in-run)"}
 
     extra = {}
     if not args.no_kernel_suite:

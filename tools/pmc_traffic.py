@@ -72,6 +72,13 @@ def main():
         wm = sum(w) / len(w) if w else 0.0
         out[k] = {"launches": len(f), "FETCH_SIZE_KiB": fm, "WRITE_SIZE_KiB": wm, "read_bytes": fm * 1024 * f_fac,
                   "write_bytes": wm * 1024 * w_fac, "hbm_bytes_per_launch": fm * 1024 * f_fac + wm * 1024 * w_fac}
+    # per hot-path op (what bench.py's event brackets cover): sum over the op's kernels
+    ops = {"K1_patch_apply_fwd": ("patch_apply_fwd_kernel",), "K2_patch_grad_gather": ("patch_grad_scatter_kernel", "patch_grad_reduce_kernel"),
+           "K3_loss_fwd_bwd": ("loss_stats_kernel", "loss_grad_kernel"), "K4_patch_update": ("patch_update_kernel",)}
+    out["ops"] = {}
+    for op, kns in ops.items():
+        tot = sum(v["hbm_bytes_per_launch"] for k, v in out.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v and any(kn in k for kn in kns))
+        out["ops"][op] = {"hbm_bytes_per_launch": tot, "kernels": list(kns)}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
