@@ -53,6 +53,8 @@ def main(args):
         "maskidx": args.maskidx, "innerLoop": args.innerLoop, "geometry": args.geometry,
         "use_wandb": args.wandb_project != "false", "MSE_weights": args.MSE_weights,
     }
+    if args.attack != "UADA":  # extension: the same data-parallel loop for UPA / TMA (BASELINE configs 4-5)
+        instance_params.update(attack_type=args.attack, alpha=args.alpha, belta=args.belta, target_action=args.targetAction)
     OpenVLAAttacker._attack_entry(rank, instance_params, world)
     print("Attack done!")
 
@@ -62,6 +64,11 @@ def arg_parser(argv=None):
     cli.add_common(parser, lr=1e-3, maskidx="0", iters=2000, warmup=20, inner=50, device_default=None, tags=[""])
     parser.add_argument("--MSE_weights", default=5, type=int)
     parser.add_argument("--reverse_direction", type=cli.str2bool, default=True)
+    # extensions (not in the reference): run the UPA / TMA objectives in the same data-parallel loop
+    parser.add_argument("--attack", default="UADA", choices=["UADA", "UPA", "TMA"])
+    parser.add_argument("--alpha", type=float, default=0.8)
+    parser.add_argument("--belta", type=float, default=0.2)
+    parser.add_argument("--targetAction", default=0, type=float)
     return parser.parse_args(argv)
 
 

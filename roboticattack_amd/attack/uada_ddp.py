@@ -55,7 +55,9 @@ class OpenVLAAttacker(AttackBase):
 
     def __init__(self, vla_path, dataset_name, save_dir="", resize_patch=False, patch_size=[3, 50, 50], lr=0.01, bs=1, warmup=20,
                  num_iter=10000, maskidx=[], innerLoop=1, geometry=True, use_wandb=True, MSE_weights=1,
-                 model_factory=None, dataset_factory=None, device=None):
+                 model_factory=None, dataset_factory=None, device=None, attack_type="UADA", alpha=0.8, belta=0.2, target_action=0.0):
+        """`attack_type`, `alpha`, `belta`, `target_action` are EXTENSIONS (the reference ships DDP for UADA only):
+        "UPA" = UPA.py's reverse-direction loss + L1 grad clip, "TMA" = TMA.py's target-token CE, same data-parallel loop."""
         rank, world, local = vdist.env_rank_world()
         if device is None:
             device = torch.device(f"cuda:{local}") if torch.cuda.is_available() else torch.device("cpu")
@@ -71,6 +73,9 @@ class OpenVLAAttacker(AttackBase):
         self.patch_size = patch_size
         self.val_CE_loss, self.val_MSE_Distance, self.val_UAD = [], [], []
         self.MSE_weights = MSE_weights
+        if attack_type not in ("UADA", "UPA", "TMA"):
+            raise ValueError(f"attack_type must be UADA, UPA or TMA, got {attack_type!r}")
+        self.attack_type, self.alpha, self.belta, self.target_action = attack_type, alpha, belta, target_action
 
     def setup(self, rank, world_size):
         vdist.init_process_group(device=self.device if self.device.type == "cuda" else None)
@@ -96,8 +101,12 @@ class OpenVLAAttacker(AttackBase):
         vdist.broadcast_patch(patch, src=0)  # C1
         patch.requires_grad_(True)
         self.patch = patch
-        optimizer = PatchOptimizer(patch, self.lr, "adamW")
+        optimizer = PatchOptimizer(patch, self.lr, "adamW", l1_clip=1e-3 if self.attack_type == "UPA" else 0.0)  # UPA.py:157
         scheduler = CosineWarmupSchedule(optimizer, self.warmup, int(self.num_iter), 0.5)
+        if self.attack_type == "TMA":
+            from ..labels import tma_target_tokens
+
+            self._tma_target = tma_target_tokens(float(self.target_action) * torch.ones(7).numpy(), self.maskidx, self.action_tokenizer).to(dev)
         sync = vdist.PatchGradSync(patch.numel(), 4, dev)
         inv_world = 1.0 / world_size
         log_max_grad = 0.0
@@ -106,13 +115,14 @@ class OpenVLAAttacker(AttackBase):
             if i == self.num_iter:
                 break
             pixel_values, labels, attention_mask, input_ids = to_dev(data, dev)
-            labels = self.mask_labels(labels, self.maskidx)
+            labels = self._prepare_labels(labels)
             local_stats = None
             for inner_loop in range(self.innerLoop):
                 optimizer.zero_grad()
                 pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
                                                                           geometry=self.geometry)
-                total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, ops.LOSS_UADA_DDP, w=float(self.MSE_weights))
+                total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, self._loss_mode(), w=float(self.MSE_weights),
+                                                       alpha=self.alpha, beta=self.belta)
                 total.backward()  # K2 inside
                 local_stats = (patch.grad.mean(), scalars)
                 # C3 + C4 in one message: [grad | CE, MSE, UAD, mean-grad]
@@ -132,6 +142,18 @@ class OpenVLAAttacker(AttackBase):
         self.cleanup()
         return patch
 
+    def _loss_mode(self):
+        return {"UADA": ops.LOSS_UADA_DDP, "UPA": ops.LOSS_UPA, "TMA": ops.LOSS_CE}[self.attack_type]
+
+    def _prepare_labels(self, labels):
+        if self.attack_type == "UADA":
+            return self.mask_labels(labels, self.maskidx)
+        if self.attack_type == "TMA":
+            from ..labels import tma_target_labels
+
+            return tma_target_labels(labels, self._tma_target)
+        return labels  # UPA reverse_direction: labels stay unmasked (UPA.py:127-129)
+
     def validate(self, i, patch, rank):
         """UADA_ddp.py:233-324: 100 local val batches, 3 scalar all-reduces (C5), rank 0 writes the files."""
         avg_CE = avg_MSE = avg_UAD = 0.0
@@ -143,11 +165,11 @@ class OpenVLAAttacker(AttackBase):
                 pixel_values, labels, attention_mask, input_ids = to_dev(data, self.device)
                 modified_images = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch.detach(), mean=self.mean,
                                                                                       std=self.std, geometry=self.geometry)
-                labels = self.mask_labels(labels, self.maskidx)
-                _, scalars, _ = self.model_loss(input_ids, attention_mask, modified_images, labels, ops.LOSS_UADA_DDP,
-                                                w=float(self.MSE_weights), need_grad=False)
+                labels = self._prepare_labels(labels)
+                _, scalars, _ = self.model_loss(input_ids, attention_mask, modified_images, labels, self._loss_mode(),
+                                                w=float(self.MSE_weights), alpha=self.alpha, beta=self.belta, need_grad=False)
                 s = scalars.cpu().numpy()
-                avg_MSE += float(s[2])
+                avg_MSE += float(s[2] if self.attack_type == "UADA" else s[0])  # selection metric: MSE distance (UADA) or the attack loss
                 avg_UAD += float(s[7])
                 avg_CE += float(s[1])
         avg_MSE /= self.val_batches

@@ -250,3 +250,36 @@ def test_tiny_openvla_shaped_model_step():
     total, scalars, pred = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
     total.backward()
     assert bool(torch.isfinite(patch.grad).all()) and float(patch.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("attack", ["UADA", "UPA", "TMA"])
+def test_ddp_attacker_single_rank(tmp_path, attack, monkeypatch):
+    """The data-parallel attacker (UADA_ddp.py entry points) end to end on one rank: RCCL group of size 1, patch broadcast,
+    fused grad+scalar all-reduce, K4 with grad_scale, validation + rank-0 checkpoints. UPA / TMA modes are extensions."""
+    import socket
+
+    from roboticattack_amd.attack.uada_ddp import OpenVLAAttacker
+    from roboticattack_amd.synthetic import SyntheticLoader
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    for k, v in dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+    _seed()
+    params = dict(vla_path="surrogate:2", dataset_name="synthetic", save_dir=str(tmp_path), resize_patch=False, patch_size=[3, 50, 50],
+                  lr=0.02, bs=2, warmup=1, num_iter=3, maskidx=[0, 1, 2] if attack != "UADA" else [0], innerLoop=2, geometry=True,
+                  use_wandb=False, MSE_weights=5,
+                  dataset_factory=lambda name, bs, rank, world: (SyntheticLoader(bs, seed=1, kind="smooth"), SyntheticLoader(bs, seed=2, kind="smooth", length=2)))
+    if attack != "UADA":
+        params.update(attack_type=attack, target_action=0.25)
+    OpenVLAAttacker.val_batches = 2
+    try:
+        patch = OpenVLAAttacker._attack_entry(0, params, 1)
+    finally:
+        OpenVLAAttacker.val_batches = 100
+    assert bool(torch.isfinite(patch).all()) and float(patch.min()) >= 0 and float(patch.max()) <= 1
+    saved = torch.load(os.path.join(str(tmp_path), "last", "patch.pt"))
+    assert saved.dtype == torch.float32 and tuple(saved.shape) == (3, 50, 50)
+    assert os.path.exists(os.path.join(str(tmp_path), "0", "patch.pt"))
