@@ -122,6 +122,17 @@ int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const int64_t* l
 int vaa_patch_update(float* patch, const float* g, float* m, float* v, int n, int mode, float lr, float beta1, float beta2,
                      float eps, int step, float l1_clip, float grad_scale, float* stats, void* stream);
 
+/*
+ * Eval-time paste — replaces RandomPatchTransform.simulation_random_patch
+ * (appply_random_transform.py:43-78), called per simulator frame by the LIBERO evaluation
+ * (experiments/robot/libero/run_libero_eval_args_geo_batch.py:207): patch quantised to uint8 (ToPILImage), fixed
+ * rotation+shear warp when geometry[b] != 0, composite where canvas >= 0, uint8 HWC in and out. Batched over B frames.
+ *   img_u8, out_u8 dev [B,224,224,3] uint8;  patch dev [3,ph,pw] float32 in [0,1];  xy dev [B,2] int32 (position);
+ *   theta dev [B,6] float32 (rows 0-1 of shear_matrix(shx,shy) @ rotation_matrix(angle), :69-74);  geometry dev [B] int32
+ */
+int vaa_patch_apply_eval(const uint8_t* img_u8, const float* patch, const int32_t* xy, const float* theta, const int32_t* geometry,
+                         int B, int ph, int pw, uint8_t* out_u8, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

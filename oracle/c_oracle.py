@@ -99,3 +99,16 @@ def patch_update(patch, g, m, v, mode, lr, step, b1=0.9, b2=0.999, eps=1e-6, l1_
     return lib().vaa_oracle_patch_update(_p(patch, C.c_float), _p(g, C.c_float), _p(m, C.c_float), _p(v, C.c_float), patch.size,
                                          int(mode), C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), int(step),
                                          C.c_float(l1_clip), C.c_float(grad_scale))
+
+
+def patch_apply_eval(img_u8, patch, xy, theta, geometry):
+    """simulation_random_patch for a batch: geometry is a per-image bool array."""
+    img_u8 = np.ascontiguousarray(img_u8, np.uint8)
+    patch = np.ascontiguousarray(patch, np.float32)
+    xy = np.ascontiguousarray(xy, np.int32)
+    theta = np.ascontiguousarray(theta, np.float32).reshape(-1, 6)
+    geo = np.ascontiguousarray(np.asarray(geometry).astype(np.int32))
+    out = np.empty_like(img_u8)
+    lib().vaa_oracle_patch_apply_eval(_p(img_u8, C.c_uint8), _p(patch, C.c_float), _p(xy, C.c_int32), _p(theta, C.c_float), img_u8.shape[0],
+                                      patch.shape[1], patch.shape[2], _p(geo, C.c_int32), _p(out, C.c_uint8))
+    return out

@@ -348,3 +348,31 @@ float vaa_oracle_patch_update(float* patch, const float* g_in, float* m, float* 
     }
     return (float)l1;
 }
+
+/* Eval-time paste: RandomPatchTransform.simulation_random_patch (appply_random_transform.py:43-78).
+ * The patch is quantised like torchvision ToPILImage on a float tensor [3p]: mul(255).byte() (truncation), pasted on the
+ * -100 canvas as float, optionally warped (same affine_grid/grid_sample numerics as K1), composited where canvas >= 0,
+ * and the float result is truncated to uint8 (numpy astype). img_u8 / out_u8 are [B,224,224,3] HWC. */
+void vaa_oracle_patch_apply_eval(const uint8_t* img_u8, const float* patch, const int32_t* xy, const float* theta, int B, int ph,
+                                 int pw, const int32_t* geometry /*[B]*/, uint8_t* out_u8) {
+    float bgrid[IMG];
+    base_grid(bgrid);
+    const int n = 3 * ph * pw;
+    float* q = (float*)malloc(sizeof(float) * n);
+    for (int k = 0; k < n; ++k) q[k] = (float)(uint8_t)(patch[k] * 255.0f); /* mul(255).byte() */
+    for (int b = 0; b < B; ++b) {
+        const int px = xy[2 * b], py = xy[2 * b + 1];
+        const float* th = theta + 6 * b;
+        for (int i = 0; i < IMG; ++i)
+            for (int j = 0; j < IMG; ++j) {
+                samp_t s = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+                if (geometry[b]) s = sample_pos(bgrid, th, i, j);
+                for (int c = 0; c < 3; ++c) {
+                    float cv = geometry[b] ? sample_canvas(q, c, ph, pw, px, py, &s) : canvas_at(q, c, ph, pw, px, py, j, i);
+                    size_t o = ((size_t)(b * IMG + i) * IMG + j) * 3 + c;
+                    out_u8[o] = (cv < 0.0f) ? img_u8[o] : (uint8_t)cv; /* torch.where(canvas < 0, image, canvas) -> astype(uint8) */
+                }
+            }
+    }
+    free(q);
+}

@@ -28,6 +28,7 @@ EXPORTS = (
     "vaa_loss_ws_bytes",
     "vaa_loss_fwd_bwd",
     "vaa_patch_update",
+    "vaa_patch_apply_eval",
 )
 
 
@@ -78,6 +79,8 @@ def lib() -> C.CDLL:
     L.vaa_loss_fwd_bwd.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, vp, vp, sz, vp]
     L.vaa_patch_update.restype = i32
     L.vaa_patch_update.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp, vp]
+    L.vaa_patch_apply_eval.restype = i32
+    L.vaa_patch_apply_eval.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     _lib = L
     return L
 

@@ -222,3 +222,22 @@ def patch_update(patch, grad, m, v, mode: int, lr: float, step: int, beta1: floa
             float(grad_scale), stats.data_ptr() if want_stats else None, _stream())
     _lib.check(rc, "vaa_patch_update")
     return stats
+
+
+# ------------------------------------------------------------------------------------------------------
+# eval-time paste (simulation_random_patch)
+# ------------------------------------------------------------------------------------------------------
+def patch_apply_eval(img_u8, patch, xy, theta, geometry):
+    """uint8 frames [B,224,224,3] + float patch [3,ph,pw] -> uint8 frames with the (uint8-quantised, optionally warped) patch."""
+    B = img_u8.shape[0]
+    _need(img_u8, torch.uint8, "img_u8", (B, IMG, IMG, 3))
+    _need(patch, torch.float32, "patch")
+    _need(xy, torch.int32, "xy", (B, 2))
+    _need(theta, torch.float32, "theta", (B, 6))
+    _need(geometry, torch.int32, "geometry", (B,))
+    out = torch.empty_like(img_u8)
+    with _timed("K5_patch_apply_eval", B=B):
+        rc = _lib.lib().vaa_patch_apply_eval(img_u8.data_ptr(), patch.data_ptr(), xy.data_ptr(), theta.data_ptr(), geometry.data_ptr(), B,
+                                             int(patch.shape[1]), int(patch.shape[2]), out.data_ptr(), _stream())
+    _lib.check(rc, "vaa_patch_apply_eval")
+    return out

@@ -160,6 +160,23 @@ class RandomPatchTransform:
             canvases.append(c)
         return out, canvases
 
+    def simulation_random_patch(self, image, patch, geometry=False, colorjitter=False, angle=1, shx=0.1, shy=0.1, position=(0, 0)):
+        """:43-78 — eval-time paste on ONE uint8 HWC frame (numpy in, numpy out) with a fixed angle/shear/position."""
+        out = self.simulation_patch_batch(np.asarray(image, dtype=np.uint8)[None], patch, [geometry], [angle], [shx], [shy], [position])
+        return out[0].cpu().numpy()
+
+    def simulation_patch_batch(self, images_u8, patch, geometry, angle, shx, shy, position) -> torch.Tensor:
+        """Batched form for rollouts: per-frame geometry flag, angle (deg), shears and (x, y); returns uint8 [B,224,224,3] on device."""
+        img = self.stage_images(torch.as_tensor(np.asarray(images_u8)) if not isinstance(images_u8, torch.Tensor) else images_u8)
+        B = img.shape[0]
+        theta = np.empty((B, 6), np.float32)
+        for b in range(B):
+            m = np.dot(self.shear_matrix(shx[b], shy[b]), self.rotation_matrix(angle[b])) if geometry[b] else np.eye(3, dtype=np.float32)  # :66-73
+            theta[b] = m[:2].reshape(6)
+        xy = torch.from_numpy(np.asarray(position, np.int32).reshape(B, 2)).to(self.device)
+        geo = torch.from_numpy(np.asarray(geometry).astype(np.int32)).to(self.device)
+        return ops.patch_apply_eval(img, patch.detach().to(self.device, torch.float32).contiguous(), xy, torch.from_numpy(theta).to(self.device), geo)
+
     def im_process(self, images, mean, std, out_dtype=torch.bfloat16):
         """:190-197 — normalise the clean frames only (K1 with a 1x1 sentinel patch that is never kept)."""
         mean6, std6 = _six(mean, std)

@@ -374,3 +374,27 @@ def test_capi_error_paths_on_gpu(ops):
     rc = L.vaa_loss_fwd_bwd(g.data_ptr(), 7, 0, xy.data_ptr(), 2, 300, 40, 32064, 0, _lib.f32x([5, 0, 0, 1]), out.data_ptr(), None, None,
                             ws.data_ptr(), 16, None)
     assert rc == -1
+
+
+def test_eval_paste_vs_reference_and_oracle(ops):
+    """K5 (simulation_random_patch): byte-exact frames vs the reference's golden and vs the C oracle on a random batch."""
+    from roboticattack_amd.transform import RandomPatchTransform
+
+    d = np.load(os.path.join(GOLDEN, "sim_patch.npz"))
+    n = len(d["crc"])
+    imgs = synthetic.synth_images(int(d["img_seed"]), n, "smooth")
+    t = RandomPatchTransform(DEV)
+    patch = torch.from_numpy(d["patch"])
+    out = t.simulation_patch_batch(imgs, patch, list(d["geometry"]), list(d["angle"]), list(d["shx"]), list(d["shy"]), d["xy"]).cpu().numpy()
+    assert [zlib.crc32(o.tobytes()) for o in out] == [int(c) for c in d["crc"]]
+    one = t.simulation_random_patch(imgs[0], patch, geometry=bool(d["geometry"][0]), angle=float(d["angle"][0]), shx=float(d["shx"][0]),
+                                    shy=float(d["shy"][0]), position=tuple(int(v) for v in d["xy"][0]))
+    assert isinstance(one, np.ndarray) and one.dtype == np.uint8 and np.array_equal(one, out[0])
+    rs = np.random.RandomState(5)
+    B = 24
+    imgs2 = synthetic.synth_images(3, B, "noise")
+    p2 = rs.rand(3, 61, 37).astype(np.float32)
+    xy, th = _random_case(rs, B, 61, 37)
+    geo = rs.rand(B) < 0.7
+    got = ops.patch_apply_eval(_t(imgs2), _t(p2), _t(xy, torch.int32), _t(th.reshape(-1, 6)), _t(geo.astype(np.int32))).cpu().numpy()
+    assert np.array_equal(got, c_oracle.patch_apply_eval(imgs2, p2, xy, th, geo))

@@ -200,3 +200,13 @@ def test_adamw_restatement_self_consistency():
     torch.nn.utils.clip_grad_norm_([pt], max_norm=1e-3, norm_type=1)
     np.testing.assert_allclose(gt.numpy(), pt.grad.numpy(), rtol=1e-6)
     assert abs(tot.item() - np.abs(g).sum()) < 1e-3
+
+
+def test_c_oracle_eval_paste_byte_exact():
+    """simulation_random_patch (eval-time op): whole frames byte-identical to the reference (CRC) + the changed-pixel record."""
+    d = np.load(os.path.join(GOLDEN, "sim_patch.npz"))
+    imgs = synthetic.synth_images(int(d["img_seed"]), len(d["crc"]), "smooth")
+    out = c_oracle.patch_apply_eval(imgs, d["patch"], d["xy"], d["theta"], d["geometry"])
+    assert [zlib.crc32(o.tobytes()) for o in out] == [int(c) for c in d["crc"]]
+    ch = (out != imgs).any(-1)
+    assert np.array_equal(np.argwhere(ch).astype(np.int16), d["changed_idx"]) and np.array_equal(out[ch], d["changed_val"])

@@ -545,9 +545,32 @@ def gen_trajectory_tma_upa():
         "upa", dict(lr=2e-2, warmup=1, maskidx=np.array([0, 1, 2]), alpha=0.8, belta=0.2, **common))
 
 
+# ------------------------------------------------------------------------------------------------
+# eval-time paste: RandomPatchTransform.simulation_random_patch (appply_random_transform.py:43-78)
+# ------------------------------------------------------------------------------------------------
+def gen_sim():
+    t = TR.RandomPatchTransform(torch.device("cpu"), False)
+    imgs = synthetic.synth_images(77, 6, "smooth")
+    patch = _make_patch(42, (3, 50, 50))
+    cases = [(True, 10.0, 0.1, -0.1, (160, 80)), (True, -30.0, 0.2, 0.2, (0, 0)), (True, 25.0, -0.2, 0.05, (174, 174)),
+             (False, 1.0, 0.1, 0.1, (30, 140)), (True, 0.0, 0.0, 0.0, (100, 0)), (False, 0.0, 0.0, 0.0, (174, 0))]
+    outs, th = [], []
+    for b, (geo, ang, shx, shy, pos) in enumerate(cases):
+        outs.append(t.simulation_random_patch(imgs[b].copy(), patch.clone(), geometry=geo, angle=ang, shx=shx, shy=shy, position=pos))
+        th.append(np.dot(t.shear_matrix(shx, shy), t.rotation_matrix(ang))[:2] if geo else np.eye(3, dtype=np.float32)[:2])
+    out = np.stack(outs)
+    changed = (out != imgs).any(axis=-1)  # sparse record: every pixel that differs from the input frame + a CRC of each whole frame
+    np.savez_compressed(os.path.join(GOLD, "sim_patch.npz"), img_seed=77, patch=patch.numpy(), geometry=np.array([c[0] for c in cases]),
+                        angle=np.array([c[1] for c in cases]), shx=np.array([c[2] for c in cases]), shy=np.array([c[3] for c in cases]),
+                        xy=np.array([c[4] for c in cases], np.int32), theta=np.stack(th).astype(np.float32),
+                        changed_idx=np.argwhere(changed).astype(np.int16), changed_val=out[changed],
+                        crc=np.array([zlib.crc32(o.tobytes()) for o in outs], np.uint32))
+    print("sim_patch:", np.stack(outs).shape, [int((o != imgs[b]).any(axis=-1).sum()) for b, o in enumerate(outs)])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1k2", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2"]
+    which = sys.argv[1:] or ["k1k2", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "sim"]
     fns = dict(k1k2=gen_k1k2, rng=gen_rng_stream, labels=gen_labels_tokenizer, k3=gen_k3, sched=gen_sched, fmt=gen_patch_format,
-               traj=gen_trajectory, traj2=gen_trajectory_tma_upa)
+               traj=gen_trajectory, traj2=gen_trajectory_tma_upa, sim=gen_sim)
     for w in which:
         fns[w]()
