@@ -251,8 +251,30 @@ class OpenVLAShaped(nn.Module):
         return types.SimpleNamespace(loss=loss, logits=logits)
 
 
+def enable_tuned_gemms() -> bool:
+    """Point PyTorch-ROCm's TunableOp at the GEMM selections recorded on an MI355X for the bs=64 OpenVLA-7B step
+    (roboticattack_amd/tunableop/*.csv, one identical copy per device ordinal; made with PYTORCH_TUNABLEOP_TUNING=1, 30 ms per
+    candidate). Tuning itself stays off: unknown shapes fall back to the default hipBLASLt heuristic, a validator mismatch
+    (different ROCm / hipBLASLt build) ignores the file. Worth ~3 % of the step; honours a user's own PYTORCH_TUNABLEOP_* env."""
+    import os
+
+    if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is not None or os.environ.get("VAA_NO_TUNED_GEMMS"):
+        return False
+    try:
+        import torch.cuda.tunable as tunable
+
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.set_filename(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop", "openvla7b_bs64_mi355x.csv"), insert_device_ordinal=True)
+        return True
+    except Exception:
+        return False
+
+
 def build_openvla(cfg: OpenVLACfg | None = None, device="cuda", dtype=torch.bfloat16, seed: int = 0) -> OpenVLAShaped:
     """Random-init OpenVLA-7B-shaped model created directly on `device` in `dtype` (15 GB in bf16)."""
+    if torch.device(device).type == "cuda" and dtype == torch.bfloat16:
+        enable_tuned_gemms()
     with torch.device(device):
         m = OpenVLAShaped(cfg)
     m = m.to(dtype)
