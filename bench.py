@@ -259,7 +259,7 @@ def main():
         gpu_ops_s = sum(v["mean_us"] for v in ks.values()) * 1e-6
         extra["gpu_patch_path_steps_per_s"] = 1.0 / gpu_ops_s
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # host-CPU leg only at N=1 (rank 0), as the bench contract asks
         cpu = cpu_baseline(B, patch_shape, args.cpu_budget)
 
     line = {

@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("VAA_LIB_PATH") and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        build()  # compiling the HIP extension is not a fallback: the product still runs only through libvaa_hip.so
     if not os.path.exists(LIB_PATH):
         raise VaaError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
