@@ -398,3 +398,53 @@ def test_eval_paste_vs_reference_and_oracle(ops):
     geo = rs.rand(B) < 0.7
     got = ops.patch_apply_eval(_t(imgs2), _t(p2), _t(xy, torch.int32), _t(th.reshape(-1, 6)), _t(geo.astype(np.int32))).cpu().numpy()
     assert np.array_equal(got, c_oracle.patch_apply_eval(imgs2, p2, xy, th, geo))
+
+
+@pytest.mark.parametrize("name,B,ph,pw,geo,maskidx,mode", [
+    ("cfg1_uada_bs1", 1, 50, 50, 1, [0], "UADA"),                 # BASELINE.json configs[0]: bs=1 plumbing case
+    ("cfg2_uada_bs16_nogeo", 16, 50, 50, 0, [0], "UADA"),         # configs[1]: bs=16, geometry=False
+    ("cfg3_ddp_rank_bs8", 8, 50, 50, 1, [0], "UADA_DDP"),         # configs[2]: 64 over 8 ranks -> 8 per rank
+    ("cfg4_tma_rank_bs8", 8, 50, 50, 1, [0, 1, 2, 3, 4, 5, 6], "CE"),   # configs[3]: TMA, 32 over 4 ranks
+    ("cfg5_upa_rank_bs4_100", 4, 100, 100, 1, [0, 1, 2], "UPA"),  # configs[4]: UPA, 3x100x100, 32 over 8 ranks
+])
+def test_baseline_config_shapes_one_step_vs_oracle(ops, name, B, ph, pw, geo, maskidx, mode):
+    """One hot-path step (K1 -> K3 -> K2 -> K4) at the per-GPU shapes of every BASELINE.json config, each op against the oracle."""
+    from roboticattack_amd.labels import mask_labels, tma_target_labels, tma_target_tokens
+
+    rs = np.random.RandomState(len(name) + B)
+    imgs = synthetic.synth_images(B + ph, B, "smooth")
+    patch = rs.rand(3, ph, pw).astype(np.float32)
+    xy, theta = _random_case(rs, B, ph, pw)
+    out, keep = _run_k1(ops, imgs, patch, xy, theta, geo, 0)
+    _, o_bf16, o_keep = c_oracle.patch_apply_fwd(imgs, patch, xy, theta, geo, 0)
+    assert np.array_equal(_bits(out), o_bf16) and np.array_equal(_keep_unpack(keep), o_keep)
+    # K3 on bf16 rows, as the attack loops feed it
+    _, labels, _ = synthetic.synth_text_batch(31 + B, B)
+    if mode == "CE":
+        labels = tma_target_labels(labels, tma_target_tokens(np.zeros(7), maskidx))
+    elif mode != "UPA":
+        labels = mask_labels(labels, maskidx)
+    L = labels.shape[1]
+    rows = _rows(labels.numpy())
+    full = torch.zeros((B, 256 + L, 32064), dtype=torch.float32)
+    for (b, p) in rows:
+        full[b, p] = torch.from_numpy((rs.standard_normal(32064) * 2).astype(np.float32)).to(torch.bfloat16).float()
+    compact = full[torch.tensor([r[0] for r in rows]), torch.tensor([r[1] for r in rows])].to(torch.bfloat16).contiguous().to(DEV)
+    kmode = {"UADA": ops.LOSS_UADA, "UADA_DDP": ops.LOSS_UADA_DDP, "CE": ops.LOSS_CE, "UPA": ops.LOSS_UPA}[mode]
+    omode = {"UADA": c_oracle.MODE_UADA, "UADA_DDP": c_oracle.MODE_UADA_DDP, "CE": c_oracle.MODE_CE, "UPA": c_oracle.MODE_UPA}[mode]
+    sc, _, g = ops.loss_fwd_bwd(compact, labels.to(DEV), kmode, w=5.0, layout=ops.LAYOUT_ROWS)
+    so, go = c_oracle.loss(full.numpy(), labels.numpy(), omode, w=5.0)
+    assert np.allclose(sc.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5)
+    gor = go[np.array([r[0] for r in rows]), np.array([r[1] for r in rows])]
+    assert np.abs(g.float().cpu().numpy() - gor).max() <= 1e-2 * max(np.abs(gor).max(), 1e-30)  # bf16 gradient storage
+    # K2 + K4
+    gup = synthetic.synth_upstream_grad(17, B)
+    og = c_oracle.patch_grad(_bits(gup), patch, xy, theta, geo, 0)
+    gg = ops.patch_grad_gather(gup.to(DEV), _t(patch), _t(xy, torch.int32), _t(theta.reshape(-1, 6)), keep, bool(geo), 0)
+    assert np.abs(gg.cpu().numpy() - og).max() <= 3e-6 * np.abs(og).max()
+    p = _t(patch)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    ops.patch_update(p, gg, m, v, ops.OPT_ADAMW_HF, 2e-3, 1, l1_clip=1e-3 if mode == "UPA" else 0.0)
+    pc, mc, vc = patch.copy().ravel(), np.zeros(patch.size, np.float32), np.zeros(patch.size, np.float32)
+    c_oracle.patch_update(pc, og.ravel().copy(), mc, vc, 0, 2e-3, 1, l1_clip=1e-3 if mode == "UPA" else 0.0)
+    assert np.abs(p.cpu().numpy().ravel() - pc).max() <= 1e-4  # north-star tolerance on the updated pixels
