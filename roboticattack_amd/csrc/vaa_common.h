@@ -129,6 +129,18 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -163,12 +163,13 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
     if (tid == 0) { red_min = VAA_IMG; red_max = -1; red_n = 0; }
     if (tid < VAA_IMG) bgrid[tid] = base_coord(tid);
     __syncthreads();
-    if (tid < VAA_IMG) {
-        int lo, hi;
-        row_items(a, b, tid, lo, hi);
+    {   // row table + footprint extent; same-address LDS atomics serialise, so reduce in the wave first (4 atomics, not 224)
+        int lo = 0, hi = -1;
+        if (tid < VAA_IMG) row_items(a, b, tid, lo, hi);
         const int n = hi - lo + 1;
-        row_word[tid] = ((uint32_t)(lo & 0xff) << 8) | (uint32_t)(n > 0 ? n : 0);
-        if (n > 0) { atomicMin(&red_min, tid); atomicMax(&red_max, tid); atomicMax(&red_n, n); }
+        if (tid < VAA_IMG) row_word[tid] = ((uint32_t)(lo & 0xff) << 8) | (uint32_t)(n > 0 ? n : 0);
+        const int wmin = wave_min_i(n > 0 ? tid : VAA_IMG), wmax = wave_max_i(n > 0 ? tid : -1), wn = wave_max_i(n > 0 ? n : 0);
+        if ((tid & 63) == 0) { atomicMin(&red_min, wmin); atomicMax(&red_max, wmax); atomicMax(&red_n, wn); }
     }
     __syncthreads();
     const int rmin = red_min, nrows = red_max - rmin + 1;

@@ -30,7 +30,7 @@ struct GradArgs {
     const uint8_t* keep;
     float* partial;
     int B, ph, pw, geometry, mask_mode;
-    float std6[6];
+    float istd6[6];  // 1/std, rounded from double on the host
 };
 
 constexpr int kGradThreads = 1024;  // 16 waves: two workgroups per CU with the 60 KB fp64 tile
@@ -66,39 +66,46 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
         if (tid < kImgsPerPass) { row_min[tid] = VAA_IMG; row_max[tid] = -1; len_max[tid] = 0; }
         __syncthreads();
         // ---- per-row column bounds of each footprint (conservative) ----
-        for (int r = tid; r < nimg * VAA_IMG; r += kGradThreads) {
-            const int q = r / VAA_IMG, i = r - q * VAA_IMG;
-            const int b = b0 + q * gx;
-            const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
-            int jlo = 0, jhi = -1;
-            if (a.geometry) {
-                float th[6];
+        // 1024 threads cover 4 images x 256 row slots per round (rows 224..255 idle), so a wave never straddles two images
+        // and the extent reduction is one shuffle tree + 3 LDS atomics per wave instead of 3 same-address atomics per row
+        for (int r0 = 0; r0 < nimg * 256; r0 += kGradThreads) {
+            const int r = r0 + tid;
+            const int q = r >> 8, i = r & 255;
+            int len = 0;
+            if (q < nimg && i < VAA_IMG) {
+                const int b = b0 + q * gx;
+                const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
+                int jlo = 0, jhi = -1;
+                if (a.geometry) {
+                    float th[6];
 #pragma unroll
-                for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
-                const PixAffine pa = pix_affine(th);
-                // source x must fall in [px-1, px+pw) (corner x0 or x0+1 on the patch); a side that lies on the
-                // frame edge also receives every clamped out-of-frame sample (padding_mode='border').
-                const float xlo = (px == 0) ? -1e30f : (float)(px - 1);
-                const float xhi = (px + a.pw == VAA_IMG) ? 1e30f : (float)(px + a.pw);
-                const float ylo = (py == 0) ? -1e30f : (float)(py - 1);
-                const float yhi = (py + a.ph == VAA_IMG) ? 1e30f : (float)(py + a.ph);
-                float jl = -1e30f, jh = 1e30f;
-                solve_interval(pa.a00, pa.a01 * (float)i + pa.c0, xlo, xhi, jl, jh);
-                solve_interval(pa.a10, pa.a11 * (float)i + pa.c1, ylo, yhi, jl, jh);
-                if (jl <= jh) {
-                    jlo = (int)fmaxf(0.0f, floorf(jl) - 1.0f);
-                    jhi = (int)fminf((float)(VAA_IMG - 1), ceilf(jh) + 1.0f);
+                    for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
+                    const PixAffine pa = pix_affine(th);
+                    // source x must fall in [px-1, px+pw) (corner x0 or x0+1 on the patch); a side that lies on the
+                    // frame edge also receives every clamped out-of-frame sample (padding_mode='border').
+                    const float xlo = (px == 0) ? -1e30f : (float)(px - 1);
+                    const float xhi = (px + a.pw == VAA_IMG) ? 1e30f : (float)(px + a.pw);
+                    const float ylo = (py == 0) ? -1e30f : (float)(py - 1);
+                    const float yhi = (py + a.ph == VAA_IMG) ? 1e30f : (float)(py + a.ph);
+                    float jl = -1e30f, jh = 1e30f;
+                    solve_interval(pa.a00, pa.a01 * (float)i + pa.c0, xlo, xhi, jl, jh);
+                    solve_interval(pa.a10, pa.a11 * (float)i + pa.c1, ylo, yhi, jl, jh);
+                    if (jl <= jh) {
+                        jlo = (int)fmaxf(0.0f, floorf(jl) - 1.0f);
+                        jhi = (int)fminf((float)(VAA_IMG - 1), ceilf(jh) + 1.0f);
+                    }
+                } else if (i >= py && i < py + a.ph) {
+                    jlo = px;
+                    jhi = px + a.pw - 1;
                 }
-            } else if (i >= py && i < py + a.ph) {
-                jlo = px;
-                jhi = px + a.pw - 1;
+                len = max(0, jhi - jlo + 1);
+                row_word[q][i] = ((uint32_t)jlo << 16) | (uint32_t)len;
             }
-            const int len = max(0, jhi - jlo + 1);
-            row_word[q][i] = ((uint32_t)jlo << 16) | (uint32_t)len;
-            if (len > 0) {
-                atomicMin(&row_min[q], i);
-                atomicMax(&row_max[q], i);
-                atomicMax(&len_max[q], len);
+            const int wmin = wave_min_i(len > 0 ? i : VAA_IMG), wmax = wave_max_i(len > 0 ? i : -1), wlen = wave_max_i(len);
+            if ((tid & 63) == 0 && q < nimg && wlen > 0) {
+                atomicMin(&row_min[q], wmin);
+                atomicMax(&row_max[q], wmax);
+                atomicMax(&len_max[q], wlen);
             }
         }
         __syncthreads();
@@ -134,8 +141,15 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
                 }
                 const int u0 = s.x0 - px, v0 = s.y0 - py;
                 if (u0 < -1 || u0 >= a.pw || v0 < -1 || v0 >= a.ph) continue;
+                // corners that fall off the patch (or off the frame) get weight 0 and are redirected to an in-tile cell:
+                // x + 0.0 is exact, so the four LDS adds need no per-corner branch.
                 const bool uin0 = u0 >= 0, uin1 = (u0 + 1 < a.pw) && (s.x0 + 1 < VAA_IMG);
                 const bool vin0 = v0 >= 0, vin1 = (v0 + 1 < a.ph) && (s.y0 + 1 < VAA_IMG);
+                const int uc0 = uin0 ? u0 : u0 + 1, uc1 = uin1 ? u0 + 1 : u0;   // at least one of each pair is inside
+                const int vc0 = vin0 ? v0 : v0 + 1, vc1 = vin1 ? v0 + 1 : v0;
+                const float wnw = (vin0 && uin0) ? s.nw : 0.0f, wne = (vin0 && uin1) ? s.ne : 0.0f;
+                const float wsw = (vin1 && uin0) ? s.sw : 0.0f, wse = (vin1 && uin1) ? s.se : 0.0f;
+                const int o_nw = vc0 * a.pw + uc0, o_ne = vc0 * a.pw + uc1, o_sw = vc1 * a.pw + uc0, o_se = vc1 * a.pw + uc1;
                 const int pix = i * VAA_IMG + j;
                 const uint16_t* gb = gimg + pix;
                 // issue every load of this pixel before the first use
@@ -159,14 +173,15 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
                         kept = keep_rule(cv, a.mask_mode);
                     }
                     if (!kept) continue;
-                    // d/d(im) of (im-mean)/std for both normalisations (true divisions, as autograd does), fp32 products
-                    // exactly like the reference's scatter; only the ACCUMULATION is fp64 (order-independent sum).
-                    const float G = bf16_bits_to_f32(g0[cc]) / a.std6[c] + bf16_bits_to_f32(g1[cc]) / a.std6[c + 3];
-                    ACC* t0 = acc + cc * plane + v0 * a.pw + u0;
-                    if (vin0 && uin0) atomicAdd(t0, (ACC)(G * s.nw));
-                    if (vin0 && uin1) atomicAdd(t0 + 1, (ACC)(G * s.ne));
-                    if (vin1 && uin0) atomicAdd(t0 + a.pw, (ACC)(G * s.sw));
-                    if (vin1 && uin1) atomicAdd(t0 + a.pw + 1, (ACC)(G * s.se));
+                    // d/d(im) of (im-mean)/std for both normalisations. Reciprocals are rounded once on the host (exact for
+                    // the 0.5 of the second normalisation, <= 1 ulp for the first); only the ACCUMULATION is fp64, which
+                    // makes the sum independent of arrival order.
+                    const float G = bf16_bits_to_f32(g0[cc]) * a.istd6[c] + bf16_bits_to_f32(g1[cc]) * a.istd6[c + 3];
+                    ACC* tb = acc + cc * plane;
+                    atomicAdd(tb + o_nw, (ACC)(G * wnw));
+                    atomicAdd(tb + o_ne, (ACC)(G * wne));
+                    atomicAdd(tb + o_sw, (ACC)(G * wsw));
+                    atomicAdd(tb + o_se, (ACC)(G * wse));
                 }
             }
         }
@@ -249,7 +264,7 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     GradArgs a;
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
-    for (int q = 0; q < 6; ++q) a.std6[q] = std6[q];
+    for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
     const GradSched gs = grad_sched(B);
     const int G = gs.gx * gs.split;  // workgroups (x) == partial tiles
     const size_t plane = (size_t)ph * pw;
