@@ -198,6 +198,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # PCIe leg, outside the timed region: staging the batch's frames (host list of uint8 HWC arrays -> HBM), done once per
+    # OUTER iteration by the attack loops; the reference re-does ToTensor + H2D for every image on every inner step.
+    host_frames = [np.ascontiguousarray(f) for f in batch["pixel_values"]]
+    tr.stage_images(host_frames)
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter()
+    tr._staged_key = None
+    tr.stage_images(host_frames)
+    torch.cuda.synchronize()
+    stage_ms = (time.perf_counter() - t_stage) * 1e3
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -270,7 +281,9 @@ def main():
         "config": {"workload": f"UADA_wrapper_ddp inner step: bs={B} per rank (global {B * world}), patch {args.patch}, geometry=True, maskidx=[0], "
                                f"{model_desc}; frames resident in HBM as u8",
                    "global_batch": B * world, "images_per_s": B * world * args.steps / dt, "parallelism": f"dp{world}",
-                   "labelled_rows_per_rank": R, "lm_head": "labelled rows only" if use_rows else "full logits"},
+                   "labelled_rows_per_rank": R, "lm_head": "labelled rows only" if use_rows else "full logits",
+                   "h2d_stage_ms_per_outer_iteration": stage_ms,
+                   "pcie_inclusive_value_if_restaged_every_step": world * args.steps / (dt + args.steps * stage_ms * 1e-3)},
         "roofline": roofline, "roofline_kernels": kern, "cpu_baseline": cpu,
         "peak_mem_GiB": peak_mem, "loss_finite": finite,
     }

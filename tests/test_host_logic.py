@@ -136,3 +136,47 @@ def test_tiny_model_rows_equal_full_logits():
     full = torch.stack([out.logits[b, p] for b, p in sel])
     assert torch.allclose(full, rows, atol=1e-5) and out.logits.shape == (3, 256 + L, 32064)
     assert all(not p.requires_grad for p in m.parameters())
+
+
+def test_hf_checkpoint_name_mapping_roundtrip(tmp_path):
+    """`load_hf_openvla` maps an HF-OpenVLA-named safetensors checkpoint (modeling_prismatic.py module tree: vision_backbone.
+    {featurizer,fused_featurizer}.blocks.N.attn.qkv ..., projector.fcK, language_model.model.layers.N.self_attn.q_proj ...) onto the
+    plain module tree. No real weights exist in this image, so a tiny checkpoint with HF names is synthesised from a reference
+    instance and must load back bit-identically (logits equal)."""
+    from safetensors.torch import save_file
+
+    from roboticattack_amd.openvla_model import OpenVLAShaped, load_hf_openvla, tiny_cfg
+
+    src = OpenVLAShaped(tiny_cfg()).init_random(3).eval()
+    hf = {}
+    for name, p in src.named_parameters():
+        n = name
+        if n.startswith("featurizer.") or n.startswith("fused_featurizer."):
+            pre, rest = n.split(".", 1)
+            if rest == "prefix":
+                hf[f"vision_backbone.{pre}.cls_token"] = p[:, :1].clone()
+                hf[f"vision_backbone.{pre}.reg_token"] = p[:, 1:].clone()
+                continue
+            rest = rest.replace("patch_embed.", "patch_embed.proj.")
+            rest = rest.replace(".qkv.", ".attn.qkv.").replace(".proj.weight", ".attn.proj.weight").replace(".proj.bias", ".attn.proj.bias")
+            rest = rest.replace("patch_embed.attn.proj", "patch_embed.proj")  # undo the attn rename on the patch embed
+            rest = rest.replace(".fc1.", ".mlp.fc1.").replace(".fc2.", ".mlp.fc2.").replace(".ls1", ".ls1.scale_factor").replace(".ls2", ".ls2.scale_factor")
+            hf[f"vision_backbone.{pre}.{rest}"] = p.detach().clone()
+        elif n.startswith("fc"):
+            hf[f"projector.{n}"] = p.detach().clone()
+        elif n.startswith("lm_head."):
+            hf[f"language_model.{n}"] = p.detach().clone()
+        else:
+            n2 = n
+            for proj in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                n2 = n2.replace(f".{proj}.", f".self_attn.{proj}.")
+            for proj in ("gate_proj", "up_proj", "down_proj"):
+                n2 = n2.replace(f".{proj}.", f".mlp.{proj}.")
+            hf[f"language_model.model.{n2}"] = p.detach().clone()
+    save_file({k: v.contiguous() for k, v in hf.items()}, str(tmp_path / "model-00001-of-00001.safetensors"))
+    dst = load_hf_openvla(OpenVLAShaped(tiny_cfg()).eval(), str(tmp_path))
+    for (n1, p1), (n2, p2) in zip(src.named_parameters(), dst.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    ids, labels, attn = synthetic.synth_text_batch(2, 2, 18, 20)
+    pix = torch.randn(2, 6, 224, 224)
+    assert torch.equal(src(ids, attn, pix, labels).logits, dst(ids, attn, pix, labels).logits)
