@@ -18,6 +18,8 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 LAYOUT_FULL, LAYOUT_ROWS = 0, 1
 OPT_ADAMW_HF, OPT_PGD_SIGN = 0, 1
 
+MODEL_OP_EXPORTS = ("vaa_model_rope", "vaa_model_swiglu_fwd", "vaa_model_swiglu_bwd")
+
 EXPORTS = (
     "vaa_last_error",
     "vaa_version",
@@ -83,6 +85,14 @@ def lib() -> C.CDLL:
     L.vaa_patch_update.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp, vp]
     L.vaa_patch_apply_eval.restype = i32
     L.vaa_patch_apply_eval.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    # optional model-side operators (include/vaa_model_ops.h)
+    lng = C.c_long
+    L.vaa_model_rope.restype = i32
+    L.vaa_model_rope.argtypes = [vp, lng, lng, lng, vp, vp, i32, i32, i32, i32, f32, vp, vp]
+    L.vaa_model_swiglu_fwd.restype = i32
+    L.vaa_model_swiglu_fwd.argtypes = [vp, vp, vp, lng, vp]
+    L.vaa_model_swiglu_bwd.restype = i32
+    L.vaa_model_swiglu_bwd.argtypes = [vp, vp, vp, vp, vp, lng, vp]
     _lib = L
     return L
 

@@ -1,0 +1,130 @@
+// vaa_model_ops.hip — OPTIONAL fused elementwise operators for the PyTorch-ROCm model around the hot path.
+//
+// NOT part of the SURVEY.md section-8 contract: the reference keeps the OpenVLA forward/backward as stock PyTorch and so
+// does this build (roboticattack_amd/openvla_model.py). rocprofv3 shows 25 % of the bs=64 step in eager elementwise /
+// copy kernels of the Llama layers (RoPE = neg + cat + 2 mul + add per tensor, SwiGLU = silu + mul and their multi-kernel
+// backwards); the two kernels below replace those chains by single HBM-bound passes. The model falls back to the eager
+// PyTorch ops when they are disabled (VAA_NO_FUSED_MODEL_OPS=1) or the tensors are not bf16 on a ROCm device.
+#include "vaa_common.h"
+
+namespace vaa {
+
+// ---- rotary embedding, forward and backward (the backward is the same rotation with -sin) ----
+// x: bf16 [B,T,H,hd] addressed through element strides (sb, st, sh), last dim contiguous; out: bf16 contiguous [B,T,H,hd].
+// out[..., i]        = x[i]*cos[t,i]        - x[i+hd/2]*sin[t,i]*sgn
+// out[..., i+hd/2]   = x[i+hd/2]*cos[t,i]   + x[i]*sin[t,i]*sgn                 (HF rotate_half convention)
+struct RopeArgs {
+    const uint16_t* x;
+    uint16_t* out;
+    const float* cos;  // [T, hd/2]
+    const float* sin;  // [T, hd/2]
+    long sb, st, sh;
+    int B, T, H, hd;
+    float sgn;
+};
+
+__global__ __launch_bounds__(256) void rope_kernel(const RopeArgs a) {
+    const int half = a.hd >> 1, vec_per_row = half >> 3;  // 8 bf16 per 16-byte vector
+    const long nvec = (long)a.B * a.T * a.H * vec_per_row;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const int iv = (int)(v % vec_per_row);
+        const long row = v / vec_per_row;  // (b*T + t)*H + h
+        const int h = (int)(row % a.H);
+        const long bt = row / a.H;
+        const int t = (int)(bt % a.T), b = (int)(bt / a.T);
+        const uint16_t* xp = a.x + (long)b * a.sb + (long)t * a.st + (long)h * a.sh + iv * 8;
+        const uint4 lo = *reinterpret_cast<const uint4*>(xp), hi = *reinterpret_cast<const uint4*>(xp + half);
+        const float4 c0 = *reinterpret_cast<const float4*>(a.cos + (long)t * half + iv * 8), c1 = *reinterpret_cast<const float4*>(a.cos + (long)t * half + iv * 8 + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(a.sin + (long)t * half + iv * 8), s1 = *reinterpret_cast<const float4*>(a.sin + (long)t * half + iv * 8 + 4);
+        const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const uint32_t lw[4] = {lo.x, lo.y, lo.z, lo.w}, hw[4] = {hi.x, hi.y, hi.z, hi.w};
+        uint32_t ol[4], oh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x1a = __uint_as_float(lw[q] << 16), x1b = __uint_as_float(lw[q] & 0xffff0000u);
+            const float x2a = __uint_as_float(hw[q] << 16), x2b = __uint_as_float(hw[q] & 0xffff0000u);
+            const float sa = sn[2 * q] * a.sgn, sb2 = sn[2 * q + 1] * a.sgn;
+            const float o1a = x1a * cs[2 * q] - x2a * sa, o1b = x1b * cs[2 * q + 1] - x2b * sb2;
+            const float o2a = x2a * cs[2 * q] + x1a * sa, o2b = x2b * cs[2 * q + 1] + x1b * sb2;
+            ol[q] = f32_to_bf16_bits(o1a) | (f32_to_bf16_bits(o1b) << 16);
+            oh[q] = f32_to_bf16_bits(o2a) | (f32_to_bf16_bits(o2b) << 16);
+        }
+        uint16_t* op = a.out + row * a.hd + iv * 8;
+        *reinterpret_cast<uint4*>(op) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+        *reinterpret_cast<uint4*>(op + half) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+    }
+}
+
+// ---- SwiGLU: y = silu(g) * u ;  backward: dg = dy * u * sig(g) * (1 + g*(1 - sig(g))), du = dy * silu(g) ----
+__device__ __forceinline__ void unpack8(const uint4& r, float* v) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    return make_uint4(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16), f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16),
+                      f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16), f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16));
+}
+
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ u, uint16_t* __restrict__ y, long nvec) {
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        float gv[8], uv[8], o[8];
+        unpack8(reinterpret_cast<const uint4*>(g)[v], gv);
+        unpack8(reinterpret_cast<const uint4*>(u)[v], uv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = gv[e] / (1.0f + __expf(-gv[e])) * uv[e];
+        reinterpret_cast<uint4*>(y)[v] = pack8(o);
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ g, const uint16_t* __restrict__ u,
+                                                          uint16_t* __restrict__ dg, uint16_t* __restrict__ du, long nvec) {
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        float dv[8], gv[8], uv[8], og[8], ou[8];
+        unpack8(reinterpret_cast<const uint4*>(dy)[v], dv);
+        unpack8(reinterpret_cast<const uint4*>(g)[v], gv);
+        unpack8(reinterpret_cast<const uint4*>(u)[v], uv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = 1.0f / (1.0f + __expf(-gv[e]));
+            ou[e] = dv[e] * gv[e] * sg;
+            og[e] = dv[e] * uv[e] * sg * (1.0f + gv[e] * (1.0f - sg));
+        }
+        reinterpret_cast<uint4*>(dg)[v] = pack8(og);
+        reinterpret_cast<uint4*>(du)[v] = pack8(ou);
+    }
+}
+
+static unsigned stream_grid(long nvec) {
+    long b = (nvec + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace vaa
+
+extern "C" int vaa_model_rope(const uint16_t* x, long sb, long st, long sh, const float* cos_t, const float* sin_t, int B, int T, int H, int hd,
+                              float sin_sign, uint16_t* out, void* stream) {
+    using namespace vaa;
+    if (!x || !cos_t || !sin_t || !out) { set_error("vaa_model_rope: null pointer argument"); return VAA_E_INVALID; }
+    if (B <= 0 || T <= 0 || H <= 0 || hd <= 0 || (hd % 16) != 0) { set_error("vaa_model_rope: bad sizes (hd must be a multiple of 16)"); return VAA_E_INVALID; }
+    RopeArgs a;
+    a.x = x; a.out = out; a.cos = cos_t; a.sin = sin_t; a.sb = sb; a.st = st; a.sh = sh; a.B = B; a.T = T; a.H = H; a.hd = hd; a.sgn = sin_sign;
+    const long nvec = (long)B * T * H * (hd / 16);
+    hipLaunchKernelGGL(rope_kernel, dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("vaa_model_rope");
+}
+
+extern "C" int vaa_model_swiglu_fwd(const uint16_t* gate, const uint16_t* up, uint16_t* y, long n, void* stream) {
+    using namespace vaa;
+    if (!gate || !up || !y || n <= 0 || (n % 8) != 0) { set_error("vaa_model_swiglu_fwd: bad arguments (n must be a positive multiple of 8)"); return VAA_E_INVALID; }
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, gate, up, y, n / 8);
+    return check_launch("vaa_model_swiglu_fwd");
+}
+
+extern "C" int vaa_model_swiglu_bwd(const uint16_t* dy, const uint16_t* gate, const uint16_t* up, uint16_t* dgate, uint16_t* dup, long n, void* stream) {
+    using namespace vaa;
+    if (!dy || !gate || !up || !dgate || !dup || n <= 0 || (n % 8) != 0) { set_error("vaa_model_swiglu_bwd: bad arguments"); return VAA_E_INVALID; }
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, dy, gate, up, dgate, dup, n / 8);
+    return check_launch("vaa_model_swiglu_bwd");
+}

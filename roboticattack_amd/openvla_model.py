@@ -156,17 +156,27 @@ class LlamaLayer(nn.Module):
         self.up_proj = nn.Linear(d, c.llm_mlp, bias=False)
         self.down_proj = nn.Linear(c.llm_mlp, d, bias=False)
 
-    def forward(self, x, cos, sin):
+    def forward(self, x, cos, sin, rope_tab=None):
+        from . import model_ops
+
         B, T, D = x.shape
         h = self.input_layernorm(x)
         hd = D // self.heads
-        q = self.q_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
-        k = self.k_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
-        v = self.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
-        q, k = _rope(q, k, cos, sin)
+        fused = rope_tab is not None and model_ops.enabled(h) and hd % 16 == 0
+        if fused:  # one HBM pass per tensor instead of neg + cat + 2 mul + add (and their autograd chains)
+            q = model_ops.RopeFn.apply(self.q_proj(h).view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)
+            k = model_ops.RopeFn.apply(self.k_proj(h).view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)
+            v = self.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+        else:
+            q = self.q_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+            k = self.k_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+            v = self.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+            q, k = _rope(q, k, cos, sin)
         a = F.scaled_dot_product_attention(q, k, v, is_causal=True)  # right padding + causal == HF's mask on real tokens
         x = x + self.o_proj(a.transpose(1, 2).reshape(B, T, D))
         h = self.post_attention_layernorm(x)
+        if fused and (h.shape[0] * h.shape[1] * self.gate_proj.out_features) % 8 == 0:
+            return x + self.down_proj(model_ops.SwiGLUFn.apply(self.gate_proj(h), self.up_proj(h)))
         return x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
 
 
@@ -219,8 +229,11 @@ class OpenVLAShaped(nn.Module):
         ang = torch.outer(torch.arange(T, device=x.device, dtype=torch.float32), inv)
         ang = torch.cat([ang, ang], dim=-1)
         cos, sin = ang.cos().to(x.dtype)[None, None], ang.sin().to(x.dtype)[None, None]
+        half = ang[:, : hd // 2]
+        # fused path: HF rounds cos/sin to the activation dtype before use (modeling_llama rotary) — keep that rounding
+        rope_tab = (half.cos().to(x.dtype).float().contiguous(), half.sin().to(x.dtype).float().contiguous())
         for layer in self.layers:
-            x = layer(x, cos, sin)
+            x = layer(x, cos, sin, rope_tab)
         return self.norm(x)
 
     @staticmethod

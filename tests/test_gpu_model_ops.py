@@ -1,0 +1,87 @@
+"""Optional model-side fused operators (include/vaa_model_ops.h) against the eager PyTorch formulation they replace."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rope_ref(q, k, cos, sin):
+    from roboticattack_amd.openvla_model import _rope
+
+    return _rope(q, k, cos, sin)
+
+
+def test_rope_fwd_bwd_matches_eager():
+    from roboticattack_amd import model_ops
+
+    torch.manual_seed(0)
+    B, T, H, hd = 3, 37, 4, 128
+    x = torch.randn(B, T, H * hd, device=DEV, dtype=torch.bfloat16)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=DEV, dtype=torch.float32) / hd))
+    ang = torch.outer(torch.arange(T, device=DEV, dtype=torch.float32), inv)
+    full = torch.cat([ang, ang], -1)
+    cos, sin = full.cos().to(torch.bfloat16)[None, None], full.sin().to(torch.bfloat16)[None, None]
+    tab = (ang.cos().to(torch.bfloat16).float().contiguous(), ang.sin().to(torch.bfloat16).float().contiguous())
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    qa = xa.view(B, T, H, hd).transpose(1, 2)
+    ref, _ = _rope_ref(qa.float(), qa.float(), cos.float(), sin.float())  # fp32 reference of the same formula
+    got = model_ops.RopeFn.apply(xb.view(B, T, H, hd), *tab).transpose(1, 2)
+    assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+    assert (got.float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()  # one bf16 rounding
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    got.backward(g.to(torch.bfloat16))
+    assert (xb.grad.float() - xa.grad.float()).abs().max() <= 2 ** -6 * xa.grad.float().abs().max()
+    # strided input (e.g. a gradient arriving in [B,H,T,hd] memory order) takes the same kernel
+    y = torch.randn(B, H, T, hd, device=DEV, dtype=torch.bfloat16)
+    s1 = model_ops.RopeFn.apply(y.transpose(1, 2), *tab)
+    s2 = model_ops.RopeFn.apply(y.transpose(1, 2).contiguous(), *tab)
+    assert torch.equal(s1, s2)
+
+
+def test_swiglu_fwd_bwd_matches_eager():
+    import torch.nn.functional as F
+
+    from roboticattack_amd import model_ops
+
+    torch.manual_seed(1)
+    g = (torch.randn(50, 11008, device=DEV) * 2).to(torch.bfloat16)
+    u = torch.randn(50, 11008, device=DEV).to(torch.bfloat16)
+    ga, ua = g.float().requires_grad_(True), u.float().requires_grad_(True)
+    gb, ub = g.clone().requires_grad_(True), u.clone().requires_grad_(True)
+    ref = F.silu(ga) * ua
+    got = model_ops.SwiGLUFn.apply(gb, ub)
+    assert (got.float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    got.backward(dy.to(torch.bfloat16))
+    assert (gb.grad.float() - ga.grad).abs().max() <= 2 ** -6 * ga.grad.abs().max()
+    assert (ub.grad.float() - ua.grad).abs().max() <= 2 ** -6 * ua.grad.abs().max()
+
+
+def test_model_with_and_without_fused_ops(monkeypatch):
+    """Same tiny-width OpenVLA-shaped model, bf16: fused RoPE/SwiGLU vs the eager chain — logits and pixel gradient agree to bf16 noise."""
+    from roboticattack_amd import synthetic
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+
+    cfg = OpenVLACfg(dino=VitCfg(32, 3, 2, 64, 5, True, True), siglip=VitCfg(48, 3, 2, 80, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)  # head dim 128 like Llama-2
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=2)
+    ids, labels, _ = synthetic.synth_text_batch(5, 2, 18, 22)
+    labels = mask_labels(labels, [0]).to(DEV)
+    pix0 = torch.randn(2, 6, 224, 224, device=DEV).to(torch.bfloat16)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("VAA_NO_FUSED_MODEL_OPS", "1")
+        pix = pix0.clone().requires_grad_(True)
+        rows = m.forward_rows(ids.to(DEV), pix, labels)
+        rows.float().square().mean().backward()
+        outs.append((rows.detach().float(), pix.grad.detach().float()))
+    (r1, g1), (r2, g2) = outs
+    assert (r1 - r2).abs().max() <= 0.05 * r2.abs().max() + 1e-3
+    assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.99
