@@ -173,10 +173,11 @@ class LlamaLayer(nn.Module):
             v = self.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
             q, k = _rope(q, k, cos, sin)
         a = F.scaled_dot_product_attention(q, k, v, is_causal=True)  # right padding + causal == HF's mask on real tokens
-        x = x + self.o_proj(a.transpose(1, 2).reshape(B, T, D))
+        x = torch.addmm(x.reshape(-1, D), a.transpose(1, 2).reshape(-1, D), self.o_proj.weight.t()).view(B, T, D)  # residual in the GEMM epilogue
         h = self.post_attention_layernorm(x)
         if fused and (h.shape[0] * h.shape[1] * self.gate_proj.out_features) % 8 == 0:
-            return x + self.down_proj(model_ops.SwiGLUFn.apply(self.gate_proj(h), self.up_proj(h)))
+            y = model_ops.SwiGLUFn.apply(self.gate_proj(h), self.up_proj(h))
+            return torch.addmm(x.reshape(-1, D), y.reshape(-1, y.shape[-1]), self.down_proj.weight.t()).view(B, T, D)
         return x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
 
 
