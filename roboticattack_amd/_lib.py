@@ -18,7 +18,7 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 LAYOUT_FULL, LAYOUT_ROWS = 0, 1
 OPT_ADAMW_HF, OPT_PGD_SIGN = 0, 1
 
-MODEL_OP_EXPORTS = ("vaa_model_rope", "vaa_model_swiglu_fwd", "vaa_model_swiglu_bwd")
+MODEL_OP_EXPORTS = ("vaa_model_rope", "vaa_model_swiglu_fwd", "vaa_model_swiglu_bwd", "vaa_model_rmsnorm_fwd", "vaa_model_rmsnorm_bwd")
 
 EXPORTS = (
     "vaa_last_error",
@@ -93,6 +93,10 @@ def lib() -> C.CDLL:
     L.vaa_model_swiglu_fwd.argtypes = [vp, vp, vp, lng, vp]
     L.vaa_model_swiglu_bwd.restype = i32
     L.vaa_model_swiglu_bwd.argtypes = [vp, vp, vp, vp, vp, lng, vp]
+    L.vaa_model_rmsnorm_fwd.restype = i32
+    L.vaa_model_rmsnorm_fwd.argtypes = [vp, vp, vp, vp, lng, i32, f32, vp]
+    L.vaa_model_rmsnorm_bwd.restype = i32
+    L.vaa_model_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, lng, i32, vp]
     _lib = L
     return L
 

@@ -96,6 +96,90 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint16_t* __restr
     }
 }
 
+
+// ---- RMSNorm with residual pass-through: h = x * rstd * w ; backward: gx = g_pass + rstd*(gh*w - xhat*mean(gh*w*xhat)) ----
+// One 256-thread workgroup per row of D bf16 (D % 8 == 0, D <= 8192); the row lives in registers between the two passes.
+constexpr int kNormThreads = 256, kNormMaxVec = 4;  // 4 x 8 elements per thread -> D <= 8192
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(kNormThreads) void rmsnorm_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, uint16_t* __restrict__ h,
+                                                                    float* __restrict__ rstd, int D, float eps) {
+    __shared__ float sh[4];
+    const long row = blockIdx.x;
+    const int nv = D >> 3;
+    float xv[kNormMaxVec][8];
+    float ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kNormMaxVec; ++c) {
+        const int q = threadIdx.x + c * kNormThreads;
+        if (q < nv) {
+            unpack8(reinterpret_cast<const uint4*>(x + row * D)[q], xv[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += xv[c][e] * xv[c][e];
+        }
+    }
+    ss = block_sum_256(ss, sh);
+    const float r = rsqrtf(ss / (float)D + eps);
+    if (threadIdx.x == 0) rstd[row] = r;
+#pragma unroll
+    for (int c = 0; c < kNormMaxVec; ++c) {
+        const int q = threadIdx.x + c * kNormThreads;
+        if (q < nv) {
+            float wv[8], o[8];
+            unpack8(reinterpret_cast<const uint4*>(w)[q], wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = bf16_bits_to_f32(f32_to_bf16_bits(xv[c][e] * r)) * wv[e];  // HF: (x*rstd).to(bf16) * weight
+            reinterpret_cast<uint4*>(h + row * D)[q] = pack8(o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kNormThreads) void rmsnorm_bwd_kernel(const uint16_t* __restrict__ gh, const uint16_t* __restrict__ gpass,
+                                                                    const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                                    const float* __restrict__ rstd, uint16_t* __restrict__ gx, int D) {
+    __shared__ float sh[4];
+    const long row = blockIdx.x;
+    const int nv = D >> 3;
+    const float r = rstd[row];
+    float xh[kNormMaxVec][8], gw[kNormMaxVec][8];
+    float dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kNormMaxVec; ++c) {
+        const int q = threadIdx.x + c * kNormThreads;
+        if (q < nv) {
+            float wv[8];
+            unpack8(reinterpret_cast<const uint4*>(x + row * D)[q], xh[c]);
+            unpack8(reinterpret_cast<const uint4*>(gh + row * D)[q], gw[c]);
+            unpack8(reinterpret_cast<const uint4*>(w)[q], wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[c][e] *= r;
+                gw[c][e] *= wv[e];
+                dot += gw[c][e] * xh[c][e];
+            }
+        }
+    }
+    dot = block_sum_256(dot, sh) / (float)D;
+#pragma unroll
+    for (int c = 0; c < kNormMaxVec; ++c) {
+        const int q = threadIdx.x + c * kNormThreads;
+        if (q < nv) {
+            float o[8], gp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gpass) unpack8(reinterpret_cast<const uint4*>(gpass + row * D)[q], gp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gp[e] + r * (gw[c][e] - xh[c][e] * dot);
+            reinterpret_cast<uint4*>(gx + row * D)[q] = pack8(o);
+        }
+    }
+}
+
 static unsigned stream_grid(long nvec) {
     long b = (nvec + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -127,4 +211,25 @@ extern "C" int vaa_model_swiglu_bwd(const uint16_t* dy, const uint16_t* gate, co
     if (!dy || !gate || !up || !dgate || !dup || n <= 0 || (n % 8) != 0) { set_error("vaa_model_swiglu_bwd: bad arguments"); return VAA_E_INVALID; }
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, dy, gate, up, dgate, dup, n / 8);
     return check_launch("vaa_model_swiglu_bwd");
+}
+
+extern "C" int vaa_model_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* h, float* rstd, long rows, int D, float eps, void* stream) {
+    using namespace vaa;
+    if (!x || !w || !h || !rstd || rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * kNormThreads * kNormMaxVec) {
+        set_error("vaa_model_rmsnorm_fwd: bad arguments (D must be a multiple of 8, <= 8192)");
+        return VAA_E_INVALID;
+    }
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, x, w, h, rstd, D, eps);
+    return check_launch("vaa_model_rmsnorm_fwd");
+}
+
+extern "C" int vaa_model_rmsnorm_bwd(const uint16_t* gh, const uint16_t* gpass, const uint16_t* x, const uint16_t* w, const float* rstd, uint16_t* gx,
+                                     long rows, int D, void* stream) {
+    using namespace vaa;
+    if (!gh || !x || !w || !rstd || !gx || rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * kNormThreads * kNormMaxVec) {
+        set_error("vaa_model_rmsnorm_bwd: bad arguments");
+        return VAA_E_INVALID;
+    }
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, gh, gpass, x, w, rstd, gx, D);
+    return check_launch("vaa_model_rmsnorm_bwd");
 }

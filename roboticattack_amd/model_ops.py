@@ -65,3 +65,34 @@ class SwiGLUFn(torch.autograd.Function):
         _lib.check(_lib.lib().vaa_model_swiglu_bwd(dy.data_ptr(), gate.data_ptr(), up.data_ptr(), dg.data_ptr(), du.data_ptr(), gate.numel(), _stream()),
                    "vaa_model_swiglu_bwd")
         return dg, du
+
+
+class ResidualRMSNormFn(torch.autograd.Function):
+    """(x) -> (x, rmsnorm(x) * w): the residual stream passes through untouched, so autograd hands BOTH incoming gradients to
+    one backward kernel (no separate grad-accumulation add, no multi-kernel norm backward). The weight is frozen (no grad)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        x = x.contiguous()
+        D = x.shape[-1]
+        rows = x.numel() // D
+        h = torch.empty_like(x)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().vaa_model_rmsnorm_fwd(x.data_ptr(), weight.data_ptr(), h.data_ptr(), rstd.data_ptr(), rows, D, float(eps), _stream()),
+                   "vaa_model_rmsnorm_fwd")
+        ctx.save_for_backward(x, weight, rstd)
+        return x, h
+
+    @staticmethod
+    def backward(ctx, g_pass, g_h):
+        x, weight, rstd = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        if g_h is None:
+            return g_pass, None, None
+        g_h = g_h.contiguous()
+        gp = g_pass.contiguous() if g_pass is not None else None
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().vaa_model_rmsnorm_bwd(g_h.data_ptr(), gp.data_ptr() if gp is not None else None, x.data_ptr(), weight.data_ptr(),
+                                                    rstd.data_ptr(), gx.data_ptr(), rows, D, _stream()), "vaa_model_rmsnorm_bwd")
+        return gx, None, None

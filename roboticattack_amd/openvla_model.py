@@ -160,9 +160,12 @@ class LlamaLayer(nn.Module):
         from . import model_ops
 
         B, T, D = x.shape
-        h = self.input_layernorm(x)
         hd = D // self.heads
-        fused = rope_tab is not None and model_ops.enabled(h) and hd % 16 == 0
+        fused = rope_tab is not None and model_ops.enabled(x) and hd % 16 == 0 and D % 8 == 0 and D <= 8192
+        if fused:
+            x, h = model_ops.ResidualRMSNormFn.apply(x, self.input_layernorm.weight, self.input_layernorm.eps)
+        else:
+            h = self.input_layernorm(x)
         if fused:  # one HBM pass per tensor instead of neg + cat + 2 mul + add (and their autograd chains)
             q = model_ops.RopeFn.apply(self.q_proj(h).view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)
             k = model_ops.RopeFn.apply(self.k_proj(h).view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)
@@ -174,7 +177,10 @@ class LlamaLayer(nn.Module):
             q, k = _rope(q, k, cos, sin)
         a = F.scaled_dot_product_attention(q, k, v, is_causal=True)  # right padding + causal == HF's mask on real tokens
         x = torch.addmm(x.reshape(-1, D), a.transpose(1, 2).reshape(-1, D), self.o_proj.weight.t()).view(B, T, D)  # residual in the GEMM epilogue
-        h = self.post_attention_layernorm(x)
+        if fused:
+            x, h = model_ops.ResidualRMSNormFn.apply(x, self.post_attention_layernorm.weight, self.post_attention_layernorm.eps)
+        else:
+            h = self.post_attention_layernorm(x)
         if fused and (h.shape[0] * h.shape[1] * self.gate_proj.out_features) % 8 == 0:
             y = model_ops.SwiGLUFn.apply(self.gate_proj(h), self.up_proj(h))
             return torch.addmm(x.reshape(-1, D), y.reshape(-1, y.shape[-1]), self.down_proj.weight.t()).view(B, T, D)

@@ -62,6 +62,32 @@ def test_swiglu_fwd_bwd_matches_eager():
     assert (ub.grad.float() - ua.grad).abs().max() <= 2 ** -6 * ua.grad.abs().max()
 
 
+def test_residual_rmsnorm_fwd_bwd_matches_eager():
+    import torch.nn.functional as F
+
+    from roboticattack_amd import model_ops
+
+    torch.manual_seed(2)
+    x = torch.randn(3, 70, 4096, device=DEV).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(4096, device=DEV)).to(torch.bfloat16)
+    xa = x.float().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ref_h = F.rms_norm(xa, (4096,), w.float(), 1e-6)
+    xo, h = model_ops.ResidualRMSNormFn.apply(xb, w, 1e-6)
+    assert torch.equal(xo, xb) and (h.float() - ref_h).abs().max() <= 2 ** -6 * ref_h.abs().max()
+    g_h, g_p = torch.randn_like(ref_h), torch.randn_like(ref_h)
+    (ref_h * g_h + xa * g_p).sum().backward()  # residual stream used twice: through the norm and straight through
+    (h.float() * g_h.to(torch.bfloat16).float() + xo.float() * g_p.to(torch.bfloat16).float()).sum().backward()
+    assert (xb.grad.float() - xa.grad).abs().max() <= 2 ** -5 * xa.grad.abs().max()
+    # norm output only (no pass-through gradient)
+    xc = x.clone().requires_grad_(True)
+    _, h2 = model_ops.ResidualRMSNormFn.apply(xc, w, 1e-6)
+    h2.float().sum().backward()
+    xd = x.float().requires_grad_(True)
+    F.rms_norm(xd, (4096,), w.float(), 1e-6).sum().backward()
+    assert (xc.grad.float() - xd.grad).abs().max() <= 2 ** -5 * xd.grad.abs().max() + 1e-3
+
+
 def test_model_with_and_without_fused_ops(monkeypatch):
     """Same tiny-width OpenVLA-shaped model, bf16: fused RoPE/SwiGLU vs the eager chain — logits and pixel gradient agree to bf16 noise."""
     from roboticattack_amd import synthetic
