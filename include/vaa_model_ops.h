@@ -21,6 +21,18 @@ int vaa_model_swiglu_bwd(const uint16_t* dy, const uint16_t* gate, const uint16_
 int vaa_model_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* h, float* rstd, long rows, int D, float eps, void* stream);
 int vaa_model_rmsnorm_bwd(const uint16_t* gh, const uint16_t* gpass, const uint16_t* x, const uint16_t* w, const float* rstd, uint16_t* gx,
                           long rows, int D, void* stream);
+/* Softmax attention on the matrix cores for short sequences. q,k,v,o: bf16 views [B,T,H,hd] given by element strides
+ * {batch, token, head} (last dim contiguous, all strides % 8 == 0), hd % 8 == 0, hd <= 128. lse: float32 [B,H,T] (natural log).
+ * causal != 0: query t sees keys <= t. */
+int vaa_model_attention_fwd(const uint16_t* q, const int64_t* q_str, const uint16_t* k, const int64_t* k_str, const uint16_t* v,
+                            const int64_t* v_str, uint16_t* o, const int64_t* o_str, float* lse, int B, int H, int T, int hd, int causal,
+                            float scale, void* stream);
+/* Backward of vaa_model_attention_fwd: o, lse from the forward; dsum: float32 [B,H,T] workspace; dq/dk/dv: bf16 [B,T,H,hd] views
+ * given by strides (e.g. the three slices of one packed [B,T,3,H,hd] gradient buffer). Two launches (dq, then dk/dv). */
+int vaa_model_attention_bwd(const uint16_t* q, const int64_t* q_str, const uint16_t* k, const int64_t* k_str, const uint16_t* v,
+                            const int64_t* v_str, const uint16_t* o, const int64_t* o_str, const uint16_t* dout, const int64_t* do_str,
+                            const float* lse, float* dsum, uint16_t* dq, const int64_t* dq_str, uint16_t* dk, const int64_t* dk_str,
+                            uint16_t* dv, const int64_t* dv_str, int B, int H, int T, int hd, int causal, float scale, void* stream);
 #ifdef __cplusplus
 }
 #endif

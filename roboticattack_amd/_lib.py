@@ -18,7 +18,8 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 LAYOUT_FULL, LAYOUT_ROWS = 0, 1
 OPT_ADAMW_HF, OPT_PGD_SIGN = 0, 1
 
-MODEL_OP_EXPORTS = ("vaa_model_rope", "vaa_model_swiglu_fwd", "vaa_model_swiglu_bwd", "vaa_model_rmsnorm_fwd", "vaa_model_rmsnorm_bwd")
+MODEL_OP_EXPORTS = ("vaa_model_rope", "vaa_model_swiglu_fwd", "vaa_model_swiglu_bwd", "vaa_model_rmsnorm_fwd", "vaa_model_rmsnorm_bwd",
+                    "vaa_model_attention_fwd", "vaa_model_attention_bwd")
 
 EXPORTS = (
     "vaa_last_error",
@@ -97,6 +98,11 @@ def lib() -> C.CDLL:
     L.vaa_model_rmsnorm_fwd.argtypes = [vp, vp, vp, vp, lng, i32, f32, vp]
     L.vaa_model_rmsnorm_bwd.restype = i32
     L.vaa_model_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, lng, i32, vp]
+    i64p = C.POINTER(C.c_int64)
+    L.vaa_model_attention_fwd.restype = i32
+    L.vaa_model_attention_fwd.argtypes = [vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, i32, i32, i32, i32, i32, f32, vp]
+    L.vaa_model_attention_bwd.restype = i32
+    L.vaa_model_attention_bwd.argtypes = [vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, vp, vp, i64p, vp, i64p, vp, i64p, i32, i32, i32, i32, i32, f32, vp]
     _lib = L
     return L
 

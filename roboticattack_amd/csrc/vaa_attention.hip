@@ -1,0 +1,540 @@
+// vaa_attention.hip — OPTIONAL model-side operator (include/vaa_model_ops.h): softmax attention forward + backward on the
+// gfx950 matrix cores for the short sequences of the OpenVLA step (T = 256..~330 tokens, head dim 64 / 72 / 128).
+//
+// Everything is formulated TRANSPOSED so that no operand ever has to be re-laid-out in registers:
+//   forward   S^T = K Q^T            A = K rows from LDS (16 B reads), B = Q^T held in registers (16 B global reads of Q rows)
+//             O^T += V^T P^T         A = V^T through ds_read_b64_tr_b16 (hardware transpose read of the row-major V tile),
+//                                    B = P^T = exp2(S^T - m) straight from the S^T accumulators
+// In the C/D layout of mfma_f32_16x16x32_bf16 (col = lane&15, row = 4*(lane>>4)+reg) a lane's column is its QUERY, so the
+// online-softmax state (running max, running sum, rescale factor) is one scalar per lane, and the 8 accumulator values of two
+// 16-key tiles are exactly the 8 k-slots of that lane's B operand for the next MFMA (k-slot j<4 <-> key 4g+j, j>=4 <-> key
+// 16+4g+(j-4); the A operand is fetched with the same permutation, which the transpose read delivers for free).
+// The backward (dq kernel, dk/dv kernel) uses the same two access patterns; see the kernels.
+//
+// One workgroup = 4 waves = 64 queries (forward, dq) or 64 keys (dk/dv) of one (batch, head); K/V (or Q/dO) stream through
+// LDS in 64-row tiles, register-staged so the next tile's global loads are in flight during the MFMAs. Workgroups of the same
+// (batch, head) are placed on the same XCD (blockIdx % 8) so that its K/V stay in that XCD's L2.
+#include "vaa_common.h"
+
+#include "../../include/vaa_model_ops.h"
+
+namespace vaa {
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s* lds_v4s_ptr;
+
+struct AttnStr {
+    long b, t, h;  // element strides of a [B,T,H,hd] view (last dim contiguous)
+};
+
+struct AttnFwdArgs {
+    const uint16_t *q, *k, *v;
+    uint16_t* o;
+    float* lse;  // [B,H,T] natural-log logsumexp of scale*q.k over the visible keys
+    AttnStr sq, sk, sv, so;
+    int B, H, T, hd;
+    float scale_log2;  // softmax scale * log2(e)
+};
+
+constexpr int kTile = 64;  // rows (keys or queries) per LDS tile = queries per workgroup
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ v4s lds_tr16(const uint16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(p));
+}
+
+__device__ __forceinline__ v8s cat8(v4s lo, v4s hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+__device__ __forceinline__ v8s pack8(v4f a, v4f b) {
+    v8s r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (short)f32_to_bf16_bits(a[j]);
+        r[4 + j] = (short)f32_to_bf16_bits(b[j]);
+    }
+    return r;
+}
+
+// Register-staged copy of a [kTile x HDP] tile of a [*,T,*,hd] tensor (rows >= T and columns >= hd read as zero).
+template <int HDP>
+struct TileRegs {
+    static constexpr int kChunks = kTile * (HDP / 8) / 256;  // 16-byte chunks per thread
+    uint4 r[kChunks];
+    __device__ __forceinline__ void load(const uint16_t* base, long st, int row0, int T, int hd) {
+#pragma unroll
+        for (int it = 0; it < kChunks; ++it) {
+            const int ch = threadIdx.x + it * 256;
+            const int row = ch / (HDP / 8), cc = ch % (HDP / 8);
+            r[it] = make_uint4(0, 0, 0, 0);
+            if (row0 + row < T && cc * 8 < hd) r[it] = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * st + cc * 8);
+        }
+    }
+    __device__ __forceinline__ void store(uint16_t* lds, int stride) const {
+#pragma unroll
+        for (int it = 0; it < kChunks; ++it) {
+            const int ch = threadIdx.x + it * 256;
+            const int row = ch / (HDP / 8), cc = ch % (HDP / 8);
+            *reinterpret_cast<uint4*>(lds + row * stride + cc * 8) = r[it];
+        }
+    }
+};
+
+// blockIdx -> (batch*head pair, 64-row block); all blocks of a pair share blockIdx % 8 (one XCD, one L2); heavy (late) causal
+// blocks first.
+__device__ __forceinline__ bool block_to_pair(int nblk, int npairs, int& pair, int& blk, bool late_first = true) {
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    pair = (slot / nblk) * 8 + xcd;
+    blk = late_first ? nblk - 1 - (slot % nblk) : slot % nblk;
+    return pair < npairs;
+}
+
+// ---------------------------------------------------------------- forward ----------------------------------------------------------------
+template <int KS, int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
+    constexpr int HDP = KS * 32;
+    constexpr int SK = HDP + 8;   // K tile row stride (bf16): dword stride = 4 mod 8 -> conflict-free 16-byte row reads
+    constexpr int SV = HDP + 16;  // V tile row stride: dword stride = 8 mod 16 -> conflict-free transpose reads
+    __shared__ __attribute__((aligned(16))) uint16_t sK[kTile * SK];
+    __shared__ __attribute__((aligned(16))) uint16_t sV[kTile * SV];
+
+    const int nqb = (a.T + kTile - 1) / kTile;
+    int pair, qb;
+    if (!block_to_pair(nqb, a.B * a.H, pair, qb)) return;
+    const int b = pair / a.H, h = pair - b * a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int q0 = qb * kTile + wv * 16;  // this wave's 16 queries
+    const int q = q0 + c;                 // this lane's query (column of every S^T / O^T tile)
+
+    const uint16_t* qp = a.q + (long)b * a.sq.b + (long)h * a.sq.h;
+    const uint16_t* kp = a.k + (long)b * a.sk.b + (long)h * a.sk.h;
+    const uint16_t* vp = a.v + (long)b * a.sv.b + (long)h * a.sv.h;
+
+    // Q^T fragments: lane (c,g), k-step ks <-> Q[q][32 ks + 8 g .. +8]
+    v8s qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 32 + g * 8;
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (q < a.T && d0 < a.hd) r = *reinterpret_cast<const uint4*>(qp + (long)q * a.sq.t + d0);
+        qf[ks] = *reinterpret_cast<v8s*>(&r);
+    }
+
+    const int kend = CAUSAL ? min(a.T, (qb + 1) * kTile) : a.T;  // keys [0, kend) are visible to this workgroup
+    const int ntile = (kend + kTile - 1) / kTile;
+
+    v4f acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lsum = 0.0f;
+
+    TileRegs<HDP> rk, rv;
+    rk.load(kp, a.sk.t, 0, a.T, a.hd);
+    rv.load(vp, a.sv.t, 0, a.T, a.hd);
+    for (int kt = 0; kt < ntile; ++kt) {
+        __syncthreads();  // every wave is done reading the previous tile
+        rk.store(sK, SK);
+        rv.store(sV, SV);
+        __syncthreads();
+        if (kt + 1 < ntile) {  // next tile's loads fly during the MFMAs
+            rk.load(kp, a.sk.t, (kt + 1) * kTile, a.T, a.hd);
+            rv.load(vp, a.sv.t, (kt + 1) * kTile, a.T, a.hd);
+        }
+        const int key0 = kt * kTile;
+        if (CAUSAL && key0 > q0 + 15) continue;  // nothing visible to this wave in this tile (wave-uniform)
+
+        v4f st[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            st[rt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v8s kf = *reinterpret_cast<const v8s*>(&sK[(rt * 16 + c) * SK + ks * 32 + g * 8]);
+                st[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[rt], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + rt * 16 + g * 4 + r;
+                float s = st[rt][r] * a.scale_log2;
+                if (key >= a.T || (CAUSAL && key > q)) s = -INFINITY;
+                st[rt][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float mu = (mn == -INFINITY) ? 0.0f : mn;
+        const float alpha = fast_exp2(m - mu);  // m = -inf -> 0
+        m = mn;
+        float ps = 0.0f;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = fast_exp2(st[rt][r] - mu);
+                st[rt][r] = p;
+                ps += p;
+            }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] *= alpha;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const v8s pf = pack8(st[2 * half], st[2 * half + 1]);
+            const uint16_t* vrow = &sV[(half * 32 + 4 * g + (c >> 2)) * SV + (c & 3) * 4];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const v8s vf = cat8(lds_tr16(vrow + nt * 16), lds_tr16(vrow + 16 * SV + nt * 16));
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (q < a.T) {
+        const float inv = lsum > 0.0f ? 1.0f / lsum : 0.0f;
+        uint16_t* op = a.o + (long)b * a.so.b + (long)q * a.so.t + (long)h * a.so.h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int d0 = nt * 16 + g * 4;
+            if (d0 < a.hd) {
+                uint2 w;
+                w.x = f32_to_bf16_bits(acc[nt][0] * inv) | (f32_to_bf16_bits(acc[nt][1] * inv) << 16);
+                w.y = f32_to_bf16_bits(acc[nt][2] * inv) | (f32_to_bf16_bits(acc[nt][3] * inv) << 16);
+                *reinterpret_cast<uint2*>(op + d0) = w;
+            }
+        }
+        if (g == 0) a.lse[((long)b * a.H + h) * a.T + q] = (m + __builtin_log2f(lsum)) * 0.69314718055994531f;
+    }
+}
+
+// ---------------------------------------------------------------- backward ---------------------------------------------------------------
+struct AttnBwdArgs {
+    const uint16_t *q, *k, *v, *o, *dout;
+    const float* lse;  // [B,H,T] from the forward
+    float* dsum;       // [B,H,T] workspace: D = rowsum(dO * O), written by the dq kernel, read by the dk/dv kernel
+    uint16_t *dq, *dk, *dv;
+    AttnStr sq, sk, sv, so, sdo, sdq, sdk, sdv;
+    int B, H, T, hd;
+    float scale, scale_log2;
+};
+
+// B-operand fragments of a row-major [*, hd] matrix row: lane (c,g), k-step ks <-> row[32 ks + 8 g .. +8] (zero outside).
+template <int KS>
+__device__ __forceinline__ void load_row_frags(v8s (&f)[KS], const uint16_t* row, bool valid, int g, int hd) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 32 + g * 8;
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (valid && d0 < hd) r = *reinterpret_cast<const uint4*>(row + d0);
+        f[ks] = *reinterpret_cast<v8s*>(&r);
+    }
+}
+
+// sum_ks mfma(A = rows [rt*16, rt*16+16) of an LDS tile, B = register fragments): a 16x16 tile of (tile rows) x (lane columns)
+template <int KS>
+__device__ __forceinline__ v4f tile_dot(const uint16_t* tile, int stride, int rt, int c, int g, const v8s (&bf)[KS]) {
+    v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const v8s af = *reinterpret_cast<const v8s*>(&tile[(rt * 16 + c) * stride + ks * 32 + g * 8]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[ks], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// dQ^T = sum over key tiles of K^T dS^T, with S^T = K Q^T and dP^T = V dO^T recomputed; dS^T = P^T o (dP^T - D). One workgroup =
+// 64 queries; a lane's column is its query, so lse and D are per-lane scalars. Also produces D for the dk/dv kernel.
+template <int KS, int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+    constexpr int HDP = KS * 32;
+    constexpr int SK = HDP + 8, SV = HDP + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t sK[kTile * SK];
+    __shared__ __attribute__((aligned(16))) uint16_t sV[kTile * SV];
+
+    const int nqb = (a.T + kTile - 1) / kTile;
+    int pair, qb;
+    if (!block_to_pair(nqb, a.B * a.H, pair, qb)) return;
+    const int b = pair / a.H, h = pair - b * a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int q0 = qb * kTile + wv * 16, q = q0 + c;
+    const bool qv = q < a.T;
+
+    const uint16_t* kp = a.k + (long)b * a.sk.b + (long)h * a.sk.h;
+    const uint16_t* vp = a.v + (long)b * a.sv.b + (long)h * a.sv.h;
+    v8s qf[KS], dof[KS];
+    load_row_frags<KS>(qf, a.q + (long)b * a.sq.b + (long)q * a.sq.t + (long)h * a.sq.h, qv, g, a.hd);
+    load_row_frags<KS>(dof, a.dout + (long)b * a.sdo.b + (long)q * a.sdo.t + (long)h * a.sdo.h, qv, g, a.hd);
+    float Dq = 0.0f;
+    {
+        v8s of[KS];
+        load_row_frags<KS>(of, a.o + (long)b * a.so.b + (long)q * a.so.t + (long)h * a.so.h, qv, g, a.hd);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Dq += bf16_bits_to_f32((uint16_t)of[ks][j]) * bf16_bits_to_f32((uint16_t)dof[ks][j]);
+        Dq += __shfl_xor(Dq, 16, 64);
+        Dq += __shfl_xor(Dq, 32, 64);
+    }
+    const long rowid = ((long)b * a.H + h) * a.T + q;
+    if (qv && g == 0) a.dsum[rowid] = Dq;
+    const float lse2 = qv ? a.lse[rowid] * 1.4426950408889634f : INFINITY;  // invalid query -> P = 0
+
+    const int kend = CAUSAL ? min(a.T, (qb + 1) * kTile) : a.T;
+    const int ntile = (kend + kTile - 1) / kTile;
+    v4f acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    TileRegs<HDP> rk, rv;
+    rk.load(kp, a.sk.t, 0, a.T, a.hd);
+    rv.load(vp, a.sv.t, 0, a.T, a.hd);
+    for (int kt = 0; kt < ntile; ++kt) {
+        __syncthreads();
+        rk.store(sK, SK);
+        rv.store(sV, SV);
+        __syncthreads();
+        if (kt + 1 < ntile) {
+            rk.load(kp, a.sk.t, (kt + 1) * kTile, a.T, a.hd);
+            rv.load(vp, a.sv.t, (kt + 1) * kTile, a.T, a.hd);
+        }
+        const int key0 = kt * kTile;
+        if (CAUSAL && key0 > q0 + 15) continue;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (CAUSAL && key0 + half * 32 > q0 + 15) continue;
+            v4f ds[2];
+#pragma unroll
+            for (int rl = 0; rl < 2; ++rl) {
+                const int rt = 2 * half + rl;
+                const v4f st = tile_dot<KS>(sK, SK, rt, c, g, qf);
+                const v4f dp = tile_dot<KS>(sV, SV, rt, c, g, dof);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + rt * 16 + g * 4 + r;
+                    const bool masked = key >= a.T || (CAUSAL && key > q);
+                    const float p = masked ? 0.0f : fast_exp2(st[r] * a.scale_log2 - lse2);
+                    ds[rl][r] = p * (dp[r] - Dq);
+                }
+            }
+            const v8s dsf = pack8(ds[0], ds[1]);
+            const uint16_t* krow = &sK[(half * 32 + 4 * g + (c >> 2)) * SK + (c & 3) * 4];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const v8s kf = cat8(lds_tr16(krow + nt * 16), lds_tr16(krow + 16 * SK + nt * 16));
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    if (qv) {
+        uint16_t* op = a.dq + (long)b * a.sdq.b + (long)q * a.sdq.t + (long)h * a.sdq.h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int d0 = nt * 16 + g * 4;
+            if (d0 < a.hd) {
+                uint2 w;
+                w.x = f32_to_bf16_bits(acc[nt][0] * a.scale) | (f32_to_bf16_bits(acc[nt][1] * a.scale) << 16);
+                w.y = f32_to_bf16_bits(acc[nt][2] * a.scale) | (f32_to_bf16_bits(acc[nt][3] * a.scale) << 16);
+                *reinterpret_cast<uint2*>(op + d0) = w;
+            }
+        }
+    }
+}
+
+// dK^T += Q^T dS, dV^T += dO^T P over query tiles, with S = Q K^T and dP = dO V^T recomputed (A = Q / dO rows from LDS, B = K^T / V^T
+// fragments of this wave's 16 keys held in registers): a lane's column is its KEY, rows are queries, so lse and D come from LDS.
+template <int KS, int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
+    constexpr int HDP = KS * 32;
+    constexpr int SQ = HDP + 16;  // both tiles are read by rows AND transposed; the transpose reads are twice as many -> their stride
+    __shared__ __attribute__((aligned(16))) uint16_t sQ[kTile * SQ];
+    __shared__ __attribute__((aligned(16))) uint16_t sDO[kTile * SQ];
+    __shared__ float sL[kTile], sD[kTile];
+
+    const int nkb = (a.T + kTile - 1) / kTile;
+    int pair, kb;
+    if (!block_to_pair(nkb, a.B * a.H, pair, kb, !CAUSAL)) return;  // causal: early key blocks see the most queries -> first
+    const int b = pair / a.H, h = pair - b * a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int key0w = kb * kTile + wv * 16, key = key0w + c;
+    const bool kv = key < a.T;
+
+    v8s kf[KS], vf[KS];
+    load_row_frags<KS>(kf, a.k + (long)b * a.sk.b + (long)key * a.sk.t + (long)h * a.sk.h, kv, g, a.hd);
+    load_row_frags<KS>(vf, a.v + (long)b * a.sv.b + (long)key * a.sv.t + (long)h * a.sv.h, kv, g, a.hd);
+    const uint16_t* qp = a.q + (long)b * a.sq.b + (long)h * a.sq.h;
+    const uint16_t* dop = a.dout + (long)b * a.sdo.b + (long)h * a.sdo.h;
+    const float* lsep = a.lse + ((long)b * a.H + h) * a.T;
+    const float* dsp = a.dsum + ((long)b * a.H + h) * a.T;
+
+    v4f dk[NT], dv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        dk[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        dv[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    const int nqt = (a.T + kTile - 1) / kTile;
+    const int qt0 = CAUSAL ? kb : 0;
+    TileRegs<HDP> rq, rdo;
+    float rstat = 0.0f;  // threads 0..63: lse of query tid (log2 units, +inf when invalid); 64..127: D
+    auto load_stats = [&](int qbase) {
+        if (tid < 128) {
+            const int qq = qbase + (tid & 63);
+            if (tid < 64) rstat = qq < a.T ? lsep[qq] * 1.4426950408889634f : INFINITY;
+            else rstat = qq < a.T ? dsp[qq] : 0.0f;
+        }
+    };
+    rq.load(qp, a.sq.t, qt0 * kTile, a.T, a.hd);
+    rdo.load(dop, a.sdo.t, qt0 * kTile, a.T, a.hd);
+    load_stats(qt0 * kTile);
+    for (int qt = qt0; qt < nqt; ++qt) {
+        __syncthreads();
+        rq.store(sQ, SQ);
+        rdo.store(sDO, SQ);
+        if (tid < 64) sL[tid] = rstat;
+        else if (tid < 128) sD[tid - 64] = rstat;
+        __syncthreads();
+        if (qt + 1 < nqt) {
+            rq.load(qp, a.sq.t, (qt + 1) * kTile, a.T, a.hd);
+            rdo.load(dop, a.sdo.t, (qt + 1) * kTile, a.T, a.hd);
+            load_stats((qt + 1) * kTile);
+        }
+        const int qb0 = qt * kTile;
+        if (CAUSAL && qb0 + kTile - 1 < key0w) continue;  // every query of the tile precedes this wave's keys
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (CAUSAL && qb0 + half * 32 + 31 < key0w) continue;
+            v4f p[2], ds[2];
+#pragma unroll
+            for (int rl = 0; rl < 2; ++rl) {
+                const int rt = 2 * half + rl;
+                const v4f s = tile_dot<KS>(sQ, SQ, rt, c, g, kf);
+                const v4f dp = tile_dot<KS>(sDO, SQ, rt, c, g, vf);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = rt * 16 + g * 4 + r, qq = qb0 + ql;
+                    const bool masked = !kv || (CAUSAL && key > qq);
+                    const float pe = masked ? 0.0f : fast_exp2(s[r] * a.scale_log2 - sL[ql]);  // invalid query: lse = +inf -> 0
+                    p[rl][r] = pe;
+                    ds[rl][r] = pe * (dp[r] - sD[ql]);
+                }
+            }
+            const v8s pf = pack8(p[0], p[1]), dsf = pack8(ds[0], ds[1]);
+            const int ro = (half * 32 + 4 * g + (c >> 2)) * SQ + (c & 3) * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const v8s dot = cat8(lds_tr16(&sDO[ro + nt * 16]), lds_tr16(&sDO[ro + 16 * SQ + nt * 16]));
+                dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf, dv[nt], 0, 0, 0);
+                const v8s qt_ = cat8(lds_tr16(&sQ[ro + nt * 16]), lds_tr16(&sQ[ro + 16 * SQ + nt * 16]));
+                dk[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsf, dk[nt], 0, 0, 0);
+            }
+        }
+    }
+    if (kv) {
+        uint16_t* okp = a.dk + (long)b * a.sdk.b + (long)key * a.sdk.t + (long)h * a.sdk.h;
+        uint16_t* ovp = a.dv + (long)b * a.sdv.b + (long)key * a.sdv.t + (long)h * a.sdv.h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int d0 = nt * 16 + g * 4;
+            if (d0 < a.hd) {
+                uint2 w;
+                w.x = f32_to_bf16_bits(dk[nt][0] * a.scale) | (f32_to_bf16_bits(dk[nt][1] * a.scale) << 16);
+                w.y = f32_to_bf16_bits(dk[nt][2] * a.scale) | (f32_to_bf16_bits(dk[nt][3] * a.scale) << 16);
+                *reinterpret_cast<uint2*>(okp + d0) = w;
+                w.x = f32_to_bf16_bits(dv[nt][0]) | (f32_to_bf16_bits(dv[nt][1]) << 16);
+                w.y = f32_to_bf16_bits(dv[nt][2]) | (f32_to_bf16_bits(dv[nt][3]) << 16);
+                *reinterpret_cast<uint2*>(ovp + d0) = w;
+            }
+        }
+    }
+}
+
+template <bool CAUSAL>
+static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
+    const int nb = (a.T + kTile - 1) / kTile;
+    const unsigned grid = (unsigned)(((long)a.B * a.H + 7) / 8 * 8 * nb);
+#define VAA_ATT_BWD(KS, NT)                                                                                   \
+    do {                                                                                                      \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, NT, CAUSAL>), dim3(grid), dim3(256), 0, st, a);            \
+        int rc = check_launch("vaa_model_attention_bwd(dq)");                                                 \
+        if (rc != VAA_OK) return rc;                                                                          \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, NT, CAUSAL>), dim3(grid), dim3(256), 0, st, a);           \
+        return check_launch("vaa_model_attention_bwd(dkv)");                                                  \
+    } while (0)
+    if (a.hd <= 64) VAA_ATT_BWD(2, 4);
+    else if (a.hd <= 80) VAA_ATT_BWD(3, 5);
+    else if (a.hd <= 96) VAA_ATT_BWD(3, 6);
+    else VAA_ATT_BWD(4, 8);
+#undef VAA_ATT_BWD
+}
+
+template <bool CAUSAL>
+static int launch_fwd(const AttnFwdArgs& a, hipStream_t st) {
+    const int nqb = (a.T + kTile - 1) / kTile;
+    const unsigned grid = (unsigned)(((long)a.B * a.H + 7) / 8 * 8 * nqb);
+    if (a.hd <= 64) hipLaunchKernelGGL((attn_fwd_kernel<2, 4, CAUSAL>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.hd <= 80) hipLaunchKernelGGL((attn_fwd_kernel<3, 5, CAUSAL>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.hd <= 96) hipLaunchKernelGGL((attn_fwd_kernel<3, 6, CAUSAL>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<4, 8, CAUSAL>), dim3(grid), dim3(256), 0, st, a);
+    return check_launch("vaa_model_attention_fwd");
+}
+
+static bool strides_ok(const int64_t* s) { return s && (s[0] % 8) == 0 && (s[1] % 8) == 0 && (s[2] % 8) == 0; }
+static AttnStr mk(const int64_t* s) { AttnStr r; r.b = s[0]; r.t = s[1]; r.h = s[2]; return r; }
+
+}  // namespace vaa
+
+extern "C" int vaa_model_attention_fwd(const uint16_t* q, const int64_t* q_str, const uint16_t* k, const int64_t* k_str, const uint16_t* v,
+                                       const int64_t* v_str, uint16_t* o, const int64_t* o_str, float* lse, int B, int H, int T, int hd,
+                                       int causal, float scale, void* stream) {
+    using namespace vaa;
+    if (!q || !k || !v || !o || !lse) {
+        set_error("vaa_model_attention_fwd: null pointer argument");
+        return VAA_E_INVALID;
+    }
+    if (B <= 0 || H <= 0 || T <= 0 || hd <= 0 || hd > 128 || (hd % 8) != 0 || !strides_ok(q_str) || !strides_ok(k_str) || !strides_ok(v_str) ||
+        !strides_ok(o_str)) {
+        set_error("vaa_model_attention_fwd: unsupported shape (B=%d H=%d T=%d hd=%d; hd %% 8 == 0, hd <= 128, strides %% 8 == 0)", B, H, T, hd);
+        return VAA_E_UNSUPPORTED;
+    }
+    AttnFwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
+    a.sq = mk(q_str); a.sk = mk(k_str); a.sv = mk(v_str); a.so = mk(o_str);
+    a.B = B; a.H = H; a.T = T; a.hd = hd;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    return causal ? launch_fwd<true>(a, (hipStream_t)stream) : launch_fwd<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int vaa_model_attention_bwd(const uint16_t* q, const int64_t* q_str, const uint16_t* k, const int64_t* k_str, const uint16_t* v,
+                                       const int64_t* v_str, const uint16_t* o, const int64_t* o_str, const uint16_t* dout,
+                                       const int64_t* do_str, const float* lse, float* dsum, uint16_t* dq, const int64_t* dq_str, uint16_t* dk,
+                                       const int64_t* dk_str, uint16_t* dv, const int64_t* dv_str, int B, int H, int T, int hd, int causal,
+                                       float scale, void* stream) {
+    using namespace vaa;
+    if (!q || !k || !v || !o || !dout || !lse || !dsum || !dq || !dk || !dv) {
+        set_error("vaa_model_attention_bwd: null pointer argument");
+        return VAA_E_INVALID;
+    }
+    if (B <= 0 || H <= 0 || T <= 0 || hd <= 0 || hd > 128 || (hd % 8) != 0 || !strides_ok(q_str) || !strides_ok(k_str) || !strides_ok(v_str) ||
+        !strides_ok(o_str) || !strides_ok(do_str) || !strides_ok(dq_str) || !strides_ok(dk_str) || !strides_ok(dv_str)) {
+        set_error("vaa_model_attention_bwd: unsupported shape (B=%d H=%d T=%d hd=%d; hd %% 8 == 0, hd <= 128, strides %% 8 == 0)", B, H, T, hd);
+        return VAA_E_UNSUPPORTED;
+    }
+    AttnBwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.lse = lse; a.dsum = dsum; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.sq = mk(q_str); a.sk = mk(k_str); a.sv = mk(v_str); a.so = mk(o_str); a.sdo = mk(do_str);
+    a.sdq = mk(dq_str); a.sdk = mk(dk_str); a.sdv = mk(dv_str);
+    a.B = B; a.H = H; a.T = T; a.hd = hd;
+    a.scale = scale;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    return causal ? launch_bwd<true>(a, (hipStream_t)stream) : launch_bwd<false>(a, (hipStream_t)stream);
+}

@@ -17,6 +17,13 @@ def enabled(x: torch.Tensor) -> bool:
     return x.is_cuda and x.dtype == torch.bfloat16 and not os.environ.get("VAA_NO_FUSED_MODEL_OPS")
 
 
+def attention_enabled(x_bthd: torch.Tensor) -> bool:
+    """Matrix-core attention (vaa_attention.hip) applies: bf16 on ROCm, head dim % 8 == 0 and <= 128, 16-byte aligned strides."""
+    hd = x_bthd.shape[-1]
+    return (enabled(x_bthd) and not os.environ.get("VAA_NO_FUSED_ATTENTION") and hd % 8 == 0 and hd <= 128
+            and all(s % 8 == 0 for s in x_bthd.stride()[:-1]) and x_bthd.stride(-1) == 1)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -96,3 +103,120 @@ class ResidualRMSNormFn(torch.autograd.Function):
         _lib.check(_lib.lib().vaa_model_rmsnorm_bwd(g_h.data_ptr(), gp.data_ptr() if gp is not None else None, x.data_ptr(), weight.data_ptr(),
                                                     rstd.data_ptr(), gx.data_ptr(), rows, D, _stream()), "vaa_model_rmsnorm_bwd")
         return gx, None, None
+
+
+def tn_dgrad_enabled() -> bool:
+    return not os.environ.get("VAA_NO_TN_DGRAD")
+
+
+class FrozenLinearsFn(torch.autograd.Function):
+    """(x, res, W_0, Wt_0, W_1, Wt_1, ...) -> tuple of x @ W_i^T (+ res for a single weight, fused as the GEMM epilogue).
+
+    The weights are frozen, so the backward is data-gradient only: dx = sum_i dy_i @ W_i. Autograd's `dy @ W` is an NN-layout
+    GEMM, which hipBLASLt runs 20-25 % slower on gfx950 than the TN layout of the forward (tools/gemm_layout.py:
+    19200x11008x4096 1440 vs 1134 us). With 288 GB of HBM the transposed copy W_i^T (`Wt_i`, [in,out] contiguous) of every
+    Llama projection is simply kept resident (+12.9 GB), which turns each dgrad into a TN GEMM of an already-tuned forward
+    shape; the sum over i runs in the GEMM epilogue (addmm beta=1) instead of autograd's separate accumulation kernels."""
+
+    @staticmethod
+    def forward(ctx, x, res, *ws):
+        x2 = x.reshape(-1, x.shape[-1])
+        W, Wt = ws[0::2], ws[1::2]
+        ctx.wt = Wt
+        ctx.xshape = x.shape
+        ctx.has_res = res is not None
+        if res is not None:
+            return (torch.addmm(res.reshape(-1, W[0].shape[0]), x2, W[0].t()).view(*x.shape[:-1], W[0].shape[0]),)
+        return tuple(torch.nn.functional.linear(x2, w).view(*x.shape[:-1], w.shape[0]) for w in W)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        dx = None
+        for dy, wt in zip(dys, ctx.wt):
+            if dy is None:
+                continue
+            d2 = dy.reshape(-1, dy.shape[-1])
+            if dx is None:
+                dx = torch.nn.functional.linear(d2, wt)  # [M,out] x [in,out]^T
+            else:
+                dx.addmm_(d2, wt.t())
+        dx = dx.view(ctx.xshape) if dx is not None else None
+        dres = dys[0] if ctx.has_res else None
+        return (dx, dres) + (None,) * (2 * len(ctx.wt))
+
+
+def _str3(x: torch.Tensor):
+    """Element strides {batch, token, head} of a [B,T,H,hd] view as a C int64[3]."""
+    import ctypes
+
+    if x.stride(3) != 1:
+        raise ValueError("attention operands need a contiguous head dimension")
+    return (ctypes.c_int64 * 3)(x.stride(0), x.stride(1), x.stride(2))
+
+
+def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool, scale: float | None = None):
+    """softmax(scale * q k^T [causal]) v for bf16 [B,T,H,hd] views (any batch/token/head strides); returns (o [B,T,H,hd]
+    contiguous, lse float32 [B,H,T])."""
+    B, T, H, hd = q.shape
+    scale = float(hd) ** -0.5 if scale is None else float(scale)
+    o = torch.empty((B, T, H, hd), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    rc = _lib.lib().vaa_model_attention_fwd(q.data_ptr(), _str3(q), k.data_ptr(), _str3(k), v.data_ptr(), _str3(v), o.data_ptr(), _str3(o),
+                                            lse.data_ptr(), B, H, T, hd, int(bool(causal)), scale, _stream())
+    _lib.check(rc, "vaa_model_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, lse, dout, causal: bool, scale: float, packed_grad: bool = False):
+    """Gradients of attention_fwd. packed_grad=True returns one [B,T,3,H,hd] buffer (dq|dk|dv slices) — the layout of a fused
+    qkv projection's output gradient — instead of three [B,T,H,hd] tensors."""
+    B, T, H, hd = q.shape
+    if dout.stride(3) != 1:
+        dout = dout.contiguous()
+    if packed_grad:
+        buf = torch.empty((B, T, 3, H, hd), dtype=torch.bfloat16, device=q.device)
+        dq, dk, dv = buf[:, :, 0], buf[:, :, 1], buf[:, :, 2]
+    else:
+        buf = None
+        dq, dk, dv = (torch.empty((B, T, H, hd), dtype=torch.bfloat16, device=q.device) for _ in range(3))
+    dsum = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    rc = _lib.lib().vaa_model_attention_bwd(q.data_ptr(), _str3(q), k.data_ptr(), _str3(k), v.data_ptr(), _str3(v), o.data_ptr(), _str3(o),
+                                            dout.data_ptr(), _str3(dout), lse.data_ptr(), dsum.data_ptr(), dq.data_ptr(), _str3(dq),
+                                            dk.data_ptr(), _str3(dk), dv.data_ptr(), _str3(dv), B, H, T, hd, int(bool(causal)), float(scale), _stream())
+    _lib.check(rc, "vaa_model_attention_bwd")
+    return buf if packed_grad else (dq, dk, dv)
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(scale q k^T [causal]) v on [B,T,H,hd] bf16 views -> [B,T,H,hd] (vaa_attention.hip, fwd + 2-kernel bwd)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal, scale):
+        scale = float(q.shape[-1]) ** -0.5 if scale is None else float(scale)
+        o, lse = attention_fwd(q, k, v, causal, scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.causal, ctx.scale = bool(causal), scale
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = attention_bwd(q, k, v, o, lse, dout, ctx.causal, ctx.scale)
+        return dq, dk, dv, None, None
+
+
+class PackedAttentionFn(torch.autograd.Function):
+    """Same on a packed qkv [B,T,3,H,hd] (the ViT blocks' fused projection); the gradient comes back packed, in one buffer."""
+
+    @staticmethod
+    def forward(ctx, qkv, causal, scale):
+        scale = float(qkv.shape[-1]) ** -0.5 if scale is None else float(scale)
+        o, lse = attention_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal, scale)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.causal, ctx.scale = bool(causal), scale
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, o, lse = ctx.saved_tensors
+        return attention_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, lse, dout, ctx.causal, ctx.scale, packed_grad=True), None, None

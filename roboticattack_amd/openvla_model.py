@@ -84,8 +84,14 @@ class VitBlock(nn.Module):
 
     def forward(self, x):
         B, T, D = x.shape
-        qkv = self.qkv(self.norm1(x)).view(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
-        a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, T, D)
+        from . import model_ops
+
+        qkv = self.qkv(self.norm1(x)).view(B, T, 3, self.heads, D // self.heads)
+        if model_ops.attention_enabled(qkv):  # matrix-core attention on the packed projection; packed gradient, no permute copies
+            a = model_ops.PackedAttentionFn.apply(qkv, False, None).reshape(B, T, D)
+        else:
+            qkv = qkv.permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, T, D)
         a = self.proj(a)
         x = x + (a * self.ls1 if self.ls1 is not None else a)
         h = self.fc2(F.gelu(self.fc1(self.norm2(x))))
@@ -155,36 +161,82 @@ class LlamaLayer(nn.Module):
         self.gate_proj = nn.Linear(d, c.llm_mlp, bias=False)
         self.up_proj = nn.Linear(d, c.llm_mlp, bias=False)
         self.down_proj = nn.Linear(c.llm_mlp, d, bias=False)
+        self._wt_cache = {}
 
-    def forward(self, x, cos, sin, rope_tab=None):
+    def _wt(self, name):
+        """Resident transposed copy of a frozen projection ([in,out] contiguous) for the TN-layout dgrad (model_ops.FrozenLinearsFn)."""
+        w = getattr(self, name).weight
+        hit = self._wt_cache.get(name)
+        if hit is None or hit[0] != w._version or hit[1] is not w:
+            hit = (w._version, w, w.detach().t().contiguous())
+            self._wt_cache[name] = hit
+        return hit[2]
+
+    def _lin(self, x, names, res=None):
+        from . import model_ops
+
+        ws = []
+        for n in names:
+            ws += [getattr(self, n).weight, self._wt(n)]
+        return model_ops.FrozenLinearsFn.apply(x, res, *ws)
+
+    def forward(self, x, cos, sin, rope_tab=None, rows=None):
+        """`rows` (flat indices into the B*T positions): everything after the attention — o_proj, residual, MLP — is evaluated
+        for those rows only and [R,D] is returned (last layer of `forward_rows`: no other position reaches the loss)."""
         from . import model_ops
 
         B, T, D = x.shape
         hd = D // self.heads
         fused = rope_tab is not None and model_ops.enabled(x) and hd % 16 == 0 and D % 8 == 0 and D <= 8192
+        tn = fused and model_ops.tn_dgrad_enabled()
         if fused:
             x, h = model_ops.ResidualRMSNormFn.apply(x, self.input_layernorm.weight, self.input_layernorm.eps)
         else:
             h = self.input_layernorm(x)
-        if fused:  # one HBM pass per tensor instead of neg + cat + 2 mul + add (and their autograd chains)
-            q = model_ops.RopeFn.apply(self.q_proj(h).view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)
-            k = model_ops.RopeFn.apply(self.k_proj(h).view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)
-            v = self.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+        if tn:
+            q, k, v = self._lin(h, ("q_proj", "k_proj", "v_proj"))
         else:
-            q = self.q_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
-            k = self.k_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
-            v = self.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+            q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
+        if fused and model_ops.attention_enabled(q.view(B, T, self.heads, hd)):
+            q = model_ops.RopeFn.apply(q.view(B, T, self.heads, hd), *rope_tab)
+            k = model_ops.RopeFn.apply(k.view(B, T, self.heads, hd), *rope_tab)
+            a = model_ops.AttentionFn.apply(q, k, v.view(B, T, self.heads, hd), True, None).view(B, T, D)
+        elif fused:  # one HBM pass per tensor instead of neg + cat + 2 mul + add (and their autograd chains)
+            q = model_ops.RopeFn.apply(q.view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)
+            k = model_ops.RopeFn.apply(k.view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)
+            v = v.view(B, T, self.heads, hd).transpose(1, 2)
+            a = None
+        else:
+            q = q.view(B, T, self.heads, hd).transpose(1, 2)
+            k = k.view(B, T, self.heads, hd).transpose(1, 2)
+            v = v.view(B, T, self.heads, hd).transpose(1, 2)
             q, k = _rope(q, k, cos, sin)
-        a = F.scaled_dot_product_attention(q, k, v, is_causal=True)  # right padding + causal == HF's mask on real tokens
-        x = torch.addmm(x.reshape(-1, D), a.transpose(1, 2).reshape(-1, D), self.o_proj.weight.t()).view(B, T, D)  # residual in the GEMM epilogue
+            a = None
+        if a is None:
+            a = F.scaled_dot_product_attention(q, k, v, is_causal=True)  # right padding + causal == HF's mask on real tokens
+            a = a.transpose(1, 2).reshape(B, T, D)
+        if rows is not None:
+            a = a.reshape(-1, D).index_select(0, rows)[None]
+            x = x.reshape(-1, D).index_select(0, rows)[None]
+            B, T = 1, a.shape[1]
+        if tn:
+            (x,) = self._lin(a, ("o_proj",), res=x)  # residual in the GEMM epilogue
+        else:
+            x = torch.addmm(x.reshape(-1, D), a.reshape(-1, D), self.o_proj.weight.t()).view(B, T, D)
         if fused:
             x, h = model_ops.ResidualRMSNormFn.apply(x, self.post_attention_layernorm.weight, self.post_attention_layernorm.eps)
         else:
             h = self.post_attention_layernorm(x)
         if fused and (h.shape[0] * h.shape[1] * self.gate_proj.out_features) % 8 == 0:
+            if tn:
+                g, u = self._lin(h, ("gate_proj", "up_proj"))
+                (x,) = self._lin(model_ops.SwiGLUFn.apply(g, u), ("down_proj",), res=x)
+                return x[0] if rows is not None else x
             y = model_ops.SwiGLUFn.apply(self.gate_proj(h), self.up_proj(h))
-            return torch.addmm(x.reshape(-1, D), y.reshape(-1, y.shape[-1]), self.down_proj.weight.t()).view(B, T, D)
-        return x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
+            x = torch.addmm(x.reshape(-1, D), y.reshape(-1, y.shape[-1]), self.down_proj.weight.t()).view(B, T, D)
+        else:
+            x = x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
+        return x[0] if rows is not None else x
 
 
 class OpenVLAShaped(nn.Module):
@@ -223,8 +275,9 @@ class OpenVLAShaped(nn.Module):
                 p.fill_(1.0)
         return self
 
-    def hidden_states(self, input_ids, pixel_values):
-        """[B, 1+256+(L-1), D] final-norm hidden states of the multimodal sequence (modeling_prismatic.py:366-415)."""
+    def hidden_states(self, input_ids, pixel_values, rows=None):
+        """[B, 1+256+(L-1), D] final-norm hidden states of the multimodal sequence (modeling_prismatic.py:366-415); with
+        `rows` (flat position indices) only those positions of the LAST layer are evaluated and [R,D] is returned."""
         img, img_fused = torch.split(pixel_values, [3, 3], dim=1)
         feats = torch.cat([self.featurizer(img), self.fused_featurizer(img_fused)], dim=2)
         proj = self.fc3(F.gelu(self.fc2(F.gelu(self.fc1(feats)))))
@@ -239,8 +292,9 @@ class OpenVLAShaped(nn.Module):
         half = ang[:, : hd // 2]
         # fused path: HF rounds cos/sin to the activation dtype before use (modeling_llama rotary) — keep that rounding
         rope_tab = (half.cos().to(x.dtype).float().contiguous(), half.sin().to(x.dtype).float().contiguous())
-        for layer in self.layers:
-            x = layer(x, cos, sin, rope_tab)
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            x = layer(x, cos, sin, rope_tab, rows if i == last else None)
         return self.norm(x)
 
     @staticmethod
@@ -256,11 +310,9 @@ class OpenVLAShaped(nn.Module):
         """Logits [R,V] of the labelled rows only, in (b,k) row-major order of labels[b,k+1] != -100 (VAA_LAYOUT_ROWS):
         row (b,k) is model position S-L+k = 256+k, the position whose next-token target is labels[b,k+1].
         Pass `row_index=label_row_index(labels)` to keep the step free of host synchronisation."""
-        h = self.hidden_states(input_ids, pixel_values)
         if row_index is None:
             row_index = self.label_row_index(labels)
-        rows = h.reshape(-1, h.shape[-1]).index_select(0, row_index)  # [R, D]
-        return self.lm_head(rows)
+        return self.lm_head(self.hidden_states(input_ids, pixel_values, rows=row_index))  # [R, D] -> [R, V]
 
     def forward(self, input_ids, attention_mask=None, pixel_values=None, labels=None, **_):
         """Drop-in contract of PrismaticForConditionalGeneration.forward: full fp32 logits and HF's mean CE."""

@@ -111,3 +111,93 @@ def test_model_with_and_without_fused_ops(monkeypatch):
     (r1, g1), (r2, g2) = outs
     assert (r1 - r2).abs().max() <= 0.05 * r2.abs().max() + 1e-3
     assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.99
+
+
+def test_model_tn_dgrad_matches_autograd(monkeypatch):
+    """Resident W^T + TN-layout dgrad (FrozenLinearsFn) vs autograd's `dy @ W`: same logits, same pixel gradient up to GEMM summation order."""
+    from roboticattack_amd import synthetic
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+
+    cfg = OpenVLACfg(dino=VitCfg(32, 3, 2, 64, 5, True, True), siglip=VitCfg(48, 3, 2, 80, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=4)
+    ids, labels, _ = synthetic.synth_text_batch(6, 2, 18, 22)
+    labels = mask_labels(labels, [0]).to(DEV)
+    pix0 = torch.randn(2, 6, 224, 224, device=DEV).to(torch.bfloat16)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("VAA_NO_TN_DGRAD", "1")
+        pix = pix0.clone().requires_grad_(True)
+        rows = m.forward_rows(ids.to(DEV), pix, labels)
+        rows.float().square().mean().backward()
+        outs.append((rows.detach().float(), pix.grad.detach().float()))
+    (r1, g1), (r2, g2) = outs
+    assert (r1 - r2).abs().max() <= 1e-2 * r2.abs().max() + 1e-4
+    assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.999
+    # a weight update invalidates the cached transpose
+    lyr = m.layers[0]
+    wt_old = lyr._wt("q_proj")
+    with torch.no_grad():
+        lyr.q_proj.weight.mul_(2.0)
+    assert torch.equal(lyr._wt("q_proj"), lyr.q_proj.weight.t()) and lyr._wt("q_proj") is not wt_old
+
+
+@pytest.mark.parametrize("B,H,T,hd,causal,packed", [(2, 4, 300, 128, True, False), (2, 3, 261, 64, False, True), (2, 3, 256, 72, False, True),
+                                                    (1, 2, 17, 128, True, False), (3, 2, 64, 64, True, True), (1, 9, 65, 72, False, True),
+                                                    (2, 2, 130, 128, False, False), (1, 1, 1, 64, True, False), (1, 2, 333, 128, True, False),
+                                                    (2, 2, 40, 16, True, False), (1, 2, 257, 24, False, True)])
+def test_attention_fwd_bwd_vs_fp32(B, H, T, hd, causal, packed):
+    """vaa_model_attention_{fwd,bwd} (MFMA, transposed formulation) vs fp32 softmax attention + autograd on the same bf16 inputs."""
+    from roboticattack_amd import model_ops
+
+    g = torch.Generator(device=DEV).manual_seed(T * 131 + hd)
+    if packed:
+        qkv = torch.randn(B, T, 3, H, hd, device=DEV, generator=g).to(torch.bfloat16)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    else:
+        q, k, v = [(torch.randn(B, T, H, hd, device=DEV, generator=g) * 1.5).to(torch.bfloat16) for _ in range(3)]
+    scale = hd ** -0.5
+    go = torch.randn(B, T, H, hd, device=DEV, generator=g).to(torch.bfloat16)
+    qf, kf, vf = [x.detach().float().requires_grad_(True) for x in (q, k, v)]
+    s = torch.einsum("bthd,bshd->bhts", qf, kf) * scale
+    if causal:
+        s = s.masked_fill(torch.ones(T, T, device=DEV, dtype=torch.bool).triu(1), float("-inf"))
+    ref = torch.einsum("bhts,bshd->bthd", torch.softmax(s, -1), vf)
+    ref.backward(go.float())
+    o, lse = model_ops.attention_fwd(q, k, v, causal, scale)
+    assert (lse - torch.logsumexp(s, -1)).abs().max() < 1e-4
+    assert (o.float() - ref).abs().max() <= 2 ** -7 * ref.abs().max() + 1e-3  # bf16 output rounding + bf16 P
+    if packed:
+        buf = model_ops.attention_bwd(q, k, v, o, lse, go, causal, scale, packed_grad=True)
+        grads = (buf[:, :, 0], buf[:, :, 1], buf[:, :, 2])
+    else:
+        grads = model_ops.attention_bwd(q, k, v, o, lse, go, causal, scale)
+    for d, r in zip(grads, (qf.grad, kf.grad, vf.grad)):
+        assert (d.float() - r).abs().max() <= 2e-2 * r.abs().max() + 1e-5
+
+
+def test_model_attention_matches_sdpa(monkeypatch):
+    """The model with the matrix-core attention vs the same model on F.scaled_dot_product_attention (both bf16)."""
+    from roboticattack_amd import synthetic
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+
+    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, True, True), siglip=VitCfg(144, 3, 2, 288, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)  # head dims 64 / 72 / 128 like the real towers
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=6)
+    ids, labels, _ = synthetic.synth_text_batch(8, 2, 18, 22)
+    labels = mask_labels(labels, [0]).to(DEV)
+    pix0 = torch.randn(2, 6, 224, 224, device=DEV).to(torch.bfloat16)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("VAA_NO_FUSED_ATTENTION", "1")
+        pix = pix0.clone().requires_grad_(True)
+        rows = m.forward_rows(ids.to(DEV), pix, labels)
+        rows.float().square().mean().backward()
+        outs.append((rows.detach().float(), pix.grad.detach().float()))
+    (r1, g1), (r2, g2) = outs
+    assert (r1 - r2).abs().max() <= 0.03 * r2.abs().max() + 1e-3
+    assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.995

@@ -135,6 +135,18 @@ def test_tiny_model_rows_equal_full_logits():
     sel = [(b, 256 + k) for b in range(3) for k in range(L - 1) if labels[b, k + 1] != -100]
     full = torch.stack([out.logits[b, p] for b, p in sel])
     assert torch.allclose(full, rows, atol=1e-5) and out.logits.shape == (3, 256 + L, 32064)
+    # the rows-only last layer gives the same pixel gradient as the full sequence
+    gs = []
+    for use_rows in (True, False):
+        p = pix.clone().requires_grad_(True)
+        if use_rows:
+            z = m.forward_rows(ids, p, labels)
+        else:
+            lg = m(ids, attn, p, labels).logits
+            z = torch.stack([lg[b, q] for b, q in sel])
+        z.square().mean().backward()
+        gs.append(p.grad)
+    assert torch.allclose(gs[0], gs[1], rtol=1e-4, atol=1e-9 + 1e-4 * float(gs[1].abs().max()))
     assert all(not p.requires_grad for p in m.parameters())
 
 
@@ -180,3 +192,34 @@ def test_hf_checkpoint_name_mapping_roundtrip(tmp_path):
     ids, labels, attn = synthetic.synth_text_batch(2, 2, 18, 20)
     pix = torch.randn(2, 6, 224, 224)
     assert torch.equal(src(ids, attn, pix, labels).logits, dst(ids, attn, pix, labels).logits)
+
+
+def test_frozen_linears_fn_matches_autograd():
+    """model_ops.FrozenLinearsFn (TN-layout dgrad through a resident W^T, epilogue-fused sums) == plain autograd, fp32 on CPU."""
+    import torch
+
+    from roboticattack_amd.model_ops import FrozenLinearsFn
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 5, 8, generator=g, requires_grad=True)
+    res = torch.randn(3, 5, 6, generator=g, requires_grad=True)
+    Ws = [torch.randn(6, 8, generator=g) for _ in range(3)]
+    ws = []
+    for w in Ws:
+        ws += [w, w.t().contiguous()]
+    outs = FrozenLinearsFn.apply(x, None, *ws)
+    sum((o * (i + 1)).sin().sum() for i, o in enumerate(outs)).backward()
+    gx = x.grad.clone()
+    x.grad = None
+    ref = [torch.nn.functional.linear(x, w) for w in Ws]
+    sum((o * (i + 1)).sin().sum() for i, o in enumerate(ref)).backward()
+    for o, r in zip(outs, ref):
+        assert torch.allclose(o, r, atol=1e-6)
+    assert torch.allclose(gx, x.grad, atol=1e-5)
+    x.grad = None
+    (y,) = FrozenLinearsFn.apply(x, res, Ws[0], Ws[0].t().contiguous())
+    y.cos().sum().backward()
+    gx, gr = x.grad.clone(), res.grad.clone()
+    x.grad = res.grad = None
+    (res + torch.nn.functional.linear(x, Ws[0])).cos().sum().backward()
+    assert torch.allclose(gx, x.grad, atol=1e-5) and torch.allclose(gr, res.grad, atol=1e-6)
