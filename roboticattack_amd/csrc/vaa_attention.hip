@@ -48,28 +48,44 @@ __device__ __forceinline__ v4s lds_tr16(const uint16_t* p) {
 
 __device__ __forceinline__ v8s cat8(v4s lo, v4s hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
-__device__ __forceinline__ v8s pack8(v4f a, v4f b) {
-    v8s r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r[j] = (short)f32_to_bf16_bits(a[j]);
-        r[4 + j] = (short)f32_to_bf16_bits(b[j]);
-    }
-    return r;
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// two floats -> packed bf16 pair (v_cvt_pk_bf16_f32, round-to-nearest-even)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    const bf2 r = __builtin_convertvector((f2){lo, hi}, bf2);
+    return *reinterpret_cast<const uint32_t*>(&r);
 }
 
-// Register-staged copy of a [kTile x HDP] tile of a [*,T,*,hd] tensor (rows >= T and columns >= hd read as zero).
+__device__ __forceinline__ v8s pack8(v4f a, v4f b) {
+    uint4 r;
+    r.x = cvt_pk_bf16(a[0], a[1]);
+    r.y = cvt_pk_bf16(a[2], a[3]);
+    r.z = cvt_pk_bf16(b[0], b[1]);
+    r.w = cvt_pk_bf16(b[2], b[3]);
+    return *reinterpret_cast<v8s*>(&r);
+}
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor over the rows [0,T) of one (batch, head) slice: loads past the last valid element return 0, so tile
+// rows >= T need no branch. (Columns hd..HDP of a padded head dim read the neighbouring head's finite values; every product
+// they enter has a zero-padded register operand on the other side, and output rows >= hd are never stored.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const uint16_t* base, long st, int T, int hd) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((((long)T - 1) * st + hd) * 2), 0x00020000);
+}
+
+// Register-staged copy of a [kTile x HDP] tile of a [*,T,*,hd] tensor.
 template <int HDP>
 struct TileRegs {
     static constexpr int kChunks = kTile * (HDP / 8) / 256;  // 16-byte chunks per thread
-    uint4 r[kChunks];
-    __device__ __forceinline__ void load(const uint16_t* base, long st, int row0, int T, int hd) {
+    v4u r[kChunks];
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int st_bytes, int row0) {
 #pragma unroll
         for (int it = 0; it < kChunks; ++it) {
             const int ch = threadIdx.x + it * 256;
             const int row = ch / (HDP / 8), cc = ch % (HDP / 8);
-            r[it] = make_uint4(0, 0, 0, 0);
-            if (row0 + row < T && cc * 8 < hd) r[it] = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * st + cc * 8);
+            r[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (row0 + row) * st_bytes + cc * 16, 0, 0);
         }
     }
     __device__ __forceinline__ void store(uint16_t* lds, int stride) const {
@@ -77,7 +93,7 @@ struct TileRegs {
         for (int it = 0; it < kChunks; ++it) {
             const int ch = threadIdx.x + it * 256;
             const int row = ch / (HDP / 8), cc = ch % (HDP / 8);
-            *reinterpret_cast<uint4*>(lds + row * stride + cc * 8) = r[it];
+            *reinterpret_cast<v4u*>(lds + row * stride + cc * 8) = r[it];
         }
     }
 };
@@ -130,45 +146,57 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, lsum = 0.0f;
 
+    const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, a.T, a.hd), vrs = slice_rsrc(vp, a.sv.t, a.T, a.hd);
+    const int kst = (int)a.sk.t * 2, vst = (int)a.sv.t * 2;
     TileRegs<HDP> rk, rv;
-    rk.load(kp, a.sk.t, 0, a.T, a.hd);
-    rv.load(vp, a.sv.t, 0, a.T, a.hd);
+    rk.load(krs, kst, 0);
+    rv.load(vrs, vst, 0);
     for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();  // every wave is done reading the previous tile
         rk.store(sK, SK);
         rv.store(sV, SV);
         __syncthreads();
         if (kt + 1 < ntile) {  // next tile's loads fly during the MFMAs
-            rk.load(kp, a.sk.t, (kt + 1) * kTile, a.T, a.hd);
-            rv.load(vp, a.sv.t, (kt + 1) * kTile, a.T, a.hd);
+            rk.load(krs, kst, (kt + 1) * kTile);
+            rv.load(vrs, vst, (kt + 1) * kTile);
         }
         const int key0 = kt * kTile;
         if (CAUSAL && key0 > q0 + 15) continue;  // nothing visible to this wave in this tile (wave-uniform)
 
         v4f st[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            st[rt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int rp = 0; rp < 2; ++rp) {  // all fragment reads of two 16-key tiles first, then their MFMAs
+            v8s kfr[2][KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const v8s kf = *reinterpret_cast<const v8s*>(&sK[(rt * 16 + c) * SK + ks * 32 + g * 8]);
-                st[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[rt], 0, 0, 0);
+            for (int rl = 0; rl < 2; ++rl)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kfr[rl][ks] = *reinterpret_cast<const v8s*>(&sK[((2 * rp + rl) * 16 + c) * SK + ks * 32 + g * 8]);
+#pragma unroll
+            for (int rl = 0; rl < 2; ++rl) {
+                v4f t = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[rl][ks], qf[ks], t, 0, 0, 0);
+                st[2 * rp + rl] = t;
             }
+        }
+        const bool need_mask = (key0 + kTile > a.T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform
+        if (need_mask) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + rt * 16 + g * 4 + r;
+                    if (key >= a.T || (CAUSAL && key > q)) st[rt][r] = -INFINITY;
+                }
         }
         float mx = -INFINITY;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = key0 + rt * 16 + g * 4 + r;
-                float s = st[rt][r] * a.scale_log2;
-                if (key >= a.T || (CAUSAL && key > q)) s = -INFINITY;
-                st[rt][r] = s;
-                mx = fmaxf(mx, s);
-            }
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[rt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
+        const float mn = fmaxf(m, mx * a.scale_log2);  // scale > 0: max commutes with the scaling
         const float mu = (mn == -INFINITY) ? 0.0f : mn;
         const float alpha = fast_exp2(m - mu);  // m = -inf -> 0
         m = mn;
@@ -177,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(st[rt][r] - mu);
+                const float p = fast_exp2(__builtin_fmaf(st[rt][r], a.scale_log2, -mu));
                 st[rt][r] = p;
                 ps += p;
             }
@@ -188,11 +216,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
         for (int half = 0; half < 2; ++half) {
             const v8s pf = pack8(st[2 * half], st[2 * half + 1]);
             const uint16_t* vrow = &sV[(half * 32 + 4 * g + (c >> 2)) * SV + (c & 3) * 4];
+            v8s vfr[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const v8s vf = cat8(lds_tr16(vrow + nt * 16), lds_tr16(vrow + 16 * SV + nt * 16));
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[nt], 0, 0, 0);
-            }
+            for (int nt = 0; nt < NT; ++nt) vfr[nt] = cat8(lds_tr16(vrow + nt * 16), lds_tr16(vrow + 16 * SV + nt * 16));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[nt], pf, acc[nt], 0, 0, 0);
         }
     }
     lsum += __shfl_xor(lsum, 16, 64);
@@ -205,8 +233,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
             const int d0 = nt * 16 + g * 4;
             if (d0 < a.hd) {
                 uint2 w;
-                w.x = f32_to_bf16_bits(acc[nt][0] * inv) | (f32_to_bf16_bits(acc[nt][1] * inv) << 16);
-                w.y = f32_to_bf16_bits(acc[nt][2] * inv) | (f32_to_bf16_bits(acc[nt][3] * inv) << 16);
+                w.x = cvt_pk_bf16(acc[nt][0] * inv, acc[nt][1] * inv);
+                w.y = cvt_pk_bf16(acc[nt][2] * inv, acc[nt][3] * inv);
                 *reinterpret_cast<uint2*>(op + d0) = w;
             }
         }
@@ -241,11 +269,11 @@ __device__ __forceinline__ void load_row_frags(v8s (&f)[KS], const uint16_t* row
 template <int KS>
 __device__ __forceinline__ v4f tile_dot(const uint16_t* tile, int stride, int rt, int c, int g, const v8s (&bf)[KS]) {
     v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+    v8s af[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const v8s af = *reinterpret_cast<const v8s*>(&tile[(rt * 16 + c) * stride + ks * 32 + g * 8]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[ks], acc, 0, 0, 0);
-    }
+    for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const v8s*>(&tile[(rt * 16 + c) * stride + ks * 32 + g * 8]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf[ks], acc, 0, 0, 0);
     return acc;
 }
 
@@ -295,20 +323,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+    const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, a.T, a.hd), vrs = slice_rsrc(vp, a.sv.t, a.T, a.hd);
+    const int kst = (int)a.sk.t * 2, vst = (int)a.sv.t * 2;
     TileRegs<HDP> rk, rv;
-    rk.load(kp, a.sk.t, 0, a.T, a.hd);
-    rv.load(vp, a.sv.t, 0, a.T, a.hd);
+    rk.load(krs, kst, 0);
+    rv.load(vrs, vst, 0);
     for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();
         rk.store(sK, SK);
         rv.store(sV, SV);
         __syncthreads();
         if (kt + 1 < ntile) {
-            rk.load(kp, a.sk.t, (kt + 1) * kTile, a.T, a.hd);
-            rv.load(vp, a.sv.t, (kt + 1) * kTile, a.T, a.hd);
+            rk.load(krs, kst, (kt + 1) * kTile);
+            rv.load(vrs, vst, (kt + 1) * kTile);
         }
         const int key0 = kt * kTile;
         if (CAUSAL && key0 > q0 + 15) continue;
+        const bool need_mask = (key0 + kTile > a.T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (CAUSAL && key0 + half * 32 > q0 + 15) continue;
@@ -320,19 +351,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
                 const v4f dp = tile_dot<KS>(sV, SV, rt, c, g, dof);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + rt * 16 + g * 4 + r;
-                    const bool masked = key >= a.T || (CAUSAL && key > q);
-                    const float p = masked ? 0.0f : fast_exp2(st[r] * a.scale_log2 - lse2);
+                    float p = fast_exp2(__builtin_fmaf(st[r], a.scale_log2, -lse2));
+                    if (need_mask) {
+                        const int key = key0 + rt * 16 + g * 4 + r;
+                        if (key >= a.T || (CAUSAL && key > q)) p = 0.0f;
+                    }
                     ds[rl][r] = p * (dp[r] - Dq);
                 }
             }
             const v8s dsf = pack8(ds[0], ds[1]);
             const uint16_t* krow = &sK[(half * 32 + 4 * g + (c >> 2)) * SK + (c & 3) * 4];
+            v8s kfr[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const v8s kf = cat8(lds_tr16(krow + nt * 16), lds_tr16(krow + 16 * SK + nt * 16));
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, acc[nt], 0, 0, 0);
-            }
+            for (int nt = 0; nt < NT; ++nt) kfr[nt] = cat8(lds_tr16(krow + nt * 16), lds_tr16(krow + 16 * SK + nt * 16));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[nt], dsf, acc[nt], 0, 0, 0);
         }
     }
     if (qv) {
@@ -342,8 +375,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
             const int d0 = nt * 16 + g * 4;
             if (d0 < a.hd) {
                 uint2 w;
-                w.x = f32_to_bf16_bits(acc[nt][0] * a.scale) | (f32_to_bf16_bits(acc[nt][1] * a.scale) << 16);
-                w.y = f32_to_bf16_bits(acc[nt][2] * a.scale) | (f32_to_bf16_bits(acc[nt][3] * a.scale) << 16);
+                w.x = cvt_pk_bf16(acc[nt][0] * a.scale, acc[nt][1] * a.scale);
+                w.y = cvt_pk_bf16(acc[nt][2] * a.scale, acc[nt][3] * a.scale);
                 *reinterpret_cast<uint2*>(op + d0) = w;
             }
         }
@@ -393,8 +426,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
             else rstat = qq < a.T ? dsp[qq] : 0.0f;
         }
     };
-    rq.load(qp, a.sq.t, qt0 * kTile, a.T, a.hd);
-    rdo.load(dop, a.sdo.t, qt0 * kTile, a.T, a.hd);
+    const __amdgpu_buffer_rsrc_t qrs = slice_rsrc(qp, a.sq.t, a.T, a.hd), dors = slice_rsrc(dop, a.sdo.t, a.T, a.hd);
+    const int qst = (int)a.sq.t * 2, dost = (int)a.sdo.t * 2;
+    rq.load(qrs, qst, qt0 * kTile);
+    rdo.load(dors, dost, qt0 * kTile);
     load_stats(qt0 * kTile);
     for (int qt = qt0; qt < nqt; ++qt) {
         __syncthreads();
@@ -404,12 +439,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         else if (tid < 128) sD[tid - 64] = rstat;
         __syncthreads();
         if (qt + 1 < nqt) {
-            rq.load(qp, a.sq.t, (qt + 1) * kTile, a.T, a.hd);
-            rdo.load(dop, a.sdo.t, (qt + 1) * kTile, a.T, a.hd);
+            rq.load(qrs, qst, (qt + 1) * kTile);
+            rdo.load(dors, dost, (qt + 1) * kTile);
             load_stats((qt + 1) * kTile);
         }
         const int qb0 = qt * kTile;
         if (CAUSAL && qb0 + kTile - 1 < key0w) continue;  // every query of the tile precedes this wave's keys
+        const bool need_mask = CAUSAL && qb0 < key0w + 15;  // wave-uniform: some (query, key) pair of this tile is hidden
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (CAUSAL && qb0 + half * 32 + 31 < key0w) continue;
@@ -421,21 +457,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
                 const v4f dp = tile_dot<KS>(sDO, SQ, rt, c, g, vf);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ql = rt * 16 + g * 4 + r, qq = qb0 + ql;
-                    const bool masked = !kv || (CAUSAL && key > qq);
-                    const float pe = masked ? 0.0f : fast_exp2(s[r] * a.scale_log2 - sL[ql]);  // invalid query: lse = +inf -> 0
+                    const int ql = rt * 16 + g * 4 + r;
+                    float pe = fast_exp2(__builtin_fmaf(s[r], a.scale_log2, -sL[ql]));  // invalid query: lse = +inf -> 0
+                    if (CAUSAL && need_mask && key > qb0 + ql) pe = 0.0f;
                     p[rl][r] = pe;
                     ds[rl][r] = pe * (dp[r] - sD[ql]);
                 }
             }
             const v8s pf = pack8(p[0], p[1]), dsf = pack8(ds[0], ds[1]);
             const int ro = (half * 32 + 4 * g + (c >> 2)) * SQ + (c & 3) * 4;
+            {
+                v8s fr[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const v8s dot = cat8(lds_tr16(&sDO[ro + nt * 16]), lds_tr16(&sDO[ro + 16 * SQ + nt * 16]));
-                dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf, dv[nt], 0, 0, 0);
-                const v8s qt_ = cat8(lds_tr16(&sQ[ro + nt * 16]), lds_tr16(&sQ[ro + 16 * SQ + nt * 16]));
-                dk[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsf, dk[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) fr[nt] = cat8(lds_tr16(&sDO[ro + nt * 16]), lds_tr16(&sDO[ro + 16 * SQ + nt * 16]));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[nt], pf, dv[nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fr[nt] = cat8(lds_tr16(&sQ[ro + nt * 16]), lds_tr16(&sQ[ro + 16 * SQ + nt * 16]));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) dk[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[nt], dsf, dk[nt], 0, 0, 0);
             }
         }
     }
@@ -447,11 +487,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
             const int d0 = nt * 16 + g * 4;
             if (d0 < a.hd) {
                 uint2 w;
-                w.x = f32_to_bf16_bits(dk[nt][0] * a.scale) | (f32_to_bf16_bits(dk[nt][1] * a.scale) << 16);
-                w.y = f32_to_bf16_bits(dk[nt][2] * a.scale) | (f32_to_bf16_bits(dk[nt][3] * a.scale) << 16);
+                w.x = cvt_pk_bf16(dk[nt][0] * a.scale, dk[nt][1] * a.scale);
+                w.y = cvt_pk_bf16(dk[nt][2] * a.scale, dk[nt][3] * a.scale);
                 *reinterpret_cast<uint2*>(okp + d0) = w;
-                w.x = f32_to_bf16_bits(dv[nt][0]) | (f32_to_bf16_bits(dv[nt][1]) << 16);
-                w.y = f32_to_bf16_bits(dv[nt][2]) | (f32_to_bf16_bits(dv[nt][3]) << 16);
+                w.x = cvt_pk_bf16(dv[nt][0], dv[nt][1]);
+                w.y = cvt_pk_bf16(dv[nt][2], dv[nt][3]);
                 *reinterpret_cast<uint2*>(ovp + d0) = w;
             }
         }
