@@ -9,8 +9,9 @@ One step = one inner-loop iteration of UADA_wrapper_ddp (UADA_ddp.py:189-209):
     -> K3 loss fwd+bwd on the labelled rows (HIP) -> K2 patch-grad gather (HIP) -> [RCCL all-reduce, 30 KB] -> K4 AdamW+clamp (HIP)
 Workload: bs=64 PER RANK (reference semantics, UADA_ddp.py:158 -> weak scaling), 3x50x50 patch, geometry=True, maskidx=[0],
 synthetic BridgeData-shaped frames resident in HBM as u8, random-init weights of the OpenVLA-7B architecture.
-Prints ONE JSON line on rank 0. `roofline` is the slowest hand-written kernel inside the timed region (HIP events on the
-launch stream); `roofline_kernels`/`k2_sweep` carry every kernel and the K2 batch sweep; `cpu_baseline` is the reference's
+Prints ONE JSON line on rank 0. `roofline` is the dominant hand-written kernel of the path — K1's `patch_apply_fwd_kernel`, which
+moves 73 % of the path's algorithmic bytes and is the longest single hand-written launch in profiles/r01_kbench_kernel_stats_*.csv —
+timed inside the timed region (HIP events on the launch stream); `roofline_kernels`/`k2_sweep` carry every op and the K2 batch sweep; `cpu_baseline` is the reference's
 PyTorch-CPU op sequence for the same replaced ops (oracle/ref_port.py) timed on this box's host cores.
 """
 from __future__ import annotations
@@ -245,7 +246,8 @@ def main():
         mean = float(np.mean(ts))
         kern[name] = {"launches": len(ts), "mean_us": mean * 1e6, "algo_bytes": nb, "achieved_GBs": nb / mean / 1e9,
                       "frac": nb / mean / 1e9 / HBM_PEAK_GBS}
-    dom = max(kern, key=lambda k: kern[k]["mean_us"]) if kern else None
+    # dominant kernel: most algorithmic bytes (K1, one launch per op -> the event bracket is the kernel); every op is in `roofline_kernels`
+    dom = max(kern, key=lambda k: kern[k]["algo_bytes"]) if kern else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")  # rocprofv3 --pmc passes of tools/pmc_traffic.py (same kernels, same shapes)
     tr_ops = json.load(open(tpath)).get("ops", {}) if os.path.exists(tpath) else {}
@@ -257,7 +259,8 @@ def main():
     if dom:
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kern[dom]["frac"], "traffic": traffic, "mean_us": kern[dom]["mean_us"], "algo_bytes": kern[dom]["algo_bytes"],
-                    "note": "event-bracketed launch sequence on the launching stream inside the timed region (includes launch gaps of multi-kernel ops); "
+                    "note": "dominant = the hot-path kernel with the most algorithmic bytes (also the longest single hand-written launch in the rocprofv3 kernel stats); "
+                            "event-bracketed on the launching stream inside the timed region; "
                             "traffic = HBM-side bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/traffic_r01.json, calibrated in-run)"}
 
     extra = {}
