@@ -28,11 +28,14 @@ int vaa_model_attention_fwd(const uint16_t* q, const int64_t* q_str, const uint1
                             const int64_t* v_str, uint16_t* o, const int64_t* o_str, float* lse, int B, int H, int T, int hd, int causal,
                             float scale, void* stream);
 /* Backward of vaa_model_attention_fwd: o, lse from the forward; dsum: float32 [B,H,T] workspace; dq/dk/dv: bf16 [B,T,H,hd] views
- * given by strides (e.g. the three slices of one packed [B,T,3,H,hd] gradient buffer). Two launches (dq, then dk/dv). */
+ * given by strides (e.g. the three slices of one packed [B,T,3,H,hd] gradient buffer). Two launches (dq, then dk/dv).
+ * rope_cos/rope_sin (both or neither; float32 [T,hd/2], hd in {64,128}): q and k had vaa_model_rope applied before the forward;
+ * dq and dk are then returned w.r.t. the un-rotated tensors (the adjoint rotation runs in the kernels' epilogues). */
 int vaa_model_attention_bwd(const uint16_t* q, const int64_t* q_str, const uint16_t* k, const int64_t* k_str, const uint16_t* v,
                             const int64_t* v_str, const uint16_t* o, const int64_t* o_str, const uint16_t* dout, const int64_t* do_str,
                             const float* lse, float* dsum, uint16_t* dq, const int64_t* dq_str, uint16_t* dk, const int64_t* dk_str,
-                            uint16_t* dv, const int64_t* dv_str, int B, int H, int T, int hd, int causal, float scale, void* stream);
+                            uint16_t* dv, const int64_t* dv_str, const float* rope_cos, const float* rope_sin, int B, int H, int T, int hd,
+                            int causal, float scale, void* stream);
 #ifdef __cplusplus
 }
 #endif

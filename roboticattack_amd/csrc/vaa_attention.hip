@@ -249,9 +249,48 @@ struct AttnBwdArgs {
     float* dsum;       // [B,H,T] workspace: D = rowsum(dO * O), written by the dq kernel, read by the dk/dv kernel
     uint16_t *dq, *dk, *dv;
     AttnStr sq, sk, sv, so, sdo, sdq, sdk, sdv;
+    const float *rope_cos, *rope_sin;  // optional float32 [T, hd/2]: q and k were rotated before the forward; dq/dk are returned
+                                       // w.r.t. the UN-rotated projections (adjoint rotation fused into the epilogues)
     int B, H, T, hd;
     float scale, scale_log2;
 };
+
+// Writes one key's / query's gradient row from transposed accumulators (lane: column = that row, rows = head-dim 16 nt + 4 g + r),
+// scaled, optionally through the adjoint of HF's rotate_half rotary embedding: g1' = g1 c + g2 s, g2' = g2 c - g1 s.
+template <int NT>
+__device__ __forceinline__ void store_grad_row(uint16_t* op, const v4f (&acc)[NT], float scale, int g, int hd, const float* cosr, const float* sinr) {
+    if (cosr) {  // host guarantees hd == 16 NT here
+#pragma unroll
+        for (int nt = 0; nt < NT / 2; ++nt) {
+            const int d0 = nt * 16 + g * 4;
+            const float4 c4 = *reinterpret_cast<const float4*>(cosr + d0), s4 = *reinterpret_cast<const float4*>(sinr + d0);
+            const float cs[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+            float o1[4], o2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g1 = acc[nt][r] * scale, g2 = acc[nt + NT / 2][r] * scale;
+                o1[r] = g1 * cs[r] + g2 * sn[r];
+                o2[r] = g2 * cs[r] - g1 * sn[r];
+            }
+            uint2 w;
+            w.x = cvt_pk_bf16(o1[0], o1[1]); w.y = cvt_pk_bf16(o1[2], o1[3]);
+            *reinterpret_cast<uint2*>(op + d0) = w;
+            w.x = cvt_pk_bf16(o2[0], o2[1]); w.y = cvt_pk_bf16(o2[2], o2[3]);
+            *reinterpret_cast<uint2*>(op + d0 + NT * 8) = w;
+        }
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int d0 = nt * 16 + g * 4;
+        if (d0 < hd) {
+            uint2 w;
+            w.x = cvt_pk_bf16(acc[nt][0] * scale, acc[nt][1] * scale);
+            w.y = cvt_pk_bf16(acc[nt][2] * scale, acc[nt][3] * scale);
+            *reinterpret_cast<uint2*>(op + d0) = w;
+        }
+    }
+}
 
 // B-operand fragments of a row-major [*, hd] matrix row: lane (c,g), k-step ks <-> row[32 ks + 8 g .. +8] (zero outside).
 template <int KS>
@@ -369,17 +408,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
         }
     }
     if (qv) {
-        uint16_t* op = a.dq + (long)b * a.sdq.b + (long)q * a.sdq.t + (long)h * a.sdq.h;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int d0 = nt * 16 + g * 4;
-            if (d0 < a.hd) {
-                uint2 w;
-                w.x = cvt_pk_bf16(acc[nt][0] * a.scale, acc[nt][1] * a.scale);
-                w.y = cvt_pk_bf16(acc[nt][2] * a.scale, acc[nt][3] * a.scale);
-                *reinterpret_cast<uint2*>(op + d0) = w;
-            }
-        }
+        const long ro = (long)q * (a.hd >> 1);
+        store_grad_row<NT>(a.dq + (long)b * a.sdq.b + (long)q * a.sdq.t + (long)h * a.sdq.h, acc, a.scale, g, a.hd,
+                           a.rope_cos ? a.rope_cos + ro : nullptr, a.rope_cos ? a.rope_sin + ro : nullptr);
     }
 }
 
@@ -480,21 +511,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         }
     }
     if (kv) {
-        uint16_t* okp = a.dk + (long)b * a.sdk.b + (long)key * a.sdk.t + (long)h * a.sdk.h;
-        uint16_t* ovp = a.dv + (long)b * a.sdv.b + (long)key * a.sdv.t + (long)h * a.sdv.h;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int d0 = nt * 16 + g * 4;
-            if (d0 < a.hd) {
-                uint2 w;
-                w.x = cvt_pk_bf16(dk[nt][0] * a.scale, dk[nt][1] * a.scale);
-                w.y = cvt_pk_bf16(dk[nt][2] * a.scale, dk[nt][3] * a.scale);
-                *reinterpret_cast<uint2*>(okp + d0) = w;
-                w.x = cvt_pk_bf16(dv[nt][0], dv[nt][1]);
-                w.y = cvt_pk_bf16(dv[nt][2], dv[nt][3]);
-                *reinterpret_cast<uint2*>(ovp + d0) = w;
-            }
-        }
+        const long ro = (long)key * (a.hd >> 1);
+        store_grad_row<NT>(a.dk + (long)b * a.sdk.b + (long)key * a.sdk.t + (long)h * a.sdk.h, dk, a.scale, g, a.hd,
+                           a.rope_cos ? a.rope_cos + ro : nullptr, a.rope_cos ? a.rope_sin + ro : nullptr);
+        store_grad_row<NT>(a.dv + (long)b * a.sdv.b + (long)key * a.sdv.t + (long)h * a.sdv.h, dv, 1.0f, g, a.hd, nullptr, nullptr);
     }
 }
 
@@ -557,8 +577,8 @@ extern "C" int vaa_model_attention_fwd(const uint16_t* q, const int64_t* q_str, 
 extern "C" int vaa_model_attention_bwd(const uint16_t* q, const int64_t* q_str, const uint16_t* k, const int64_t* k_str, const uint16_t* v,
                                        const int64_t* v_str, const uint16_t* o, const int64_t* o_str, const uint16_t* dout,
                                        const int64_t* do_str, const float* lse, float* dsum, uint16_t* dq, const int64_t* dq_str, uint16_t* dk,
-                                       const int64_t* dk_str, uint16_t* dv, const int64_t* dv_str, int B, int H, int T, int hd, int causal,
-                                       float scale, void* stream) {
+                                       const int64_t* dk_str, uint16_t* dv, const int64_t* dv_str, const float* rope_cos, const float* rope_sin,
+                                       int B, int H, int T, int hd, int causal, float scale, void* stream) {
     using namespace vaa;
     if (!q || !k || !v || !o || !dout || !lse || !dsum || !dq || !dk || !dv) {
         set_error("vaa_model_attention_bwd: null pointer argument");
@@ -573,6 +593,11 @@ extern "C" int vaa_model_attention_bwd(const uint16_t* q, const int64_t* q_str, 
     a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.lse = lse; a.dsum = dsum; a.dq = dq; a.dk = dk; a.dv = dv;
     a.sq = mk(q_str); a.sk = mk(k_str); a.sv = mk(v_str); a.so = mk(o_str); a.sdo = mk(do_str);
     a.sdq = mk(dq_str); a.sdk = mk(dk_str); a.sdv = mk(dv_str);
+    if ((rope_cos != nullptr) != (rope_sin != nullptr) || (rope_cos && hd != 64 && hd != 128)) {
+        set_error("vaa_model_attention_bwd: fused rotary adjoint needs both tables and hd in {64, 128} (hd=%d)", hd);
+        return VAA_E_UNSUPPORTED;
+    }
+    a.rope_cos = rope_cos; a.rope_sin = rope_sin;
     a.B = B; a.H = H; a.T = T; a.hd = hd;
     a.scale = scale;
     a.scale_log2 = scale * 1.4426950408889634f;

@@ -167,9 +167,10 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: boo
     return o, lse
 
 
-def attention_bwd(q, k, v, o, lse, dout, causal: bool, scale: float, packed_grad: bool = False):
+def attention_bwd(q, k, v, o, lse, dout, causal: bool, scale: float, packed_grad: bool = False, rope=None):
     """Gradients of attention_fwd. packed_grad=True returns one [B,T,3,H,hd] buffer (dq|dk|dv slices) — the layout of a fused
-    qkv projection's output gradient — instead of three [B,T,H,hd] tensors."""
+    qkv projection's output gradient — instead of three [B,T,H,hd] tensors. rope=(cos, sin) float32 [T,hd/2]: q and k are the
+    ROTATED tensors and dq/dk come back w.r.t. the un-rotated ones (adjoint rotation fused into the kernels' epilogues)."""
     B, T, H, hd = q.shape
     if dout.stride(3) != 1:
         dout = dout.contiguous()
@@ -182,7 +183,8 @@ def attention_bwd(q, k, v, o, lse, dout, causal: bool, scale: float, packed_grad
     dsum = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
     rc = _lib.lib().vaa_model_attention_bwd(q.data_ptr(), _str3(q), k.data_ptr(), _str3(k), v.data_ptr(), _str3(v), o.data_ptr(), _str3(o),
                                             dout.data_ptr(), _str3(dout), lse.data_ptr(), dsum.data_ptr(), dq.data_ptr(), _str3(dq),
-                                            dk.data_ptr(), _str3(dk), dv.data_ptr(), _str3(dv), B, H, T, hd, int(bool(causal)), float(scale), _stream())
+                                            dk.data_ptr(), _str3(dk), dv.data_ptr(), _str3(dv), rope[0].data_ptr() if rope else None,
+                                            rope[1].data_ptr() if rope else None, B, H, T, hd, int(bool(causal)), float(scale), _stream())
     _lib.check(rc, "vaa_model_attention_bwd")
     return buf if packed_grad else (dq, dk, dv)
 
@@ -203,6 +205,26 @@ class AttentionFn(torch.autograd.Function):
         q, k, v, o, lse = ctx.saved_tensors
         dq, dk, dv = attention_bwd(q, k, v, o, lse, dout, ctx.causal, ctx.scale)
         return dq, dk, dv, None, None
+
+
+class RopeAttentionFn(torch.autograd.Function):
+    """rope(q), rope(k) -> causal attention, with the rotary adjoint of dq/dk fused into the backward kernels' epilogues
+    (saves two full passes over [B,T,H,hd] per layer). q, k, v: [B,T,H,hd] bf16 views; cos/sin: float32 [T,hd/2]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cos, sin, causal, scale):
+        scale = float(q.shape[-1]) ** -0.5 if scale is None else float(scale)
+        qr, kr = _rope_launch(q, cos, sin, 1.0), _rope_launch(k, cos, sin, 1.0)
+        o, lse = attention_fwd(qr, kr, v, causal, scale)
+        ctx.save_for_backward(qr, kr, v, o, lse, cos, sin)
+        ctx.causal, ctx.scale = bool(causal), scale
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        qr, kr, v, o, lse, cos, sin = ctx.saved_tensors
+        dq, dk, dv = attention_bwd(qr, kr, v, o, lse, dout, ctx.causal, ctx.scale, rope=(cos, sin))
+        return dq, dk, dv, None, None, None, None
 
 
 class PackedAttentionFn(torch.autograd.Function):

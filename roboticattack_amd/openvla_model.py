@@ -198,9 +198,13 @@ class LlamaLayer(nn.Module):
         else:
             q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
         if fused and model_ops.attention_enabled(q.view(B, T, self.heads, hd)):
-            q = model_ops.RopeFn.apply(q.view(B, T, self.heads, hd), *rope_tab)
-            k = model_ops.RopeFn.apply(k.view(B, T, self.heads, hd), *rope_tab)
-            a = model_ops.AttentionFn.apply(q, k, v.view(B, T, self.heads, hd), True, None).view(B, T, D)
+            sh = (B, T, self.heads, hd)
+            if hd in (64, 128):  # rotary adjoint of dq/dk runs in the attention backward's epilogues
+                a = model_ops.RopeAttentionFn.apply(q.view(sh), k.view(sh), v.view(sh), *rope_tab, True, None).view(B, T, D)
+            else:
+                q = model_ops.RopeFn.apply(q.view(sh), *rope_tab)
+                k = model_ops.RopeFn.apply(k.view(sh), *rope_tab)
+                a = model_ops.AttentionFn.apply(q, k, v.view(sh), True, None).view(B, T, D)
         elif fused:  # one HBM pass per tensor instead of neg + cat + 2 mul + add (and their autograd chains)
             q = model_ops.RopeFn.apply(q.view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)
             k = model_ops.RopeFn.apply(k.view(B, T, self.heads, hd), *rope_tab).transpose(1, 2)

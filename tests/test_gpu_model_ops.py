@@ -201,3 +201,28 @@ def test_model_attention_matches_sdpa(monkeypatch):
     (r1, g1), (r2, g2) = outs
     assert (r1 - r2).abs().max() <= 0.03 * r2.abs().max() + 1e-3
     assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.995
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+def test_rope_attention_fused_backward(hd):
+    """RopeAttentionFn (rotary adjoint inside the attention backward epilogues) == RopeFn -> AttentionFn, up to one bf16 rounding."""
+    from roboticattack_amd import model_ops
+
+    B, T, H = 2, 75, 3
+    g = torch.Generator(device=DEV).manual_seed(hd)
+    ang = torch.outer(torch.arange(T, device=DEV, dtype=torch.float32), 1.0 / (10000 ** (torch.arange(0, hd, 2, device=DEV, dtype=torch.float32) / hd)))
+    cos, sin = ang.cos().to(torch.bfloat16).float().contiguous(), ang.sin().to(torch.bfloat16).float().contiguous()
+    base = [torch.randn(B, T, H, hd, device=DEV, generator=g).to(torch.bfloat16) for _ in range(3)]
+    go = torch.randn(B, T, H, hd, device=DEV, generator=g).to(torch.bfloat16)
+    res = []
+    for fused in (True, False):
+        q, k, v = [x.clone().requires_grad_(True) for x in base]
+        if fused:
+            o = model_ops.RopeAttentionFn.apply(q, k, v, cos, sin, True, None)
+        else:
+            o = model_ops.AttentionFn.apply(model_ops.RopeFn.apply(q, cos, sin), model_ops.RopeFn.apply(k, cos, sin), v, True, None)
+        o.backward(go)
+        res.append((o.detach().float(), q.grad.float(), k.grad.float(), v.grad.float()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][3], res[1][3])
+    for a, b in zip(res[0][1:3], res[1][1:3]):
+        assert (a - b).abs().max() <= 2 ** -6 * b.abs().max()
