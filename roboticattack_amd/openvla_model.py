@@ -93,9 +93,9 @@ class VitBlock(nn.Module):
             qkv = qkv.permute(2, 0, 3, 1, 4)
             a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, T, D)
         a = self.proj(a)
-        x = x + (a * self.ls1 if self.ls1 is not None else a)
+        x = torch.addcmul(x, a, self.ls1) if self.ls1 is not None else x + a  # LayerScale + residual in one pass
         h = self.fc2(F.gelu(self.fc1(self.norm2(x))))
-        return x + (h * self.ls2 if self.ls2 is not None else h)
+        return torch.addcmul(x, h, self.ls2) if self.ls2 is not None else x + h
 
 
 class Vit(nn.Module):
