@@ -112,47 +112,52 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
             row_word[tid] = ((uint32_t)(lo & 0xff) << 8) | (uint32_t)((hi - lo + 1) & 0xff);
         }
         __syncthreads();
-        const long item = item0 + tid;
-        if (item >= total) return;
-        const long grow = item / kItemsPerRow;
-        const int it = (int)(item - grow * kItemsPerRow);
-        const uint32_t w = row_word[(int)(grow - grow0)];
-        const int lo = (int)(w >> 8), n = (int)(w & 0xffu);
-        if (it >= lo && it < lo + n) return;  // owned by the footprint role
-        const int j0 = it * kPix;
-        const int b = (int)(grow / VAA_IMG), i = (int)(grow - (long)b * VAA_IMG);
-
-        const uint4* src = reinterpret_cast<const uint4*>(a.img + ((size_t)grow * VAA_IMG + j0) * 3);
-        const uint4 w0 = src[0], w1 = src[1], w2 = src[2];
-        const uint32_t d[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-        uint32_t L[3][kPix];  // packed {bf16 plane c, bf16 plane c+3} per pixel
+        // A wave owns 64 consecutive items = 1024 pixels. Lane l handles two HALF items: pixels [8l, 8l+8) of the wave's first
+        // 512 pixels and the same of its second 512, so that every store instruction writes 64 x 16 B = 1 KB CONTIGUOUS bytes
+        // of a plane (a thread storing its own 16 pixels as two 16 B halves leaves every 128 B line to be completed by a
+        // second instruction, which halves the write rate). Input: 24 B per half item as three 8 B loads at lane stride 24 B.
+        const int wv = tid >> 6, lane = tid & 63;
+        const long witem0 = item0 + (long)wv * 64;
 #pragma unroll
-        for (int p = 0; p < kPix; ++p)
+        for (int seg = 0; seg < 2; ++seg) {
+            const long item = witem0 + seg * 32 + (lane >> 1);
+            if (item >= total) continue;
+            const long grow = item / kItemsPerRow;
+            const int it = (int)(item - grow * kItemsPerRow);
+            const uint32_t w = row_word[(int)(grow - grow0)];
+            const int lo = (int)(w >> 8), n = (int)(w & 0xffu);
+            if (it >= lo && it < lo + n) continue;  // owned by the footprint role
+            const int half = lane & 1;
+            const int j0 = it * kPix + half * 8;
+            const int b = (int)(grow / VAA_IMG), i = (int)(grow - (long)b * VAA_IMG);
+            const uint2* src = reinterpret_cast<const uint2*>(a.img + ((size_t)grow * VAA_IMG + j0) * 3);
+            const uint2 r0 = src[0], r1 = src[1], r2 = src[2];
+            const uint32_t d[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+            uint32_t L[3][8];  // packed {bf16 plane c, bf16 plane c+3} per pixel
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int k = p * 3 + c;
+                    L[c][p] = lut[c * 256 + ((d[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+                }
+            const size_t obase = ((size_t)b * 6 * VAA_IMG + i) * VAA_IMG + j0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const int k = p * 3 + c;
-                L[c][p] = lut[c * 256 + ((d[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+                uint32_t lo4[4], hi4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    lo4[q] = __builtin_amdgcn_perm(L[c][2 * q + 1], L[c][2 * q], 0x05040100u);
+                    hi4[q] = __builtin_amdgcn_perm(L[c][2 * q + 1], L[c][2 * q], 0x07060302u);
+                }
+                *reinterpret_cast<uint4*>(a.out + obase + (size_t)c * VAA_NPIX) = make_uint4(lo4[0], lo4[1], lo4[2], lo4[3]);
+                *reinterpret_cast<uint4*>(a.out + obase + (size_t)(c + 3) * VAA_NPIX) = make_uint4(hi4[0], hi4[1], hi4[2], hi4[3]);
             }
-        const size_t obase = ((size_t)b * 6 * VAA_IMG + i) * VAA_IMG + j0;
+            if (a.keep) {  // one byte of the keep mask per half item
+                const size_t kbase = ((size_t)b * 3 * VAA_NPIX + (size_t)i * VAA_IMG + j0) >> 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            uint32_t lo4[8], hi4[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                lo4[q] = __builtin_amdgcn_perm(L[c][2 * q + 1], L[c][2 * q], 0x05040100u);
-                hi4[q] = __builtin_amdgcn_perm(L[c][2 * q + 1], L[c][2 * q], 0x07060302u);
+                for (int c = 0; c < 3; ++c) a.keep[kbase + (size_t)c * (VAA_NPIX / 8)] = (uint8_t)0;
             }
-            uint4* o0 = reinterpret_cast<uint4*>(a.out + obase + (size_t)c * VAA_NPIX);
-            uint4* o1 = reinterpret_cast<uint4*>(a.out + obase + (size_t)(c + 3) * VAA_NPIX);
-            o0[0] = make_uint4(lo4[0], lo4[1], lo4[2], lo4[3]);
-            o0[1] = make_uint4(lo4[4], lo4[5], lo4[6], lo4[7]);
-            o1[0] = make_uint4(hi4[0], hi4[1], hi4[2], hi4[3]);
-            o1[1] = make_uint4(hi4[4], hi4[5], hi4[6], hi4[7]);
-        }
-        if (a.keep) {
-            const size_t kbase = ((size_t)b * 3 * VAA_NPIX + (size_t)i * VAA_IMG + j0) >> 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) *reinterpret_cast<uint16_t*>(a.keep + kbase + (size_t)c * (VAA_NPIX / 8)) = (uint16_t)0;
         }
         return;
     }
