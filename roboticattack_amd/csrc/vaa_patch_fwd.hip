@@ -29,10 +29,6 @@ struct FwdArgs {
     Norm6 nrm;
 };
 
-struct FwdLut {
-    uint32_t v[3][256];  // packed {bf16 norm0(x/255), bf16 norm1(x/255)} per channel and byte value x, built on the host
-};
-
 constexpr int kPix = 16;                                  // pixels per item: 48 B in (3 x 16 B), 2 x 16 B out per plane
 constexpr int kItemsPerRow = VAA_IMG / kPix;              // 14
 constexpr int kItemsPerImg = VAA_IMG * kItemsPerRow;      // 3136
@@ -91,19 +87,33 @@ __device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it
 //   blockIdx.x <  n_fp : FOOTPRINT  — owns exactly the skipped items of one image (a 1/fsplit share of them), one LANE per
 //                        pixel: LUT value, exact warp sample, mask, normalise, 2-byte stores; keep bits by wave ballot.
 // The two roles never write the same byte, so no ordering between workgroups is needed.
-__global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdArgs a, const FwdLut hl, int n_fp, int fsplit) {
+__global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdArgs a, int n_fp, int fsplit) {
     __shared__ uint32_t lut[3 * 256];
     __shared__ float bgrid[VAA_IMG];
     __shared__ uint32_t row_word[VAA_IMG];  // footprint role: (it_lo << 8) | n_items per row; background: first kMaxRows rows
     __shared__ int red_min, red_max, red_n;
     const int tid = threadIdx.x;
+    const bool bg = (int)blockIdx.x >= n_fp;
+    // Background role: the input bytes of this lane's two half items depend on nothing but the item index, so their loads are
+    // issued first and fly while the LUT is built and the placement (xy, theta -> row table) is fetched.
+    const long item0 = bg ? (long)((int)blockIdx.x - n_fp) * kFwdThreads : 0;
+    const long total = (long)a.B * kItemsPerImg;
+    uint2 pre[2][3];
+    if (bg) {
+        const long witem0 = item0 + (long)(tid >> 6) * 64;
 #pragma unroll
-    for (int e = tid; e < 768; e += kFwdThreads) lut[e] = (&hl.v[0][0])[e];
+        for (int seg = 0; seg < 2; ++seg) {
+            const long item = witem0 + seg * 32 + ((tid & 63) >> 1);
+            const uint2* src = reinterpret_cast<const uint2*>(a.img + ((size_t)(item < total ? item : 0) * kPix + (tid & 1) * 8) * 3);
+            pre[seg][0] = src[0]; pre[seg][1] = src[1]; pre[seg][2] = src[2];
+        }
+    }
+    // camera-pixel LUT: same IEEE arithmetic as the host (true divisions, RNE), 3 entries per thread
+#pragma unroll
+    for (int e = tid; e < 768; e += kFwdThreads) lut[e] = norm_pack((float)(e & 255) / 255.0f, a.nrm, e >> 8);
 
-    if ((int)blockIdx.x >= n_fp) {  // footprint workgroups come FIRST in dispatch order: their latency chain overlaps the stream
+    if (bg) {  // footprint workgroups come FIRST in dispatch order: their latency chain overlaps the stream
         // ------------------------------------------------------------------ background role
-        const long item0 = (long)((int)blockIdx.x - n_fp) * kFwdThreads;
-        const long total = (long)a.B * kItemsPerImg;
         const long grow0 = item0 / kItemsPerRow;  // first global row (b*224 + i) this workgroup touches
         if (tid < kMaxRows) {
             const long gr = grow0 + tid;
@@ -130,9 +140,7 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
             const int half = lane & 1;
             const int j0 = it * kPix + half * 8;
             const int b = (int)(grow / VAA_IMG), i = (int)(grow - (long)b * VAA_IMG);
-            const uint2* src = reinterpret_cast<const uint2*>(a.img + ((size_t)grow * VAA_IMG + j0) * 3);
-            const uint2 r0 = src[0], r1 = src[1], r2 = src[2];
-            const uint32_t d[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+            const uint32_t d[6] = {pre[seg][0].x, pre[seg][0].y, pre[seg][1].x, pre[seg][1].y, pre[seg][2].x, pre[seg][2].y};
             uint32_t L[3][8];  // packed {bf16 plane c, bf16 plane c+3} per pixel
 #pragma unroll
             for (int p = 0; p < 8; ++p)
@@ -201,28 +209,49 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
         uint32_t L[3] = {0u, 0u, 0u};
         bool kept[3] = {false, false, false};
         if (active) {
+            // every load of this pixel (3 camera bytes, 12 patch texels) is issued before anything is consumed: texel addresses
+            // are clamped into the patch so the gather is branch-free, the canvas rule (-100 outside the paste, 0 beyond the
+            // frame) is applied to the loaded values afterwards -> one memory latency per slot instead of two.
             const uint8_t* sp = a.img + ((size_t)(b * VAA_IMG + i) * VAA_IMG + j) * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) L[c] = lut[c * 256 + sp[c]];
+            const uint32_t by0 = sp[0], by1 = sp[1], by2 = sp[2];
+            float cv[3];
+            bool inside;
             if (a.geometry) {
                 const Samp s = sample_pos(bgrid[j], bgrid[i], th);
                 const int u0 = s.x0 - px, v0 = s.y0 - py;
-                if (!(u0 < -1 || u0 >= a.pw || v0 < -1 || v0 >= a.ph)) {
+                inside = !(u0 < -1 || u0 >= a.pw || v0 < -1 || v0 >= a.ph);
+                const int uc0 = min(max(u0, 0), a.pw - 1), uc1 = min(max(u0 + 1, 0), a.pw - 1);
+                const int vc0 = min(max(v0, 0), a.ph - 1), vc1 = min(max(v0 + 1, 0), a.ph - 1);
+                float t[3][4];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float cv = sample_canvas(a.patch + c * plane, a.ph, a.pw, px, py, s);
-                        if (keep_rule(cv, a.mask_mode)) { L[c] = norm_pack(cv, a.nrm, c); kept[c] = true; }
-                    }
+                for (int c = 0; c < 3; ++c) {
+                    const float* pc = a.patch + c * plane;
+                    t[c][0] = pc[vc0 * a.pw + uc0]; t[c][1] = pc[vc0 * a.pw + uc1];
+                    t[c][2] = pc[vc1 * a.pw + uc0]; t[c][3] = pc[vc1 * a.pw + uc1];
+                }
+                const bool ux0 = (unsigned)u0 < (unsigned)a.pw, ux1 = (unsigned)(u0 + 1) < (unsigned)a.pw;
+                const bool vy0 = (unsigned)v0 < (unsigned)a.ph, vy1 = (unsigned)(v0 + 1) < (unsigned)a.ph;
+                const bool fx1 = s.x0 + 1 < VAA_IMG, fy1 = s.y0 + 1 < VAA_IMG;  // (x0, y0) itself is always inside the frame
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float vnw = (ux0 && vy0) ? t[c][0] : -100.0f;
+                    const float vne = !fx1 ? 0.0f : ((ux1 && vy0) ? t[c][1] : -100.0f);
+                    const float vsw = !fy1 ? 0.0f : ((ux0 && vy1) ? t[c][2] : -100.0f);
+                    const float vse = !(fx1 && fy1) ? 0.0f : ((ux1 && vy1) ? t[c][3] : -100.0f);
+                    cv[c] = __builtin_fmaf(vse, s.se, __builtin_fmaf(vsw, s.sw, __builtin_fmaf(vne, s.ne, vnw * s.nw)));
                 }
             } else {
                 const int u = j - px, v = i - py;
-                if ((unsigned)u < (unsigned)a.pw && (unsigned)v < (unsigned)a.ph) {
+                inside = (unsigned)u < (unsigned)a.pw && (unsigned)v < (unsigned)a.ph;
+                const int uc = min(max(u, 0), a.pw - 1), vc = min(max(v, 0), a.ph - 1);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float cv = a.patch[c * plane + v * a.pw + u];
-                        if (keep_rule(cv, a.mask_mode)) { L[c] = norm_pack(cv, a.nrm, c); kept[c] = true; }
-                    }
-                }
+                for (int c = 0; c < 3; ++c) cv[c] = a.patch[c * plane + vc * a.pw + uc];
+            }
+            L[0] = lut[by0]; L[1] = lut[256 + by1]; L[2] = lut[512 + by2];
+            if (inside) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (keep_rule(cv[c], a.mask_mode)) { L[c] = norm_pack(cv[c], a.nrm, c); kept[c] = true; }
             }
             const size_t o = ((size_t)b * 6 * VAA_IMG + i) * VAA_IMG + j;
 #pragma unroll
@@ -268,15 +297,12 @@ extern "C" int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, co
     a.img = img_u8; a.patch = patch; a.xy = xy; a.theta = theta; a.out = out_bf16; a.keep = keep_bits;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) { a.nrm.mean[q] = mean6[q]; a.nrm.stdv[q] = std6[q]; }
-    FwdLut hl;
-    for (int c = 0; c < 3; ++c)
-        for (int v = 0; v < 256; ++v) hl.v[c][v] = norm_pack((float)v / 255.0f, a.nrm, c);  // ToTensor (:108) + 2x normalise
     const long total = (long)B * kItemsPerImg;
     const long n_bg = (total + kFwdThreads - 1) / kFwdThreads;
     int fsplit = 16;  // footprint workgroups per image: ~6,400 pixel-lanes per 50x50 footprint -> 2 slot rounds each
-    while (fsplit > 1 && (long)B * fsplit > 2048) fsplit >>= 1;
+    while (fsplit > 1 && (long)B * fsplit > 1024) fsplit >>= 1;  // ~1024 footprint workgroups in total is the measured optimum
     const long n_fp = (long)B * fsplit;
-    hipLaunchKernelGGL(patch_apply_fwd_kernel, dim3((unsigned)(n_fp + n_bg)), dim3(kFwdThreads), 0, (hipStream_t)stream, a, hl,
+    hipLaunchKernelGGL(patch_apply_fwd_kernel, dim3((unsigned)(n_fp + n_bg)), dim3(kFwdThreads), 0, (hipStream_t)stream, a,
                        (int)n_fp, fsplit);
     return check_launch("vaa_patch_apply_fwd");
 }
