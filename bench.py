@@ -257,10 +257,9 @@ def main():
         kern[name]["traffic"] = tr_ops.get(name, {}).get("hbm_bytes_per_launch")
     roofline = None
     if dom:
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"timing": "one start/stop HIP event pair per launch on the launching stream inside the timed region", "kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kern[dom]["frac"], "traffic": traffic, "mean_us": kern[dom]["mean_us"], "algo_bytes": kern[dom]["algo_bytes"],
                     "note": "dominant = the hot-path kernel with the most algorithmic bytes (also the longest single hand-written launch in the rocprofv3 kernel stats); "
-                            "event-bracketed on the launching stream inside the timed region; "
                             "traffic = HBM-side bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/traffic_r01.json, calibrated in-run)"}
 
     extra = {}
@@ -279,7 +278,7 @@ def main():
             k = ks[roofline["kernel"]]
             roofline.update({"in_loop_event_bracket_us": roofline["mean_us"], "mean_us": k["mean_us"], "achieved": k["achieved_GBs"],
                              "frac": k["achieved_GBs"] / HBM_PEAK_GBS,
-                             "timing": "HIP events around hipGraph replays of 10 back-to-back launches of the kernel, same process (agrees with profiles/r01_kbench_kernel_stats_*.csv); "
+                             "timing": "mean_us/achieved/frac: HIP events around hipGraph replays of 10 back-to-back launches of the kernel, same process (agrees with profiles/r01_kbench_kernel_stats_*.csv); "
                                        "in_loop_event_bracket_us = one start/stop event pair per launch inside the timed region (includes marker packets and gaps)"})
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # host-CPU leg only at N=1 (rank 0), as the bench contract asks
