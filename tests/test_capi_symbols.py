@@ -51,3 +51,15 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises(_lib.VaaError, match="no CPU fallback"):
         ops.patch_apply_fwd(torch.zeros(1, 224, 224, 3, dtype=torch.uint8), torch.zeros(3, 50, 50), torch.zeros(1, 2, dtype=torch.int32),
                             torch.zeros(1, 6), True)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No HIP extension -> the product path raises (there is no CPU fallback to drop into)."""
+    import subprocess
+    import sys
+
+    code = ("import os; os.environ['VAA_LIB_PATH'] = %r\n"
+            "from roboticattack_amd import _lib\n"
+            "try:\n    _lib.lib()\nexcept _lib.VaaError as e:\n    print('RAISED', e)\n") % str(tmp_path / "absent.so")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "RAISED" in out.stdout and "no CPU fallback" in out.stdout, out.stdout + out.stderr
