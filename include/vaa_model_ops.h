@@ -21,6 +21,12 @@ int vaa_model_swiglu_bwd(const uint16_t* dy, const uint16_t* gate, const uint16_
 int vaa_model_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* h, float* rstd, long rows, int D, float eps, void* stream);
 int vaa_model_rmsnorm_bwd(const uint16_t* gh, const uint16_t* gpass, const uint16_t* x, const uint16_t* w, const float* rstd, uint16_t* gx,
                           long rows, int D, void* stream);
+/* LayerNorm over rows of D bf16 (weight, bias bf16 [D]; fp32 statistics, one rounding) saving {mean, rstd} float32 [rows,2]; the
+ * backward adds the residual pass-through gradient gpass (may be NULL). Weight and bias are frozen (no gradients). */
+int vaa_model_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* h, float* stats, long rows, int D, float eps,
+                            void* stream);
+int vaa_model_layernorm_bwd(const uint16_t* gh, const uint16_t* gpass, const uint16_t* x, const uint16_t* w, const float* stats, uint16_t* gx,
+                            long rows, int D, void* stream);
 /* Softmax attention on the matrix cores for short sequences. q,k,v,o: bf16 views [B,T,H,hd] given by element strides
  * {batch, token, head} (last dim contiguous, all strides % 8 == 0), hd % 8 == 0, hd <= 128. lse: float32 [B,H,T] (natural log).
  * causal != 0: query t sees keys <= t. */

@@ -19,7 +19,7 @@ LAYOUT_FULL, LAYOUT_ROWS = 0, 1
 OPT_ADAMW_HF, OPT_PGD_SIGN = 0, 1
 
 MODEL_OP_EXPORTS = ("vaa_model_rope", "vaa_model_swiglu_fwd", "vaa_model_swiglu_bwd", "vaa_model_rmsnorm_fwd", "vaa_model_rmsnorm_bwd",
-                    "vaa_model_attention_fwd", "vaa_model_attention_bwd")
+                    "vaa_model_attention_fwd", "vaa_model_attention_bwd", "vaa_model_layernorm_fwd", "vaa_model_layernorm_bwd")
 
 EXPORTS = (
     "vaa_last_error",
@@ -98,6 +98,10 @@ def lib() -> C.CDLL:
     L.vaa_model_rmsnorm_fwd.argtypes = [vp, vp, vp, vp, lng, i32, f32, vp]
     L.vaa_model_rmsnorm_bwd.restype = i32
     L.vaa_model_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, lng, i32, vp]
+    L.vaa_model_layernorm_fwd.restype = i32
+    L.vaa_model_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, lng, i32, f32, vp]
+    L.vaa_model_layernorm_bwd.restype = i32
+    L.vaa_model_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, lng, i32, vp]
     i64p = C.POINTER(C.c_int64)
     L.vaa_model_attention_fwd.restype = i32
     L.vaa_model_attention_fwd.argtypes = [vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, i32, i32, i32, i32, i32, f32, vp]

@@ -180,6 +180,103 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_bwd_kernel(const uint16_
     }
 }
 
+// ---- LayerNorm with residual pass-through (ViT blocks): h = (x - mean) * rstd * w + b, statistics in fp32, one rounding;
+//      backward: gx = g_pass + rstd * (gh*w - mean(gh*w) - xhat * mean(gh*w*xhat)). w, b frozen (no gradients). ----
+__device__ __forceinline__ void block_sum2_256(float& a, float& b, float (*sh)[2]) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = a; sh[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    a = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];
+    b = sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1];
+}
+
+__global__ __launch_bounds__(kNormThreads) void layernorm_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                                      const uint16_t* __restrict__ b, uint16_t* __restrict__ h,
+                                                                      float* __restrict__ stats, int D, float eps) {
+    __shared__ float sh[4];
+    const long row = blockIdx.x;
+    const int nv = D >> 3;
+    float xv[kNormMaxVec][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kNormMaxVec; ++c) {
+        const int q = threadIdx.x + c * kNormThreads;
+        if (q < nv) {
+            unpack8(reinterpret_cast<const uint4*>(x + row * D)[q], xv[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += xv[c][e];
+        }
+    }
+    const float mean = block_sum_256(s, sh) / (float)D;
+    float ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kNormMaxVec; ++c) {
+        const int q = threadIdx.x + c * kNormThreads;
+        if (q < nv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xv[c][e] -= mean; ss += xv[c][e] * xv[c][e]; }
+        }
+    }
+    const float r = rsqrtf(block_sum_256(ss, sh) / (float)D + eps);
+    if (threadIdx.x == 0) { stats[2 * row] = mean; stats[2 * row + 1] = r; }
+#pragma unroll
+    for (int c = 0; c < kNormMaxVec; ++c) {
+        const int q = threadIdx.x + c * kNormThreads;
+        if (q < nv) {
+            float wv[8], bv[8], o[8];
+            unpack8(reinterpret_cast<const uint4*>(w)[q], wv);
+            unpack8(reinterpret_cast<const uint4*>(b)[q], bv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = xv[c][e] * r * wv[e] + bv[e];
+            reinterpret_cast<uint4*>(h + row * D)[q] = pack8(o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kNormThreads) void layernorm_bwd_kernel(const uint16_t* __restrict__ gh, const uint16_t* __restrict__ gpass,
+                                                                      const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                                      const float* __restrict__ stats, uint16_t* __restrict__ gx, int D) {
+    __shared__ float sh2[4][2];
+    const long row = blockIdx.x;
+    const int nv = D >> 3;
+    const float mean = stats[2 * row], r = stats[2 * row + 1];
+    float xh[kNormMaxVec][8], gw[kNormMaxVec][8];
+    float sg = 0.0f, dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kNormMaxVec; ++c) {
+        const int q = threadIdx.x + c * kNormThreads;
+        if (q < nv) {
+            float wv[8];
+            unpack8(reinterpret_cast<const uint4*>(x + row * D)[q], xh[c]);
+            unpack8(reinterpret_cast<const uint4*>(gh + row * D)[q], gw[c]);
+            unpack8(reinterpret_cast<const uint4*>(w)[q], wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[c][e] = (xh[c][e] - mean) * r;
+                gw[c][e] *= wv[e];
+                sg += gw[c][e];
+                dot += gw[c][e] * xh[c][e];
+            }
+        }
+    }
+    block_sum2_256(sg, dot, sh2);
+    sg /= (float)D;
+    dot /= (float)D;
+#pragma unroll
+    for (int c = 0; c < kNormMaxVec; ++c) {
+        const int q = threadIdx.x + c * kNormThreads;
+        if (q < nv) {
+            float o[8], gp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gpass) unpack8(reinterpret_cast<const uint4*>(gpass + row * D)[q], gp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = gp[e] + r * (gw[c][e] - sg - xh[c][e] * dot);
+            reinterpret_cast<uint4*>(gx + row * D)[q] = pack8(o);
+        }
+    }
+}
+
 static unsigned stream_grid(long nvec) {
     long b = (nvec + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -232,4 +329,26 @@ extern "C" int vaa_model_rmsnorm_bwd(const uint16_t* gh, const uint16_t* gpass, 
     }
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, gh, gpass, x, w, rstd, gx, D);
     return check_launch("vaa_model_rmsnorm_bwd");
+}
+
+extern "C" int vaa_model_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* h, float* stats, long rows, int D, float eps,
+                                       void* stream) {
+    using namespace vaa;
+    if (!x || !w || !b || !h || !stats || rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * kNormThreads * kNormMaxVec) {
+        set_error("vaa_model_layernorm_fwd: bad arguments (D must be a multiple of 8, <= 8192)");
+        return VAA_E_INVALID;
+    }
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, x, w, b, h, stats, D, eps);
+    return check_launch("vaa_model_layernorm_fwd");
+}
+
+extern "C" int vaa_model_layernorm_bwd(const uint16_t* gh, const uint16_t* gpass, const uint16_t* x, const uint16_t* w, const float* stats,
+                                       uint16_t* gx, long rows, int D, void* stream) {
+    using namespace vaa;
+    if (!gh || !x || !w || !stats || !gx || rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * kNormThreads * kNormMaxVec) {
+        set_error("vaa_model_layernorm_bwd: bad arguments");
+        return VAA_E_INVALID;
+    }
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, gh, gpass, x, w, stats, gx, D);
+    return check_launch("vaa_model_layernorm_bwd");
 }

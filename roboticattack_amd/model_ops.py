@@ -105,6 +105,37 @@ class ResidualRMSNormFn(torch.autograd.Function):
         return gx, None, None
 
 
+class ResidualLayerNormFn(torch.autograd.Function):
+    """(x) -> (x, layer_norm(x) * w + b) for the ViT blocks: same pass-through trick as ResidualRMSNormFn (one backward kernel
+    receives the residual-stream gradient and the branch gradient). Weight and bias are frozen (no grads)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        D = x.shape[-1]
+        rows = x.numel() // D
+        h = torch.empty_like(x)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().vaa_model_layernorm_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), h.data_ptr(), stats.data_ptr(), rows, D,
+                                                      float(eps), _stream()), "vaa_model_layernorm_fwd")
+        ctx.save_for_backward(x, weight, stats)
+        return x, h
+
+    @staticmethod
+    def backward(ctx, g_pass, g_h):
+        x, weight, stats = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        if g_h is None:
+            return g_pass, None, None, None
+        g_h = g_h.contiguous()
+        gp = g_pass.contiguous() if g_pass is not None else None
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().vaa_model_layernorm_bwd(g_h.data_ptr(), gp.data_ptr() if gp is not None else None, x.data_ptr(), weight.data_ptr(),
+                                                      stats.data_ptr(), gx.data_ptr(), rows, D, _stream()), "vaa_model_layernorm_bwd")
+        return gx, None, None, None
+
+
 def tn_dgrad_enabled() -> bool:
     return not os.environ.get("VAA_NO_TN_DGRAD")
 

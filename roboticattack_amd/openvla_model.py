@@ -86,7 +86,12 @@ class VitBlock(nn.Module):
         B, T, D = x.shape
         from . import model_ops
 
-        qkv = self.qkv(self.norm1(x)).view(B, T, 3, self.heads, D // self.heads)
+        fused_ln = model_ops.enabled(x) and D % 8 == 0 and D <= 8192
+        if fused_ln:  # (x) -> (x, LN(x)): the backward kernel also absorbs the residual-stream gradient
+            x, h = model_ops.ResidualLayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        else:
+            h = self.norm1(x)
+        qkv = self.qkv(h).view(B, T, 3, self.heads, D // self.heads)
         if model_ops.attention_enabled(qkv):  # matrix-core attention on the packed projection; packed gradient, no permute copies
             a = model_ops.PackedAttentionFn.apply(qkv, False, None).reshape(B, T, D)
         else:
@@ -94,7 +99,11 @@ class VitBlock(nn.Module):
             a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, T, D)
         a = self.proj(a)
         x = torch.addcmul(x, a, self.ls1) if self.ls1 is not None else x + a  # LayerScale + residual in one pass
-        h = self.fc2(F.gelu(self.fc1(self.norm2(x))))
+        if fused_ln:
+            x, h = model_ops.ResidualLayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        else:
+            h = self.norm2(x)
+        h = self.fc2(F.gelu(self.fc1(h)))
         return torch.addcmul(x, h, self.ls2) if self.ls2 is not None else x + h
 
 

@@ -226,3 +226,25 @@ def test_rope_attention_fused_backward(hd):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][3], res[1][3])
     for a, b in zip(res[0][1:3], res[1][1:3]):
         assert (a - b).abs().max() <= 2 ** -6 * b.abs().max()
+
+
+@pytest.mark.parametrize("D", [1024, 1152, 48])
+def test_residual_layernorm_fwd_bwd_matches_eager(D):
+    from roboticattack_amd import model_ops
+
+    g = torch.Generator(device=DEV).manual_seed(D)
+    x = (torch.randn(3, 37, D, device=DEV, generator=g) * 2 + 0.5).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(D, device=DEV, generator=g)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(D, device=DEV, generator=g)).to(torch.bfloat16)
+    gp = torch.randn(3, 37, D, device=DEV, generator=g).to(torch.bfloat16)
+    gh = torch.randn(3, 37, D, device=DEV, generator=g).to(torch.bfloat16)
+    xa = x.clone().requires_grad_(True)
+    xo, h = model_ops.ResidualLayerNormFn.apply(xa, w, b, 1e-6)
+    (xo.float() * gp.float()).sum().backward(retain_graph=True)
+    (h.float() * gh.float()).sum().backward()
+    xb = x.float().clone().requires_grad_(True)
+    hr = torch.nn.functional.layer_norm(xb, (D,), w.float(), b.float(), 1e-6)
+    ((xb * gp.float()).sum() + (hr * gh.float()).sum()).backward()
+    assert torch.equal(xo, x)
+    assert (h.float() - hr).abs().max() <= 2 ** -7 * hr.abs().max()
+    assert (xa.grad.float() - xb.grad).abs().max() <= 2 ** -6 * xb.grad.abs().max()
