@@ -113,6 +113,22 @@ int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const int64_t* l
                      void* stream);
 
 /*
+ * K2' (optional) — K2 fed by the gradient of the ViT patch-embed OUTPUTS instead of the pixel gradient: the
+ * patch-embed backward (modeling_prismatic.py:120-123 -> timm PatchEmbed, Conv2d(3, D, 14, stride 14) == a GEMM over 588-pixel
+ * tiles) is evaluated by MFMA only for the 14x14 tiles that carry kept patch pixels and consumed in place by the gather.
+ *   dy0, dy1  dev bf16 [B,256,D0], [B,256,D1]: dL/d(patch-embed output) of the DINOv2 and SigLIP towers, tokens in tile order
+ *   wt0, wt1  dev bf16 [588,D0], [588,D1]: conv weights [D,3,14,14] flattened to [D,588] and transposed (frozen, keep resident)
+ *   keep_bits dev: K1's keep mask (required); round_bf16 != 0 rounds each tower's pixel gradient to bf16 before the 1/std scaling
+ *             (what the unfused path does: the model hands back a bf16 pixel gradient); D0, D1 multiples of 32
+ *   other arguments as vaa_patch_grad_gather; ws >= vaa_patch_embed_grad_ws_bytes(B, ph, pw)
+ */
+size_t vaa_patch_embed_grad_ws_bytes(int B, int ph, int pw);
+int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
+                                const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph, int pw,
+                                int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes,
+                                void* stream);
+
+/*
  * K4 — replaces transformers.AdamW.step + `patch.data.clamp(0,1)` + zero_grad (UADA.py:155-157; UADA_ddp.py:208-209),
  * optional `clip_grad_norm_([patch], l1_clip, norm_type=1)` (UPA.py:157) and the PGD sign step (TMA.py:171-175).
  *   patch,m,v dev [n] float32 in place; g dev [n] float32 (sum over ranks when grad_scale = 1/world, DDP mean)

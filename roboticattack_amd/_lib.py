@@ -32,6 +32,8 @@ EXPORTS = (
     "vaa_loss_fwd_bwd",
     "vaa_patch_update",
     "vaa_patch_apply_eval",
+    "vaa_patch_embed_grad_ws_bytes",
+    "vaa_patch_embed_grad_gather",
 )
 
 
@@ -78,6 +80,10 @@ def lib() -> C.CDLL:
     L.vaa_patch_grad_ws_bytes.argtypes = [i32, i32, i32]
     L.vaa_patch_grad_gather.restype = i32
     L.vaa_patch_grad_gather.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, sz, vp]
+    L.vaa_patch_embed_grad_ws_bytes.restype = sz
+    L.vaa_patch_embed_grad_ws_bytes.argtypes = [i32, i32, i32]
+    L.vaa_patch_embed_grad_gather.restype = i32
+    L.vaa_patch_embed_grad_gather.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
     L.vaa_loss_ws_bytes.restype = sz
     L.vaa_loss_ws_bytes.argtypes = [i32, i32]
     L.vaa_loss_fwd_bwd.restype = i32

@@ -46,6 +46,8 @@ class AttackBase:
         self.save_dir = save_dir
         self.device = torch.device(getattr(vla, "device", "cuda"))
         self.randomPatchTransform = RandomPatchTransform(self.device, resize_patch)
+        if hasattr(vla, "forward_rows") and hasattr(vla, "patch_embed_params") and not resize_patch:
+            self.randomPatchTransform.embed_with = vla  # training steps hand the model patch-embed outputs
         self.mean = [torch.tensor(MEAN0), torch.tensor(MEAN1)]
         self.std = [torch.tensor(STD0), torch.tensor(STD1)]
         self.optimizer = optimizer
@@ -60,7 +62,10 @@ class AttackBase:
             # cache holds a reference, so identity cannot be recycled by the allocator, and in-place edits bump _version
             if getattr(self, "_row_ref", None) is not labels or self._row_ver != labels._version:
                 self._row_ref, self._row_ver, self._row_index = labels, labels._version, self.vla.label_row_index(labels)
-            logits = self.vla.forward_rows(input_ids, pix, labels, self._row_index)
+            if isinstance(pix, ops.PatchEmbeds):  # patched batch handed over as patch-embed outputs (pixel gradient never built)
+                logits = self.vla.forward_rows(input_ids, None, labels, self._row_index, patch_embeds=pix)
+            else:
+                logits = self.vla.forward_rows(input_ids, pix, labels, self._row_index)
             layout = ops.LAYOUT_ROWS
         else:
             out = self.vla(input_ids=input_ids, attention_mask=attention_mask, pixel_values=pix, labels=None)

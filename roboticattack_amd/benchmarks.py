@@ -26,6 +26,8 @@ def algo_bytes(kernel: str, B: int, ph: int = 50, pw: int = 50, rows: int = 0, V
         return B * 4 * n + 4 * n
     if kernel == "K2_fullframe":
         return B * 602112 + 4 * n
+    if kernel == "K2e":  # ~36 kept tiles per image: their dY rows of both towers (bf16) + the two transposed weights once + gpatch
+        return B * 36 * (1024 + 1152) * 2 + 588 * (1024 + 1152) * 2 + 4 * n
     if kernel == "K3":
         return 2.0 * rows * V * esize
     if kernel == "K4":
@@ -122,6 +124,12 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
     rec("K1_patch_apply_fwd", "K1", lambda: ops.patch_apply_fwd(img, patch, xy, th, True), algo_bytes("K1", B, ph, pw), B=B)
     rec("K2_patch_grad_gather", "K2", lambda: ops.patch_grad_gather(g, patch, xy, th, keep, True), algo_bytes("K2", B, ph, pw), B=B,
         fullframe_bytes=algo_bytes("K2_fullframe", B, ph, pw))
+    dy0 = (torch.randn(B, 256, 1024, device=dev) * 0.1).to(torch.bfloat16)
+    dy1 = (torch.randn(B, 256, 1152, device=dev) * 0.1).to(torch.bfloat16)
+    wt0 = (torch.randn(588, 1024, device=dev) * 0.05).to(torch.bfloat16)
+    wt1 = (torch.randn(588, 1152, device=dev) * 0.05).to(torch.bfloat16)
+    rec("K2e_patch_embed_grad_gather", "K2e", lambda: ops.patch_embed_grad_gather(dy0, dy1, wt0, wt1, patch, xy, th, keep, True),
+        algo_bytes("K2e", B, ph, pw), B=B, note="SURVEY 8f-3: patch-embed backward on the kept tiles (MFMA) + gather; replaces 2 dgrad GEMMs + fold + K2")
     rec("K3_loss_fwd_bwd", "K3",
         lambda: ops.loss_fwd_bwd(logits, labels, ops.LOSS_UADA_DDP, w=5.0, layout=ops.LAYOUT_ROWS, glogits=glog),
         algo_bytes("K3", B, rows=R, esize=logits.element_size()), rows=R)

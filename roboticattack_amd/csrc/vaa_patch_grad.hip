@@ -31,7 +31,13 @@ struct GradArgs {
     float* partial;
     int B, ph, pw, geometry, mask_mode;
     float istd6[6];  // 1/std, rounded from double on the host
+    // TILED source (vaa_patch_embed_grad_gather): instead of the 6-plane bf16 pixel gradient `g`, the already combined and
+    // scaled gradient of the tiles that carry kept pixels: geff[b][slot][c*196 + y*14 + x], slot = tile_slot[b][ty*16 + tx]
+    const float* geff;
+    const int16_t* tile_slot;
 };
+
+constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTilePx;  // ViT patch-embed tiling of the 224x224 frame
 
 constexpr int kGradThreads = 1024;  // 16 waves: two workgroups per CU with the 60 KB fp64 tile
 constexpr int kImgsPerPass = 8;      // images whose row tables are built together (one barrier set per pass)
@@ -42,7 +48,7 @@ constexpr int kImgsPerPass = 8;      // images whose row tables are built togeth
 // Footprint walk without any per-pixel search: the footprint rows [rmin, rmax] of an image are cut into 32-column
 // segments; one half-wave owns one (row, segment) slot at a time, so a lane needs ONE LDS read (packed {jlo,len} of its
 // row) to know its pixel. Slots are dealt round-robin to the half-waves of the workgroup-row.
-template <typename ACC, int NCH>
+template <typename ACC, int NCH, bool TILED = false>
 __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradArgs a, int gx, int split) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     ACC* acc = reinterpret_cast<ACC*>(smem_raw);  // [NCH][ph][pw]
@@ -154,12 +160,25 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
                 const uint16_t* gb = gimg + pix;
                 // issue every load of this pixel before the first use
                 uint32_t kbyte[NCH], g0[NCH], g1[NCH];
+                float gt[NCH];
+                const float* gtile = nullptr;
+                if (TILED) {
+                    const int ty = i / kTilePx, tx = j / kTilePx;
+                    const int slot = a.tile_slot[b * (kTilesPerSide * kTilesPerSide) + ty * kTilesPerSide + tx];
+                    // slot < 0 only for pixels without any kept channel (their tile was not evaluated): read slot 0, never used
+                    gtile = a.geff + ((size_t)b * (kTilesPerSide * kTilesPerSide) + (slot < 0 ? 0 : slot)) * kTileElems +
+                            (i - ty * kTilePx) * kTilePx + (j - tx * kTilePx);
+                }
 #pragma unroll
                 for (int cc = 0; cc < NCH; ++cc) {
                     const int c = c_base + cc;
                     kbyte[cc] = kimg ? kimg[(size_t)c * (VAA_NPIX / 8) + (pix >> 3)] : 0u;
-                    g0[cc] = gb[(size_t)c * VAA_NPIX];
-                    g1[cc] = gb[(size_t)(c + 3) * VAA_NPIX];
+                    if (TILED) {
+                        gt[cc] = gtile[c * (kTilePx * kTilePx)];
+                    } else {
+                        g0[cc] = gb[(size_t)c * VAA_NPIX];
+                        g1[cc] = gb[(size_t)(c + 3) * VAA_NPIX];
+                    }
                 }
 #pragma unroll
                 for (int cc = 0; cc < NCH; ++cc) {
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
                     // d/d(im) of (im-mean)/std for both normalisations. Reciprocals are rounded once on the host (exact for
                     // the 0.5 of the second normalisation, <= 1 ulp for the first); only the ACCUMULATION is fp64, which
                     // makes the sum independent of arrival order.
-                    const float G = bf16_bits_to_f32(g0[cc]) * a.istd6[c] + bf16_bits_to_f32(g1[cc]) * a.istd6[c + 3];
+                    const float G = TILED ? gt[cc] : bf16_bits_to_f32(g0[cc]) * a.istd6[c] + bf16_bits_to_f32(g1[cc]) * a.istd6[c + 3];
                     ACC* tb = acc + cc * plane;
                     atomicAdd(tb + o_nw, (ACC)(G * wnw));
                     atomicAdd(tb + o_ne, (ACC)(G * wne));
@@ -226,6 +245,40 @@ static GradSched grad_sched(int B) {
     return g;
 }
 
+template <bool TILED>
+static int launch_scatter_reduce(const GradArgs& a, float* gpatch, hipStream_t st, const char* who) {
+    const int B = a.B, ph = a.ph, pw = a.pw, n = 3 * ph * pw;
+    const GradSched gs = grad_sched(B);
+    const int G = gs.gx * gs.split;  // workgroups (x) == partial tiles
+    const size_t plane = (size_t)ph * pw;
+    const size_t lds_budget = 144 * 1024;  // 160 KiB per CU minus the static row tables (~13 KB)
+    hipError_t e = hipSuccess;
+    if (3 * plane * sizeof(double) <= 64 * 1024) {  // e.g. 50x50: 60,000 B, two workgroups per CU
+        hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 3, TILED>), dim3(G), dim3(kGradThreads), 3 * plane * sizeof(double), st, a, gs.gx, gs.split);
+    } else if (plane * sizeof(double) <= lds_budget) {  // up to ~138x138: one channel per workgroup
+        const size_t bytes = plane * sizeof(double);
+        if (bytes > 64 * 1024)
+            e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<double, 1, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 1, TILED>), dim3(G, 3), dim3(kGradThreads), bytes, st, a, gs.gx, gs.split);
+    } else if (plane * sizeof(float) <= lds_budget) {  // up to ~195x195: fp32 accumulation
+        const size_t bytes = plane * sizeof(float);
+        if (bytes > 64 * 1024)
+            e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<float, 1, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<float, 1, TILED>), dim3(G, 3), dim3(kGradThreads), bytes, st, a, gs.gx, gs.split);
+    } else {
+        set_error("%s: patch %dx%d does not fit the LDS accumulator", who, ph, pw);
+        return VAA_E_UNSUPPORTED;
+    }
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+        return VAA_E_LAUNCH;
+    }
+    int rc = check_launch(who);
+    if (rc != VAA_OK) return rc;
+    hipLaunchKernelGGL(patch_grad_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, (const float*)a.partial, gpatch, n, G);
+    return check_launch(who);
+}
+
 }  // namespace vaa
 
 extern "C" size_t vaa_patch_grad_ws_bytes(int B, int ph, int pw) {
@@ -255,7 +308,6 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
         set_error("vaa_patch_grad_gather: patch %dx%d larger than the frame", ph, pw);
         return VAA_E_UNSUPPORTED;
     }
-    const int n = 3 * ph * pw;
     hipStream_t st = (hipStream_t)stream;
     if (!ws || ws_bytes < vaa_patch_grad_ws_bytes(B, ph, pw)) {
         set_error("vaa_patch_grad_gather: workspace %zu B < required %zu B", ws_bytes, vaa_patch_grad_ws_bytes(B, ph, pw));
@@ -265,33 +317,190 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    const GradSched gs = grad_sched(B);
-    const int G = gs.gx * gs.split;  // workgroups (x) == partial tiles
-    const size_t plane = (size_t)ph * pw;
-    const size_t lds_budget = 144 * 1024;  // 160 KiB per CU minus the static row tables (~13 KB)
-    hipError_t e = hipSuccess;
-    if (3 * plane * sizeof(double) <= 64 * 1024) {  // e.g. 50x50: 60,000 B, two workgroups per CU
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 3>), dim3(G), dim3(kGradThreads), 3 * plane * sizeof(double), st, a, gs.gx, gs.split);
-    } else if (plane * sizeof(double) <= lds_budget) {  // up to ~138x138: one channel per workgroup
-        const size_t bytes = plane * sizeof(double);
-        if (bytes > 64 * 1024)
-            e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 1>), dim3(G, 3), dim3(kGradThreads), bytes, st, a, gs.gx, gs.split);
-    } else if (plane * sizeof(float) <= lds_budget) {  // up to ~195x195: fp32 accumulation
-        const size_t bytes = plane * sizeof(float);
-        if (bytes > 64 * 1024)
-            e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<float, 1>), dim3(G, 3), dim3(kGradThreads), bytes, st, a, gs.gx, gs.split);
-    } else {
-        set_error("vaa_patch_grad_gather: patch %dx%d does not fit the LDS accumulator", ph, pw);
+    a.geff = nullptr; a.tile_slot = nullptr;
+    return launch_scatter_reduce<false>(a, gpatch, st, "vaa_patch_grad_gather");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// the ViT patch-embed backward restricted to the 14x14 tiles that carry kept patch pixels, fused with the gather.
+// The patch-embed conv (kernel == stride == 14) is a GEMM over 588-pixel tiles (modeling_prismatic.py:120-123 evaluates timm's
+// PatchEmbed of both towers), so dL/dpixel of one tile is dY[tile, :] @ W[:, 588]. Only ~36 of the 256 tiles of an image are under
+// the warped patch; their gradients are produced by MFMA straight into a compact fp32 buffer (both towers combined and divided by
+// the two normalisation stds) that the scatter kernel above reads in place of the 6-plane bf16 pixel gradient.
+namespace vaa {
+
+typedef short v8s_e __attribute__((ext_vector_type(8)));
+typedef float v4f_e __attribute__((ext_vector_type(4)));
+
+struct EmbedArgs {
+    const uint16_t *dy0, *dy1;  // [B,256,D0], [B,256,D1] bf16: dL/d(patch-embed output) of the two towers, tokens in tile order
+    const uint16_t *wt0, *wt1;  // [588,D0], [588,D1] bf16: conv weights [D,3,14,14] flattened and TRANSPOSED (K-contiguous)
+    const uint8_t* keep;        // [B,3,224*224/8] keep bits from K1
+    float* geff;                // [B,256,588]
+    int16_t* tile_slot;         // [B,256]
+    int B, D0, D1, round_bf16;
+    float istd6[6];
+};
+
+constexpr int kNBlocks = (kTileElems + 15) / 16;  // 37 column blocks of 16 pixels-of-a-tile
+
+__device__ __forceinline__ v8s_e frag_or_zero(const uint16_t* p, bool valid) {
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (valid) r = *reinterpret_cast<const uint4*>(p);
+    return *reinterpret_cast<v8s_e*>(&r);
+}
+
+__device__ __forceinline__ float maybe_bf16(float v, int on) { return on ? bf16_bits_to_f32(f32_to_bf16_bits(v)) : v; }
+
+constexpr int kEmbedThreads = 256;
+
+// grid = B * nch workgroups of 4 waves; workgroup (b, ch) evaluates column blocks ch*4 .. ch*4+3 (one per wave) for every flagged tile
+// of image b. (Splitting the contraction over 16 waves with an LDS reduction was measured slower: 121 vs 90 us at bs=64.)
+__global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedArgs a, int nch) {
+    __shared__ int16_t tiles[256];
+    __shared__ int wave_cnt[4];
+    const int b = blockIdx.x / nch, ch = blockIdx.x - b * nch;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+
+    // ---- which tiles carry a kept pixel (any channel): thread t = tile t ----
+    bool flag = false;
+    {
+        const int ty = tid >> 4, tx = tid & 15;
+        const uint8_t* kb = a.keep + (size_t)b * 3 * (VAA_NPIX / 8);
+        for (int ch3 = 0; ch3 < 3 && !flag; ++ch3)
+            for (int y = 0; y < kTilePx && !flag; ++y) {
+                const int bit0 = (ty * kTilePx + y) * VAA_IMG + tx * kTilePx;  // 14 consecutive bits
+                const int by = bit0 >> 3, by2 = min(by + 2, VAA_NPIX / 8 - 1);  // the third byte only matters when it exists
+                const uint8_t* p = kb + (size_t)ch3 * (VAA_NPIX / 8);
+                const uint32_t w = (uint32_t)p[by] | ((uint32_t)p[by + 1] << 8) | ((uint32_t)p[by2] << 16);
+                flag = ((w >> (bit0 & 7)) & 0x3fffu) != 0u;
+            }
+    }
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) wave_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int base = 0, M = 0;
+    for (int q = 0; q < 4; ++q) { if (q < wv) base += wave_cnt[q]; M += wave_cnt[q]; }
+    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (flag) tiles[slot] = (int16_t)tid;
+    if (ch == 0) a.tile_slot[b * 256 + tid] = flag ? (int16_t)slot : (int16_t)-1;
+    __syncthreads();
+
+    const int nb = ch * 4 + wv;
+    if (nb >= kNBlocks) return;
+    const int n = nb * 16 + c;                  // this lane's column: element n of a tile (c3*196 + y*14 + x)
+    const bool nv = n < kTileElems;
+    const int c3 = nv ? n / (kTilePx * kTilePx) : 0;
+    const float s0 = a.istd6[c3], s1 = a.istd6[c3 + 3];
+    const uint16_t* w0 = a.wt0 + (size_t)n * a.D0 + g * 8;
+    const uint16_t* w1 = a.wt1 + (size_t)n * a.D1 + g * 8;
+    // Up to four 16-tile row blocks share every weight fragment: per trip 2 B-fragments + 8 A-fragments are in flight, 8 MFMAs follow.
+    for (int mg = 0; mg * 64 < M; ++mg) {
+        v4f_e acc0[4], acc1[4];
+        const uint16_t *y0[4], *y1[4];
+        bool mv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0[q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
+            acc1[q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
+            const int mr = mg * 64 + q * 16 + c;  // A-operand row of this lane in row block q
+            mv[q] = mr < M;
+            const int tile = mv[q] ? tiles[mr] : 0;
+            y0[q] = a.dy0 + ((size_t)b * 256 + tile) * a.D0 + g * 8;
+            y1[q] = a.dy1 + ((size_t)b * 256 + tile) * a.D1 + g * 8;
+        }
+        const int nq = min(4, (M - mg * 64 + 15) / 16);  // live row blocks (wave-uniform)
+#pragma unroll
+        for (int tower = 0; tower < 2; ++tower) {
+            const int D = tower ? a.D1 : a.D0;
+            const uint16_t* wp = tower ? w1 : w0;
+            for (int ks = 0; ks * 32 < D; ks += 2) {
+                const bool more = (ks + 1) * 32 < D;
+                const v8s_e b0 = frag_or_zero(wp + ks * 32, nv), b1 = frag_or_zero(wp + (ks + 1) * 32, nv && more);
+                v8s_e a0[4], a1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint16_t* yp = tower ? y1[q] : y0[q];
+                    a0[q] = frag_or_zero(yp + ks * 32, mv[q]);
+                    a1[q] = frag_or_zero(yp + (ks + 1) * 32, mv[q] && more);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q >= nq) continue;
+                    if (tower) {
+                        acc1[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[q], b0, acc1[q], 0, 0, 0);
+                        acc1[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[q], b1, acc1[q], 0, 0, 0);
+                    } else {
+                        acc0[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[q], b0, acc0[q], 0, 0, 0);
+                        acc0[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[q], b1, acc0[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (nv) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // C/D layout: column = lane&15 (pixel n), row = 4*(lane>>4)+r (tile slot)
+                    const int sl = mg * 64 + q * 16 + g * 4 + r;
+                    if (sl < M)
+                        a.geff[((size_t)b * 256 + sl) * kTileElems + n] =
+                            maybe_bf16(acc0[q][r], a.round_bf16) * s0 + maybe_bf16(acc1[q][r], a.round_bf16) * s1;
+                }
+        }
+    }
+}
+
+}  // namespace vaa
+
+extern "C" size_t vaa_patch_embed_grad_ws_bytes(int B, int ph, int pw) {
+    if (B <= 0 || ph <= 0 || pw <= 0) return 0;
+    return vaa_patch_grad_ws_bytes(B, ph, pw) + (size_t)B * 256 * vaa::kTileElems * sizeof(float) + (size_t)B * 256 * sizeof(int16_t) + 256;
+}
+
+extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
+                                           const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph,
+                                           int pw, int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    using namespace vaa;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0 && gpatch && ph > 0 && pw > 0) {
+        if (hipMemsetAsync(gpatch, 0, (size_t)3 * ph * pw * sizeof(float), st) != hipSuccess) return check_launch("vaa_patch_embed_grad_gather(memset)");
+        return VAA_OK;
+    }
+    if (!dy0 || !dy1 || !wt0 || !wt1 || !xy || !std6 || !gpatch || !keep_bits || (geometry && !theta)) {
+        set_error("vaa_patch_embed_grad_gather: null pointer argument (the keep bits of K1 are required)");
+        return VAA_E_INVALID;
+    }
+    if (B < 0 || ph <= 0 || pw <= 0 || D0 <= 0 || D1 <= 0 || (D0 % 32) != 0 || (D1 % 32) != 0 ||
+        (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100)) {
+        set_error("vaa_patch_embed_grad_gather: bad sizes/mode (B=%d ph=%d pw=%d D0=%d D1=%d; D %% 32 == 0)", B, ph, pw, D0, D1);
+        return VAA_E_INVALID;
+    }
+    if (ph > VAA_IMG || pw > VAA_IMG) {
+        set_error("vaa_patch_embed_grad_gather: patch %dx%d larger than the frame", ph, pw);
         return VAA_E_UNSUPPORTED;
     }
-    if (e != hipSuccess) {
-        set_error("vaa_patch_grad_gather: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        return VAA_E_LAUNCH;
+    if (!ws || ws_bytes < vaa_patch_embed_grad_ws_bytes(B, ph, pw)) {
+        set_error("vaa_patch_embed_grad_gather: workspace %zu B < required %zu B", ws_bytes, vaa_patch_embed_grad_ws_bytes(B, ph, pw));
+        return VAA_E_WORKSPACE;
     }
-    int rc = check_launch("vaa_patch_grad_gather(scatter)");
+    char* wsb = reinterpret_cast<char*>(ws);
+    const size_t part_bytes = (vaa_patch_grad_ws_bytes(B, ph, pw) + 255) / 256 * 256;
+    EmbedArgs e;
+    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wt0; e.wt1 = wt1; e.keep = keep_bits;
+    e.geff = reinterpret_cast<float*>(wsb + part_bytes);
+    e.tile_slot = reinterpret_cast<int16_t*>(wsb + part_bytes + (size_t)B * 256 * kTileElems * sizeof(float));
+    e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
+    for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
+    const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
+    hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)B * nch), dim3(kEmbedThreads), 0, st, e, nch);
+    int rc = check_launch("vaa_patch_embed_grad_gather(tiles)");
     if (rc != VAA_OK) return rc;
-    hipLaunchKernelGGL(patch_grad_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, (const float*)ws, gpatch, n, G);
-    return check_launch("vaa_patch_grad_gather(reduce)");
+    GradArgs a;
+    a.g = nullptr; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws;
+    a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
+    for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
+    a.geff = e.geff; a.tile_slot = e.tile_slot;
+    return launch_scatter_reduce<true>(a, gpatch, st, "vaa_patch_embed_grad_gather");
 }

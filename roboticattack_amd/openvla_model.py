@@ -121,10 +121,23 @@ class Vit(nn.Module):
         self.prefix = nn.Parameter(torch.zeros(1, c.n_prefix, c.dim)) if c.n_prefix else None
         self.blocks = nn.ModuleList([VitBlock(c) for _ in range(c.depth - 1)])  # the last block is never evaluated
 
-    def forward(self, img):
-        B0 = img.shape[0]
-        tiles = img.reshape(B0, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(B0, 256, 588)
-        x = F.linear(tiles, self.patch_embed.weight.reshape(self.c.dim, 588), self.patch_embed.bias)  # [B,256,D]
+    def embed_params(self):
+        """(W [D,588], bias [D], W^T [588,D] contiguous, cached) of the patch-embed GEMM — what ops.PatchApplyEmbed needs."""
+        w = self.patch_embed.weight
+        hit = getattr(self, "_embed_wt", None)
+        if hit is None or hit[0] != w._version or hit[1] is not w:
+            hit = (w._version, w, w.detach().reshape(self.c.dim, 588).t().contiguous())
+            self._embed_wt = hit
+        return w.detach().reshape(self.c.dim, 588), self.patch_embed.bias.detach(), hit[2]
+
+    def forward(self, img, embedded=None):
+        """`embedded` [B,256,D]: the patch-embed output computed elsewhere (ops.PatchApplyEmbed) — `img` is then ignored."""
+        if embedded is not None:
+            x = embedded
+        else:
+            B0 = img.shape[0]
+            tiles = img.reshape(B0, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(B0, 256, 588)
+            x = F.linear(tiles, self.patch_embed.weight.reshape(self.c.dim, 588), self.patch_embed.bias)  # [B,256,D]
         if self.prefix is not None:
             B = x.shape[0]
             cls = self.prefix[:, :1].expand(B, -1, -1)
@@ -288,11 +301,25 @@ class OpenVLAShaped(nn.Module):
                 p.fill_(1.0)
         return self
 
-    def hidden_states(self, input_ids, pixel_values, rows=None):
+    def patch_embed_params(self):
+        """(w0, b0, wt0, w1, b1, wt1) for ops.PatchApplyEmbed, or None when the fused patch-embed backward does not apply
+        (tower widths must be multiples of 32, bf16 on a ROCm device)."""
+        import os
+
+        w = self.featurizer.patch_embed.weight
+        if (os.environ.get("VAA_NO_FUSED_EMBED_GRAD") or not w.is_cuda or w.dtype != torch.bfloat16 or self.cfg.dino.dim % 32 or
+                self.cfg.siglip.dim % 32):
+            return None
+        return (*self.featurizer.embed_params(), *self.fused_featurizer.embed_params())
+
+    def hidden_states(self, input_ids, pixel_values, rows=None, patch_embeds=None):
         """[B, 1+256+(L-1), D] final-norm hidden states of the multimodal sequence (modeling_prismatic.py:366-415); with
         `rows` (flat position indices) only those positions of the LAST layer are evaluated and [R,D] is returned."""
-        img, img_fused = torch.split(pixel_values, [3, 3], dim=1)
-        feats = torch.cat([self.featurizer(img), self.fused_featurizer(img_fused)], dim=2)
+        if patch_embeds is not None:
+            feats = torch.cat([self.featurizer(None, embedded=patch_embeds[0]), self.fused_featurizer(None, embedded=patch_embeds[1])], dim=2)
+        else:
+            img, img_fused = torch.split(pixel_values, [3, 3], dim=1)
+            feats = torch.cat([self.featurizer(img), self.fused_featurizer(img_fused)], dim=2)
         proj = self.fc3(F.gelu(self.fc2(F.gelu(self.fc1(feats)))))
         emb = self.embed_tokens(input_ids)
         x = torch.cat([emb[:, :1], proj.to(emb.dtype), emb[:, 1:]], dim=1)
@@ -319,13 +346,13 @@ class OpenVLAShaped(nn.Module):
         bk = (labels[:, 1:] != IGNORE_INDEX).nonzero(as_tuple=False)  # [R,2] sorted row-major
         return bk[:, 0] * S + N_IMG_TOKENS + bk[:, 1]
 
-    def forward_rows(self, input_ids, pixel_values, labels, row_index=None):
+    def forward_rows(self, input_ids, pixel_values, labels, row_index=None, patch_embeds=None):
         """Logits [R,V] of the labelled rows only, in (b,k) row-major order of labels[b,k+1] != -100 (VAA_LAYOUT_ROWS):
         row (b,k) is model position S-L+k = 256+k, the position whose next-token target is labels[b,k+1].
         Pass `row_index=label_row_index(labels)` to keep the step free of host synchronisation."""
         if row_index is None:
             row_index = self.label_row_index(labels)
-        return self.lm_head(self.hidden_states(input_ids, pixel_values, rows=row_index))  # [R, D] -> [R, V]
+        return self.lm_head(self.hidden_states(input_ids, pixel_values, rows=row_index, patch_embeds=patch_embeds))  # [R, D] -> [R, V]
 
     def forward(self, input_ids, attention_mask=None, pixel_values=None, labels=None, **_):
         """Drop-in contract of PrismaticForConditionalGeneration.forward: full fp32 logits and HF's mean CE."""

@@ -128,6 +128,35 @@ def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, ma
     return gpatch
 
 
+def patch_embed_grad_gather(dy0, dy1, wt0, wt1, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None,
+                            round_bf16: bool = True):
+    """K2' (SURVEY.md 8f-3): dL/d patch from the gradients of the two ViT patch-embed OUTPUTS. dy0 [B,256,D0], dy1 [B,256,D1] bf16
+    (tokens in tile order), wt0 [588,D0], wt1 [588,D1] bf16 (conv weights flattened and transposed). Only tiles with kept pixels are
+    evaluated (MFMA); the pixel gradient is never materialised."""
+    B = dy0.shape[0]
+    D0, D1 = int(dy0.shape[2]), int(dy1.shape[2])
+    _need(dy0, torch.bfloat16, "dy0", (B, 256, D0))
+    _need(dy1, torch.bfloat16, "dy1", (B, 256, D1))
+    _need(wt0, torch.bfloat16, "wt0", (588, D0))
+    _need(wt1, torch.bfloat16, "wt1", (588, D1))
+    _need(patch, torch.float32, "patch")
+    _need(xy, torch.int32, "xy", (B, 2))
+    if geometry:
+        _need(theta, torch.float32, "theta", (B, 6))
+    _need(keep_bits, torch.uint8, "keep_bits", (B, 3, IMG * IMG // 8))
+    ph, pw = int(patch.shape[1]), int(patch.shape[2])
+    L = _lib.lib()
+    ws = _workspace(patch.device, L.vaa_patch_embed_grad_ws_bytes(B, ph, pw))
+    gpatch = torch.empty_like(patch)
+    std_c = _STD if std6 is None else _lib.f32x(std6)
+    with _timed("K2_patch_embed_grad_gather", B=B, ph=ph, pw=pw):
+        rc = L.vaa_patch_embed_grad_gather(dy0.data_ptr(), D0, dy1.data_ptr(), D1, wt0.data_ptr(), wt1.data_ptr(), patch.data_ptr(), xy.data_ptr(),
+                                           theta.data_ptr() if geometry else None, keep_bits.data_ptr(), B, ph, pw, int(bool(geometry)),
+                                           int(mask_mode), std_c, int(bool(round_bf16)), gpatch.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "vaa_patch_embed_grad_gather")
+    return gpatch
+
+
 class PatchApply(torch.autograd.Function):
     """Differentiable (w.r.t. `patch`) K1: PyTorch-ROCm autograd hands the model's bf16 pixel gradient to K2."""
 
@@ -145,6 +174,39 @@ class PatchApply(torch.autograd.Function):
         g = patch_grad_gather(gout.to(torch.bfloat16).contiguous(), patch, xy, theta if ctx.geometry else None, keep,
                               ctx.geometry, ctx.mask_mode, std6=ctx.std6)
         return g, None, None, None, None, None, None, None
+
+
+class PatchEmbeds(tuple):
+    """(e0, e1): the two ViT patch-embed outputs [B,256,D] of a patched batch, standing in for `pixel_values` on the path that
+    keeps the pixel gradient un-materialised (PatchApplyEmbed). `OpenVLAShaped.forward_rows(..., patch_embeds=...)` consumes it."""
+
+
+def unfold_tiles(x3: torch.Tensor) -> torch.Tensor:
+    """[B,3,224,224] -> [B,256,588]: the 14x14 tiles of timm's PatchEmbed conv (kernel == stride), columns ordered (c, y, x)."""
+    B = x3.shape[0]
+    return x3.reshape(B, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(B, 256, 588)
+
+
+class PatchApplyEmbed(torch.autograd.Function):
+    """K1 + both patch-embed GEMMs forward; backward = K2' (SURVEY.md 8f-3): the gradients of the patch-embed OUTPUTS go straight to
+    `patch_embed_grad_gather`, which evaluates the patch-embed backward only for the tiles under the patch. w: [D,588], wt: [588,D]."""
+
+    @staticmethod
+    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode, mean6, std6, w0, b0, wt0, w1, b1, wt1):
+        p = patch.detach().contiguous()
+        out, keep = patch_apply_fwd(img_u8, p, xy, theta, geometry, mask_mode, want_keep=True, mean6=mean6, std6=std6)
+        e0 = torch.nn.functional.linear(unfold_tiles(out[:, :3]), w0, b0)
+        e1 = torch.nn.functional.linear(unfold_tiles(out[:, 3:]), w1, b1)
+        ctx.save_for_backward(p, xy, theta if geometry else xy, keep, wt0, wt1)
+        ctx.geometry, ctx.mask_mode, ctx.std6 = bool(geometry), int(mask_mode), std6
+        return e0, e1
+
+    @staticmethod
+    def backward(ctx, d0, d1):
+        patch, xy, theta, keep, wt0, wt1 = ctx.saved_tensors
+        g = patch_embed_grad_gather(d0.to(torch.bfloat16).contiguous(), d1.to(torch.bfloat16).contiguous(), wt0, wt1, patch, xy,
+                                    theta if ctx.geometry else None, keep, ctx.geometry, ctx.mask_mode, std6=ctx.std6)
+        return (g,) + (None,) * 13
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -42,6 +42,7 @@ class RandomPatchTransform:
         self.resize_patch = resize_patch
         self._staged_key = None
         self._staged = None
+        self.embed_with = None  # a model exposing patch_embed_params(): training calls then return ops.PatchEmbeds
         self.last_params = None  # (xy, theta) of the most recent call, host numpy (tests / logging)
 
     # ---- small tensor helpers kept for API compatibility (:16-24) ----
@@ -114,8 +115,17 @@ class RandomPatchTransform:
             return self._apply_resized(img, patch, mean6, std6, geometry, out_dtype)
         ph, pw = int(patch.shape[1]), int(patch.shape[2])
         xy, theta = self._to_dev(*self._draw(B, ph, pw, geometry))
+        emb = self._embed_params(patch, out_dtype)
+        if emb is not None:
+            return ops.PatchEmbeds(ops.PatchApplyEmbed.apply(patch, img, xy, theta, bool(geometry), ops.MASK_LT_M20, mean6, std6, *emb))
         out = ops.PatchApply.apply(patch, img, xy, theta, bool(geometry), ops.MASK_LT_M20, mean6, std6)
         return out if out_dtype == torch.bfloat16 else out.to(out_dtype)
+
+    def _embed_params(self, patch, out_dtype):
+        """Patch-embed weights for the path that never materialises the pixel gradient — only for differentiable bf16 calls."""
+        if self.embed_with is None or not patch.requires_grad or out_dtype != torch.bfloat16 or not torch.is_grad_enabled():
+            return None
+        return self.embed_with.patch_embed_params()
 
     def _apply_resized(self, img, patch, mean6, std6, geometry, out_dtype):
         """resize_patch=True (:113-116, Appendix A-D2): per image s~U(0.61,1.39) drawn BEFORE the position; the base
@@ -140,6 +150,9 @@ class RandomPatchTransform:
         img = self.stage_images(images)
         ph, pw = int(patch.shape[1]), int(patch.shape[2])
         xy, theta = self._to_dev(*self._draw(img.shape[0], ph, pw, False))
+        emb = self._embed_params(patch, out_dtype)
+        if emb is not None:
+            return ops.PatchEmbeds(ops.PatchApplyEmbed.apply(patch, img, xy, theta, False, ops.MASK_NE_M100, mean6, std6, *emb)), xy
         out = ops.PatchApply.apply(patch, img, xy, theta, False, ops.MASK_NE_M100, mean6, std6)
         return (out if out_dtype == torch.bfloat16 else out.to(out_dtype)), xy
 

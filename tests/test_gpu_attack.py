@@ -283,3 +283,41 @@ def test_ddp_attacker_single_rank(tmp_path, attack, monkeypatch):
     saved = torch.load(os.path.join(str(tmp_path), "last", "patch.pt"))
     assert saved.dtype == torch.float32 and tuple(saved.shape) == (3, 50, 50)
     assert os.path.exists(os.path.join(str(tmp_path), "0", "patch.pt"))
+
+
+def test_patch_embed_grad_path_matches_pixel_grad_path(monkeypatch):
+    """SURVEY.md 8f-3 end to end: one UADA step with the patch-embed backward restricted to the kept tiles (K2') gives the same loss and
+    the same patch gradient as the path through the dense bf16 pixel gradient (K2)."""
+    from roboticattack_amd import ops, synthetic
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+    from roboticattack_amd.transform import RandomPatchTransform
+    import random
+
+    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, True, True), siglip=VitCfg(160, 3, 2, 320, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=9)
+    assert m.patch_embed_params() is not None
+    B = 4
+    batch = synthetic.synth_batch(3, B, "noise", as_pil=False)
+    ids = batch["input_ids"].to(DEV)
+    labels = mask_labels(batch["labels"].clone(), [0, 1]).to(DEV)
+    mean = [torch.tensor([0.484375, 0.455078125, 0.40625]), torch.tensor([0.5, 0.5, 0.5])]
+    std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
+    res = []
+    for fused in (True, False):
+        tr = RandomPatchTransform(DEV, False)
+        tr.embed_with = m if fused else None
+        img = tr.stage_images(torch.from_numpy(batch["pixel_values"]))
+        random.seed(5); np.random.seed(5)
+        patch = torch.rand(3, 50, 50, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
+        pix = tr.apply_random_patch_batch(img, patch, mean, std, geometry=True)
+        assert isinstance(pix, ops.PatchEmbeds) == fused
+        logits = m.forward_rows(ids, None, labels, patch_embeds=pix) if fused else m.forward_rows(ids, pix, labels)
+        total, scalars, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
+        total.backward()
+        res.append((scalars.clone(), patch.grad.clone()))
+    (s1, g1), (s2, g2) = res
+    assert torch.allclose(s1, s2, rtol=1e-5, atol=1e-6)          # identical forward
+    assert (g1 - g2).abs().max() <= 2e-2 * g2.abs().max() + 1e-9  # same gradient up to bf16 rounding order in the embed dgrad
+    assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.9999

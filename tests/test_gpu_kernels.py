@@ -448,3 +448,34 @@ def test_baseline_config_shapes_one_step_vs_oracle(ops, name, B, ph, pw, geo, ma
     pc, mc, vc = patch.copy().ravel(), np.zeros(patch.size, np.float32), np.zeros(patch.size, np.float32)
     c_oracle.patch_update(pc, og.ravel().copy(), mc, vc, 0, 2e-3, 1, l1_clip=1e-3 if mode == "UPA" else 0.0)
     assert np.abs(p.cpu().numpy().ravel() - pc).max() <= 1e-4  # north-star tolerance on the updated pixels
+
+
+@pytest.mark.parametrize("B,ph,pw,geo,D0,D1", [(6, 50, 50, 1, 64, 96), (3, 22, 31, 0, 32, 64), (4, 100, 100, 1, 128, 64), (64, 50, 50, 1, 1024, 1152)])
+def test_patch_embed_grad_gather_vs_unfused(ops, B, ph, pw, geo, D0, D1):
+    """K2' (8f-3): patch-embed backward restricted to the kept tiles + gather == K2 on the dense pixel gradient dY @ W (folded back to
+    pixel layout and rounded to bf16 like the model's own backward hands it over)."""
+    from roboticattack_amd import benchmarks, synthetic
+
+    g = torch.Generator(device=DEV).manual_seed(B * 7 + ph)
+    img = torch.from_numpy(synthetic.synth_images(77, B, "noise")).to(DEV)
+    patch = torch.rand(3, ph, pw, device=DEV, generator=g)
+    xy_n, th_n = benchmarks.random_params(B, ph, pw, 5)
+    xy, th = torch.from_numpy(xy_n).to(DEV), torch.from_numpy(th_n).to(DEV)
+    _, keep = ops.patch_apply_fwd(img, patch, xy, th if geo else None, bool(geo), ops.MASK_LT_M20, want_keep=True)
+    dy0 = (torch.randn(B, 256, D0, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    dy1 = (torch.randn(B, 256, D1, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    w0 = (torch.randn(D0, 588, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    w1 = (torch.randn(D1, 588, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+
+    def fold(dy, w):  # [B,256,D] @ [D,588] -> [B,3,224,224] (inverse of the unfold in Vit.forward)
+        t = (dy.float() @ w.float()).to(torch.bfloat16)
+        return t.view(B, 16, 16, 3, 14, 14).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 224, 224)
+
+    gout = torch.cat([fold(dy0, w0), fold(dy1, w1)], dim=1).contiguous()
+    ref = ops.patch_grad_gather(gout, patch, xy, th if geo else None, keep, bool(geo))
+    got = ops.patch_embed_grad_gather(dy0, dy1, w0.t().contiguous(), w1.t().contiguous(), patch, xy, th if geo else None, keep, bool(geo))
+    # same bf16 rounding point; the only difference is the fp32 summation order inside the two GEMMs (rare 1-ulp bf16 flips)
+    assert (got - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-7
+    exact = ops.patch_embed_grad_gather(dy0, dy1, w0.t().contiguous(), w1.t().contiguous(), patch, xy, th if geo else None, keep, bool(geo),
+                                        round_bf16=False)
+    assert (exact - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-7

@@ -223,3 +223,19 @@ def test_frozen_linears_fn_matches_autograd():
     x.grad = res.grad = None
     (res + torch.nn.functional.linear(x, Ws[0])).cos().sum().backward()
     assert torch.allclose(gx, x.grad, atol=1e-5) and torch.allclose(gr, res.grad, atol=1e-6)
+
+
+def test_vit_accepts_precomputed_patch_embeds():
+    """`patch_embeds=` (the hand-over format of ops.PatchApplyEmbed) is the same function of the pixels as `pixel_values=`."""
+    from roboticattack_amd import ops
+    from roboticattack_amd.openvla_model import OpenVLAShaped, tiny_cfg
+
+    m = OpenVLAShaped(tiny_cfg()).init_random(1).eval()
+    ids, labels, _ = synthetic.synth_text_batch(2, 2, 18, 24)
+    labels = mask_labels(labels, [0])
+    pix = torch.randn(2, 6, 224, 224)
+    w0, b0, _ = m.featurizer.embed_params()
+    w1, b1, _ = m.fused_featurizer.embed_params()
+    e = (torch.nn.functional.linear(ops.unfold_tiles(pix[:, :3]), w0, b0), torch.nn.functional.linear(ops.unfold_tiles(pix[:, 3:]), w1, b1))
+    assert torch.allclose(m.forward_rows(ids, pix, labels), m.forward_rows(ids, None, labels, patch_embeds=e), atol=1e-5)
+    assert m.patch_embed_params() is None  # CPU / fp32 / widths not multiples of 32: the fused backward does not apply
