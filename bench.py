@@ -10,7 +10,7 @@ One step = one inner-loop iteration of UADA_wrapper_ddp (UADA_ddp.py:189-209):
 Workload: bs=64 PER RANK (reference semantics, UADA_ddp.py:158 -> weak scaling), 3x50x50 patch, geometry=True, maskidx=[0],
 synthetic BridgeData-shaped frames resident in HBM as u8, random-init weights of the OpenVLA-7B architecture.
 Prints ONE JSON line on rank 0. `roofline` is the dominant hand-written kernel of the path — K1's `patch_apply_fwd_kernel`, which
-moves 73 % of the path's algorithmic bytes and is the longest single hand-written launch in profiles/r01_kbench_kernel_stats_*.csv —
+moves 73 % of the path's algorithmic bytes and is the longest launch of the default path (K1-K4) in profiles/r01_kbench_kernel_stats_*.csv —
 timed inside the timed region (HIP events on the launch stream); `roofline_kernels`/`k2_sweep` carry every op and the K2 batch sweep; `cpu_baseline` is the reference's
 PyTorch-CPU op sequence for the same replaced ops (oracle/ref_port.py) timed on this box's host cores.
 """
@@ -160,8 +160,8 @@ def main():
     model, model_desc = build_model(args.model, dev)
     use_rows = hasattr(model, "forward_rows")
     tr = RandomPatchTransform(dev, False)
-    if use_rows and hasattr(model, "patch_embed_params") and not os.environ.get("VAA_NO_FUSED_EMBED_GRAD"):
-        tr.embed_with = model  # K2' path: the pixel gradient is never materialised
+    if use_rows and hasattr(model, "patch_embed_params") and os.environ.get("VAA_FUSED_EMBED_GRAD"):
+        tr.embed_with = model  # opt-in K2' path: the pixel gradient is never materialised; same step time at bs=64
     mean = [torch.tensor([0.484375, 0.455078125, 0.40625]), torch.tensor([0.5, 0.5, 0.5])]
     std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
 
@@ -264,7 +264,8 @@ def main():
     if dom:
         roofline = {"timing": "one start/stop HIP event pair per launch on the launching stream inside the timed region", "kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kern[dom]["frac"], "traffic": traffic, "mean_us": kern[dom]["mean_us"], "algo_bytes": kern[dom]["algo_bytes"],
-                    "note": "dominant = the hot-path kernel with the most algorithmic bytes (also the longest single hand-written launch in the rocprofv3 kernel stats); "
+                    "note": "dominant = the kernel of the default hot path (K1-K4) with the most algorithmic bytes, also its longest single launch in the rocprofv3 kernel stats "
+                            "(the opt-in K2' tile GEMM of SURVEY 8f-3 is listed under roofline_kernels_standalone as K2e); "
                             "traffic = HBM-side bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/traffic_r01.json, calibrated in-run)"}
 
     extra = {}

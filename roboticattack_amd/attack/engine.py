@@ -46,8 +46,10 @@ class AttackBase:
         self.save_dir = save_dir
         self.device = torch.device(getattr(vla, "device", "cuda"))
         self.randomPatchTransform = RandomPatchTransform(self.device, resize_patch)
-        if hasattr(vla, "forward_rows") and hasattr(vla, "patch_embed_params") and not resize_patch:
-            self.randomPatchTransform.embed_with = vla  # training steps hand the model patch-embed outputs
+        if os.environ.get("VAA_FUSED_EMBED_GRAD") and hasattr(vla, "forward_rows") and hasattr(vla, "patch_embed_params") and not resize_patch:
+            # opt-in: training steps hand the model patch-embed outputs and K2' never builds the pixel gradient.
+            # Off by default: at bs=64 the tile GEMM does not pay yet and the step time is unchanged.
+            self.randomPatchTransform.embed_with = vla
         self.mean = [torch.tensor(MEAN0), torch.tensor(MEAN1)]
         self.std = [torch.tensor(STD0), torch.tensor(STD1)]
         self.optimizer = optimizer

@@ -359,7 +359,11 @@ constexpr int kEmbedThreads = 256;
 __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedArgs a, int nch) {
     __shared__ int16_t tiles[256];
     __shared__ int wave_cnt[4];
-    const int b = blockIdx.x / nch, ch = blockIdx.x - b * nch;
+    // all workgroups of an image share blockIdx % 8, i.e. one XCD and one L2: its dY rows are then fetched from HBM once instead of
+    // once per XCD (PMC: 82 MB -> see profiles/traffic_r01.json)
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int b = (slot_id / nch) * 8 + xcd, ch = slot_id % nch;
+    if (b >= a.B) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
 
     // ---- which tiles carry a kept pixel (any channel): thread t = tile t ----
@@ -494,7 +498,7 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
     const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
-    hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)B * nch), dim3(kEmbedThreads), 0, st, e, nch);
+    hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedThreads), 0, st, e, nch);
     int rc = check_launch("vaa_patch_embed_grad_gather(tiles)");
     if (rc != VAA_OK) return rc;
     GradArgs a;

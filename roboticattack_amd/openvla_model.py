@@ -304,11 +304,8 @@ class OpenVLAShaped(nn.Module):
     def patch_embed_params(self):
         """(w0, b0, wt0, w1, b1, wt1) for ops.PatchApplyEmbed, or None when the fused patch-embed backward does not apply
         (tower widths must be multiples of 32, bf16 on a ROCm device)."""
-        import os
-
         w = self.featurizer.patch_embed.weight
-        if (os.environ.get("VAA_NO_FUSED_EMBED_GRAD") or not w.is_cuda or w.dtype != torch.bfloat16 or self.cfg.dino.dim % 32 or
-                self.cfg.siglip.dim % 32):
+        if not w.is_cuda or w.dtype != torch.bfloat16 or self.cfg.dino.dim % 32 or self.cfg.siglip.dim % 32:
             return None
         return (*self.featurizer.embed_params(), *self.fused_featurizer.embed_params())
 
