@@ -352,6 +352,24 @@ __device__ __forceinline__ v8s_e frag_or_zero(const uint16_t* p, bool valid) {
 
 __device__ __forceinline__ float maybe_bf16(float v, int on) { return on ? bf16_bits_to_f32(f32_to_bf16_bits(v)) : v; }
 
+// Does tile (ty, tx) hold a kept pixel in any channel? 3 planes x 14 rows x 14 bits, read as 126 INDEPENDENT byte loads that are all in
+// flight together (an early-exit loop makes them 42 dependent round trips: it was 35 of the kernel's 57 us).
+__device__ __forceinline__ bool tile_has_kept_pixel(const uint8_t* kb, int ty, int tx) {
+    uint32_t any = 0u;
+#pragma unroll
+    for (int ch3 = 0; ch3 < 3; ++ch3) {
+        const uint8_t* p = kb + (size_t)ch3 * (VAA_NPIX / 8);
+#pragma unroll
+        for (int y = 0; y < kTilePx; ++y) {
+            const int bit0 = (ty * kTilePx + y) * VAA_IMG + tx * kTilePx;  // 14 consecutive bits
+            const int by = bit0 >> 3, by2 = min(by + 2, VAA_NPIX / 8 - 1);  // the third byte only matters when it exists
+            const uint32_t w = (uint32_t)p[by] | ((uint32_t)p[by + 1] << 8) | ((uint32_t)p[by2] << 16);
+            any |= (w >> (bit0 & 7)) & 0x3fffu;
+        }
+    }
+    return any != 0u;
+}
+
 constexpr int kEmbedThreads = 256;
 
 // grid = B * nch workgroups of 4 waves; workgroup (b, ch) evaluates column blocks ch*4 .. ch*4+3 (one per wave) for every flagged tile
@@ -367,19 +385,7 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedA
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
 
     // ---- which tiles carry a kept pixel (any channel): thread t = tile t ----
-    bool flag = false;
-    {
-        const int ty = tid >> 4, tx = tid & 15;
-        const uint8_t* kb = a.keep + (size_t)b * 3 * (VAA_NPIX / 8);
-        for (int ch3 = 0; ch3 < 3 && !flag; ++ch3)
-            for (int y = 0; y < kTilePx && !flag; ++y) {
-                const int bit0 = (ty * kTilePx + y) * VAA_IMG + tx * kTilePx;  // 14 consecutive bits
-                const int by = bit0 >> 3, by2 = min(by + 2, VAA_NPIX / 8 - 1);  // the third byte only matters when it exists
-                const uint8_t* p = kb + (size_t)ch3 * (VAA_NPIX / 8);
-                const uint32_t w = (uint32_t)p[by] | ((uint32_t)p[by + 1] << 8) | ((uint32_t)p[by2] << 16);
-                flag = ((w >> (bit0 & 7)) & 0x3fffu) != 0u;
-            }
-    }
+    const bool flag = tile_has_kept_pixel(a.keep + (size_t)b * 3 * (VAA_NPIX / 8), tid >> 4, tid & 15);
     const unsigned long long m = __ballot(flag);
     if (lane == 0) wave_cnt[wv] = __popcll(m);
     __syncthreads();
@@ -455,6 +461,148 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedA
     }
 }
 
+
+// Fast variant for tower widths that fit the LDS (64 x (D+8) bf16 <= 150 KB, i.e. D <= 1160): the gathered dY rows of one tower are
+// staged ONCE per workgroup (all loads in flight together, one barrier), then every wave runs a barrier-free k-loop — A fragments from
+// LDS (16 B reads, each feeding two MFMAs: a wave owns two column blocks), B fragments (weights) from global, four k-steps ahead.
+// 8 waves x 2 column blocks = 16 column blocks per workgroup, 3 workgroups per image, all on the image's XCD.
+constexpr int kEmbedFastThreads = 512;
+constexpr int kEmbedFastCols = 16;   // column blocks per workgroup
+constexpr int kEmbedStageMax = 18;   // 16-byte chunks a thread stages per tower: 64 rows x 1152/8 chunks / 512 threads
+
+__global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kernel(EmbedArgs a, int nch) {
+    extern __shared__ __align__(16) unsigned char embed_smem[];
+    uint16_t* sA = reinterpret_cast<uint16_t*>(embed_smem);
+    __shared__ int16_t tiles[256];
+    __shared__ int wave_cnt[4];
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int b = (slot_id / nch) * 8 + xcd, ch = slot_id % nch;
+    if (b >= a.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+
+    bool flag = false;
+    if (tid < 256) flag = tile_has_kept_pixel(a.keep + (size_t)b * 3 * (VAA_NPIX / 8), tid >> 4, tid & 15);
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0 && wv < 4) wave_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int base = 0, M = 0;
+    for (int q = 0; q < 4; ++q) { if (q < wv) base += wave_cnt[q]; M += wave_cnt[q]; }
+    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (flag) tiles[slot] = (int16_t)tid;
+    if (ch == 0 && tid < 256) a.tile_slot[b * 256 + tid] = flag ? (int16_t)slot : (int16_t)-1;
+    __syncthreads();
+
+    int n[2];
+    bool nv[2];
+    float s0[2], s1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nb = ch * kEmbedFastCols + wv * 2 + j;
+        n[j] = nb * 16 + c;
+        nv[j] = nb < kNBlocks && n[j] < kTileElems;
+        const int c3 = nv[j] ? n[j] / (kTilePx * kTilePx) : 0;
+        s0[j] = a.istd6[c3];
+        s1[j] = a.istd6[c3 + 3];
+    }
+    for (int mg = 0; mg * 64 < M; ++mg) {
+        const int rows = min(64, M - mg * 64), nq = (rows + 15) >> 4;  // workgroup-uniform
+        float res[2][4][4];  // [column block][row block][r]: tower 0's scaled contribution, then + tower 1's
+#pragma unroll
+        for (int tower = 0; tower < 2; ++tower) {
+            const int D = tower ? a.D1 : a.D0, SA = D + 8, cpr = D >> 3;  // 16-byte chunks per row
+            const uint16_t* dy = tower ? a.dy1 : a.dy0;
+            const int nchunks = nq * 16 * cpr;
+            // ---- stage in two halves (register budget): the loads of a half are all in flight before its LDS stores ----
+            __syncthreads();  // the previous tower's k-loops are over
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                uint4 st[kEmbedStageMax / 2];
+#pragma unroll
+                for (int it = 0; it < kEmbedStageMax / 2; ++it) {
+                    const int idx = tid + (hf * (kEmbedStageMax / 2) + it) * kEmbedFastThreads;
+                    st[it] = make_uint4(0, 0, 0, 0);
+                    if (idx < nchunks) {
+                        const int row = idx / cpr, cc = idx - row * cpr, r = mg * 64 + row;
+                        if (r < M) st[it] = *reinterpret_cast<const uint4*>(dy + ((size_t)b * 256 + tiles[r]) * D + cc * 8);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < kEmbedStageMax / 2; ++it) {
+                    const int idx = tid + (hf * (kEmbedStageMax / 2) + it) * kEmbedFastThreads;
+                    if (idx < nchunks) {
+                        const int row = idx / cpr, cc = idx - row * cpr;
+                        *reinterpret_cast<uint4*>(&sA[row * SA + cc * 8]) = st[it];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- barrier-free k-loop ----
+            const uint16_t* wt = tower ? a.wt1 : a.wt0;
+            const uint16_t* wp0 = wt + (size_t)n[0] * D + g * 8;
+            const uint16_t* wp1 = wt + (size_t)n[1] * D + g * 8;
+            v4f_e acc[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
+            const int ksteps = D >> 5;
+            // software pipeline: the weight fragments of trip t+1 (two k-steps, both column blocks) are requested before trip t's
+            // LDS reads and MFMAs, so the global/L2 latency of the B operand is off the critical path
+            v8s_e bn[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bn[0][u] = frag_or_zero(wp0 + u * 32, nv[0] && u < ksteps);
+                bn[1][u] = frag_or_zero(wp1 + u * 32, nv[1] && u < ksteps);
+            }
+            for (int ks = 0; ks < ksteps; ks += 2) {
+                v8s_e bc[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    bc[0][u] = bn[0][u];
+                    bc[1][u] = bn[1][u];
+                    const bool kv = ks + 2 + u < ksteps;
+                    bn[0][u] = frag_or_zero(wp0 + (ks + 2 + u) * 32, nv[0] && kv);
+                    bn[1][u] = frag_or_zero(wp1 + (ks + 2 + u) * 32, nv[1] && kv);
+                }
+                const bool k1 = ks + 1 < ksteps;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q >= nq) continue;
+                    const uint16_t* ap = &sA[(q * 16 + c) * SA + ks * 32 + g * 8];
+                    const v8s_e a0 = *reinterpret_cast<const v8s_e*>(ap);
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bc[0][0], acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bc[1][0], acc[1][q], 0, 0, 0);
+                    if (k1) {
+                        const v8s_e a1 = *reinterpret_cast<const v8s_e*>(ap + 32);
+                        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bc[0][1], acc[0][q], 0, 0, 0);
+                        acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bc[1][1], acc[1][q], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = maybe_bf16(acc[j][q][r], a.round_bf16) * (tower ? s1[j] : s0[j]);
+                        res[j][q][r] = tower ? res[j][q][r] + v : v;
+                    }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!nv[j]) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int sl = mg * 64 + q * 16 + g * 4 + r;
+                    if (sl < M) a.geff[((size_t)b * 256 + sl) * kTileElems + n[j]] = res[j][q][r];
+                }
+        }
+    }
+}
+
 }  // namespace vaa
 
 extern "C" size_t vaa_patch_embed_grad_ws_bytes(int B, int ph, int pw) {
@@ -497,8 +645,19 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     e.tile_slot = reinterpret_cast<int16_t*>(wsb + part_bytes + (size_t)B * 256 * kTileElems * sizeof(float));
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
-    const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
-    hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedThreads), 0, st, e, nch);
+    const int Dmax = D0 > D1 ? D0 : D1;
+    const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
+    if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
+        const int nch = (kNBlocks + kEmbedFastCols - 1) / kEmbedFastCols;  // 3 workgroups per image
+        if (hipFuncSetAttribute((const void*)embed_dgrad_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast) != hipSuccess) {
+            set_error("vaa_patch_embed_grad_gather: hipFuncSetAttribute failed");
+            return VAA_E_LAUNCH;
+        }
+        hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
+    } else {  // wide towers: fragments straight from global memory
+        const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
+        hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedThreads), 0, st, e, nch);
+    }
     int rc = check_launch("vaa_patch_embed_grad_gather(tiles)");
     if (rc != VAA_OK) return rc;
     GradArgs a;

@@ -74,7 +74,7 @@ def main():
                   "write_bytes": wm * 1024 * w_fac, "hbm_bytes_per_launch": fm * 1024 * f_fac + wm * 1024 * w_fac}
     # per hot-path op (what bench.py's event brackets cover): sum over the op's kernels
     ops = {"K1_patch_apply_fwd": ("patch_apply_fwd_kernel",), "K2_patch_grad_gather": ("patch_grad_scatter_kernel<double, 3, false>", "patch_grad_reduce_kernel"),
-           "K2_patch_embed_grad_gather": ("embed_dgrad_tiles_kernel", "patch_grad_scatter_kernel<double, 3, true>", "patch_grad_reduce_kernel"),
+           "K2_patch_embed_grad_gather": ("embed_dgrad_tiles", "patch_grad_scatter_kernel<double, 3, true>", "patch_grad_reduce_kernel"),
            "K3_loss_fwd_bwd": ("loss_stats_kernel", "loss_grad_kernel"), "K4_patch_update": ("patch_update_kernel",)}
     out["ops"] = {}
     for op, kns in ops.items():
