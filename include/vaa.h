@@ -97,7 +97,9 @@ int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* patch, const i
 /*
  * K3 — replaces HF Llama's `.loss` (via modeling_prismatic.py:404-415) + OpenVLAAttacker.weighted_loss
  * (UADA.py:381-406, UADA_ddp.py:99-124, UPA.py:367-387) and their autograd backward to the logits.
- *   logits   dev  f32|bf16, layout FULL [B,S,V] or ROWS [R,V]
+ *   logits   dev  f32|bf16, layout FULL [B,S,V] or ROWS [R,V]. For ROWS pass S = R (the number of rows, which must equal the number
+ *             of labelled positions) to get the row-indexed schedule (one workgroup per row, loads issued before the labels are
+ *             consulted); S = 0 (unknown) keeps the label-driven schedule
  *   labels   dev  [B,L] int64, already masked by the caller (mask_labels, UADA.py:371-379)
  *   params   host [4] float32: {w (MSE weight: 5 or --MSE_weights), alpha, beta, scale (1/accumulate_steps)}
  *   scalars  dev  [8] float32 out: {total, CE, w^2*MSE, aux0 (UPA angle), aux1 (UPA dist), #CE rows, #action rows, UAD}

@@ -164,41 +164,99 @@ __device__ __forceinline__ void count_labelled(const Labels& lb, int B, int L, i
     for (int q = 0; q < NT / 64; ++q) { before += shi[q][0]; total += shi[q][1]; }
 }
 
+
+// Row-indexed schedule (VAA_LAYOUT_ROWS with the row count known on the host): workgroup r owns row r of the [R,V] logits, so its
+// loads are issued before the labels are even staged; this routine then finds which (sample b, position k) row r is — the r-th
+// labelled position in row-major order — from the label matrix in LDS: per-sample counts, a block scan, one ballot search.
+// Needs B <= NT and the labels in LDS. Returns false if r is not a labelled rank (R_dev <= r); R_dev = total labelled count.
+template <int NT>
+__device__ __forceinline__ bool locate_row(const Labels& lb, int B, int L, int r, int& b, int& k, int& jj, int& R_dev, int* sh_i) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int cnt = 0;
+    if (tid < B)
+        for (int e = 1; e < L; ++e) cnt += (lb.at(tid * L + e) != -100) ? 1 : 0;
+    // inclusive scan over threads (wave scan + wave totals)
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    __syncthreads();
+    if (lane == 63) sh_i[wv] = inc;
+    if (tid == 0) { sh_i[NT / 64] = -1; sh_i[NT / 64 + 1] = 0; }
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int q = 0; q < NT / 64; ++q) { if (q < wv) base += sh_i[q]; total += sh_i[q]; }
+    inc += base;
+    if (tid < B && r >= inc - cnt && r < inc) { sh_i[NT / 64] = tid; sh_i[NT / 64 + 1] = r - (inc - cnt); }
+    __syncthreads();
+    R_dev = total;
+    b = sh_i[NT / 64];
+    jj = sh_i[NT / 64 + 1];
+    if (b < 0) return false;
+    k = nth_labelled(lb, b, L, jj);
+    return k >= 0;
+}
+
 // ---- kernel A: per labelled row: compact rank, logsumexp, label logit, action-slice soft-argmax / argmax ----
-template <typename T>
+template <typename T, bool ROWMAP = false>
 __global__ __launch_bounds__(kRowThreads) void loss_stats_kernel(LossArgs a, int J) {
-    // workgroup (j, b) owns the j-th, (j+J)-th, ... labelled position of sample b (usually exactly one row, or none);
+    // legacy map: workgroup (j, b) owns the j-th, (j+J)-th, ... labelled position of sample b (usually exactly one row, or none);
     // sample index fastest: consecutive blocks (dealt round-robin to the 8 XCDs) are all active.
-    const int j = blockIdx.x / a.B, b = blockIdx.x - j * a.B;
+    // ROWMAP (ROWS layout, row count known on the host): workgroup r owns row r; its loads are issued first, see locate_row().
+    const int j = ROWMAP ? 0 : blockIdx.x / a.B;
+    int b = ROWMAP ? 0 : blockIdx.x - j * a.B;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     __shared__ int16_t lab16[kLabLds];
     __shared__ float red[16];
     __shared__ int shi[16][2];
+    __shared__ int shl[kRowThreads / 64 + 2];
     __shared__ float bmax;
-    const Labels lb = stage_labels(a, lab16);
-  for (int jj = j;; jj += J) {
-    const int k = nth_labelled(lb, b, a.L, jj);
-    if (k < 0) return;
-    const int lab = lb.at(b * a.L + k + 1);
-    int rowidx, total;
-    count_labelled(lb, a.B, a.L, b * a.L + k + 1, rowidx, total, shi);
-
-    const T* z = reinterpret_cast<const T*>(a.logits) + row_offset(a, b, k, rowidx);
     constexpr int N = Vec<T>::N;
     const int nvec = a.V / N;  // V = 32064 is a multiple of 8
-
     // one streaming pass: this thread's elements stay in registers (8 f32 or 4 bf16 16-byte vectors = 32 logits)
     constexpr int MAXV = 32 / N;
     float v[MAXV][N];
+    if (ROWMAP) {
+        const T* z0 = reinterpret_cast<const T*>(a.logits) + (size_t)blockIdx.x * a.V;
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c) {
+            const int q = tid + c * kRowThreads;
+            if (q < nvec) {
+                Vec<T>::load(z0 + (size_t)q * N, v[c]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < N; ++e) v[c][e] = -INFINITY;
+            }
+        }
+    }
+    const Labels lb = stage_labels(a, lab16);
+  for (int jj = j;; jj += J) {
+    int k, rowidx, total;
+    if (ROWMAP) {
+        if (jj != j) return;  // exactly one row per workgroup
+        rowidx = blockIdx.x;
+        if (!locate_row<kRowThreads>(lb, a.B, a.L, rowidx, b, k, jj, total, shl)) return;
+    } else {
+        k = nth_labelled(lb, b, a.L, jj);
+        if (k < 0) return;
+    }
+    const int lab = lb.at(b * a.L + k + 1);
+    if (!ROWMAP) count_labelled(lb, a.B, a.L, b * a.L + k + 1, rowidx, total, shi);
+
+    const T* z = reinterpret_cast<const T*>(a.logits) + row_offset(a, b, k, rowidx);
     float m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < MAXV; ++c) {
         const int q = tid + c * kRowThreads;
-        if (q < nvec) {
-            Vec<T>::load(z + (size_t)q * N, v[c]);
-        } else {
+        if (!ROWMAP) {
+            if (q < nvec) {
+                Vec<T>::load(z + (size_t)q * N, v[c]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < N; ++e) v[c][e] = -INFINITY;
+                for (int e = 0; e < N; ++e) v[c][e] = -INFINITY;
+            }
         }
 #pragma unroll
         for (int e = 0; e < N; ++e) m = fmaxf(m, v[c][e]);
@@ -319,20 +377,35 @@ struct Upa3 {
 //      when nothing is labelled) publishes the scalars and the predicted tokens. ----
 constexpr int kGradT = 512;  // 64 logits per thread stay in registers (256-VGPR budget), fp64 reductions do not spill
 
-template <typename T>
+template <typename T, bool ROWMAP = false>
 __global__ __launch_bounds__(kGradT) void loss_grad_kernel(LossArgs a, int J) {
-    const int j = blockIdx.x / a.B, b = blockIdx.x - j * a.B;
+    // ROWMAP (ROWS layout, row count R = a.S known on the host): workgroup r owns row r; everything it needs about the row (label,
+    // rank within its sample) is in the compact statistics the first kernel left at rank r, so no label is read here at all and the
+    // fold over the R statistics starts at once.
+    const int j = ROWMAP ? 0 : blockIdx.x / a.B, b = ROWMAP ? 0 : blockIdx.x - j * a.B;
     const int tid = threadIdx.x;
     __shared__ int16_t lab16[kLabLds];
     __shared__ int shi[kGradT / 64][2];
     __shared__ double sh[kGradT / 64][7];
-    const Labels lb = stage_labels<kGradT>(a, lab16);
+    Labels lb;
+    lb.g = a.labels;
+    lb.l = nullptr;
+    if (!ROWMAP) lb = stage_labels<kGradT>(a, lab16);
   for (int jj = j;; jj += J) {
-    const int k = nth_labelled(lb, b, a.L, jj);
+    if (ROWMAP && jj != j) return;
+    const int k = ROWMAP ? 0 : nth_labelled(lb, b, a.L, jj);
     if (k < 0 && !(blockIdx.x == 0 && jj == j)) return;  // workgroup 0 always runs once: it publishes zeros when nothing is labelled
-    const int lab = k < 0 ? -100 : lb.at(b * a.L + k + 1);
     int rowidx, R;
-    count_labelled<kGradT>(lb, a.B, a.L, k < 0 ? 0 : b * a.L + k + 1, rowidx, R, shi);
+    RowStat me;
+    me.lse = me.alse = me.E = 0.0f; me.ord = 0; me.lab = -100;
+    if (ROWMAP) {
+        rowidx = blockIdx.x;
+        R = a.S;
+        me = a.st[rowidx];
+    } else {
+        count_labelled<kGradT>(lb, a.B, a.L, k < 0 ? 0 : b * a.L + k + 1, rowidx, R, shi);
+    }
+    const int lab = ROWMAP ? me.lab : (k < 0 ? -100 : lb.at(b * a.L + k + 1));
 
     // this row's logits: issue the loads now, use them after the reductions (addresses do not depend on the statistics)
     constexpr int N = Vec<T>::N;
@@ -371,9 +444,7 @@ __global__ __launch_bounds__(kGradT) void loss_grad_kernel(LossArgs a, int J) {
 
     double total = 0.0, aux0 = 0.0, aux1 = 0.0;
     float kce = 0.0f, kE = 0.0f;
-    RowStat me;
-    me.lse = me.alse = me.E = 0.0f; me.ord = 0;
-    if (k >= 0) me = a.st[rowidx];
+    if (!ROWMAP && k >= 0) me = a.st[rowidx];
     if (a.mode == VAA_LOSS_UPA) {
         aux0 = acc[5] / a.B;
         aux1 = 1.0 / (acc[6] / a.B + 1e-3);  // UPA.py:384
@@ -487,6 +558,16 @@ extern "C" int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const
     a.w = params[0]; a.alpha = params[1]; a.beta = params[2]; a.scale = params[3];
     const int J = (L - 1) < 8 ? (L - 1) : 8;  // workgroups per sample; the attacks label at most 8 positions per sample
     const unsigned G = (unsigned)B * (unsigned)J;
+    if (layout == VAA_LAYOUT_ROWS && S > 0 && B <= kRowThreads && (long)B * L <= kLabLds) {
+        // row count known on the host: one workgroup per row, loads issued before the labels are looked at (locate_row)
+        if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL((loss_stats_kernel<float, true>), dim3((unsigned)S), dim3(kRowThreads), 0, st, a, 1);
+        else hipLaunchKernelGGL((loss_stats_kernel<uint16_t, true>), dim3((unsigned)S), dim3(kRowThreads), 0, st, a, 1);
+        int rc0 = check_launch("vaa_loss_fwd_bwd(stats)");
+        if (rc0 != VAA_OK) return rc0;
+        if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL((loss_grad_kernel<float, true>), dim3((unsigned)S), dim3(kGradT), 0, st, a, 1);
+        else hipLaunchKernelGGL((loss_grad_kernel<uint16_t, true>), dim3((unsigned)S), dim3(kGradT), 0, st, a, 1);
+        return check_launch("vaa_loss_fwd_bwd(grad)");
+    }
     if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(loss_stats_kernel<float>, dim3(G), dim3(kRowThreads), 0, st, a, J);
     else hipLaunchKernelGGL(loss_stats_kernel<uint16_t>, dim3(G), dim3(kRowThreads), 0, st, a, J);
     int rc = check_launch("vaa_loss_fwd_bwd(stats)");

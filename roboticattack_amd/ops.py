@@ -233,7 +233,7 @@ def loss_fwd_bwd(logits, labels, mode: int, w: float = 5.0, alpha: float = 0.8, 
     else:
         if logits.dim() != 2:
             raise _lib.VaaError(f"logits: ROWS layout expects [R,V], got {tuple(logits.shape)}")
-        S, V = 0, int(logits.shape[1])
+        S, V = int(logits.shape[0]), int(logits.shape[1])  # ROWS: S carries the row count R (row-indexed schedule)
     L = _lib.lib()
     ws = _workspace(logits.device, L.vaa_loss_ws_bytes(B, Lt))
     scalars = torch.empty(8, dtype=torch.float32, device=logits.device)
