@@ -50,7 +50,7 @@ def build_model(kind, dev):
     if kind == "openvla-7b":
         return build_openvla(openvla_7b_cfg(), device=dev, dtype=torch.bfloat16, seed=0), "OpenVLA-7B shape (DINOv2-L/14 + SigLIP-so400m/14 + Llama-2-7B), random init"
     if kind == "tiny":
-        return build_openvla(tiny_cfg(), device=dev, dtype=torch.float32, seed=0), "tiny topology-equal model"
+        return build_openvla(tiny_cfg(), device=dev, dtype=torch.bfloat16, seed=0), "tiny topology-equal model (bf16)"
     from roboticattack_amd.surrogate import SurrogateVLA
 
     return SurrogateVLA(seed=0).to(dev), "fp32 surrogate"

@@ -321,3 +321,29 @@ def test_patch_embed_grad_path_matches_pixel_grad_path(monkeypatch):
     assert torch.allclose(s1, s2, rtol=1e-5, atol=1e-6)          # identical forward
     assert (g1 - g2).abs().max() <= 2e-2 * g2.abs().max() + 1e-9  # same gradient up to bf16 rounding order in the embed dgrad
     assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.9999
+
+
+@pytest.mark.parametrize("model,extra_env", [("tiny", {}), ("tiny", {"VAA_FUSED_EMBED_GRAD": "1"}), ("surrogate", {})])
+def test_bench_contract_line_tiny(model, extra_env):
+    """bench.py end to end (tiny model, 2 steps): ONE JSON line on stdout with every field of the driver's contract."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--model", model, "--bs", "8", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-kernel-suite"], capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6 and d["loss_finite"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    assert d["roofline"]["kernel"] == "K1_patch_apply_fwd" and d["roofline"]["bound"] == "hbm"
