@@ -24,7 +24,7 @@ def main(args):
     cli.maybe_wandb_init(args, name)
     print(f"exp_id:{exp_id}")
     path = f"{args.server}/run/white_patch_attack/{exp_id}"
-    device = torch.device(f"cuda:{args.device}" if torch.cuda.is_available() else "cpu")
+    device = cli.resolve_device(args.device)
     vla, _ = cli.resolve_model(args, device)
     os.makedirs(path, exist_ok=True)
     train_dataloader, val_dataloader = cli.synthetic_loaders(args.bs)

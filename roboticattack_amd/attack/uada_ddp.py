@@ -34,8 +34,7 @@ def default_model_factory(vla_path: str, device):
         return SurrogateVLA(seed=seed).to(device)
     if vla_path.startswith("random:"):
         cfg = tiny_cfg() if vla_path.endswith("tiny") else openvla_7b_cfg()
-        dtype = torch.float32 if vla_path.endswith("tiny") else torch.bfloat16
-        return build_openvla(cfg, device=device, dtype=dtype)
+        return build_openvla(cfg, device=device, dtype=torch.bfloat16)  # the transform hands over bf16 pixel_values, as the reference does
     if os.path.isdir(vla_path):
         return load_hf_openvla(build_openvla(openvla_7b_cfg(), device=device), vla_path)
     raise FileNotFoundError(

@@ -80,6 +80,19 @@ def add_common(parser: argparse.ArgumentParser, *, lr, maskidx, iters, warmup, i
     parser.add_argument("--data", default="synthetic", type=str, help="data source; only 'synthetic' exists in this image")
 
 
+def resolve_device(index: int):
+    """`--device N` as the reference uses it (UADA_wrapper.py:52 defaults to GPU 1). On a box with fewer GPUs the run would die with
+    'invalid device ordinal' before doing anything; fall back to GPU 0 and say so."""
+    import torch
+
+    if not torch.cuda.is_available():
+        return torch.device("cpu")
+    if index >= torch.cuda.device_count():
+        print(f"[vaa] --device {index} does not exist on this host ({torch.cuda.device_count()} GPU(s)) -> using cuda:0")
+        index = 0
+    return torch.device(f"cuda:{index}")
+
+
 def resolve_model(args, device):
     """The reference downloads `openvla/...` from the HF hub (UADA_wrapper.py:56-65); offline, a local directory of that
     name is used if present, otherwise the shape-exact random-init model."""

@@ -347,3 +347,23 @@ def test_bench_contract_line_tiny(model, extra_env):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in d["roofline"], key
     assert d["roofline"]["kernel"] == "K1_patch_apply_fwd" and d["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.parametrize("wrapper,torchrun", [("UADA_wrapper", False), ("UPA_wrapper", False), ("TMA_wrapper", False), ("UADA_wrapper_ddp", True)])
+def test_wrapper_clis_run_end_to_end(tmp_path, wrapper, torchrun):
+    """The four reference CLIs with their DEFAULT flags (incl. the reference's `--device 1`) on a tiny model: two outer iterations each,
+    `run/<attack>/<id>/.../patch.pt` written in the reference's format."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "VLAAttacker", wrapper + ".py")
+    flags = ["--vla_path", "random:tiny", "--iter", "2", "--innerLoop", "2", "--bs", "4", "--warmup", "1", "--wandb_project", "false"]
+    cmd = [sys.executable] + (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                               "--master-port", "29541"] if torchrun else []) + [script] + flags
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    patches = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == "patch.pt"]
+    assert patches, out.stdout[-2000:]
+    p = torch.load(patches[0])
+    assert p.dtype == torch.float32 and tuple(p.shape) == (3, 50, 50) and float(p.min()) >= 0 and float(p.max()) <= 1
