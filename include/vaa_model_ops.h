@@ -29,19 +29,22 @@ int vaa_model_layernorm_bwd(const uint16_t* gh, const uint16_t* gpass, const uin
                             long rows, int D, void* stream);
 /* Softmax attention on the matrix cores for short sequences. q,k,v,o: bf16 views [B,T,H,hd] given by element strides
  * {batch, token, head} (last dim contiguous, all strides % 8 == 0), hd % 8 == 0, hd <= 128. lse: float32 [B,H,T] (natural log).
- * causal != 0: query t sees keys <= t. */
+ * causal != 0: query t sees keys <= t.
+ * cu_seqlens (int32 [B+1], may be NULL): the B sequences are PACKED back to back along the token axis (the batch stride is unused),
+ * sample b owning tokens cu[b] .. cu[b+1]-1; T is then the maximum length (lse and dsum stay [B,H,T]). */
 int vaa_model_attention_fwd(const uint16_t* q, const int64_t* q_str, const uint16_t* k, const int64_t* k_str, const uint16_t* v,
-                            const int64_t* v_str, uint16_t* o, const int64_t* o_str, float* lse, int B, int H, int T, int hd, int causal,
-                            float scale, void* stream);
+                            const int64_t* v_str, uint16_t* o, const int64_t* o_str, float* lse, const int32_t* cu_seqlens, int B, int H,
+                            int T, int hd, int causal, float scale, void* stream);
 /* Backward of vaa_model_attention_fwd: o, lse from the forward; dsum: float32 [B,H,T] workspace; dq/dk/dv: bf16 [B,T,H,hd] views
  * given by strides (e.g. the three slices of one packed [B,T,3,H,hd] gradient buffer). Two launches (dq, then dk/dv).
  * rope_cos/rope_sin (both or neither; float32 [T,hd/2], hd in {64,128}): q and k had vaa_model_rope applied before the forward;
- * dq and dk are then returned w.r.t. the un-rotated tensors (the adjoint rotation runs in the kernels' epilogues). */
+ * dq and dk are then returned w.r.t. the un-rotated tensors (the adjoint rotation runs in the kernels' epilogues); with cu_seqlens the
+ * tables are indexed by the PACKED token (one row per token, i.e. already gathered by position id). */
 int vaa_model_attention_bwd(const uint16_t* q, const int64_t* q_str, const uint16_t* k, const int64_t* k_str, const uint16_t* v,
                             const int64_t* v_str, const uint16_t* o, const int64_t* o_str, const uint16_t* dout, const int64_t* do_str,
                             const float* lse, float* dsum, uint16_t* dq, const int64_t* dq_str, uint16_t* dk, const int64_t* dk_str,
-                            uint16_t* dv, const int64_t* dv_str, const float* rope_cos, const float* rope_sin, int B, int H, int T, int hd,
-                            int causal, float scale, void* stream);
+                            uint16_t* dv, const int64_t* dv_str, const float* rope_cos, const float* rope_sin, const int32_t* cu_seqlens, int B,
+                            int H, int T, int hd, int causal, float scale, void* stream);
 #ifdef __cplusplus
 }
 #endif

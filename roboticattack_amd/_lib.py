@@ -110,9 +110,9 @@ def lib() -> C.CDLL:
     L.vaa_model_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, lng, i32, vp]
     i64p = C.POINTER(C.c_int64)
     L.vaa_model_attention_fwd.restype = i32
-    L.vaa_model_attention_fwd.argtypes = [vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, i32, i32, i32, i32, i32, f32, vp]
+    L.vaa_model_attention_fwd.argtypes = [vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, vp, i32, i32, i32, i32, i32, f32, vp]
     L.vaa_model_attention_bwd.restype = i32
-    L.vaa_model_attention_bwd.argtypes = [vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, vp, vp, i64p, vp, i64p, vp, i64p, vp, vp, i32, i32, i32, i32, i32, f32, vp]
+    L.vaa_model_attention_bwd.argtypes = [vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, i64p, vp, vp, vp, i64p, vp, i64p, vp, i64p, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
     _lib = L
     return L
 

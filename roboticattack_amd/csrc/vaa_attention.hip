@@ -34,9 +34,27 @@ struct AttnFwdArgs {
     uint16_t* o;
     float* lse;  // [B,H,T] natural-log logsumexp of scale*q.k over the visible keys
     AttnStr sq, sk, sv, so;
+    const int32_t* cu;  // optional [B+1] cumulative token counts: sequences are packed back to back along the token axis (batch stride
+                        // unused), sample b has cu[b+1]-cu[b] tokens; T is then the MAXIMUM length (grid size, lse row stride)
     int B, H, T, hd;
     float scale_log2;  // softmax scale * log2(e)
 };
+
+struct SeqInfo {
+    int T;      // tokens of this sample
+    long tok0;  // first token of this sample on the packed token axis (0 when not packed)
+    bool packed;
+};
+__device__ __forceinline__ SeqInfo seq_info(const int32_t* cu, int b, int Tmax) {
+    SeqInfo si;
+    si.packed = cu != nullptr;
+    si.tok0 = si.packed ? cu[b] : 0;
+    si.T = si.packed ? cu[b + 1] - cu[b] : Tmax;
+    return si;
+}
+__device__ __forceinline__ long row_base(const AttnStr& st, const SeqInfo& si, int b, int h) {
+    return (si.packed ? si.tok0 * st.t : (long)b * st.b) + (long)h * st.h;
+}
 
 constexpr int kTile = 64;  // rows (keys or queries) per LDS tile = queries per workgroup
 
@@ -120,13 +138,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     int pair, qb;
     if (!block_to_pair(nqb, a.B * a.H, pair, qb)) return;
     const int b = pair / a.H, h = pair - b * a.H;
+    const SeqInfo si = seq_info(a.cu, b, a.T);
+    const int T = si.T;
+    if (qb * kTile >= T) return;  // block beyond this sample's length (packed batches)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
     const int q0 = qb * kTile + wv * 16;  // this wave's 16 queries
     const int q = q0 + c;                 // this lane's query (column of every S^T / O^T tile)
 
-    const uint16_t* qp = a.q + (long)b * a.sq.b + (long)h * a.sq.h;
-    const uint16_t* kp = a.k + (long)b * a.sk.b + (long)h * a.sk.h;
-    const uint16_t* vp = a.v + (long)b * a.sv.b + (long)h * a.sv.h;
+    const uint16_t* qp = a.q + row_base(a.sq, si, b, h);
+    const uint16_t* kp = a.k + row_base(a.sk, si, b, h);
+    const uint16_t* vp = a.v + row_base(a.sv, si, b, h);
 
     // Q^T fragments: lane (c,g), k-step ks <-> Q[q][32 ks + 8 g .. +8]
     v8s qf[KS];
@@ -134,11 +155,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     for (int ks = 0; ks < KS; ++ks) {
         const int d0 = ks * 32 + g * 8;
         uint4 r = make_uint4(0, 0, 0, 0);
-        if (q < a.T && d0 < a.hd) r = *reinterpret_cast<const uint4*>(qp + (long)q * a.sq.t + d0);
+        if (q < T && d0 < a.hd) r = *reinterpret_cast<const uint4*>(qp + (long)q * a.sq.t + d0);
         qf[ks] = *reinterpret_cast<v8s*>(&r);
     }
 
-    const int kend = CAUSAL ? min(a.T, (qb + 1) * kTile) : a.T;  // keys [0, kend) are visible to this workgroup
+    const int kend = CAUSAL ? min(T, (qb + 1) * kTile) : T;  // keys [0, kend) are visible to this workgroup
     const int ntile = (kend + kTile - 1) / kTile;
 
     v4f acc[NT];
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, lsum = 0.0f;
 
-    const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, a.T, a.hd), vrs = slice_rsrc(vp, a.sv.t, a.T, a.hd);
+    const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, T, a.hd), vrs = slice_rsrc(vp, a.sv.t, T, a.hd);
     const int kst = (int)a.sk.t * 2, vst = (int)a.sv.t * 2;
     TileRegs<HDP> rk, rv;
     rk.load(krs, kst, 0);
@@ -179,14 +200,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
                 st[2 * rp + rl] = t;
             }
         }
-        const bool need_mask = (key0 + kTile > a.T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform
+        const bool need_mask = (key0 + kTile > T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform
         if (need_mask) {
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = key0 + rt * 16 + g * 4 + r;
-                    if (key >= a.T || (CAUSAL && key > q)) st[rt][r] = -INFINITY;
+                    if (key >= T || (CAUSAL && key > q)) st[rt][r] = -INFINITY;
                 }
         }
         float mx = -INFINITY;
@@ -225,9 +246,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     }
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
-    if (q < a.T) {
+    if (q < T) {
         const float inv = lsum > 0.0f ? 1.0f / lsum : 0.0f;
-        uint16_t* op = a.o + (long)b * a.so.b + (long)q * a.so.t + (long)h * a.so.h;
+        uint16_t* op = a.o + row_base(a.so, si, b, h) + (long)q * a.so.t;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int d0 = nt * 16 + g * 4;
@@ -249,6 +270,7 @@ struct AttnBwdArgs {
     float* dsum;       // [B,H,T] workspace: D = rowsum(dO * O), written by the dq kernel, read by the dk/dv kernel
     uint16_t *dq, *dk, *dv;
     AttnStr sq, sk, sv, so, sdo, sdq, sdk, sdv;
+    const int32_t* cu;  // as in AttnFwdArgs
     const float *rope_cos, *rope_sin;  // optional float32 [T, hd/2]: q and k were rotated before the forward; dq/dk are returned
                                        // w.r.t. the UN-rotated projections (adjoint rotation fused into the epilogues)
     int B, H, T, hd;
@@ -332,19 +354,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     int pair, qb;
     if (!block_to_pair(nqb, a.B * a.H, pair, qb)) return;
     const int b = pair / a.H, h = pair - b * a.H;
+    const SeqInfo si = seq_info(a.cu, b, a.T);
+    const int T = si.T;
+    if (qb * kTile >= T) return;  // block beyond this sample's length (packed batches)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
     const int q0 = qb * kTile + wv * 16, q = q0 + c;
-    const bool qv = q < a.T;
+    const bool qv = q < T;
 
-    const uint16_t* kp = a.k + (long)b * a.sk.b + (long)h * a.sk.h;
-    const uint16_t* vp = a.v + (long)b * a.sv.b + (long)h * a.sv.h;
+    const uint16_t* kp = a.k + row_base(a.sk, si, b, h);
+    const uint16_t* vp = a.v + row_base(a.sv, si, b, h);
     v8s qf[KS], dof[KS];
-    load_row_frags<KS>(qf, a.q + (long)b * a.sq.b + (long)q * a.sq.t + (long)h * a.sq.h, qv, g, a.hd);
-    load_row_frags<KS>(dof, a.dout + (long)b * a.sdo.b + (long)q * a.sdo.t + (long)h * a.sdo.h, qv, g, a.hd);
+    load_row_frags<KS>(qf, a.q + row_base(a.sq, si, b, h) + (long)q * a.sq.t, qv, g, a.hd);
+    load_row_frags<KS>(dof, a.dout + row_base(a.sdo, si, b, h) + (long)q * a.sdo.t, qv, g, a.hd);
     float Dq = 0.0f;
     {
         v8s of[KS];
-        load_row_frags<KS>(of, a.o + (long)b * a.so.b + (long)q * a.so.t + (long)h * a.so.h, qv, g, a.hd);
+        load_row_frags<KS>(of, a.o + row_base(a.so, si, b, h) + (long)q * a.so.t, qv, g, a.hd);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -356,13 +381,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     if (qv && g == 0) a.dsum[rowid] = Dq;
     const float lse2 = qv ? a.lse[rowid] * 1.4426950408889634f : INFINITY;  // invalid query -> P = 0
 
-    const int kend = CAUSAL ? min(a.T, (qb + 1) * kTile) : a.T;
+    const int kend = CAUSAL ? min(T, (qb + 1) * kTile) : T;
     const int ntile = (kend + kTile - 1) / kTile;
     v4f acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, a.T, a.hd), vrs = slice_rsrc(vp, a.sv.t, a.T, a.hd);
+    const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, T, a.hd), vrs = slice_rsrc(vp, a.sv.t, T, a.hd);
     const int kst = (int)a.sk.t * 2, vst = (int)a.sv.t * 2;
     TileRegs<HDP> rk, rv;
     rk.load(krs, kst, 0);
@@ -378,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
         }
         const int key0 = kt * kTile;
         if (CAUSAL && key0 > q0 + 15) continue;
-        const bool need_mask = (key0 + kTile > a.T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform
+        const bool need_mask = (key0 + kTile > T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (CAUSAL && key0 + half * 32 > q0 + 15) continue;
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
                     float p = fast_exp2(__builtin_fmaf(st[r], a.scale_log2, -lse2));
                     if (need_mask) {
                         const int key = key0 + rt * 16 + g * 4 + r;
-                        if (key >= a.T || (CAUSAL && key > q)) p = 0.0f;
+                        if (key >= T || (CAUSAL && key > q)) p = 0.0f;
                     }
                     ds[rl][r] = p * (dp[r] - Dq);
                 }
@@ -408,8 +433,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
         }
     }
     if (qv) {
-        const long ro = (long)q * (a.hd >> 1);
-        store_grad_row<NT>(a.dq + (long)b * a.sdq.b + (long)q * a.sdq.t + (long)h * a.sdq.h, acc, a.scale, g, a.hd,
+        const long ro = (si.tok0 + q) * (a.hd >> 1);
+        store_grad_row<NT>(a.dq + row_base(a.sdq, si, b, h) + (long)q * a.sdq.t, acc, a.scale, g, a.hd,
                            a.rope_cos ? a.rope_cos + ro : nullptr, a.rope_cos ? a.rope_sin + ro : nullptr);
     }
 }
@@ -428,15 +453,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     int pair, kb;
     if (!block_to_pair(nkb, a.B * a.H, pair, kb, !CAUSAL)) return;  // causal: early key blocks see the most queries -> first
     const int b = pair / a.H, h = pair - b * a.H;
+    const SeqInfo si = seq_info(a.cu, b, a.T);
+    const int T = si.T;
+    if (kb * kTile >= T) return;  // block beyond this sample's length (packed batches)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
     const int key0w = kb * kTile + wv * 16, key = key0w + c;
-    const bool kv = key < a.T;
+    const bool kv = key < T;
 
     v8s kf[KS], vf[KS];
-    load_row_frags<KS>(kf, a.k + (long)b * a.sk.b + (long)key * a.sk.t + (long)h * a.sk.h, kv, g, a.hd);
-    load_row_frags<KS>(vf, a.v + (long)b * a.sv.b + (long)key * a.sv.t + (long)h * a.sv.h, kv, g, a.hd);
-    const uint16_t* qp = a.q + (long)b * a.sq.b + (long)h * a.sq.h;
-    const uint16_t* dop = a.dout + (long)b * a.sdo.b + (long)h * a.sdo.h;
+    load_row_frags<KS>(kf, a.k + row_base(a.sk, si, b, h) + (long)key * a.sk.t, kv, g, a.hd);
+    load_row_frags<KS>(vf, a.v + row_base(a.sv, si, b, h) + (long)key * a.sv.t, kv, g, a.hd);
+    const uint16_t* qp = a.q + row_base(a.sq, si, b, h);
+    const uint16_t* dop = a.dout + row_base(a.sdo, si, b, h);
     const float* lsep = a.lse + ((long)b * a.H + h) * a.T;
     const float* dsp = a.dsum + ((long)b * a.H + h) * a.T;
 
@@ -446,18 +474,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         dk[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
         dv[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
     }
-    const int nqt = (a.T + kTile - 1) / kTile;
+    const int nqt = (T + kTile - 1) / kTile;
     const int qt0 = CAUSAL ? kb : 0;
     TileRegs<HDP> rq, rdo;
     float rstat = 0.0f;  // threads 0..63: lse of query tid (log2 units, +inf when invalid); 64..127: D
     auto load_stats = [&](int qbase) {
         if (tid < 128) {
             const int qq = qbase + (tid & 63);
-            if (tid < 64) rstat = qq < a.T ? lsep[qq] * 1.4426950408889634f : INFINITY;
-            else rstat = qq < a.T ? dsp[qq] : 0.0f;
+            if (tid < 64) rstat = qq < T ? lsep[qq] * 1.4426950408889634f : INFINITY;
+            else rstat = qq < T ? dsp[qq] : 0.0f;
         }
     };
-    const __amdgpu_buffer_rsrc_t qrs = slice_rsrc(qp, a.sq.t, a.T, a.hd), dors = slice_rsrc(dop, a.sdo.t, a.T, a.hd);
+    const __amdgpu_buffer_rsrc_t qrs = slice_rsrc(qp, a.sq.t, T, a.hd), dors = slice_rsrc(dop, a.sdo.t, T, a.hd);
     const int qst = (int)a.sq.t * 2, dost = (int)a.sdo.t * 2;
     rq.load(qrs, qst, qt0 * kTile);
     rdo.load(dors, dost, qt0 * kTile);
@@ -511,10 +539,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         }
     }
     if (kv) {
-        const long ro = (long)key * (a.hd >> 1);
-        store_grad_row<NT>(a.dk + (long)b * a.sdk.b + (long)key * a.sdk.t + (long)h * a.sdk.h, dk, a.scale, g, a.hd,
+        const long ro = (si.tok0 + key) * (a.hd >> 1);
+        store_grad_row<NT>(a.dk + row_base(a.sdk, si, b, h) + (long)key * a.sdk.t, dk, a.scale, g, a.hd,
                            a.rope_cos ? a.rope_cos + ro : nullptr, a.rope_cos ? a.rope_sin + ro : nullptr);
-        store_grad_row<NT>(a.dv + (long)b * a.sdv.b + (long)key * a.sdv.t + (long)h * a.sdv.h, dv, 1.0f, g, a.hd, nullptr, nullptr);
+        store_grad_row<NT>(a.dv + row_base(a.sdv, si, b, h) + (long)key * a.sdv.t, dv, 1.0f, g, a.hd, nullptr, nullptr);
     }
 }
 
@@ -554,8 +582,8 @@ static AttnStr mk(const int64_t* s) { AttnStr r; r.b = s[0]; r.t = s[1]; r.h = s
 }  // namespace vaa
 
 extern "C" int vaa_model_attention_fwd(const uint16_t* q, const int64_t* q_str, const uint16_t* k, const int64_t* k_str, const uint16_t* v,
-                                       const int64_t* v_str, uint16_t* o, const int64_t* o_str, float* lse, int B, int H, int T, int hd,
-                                       int causal, float scale, void* stream) {
+                                       const int64_t* v_str, uint16_t* o, const int64_t* o_str, float* lse, const int32_t* cu_seqlens, int B,
+                                       int H, int T, int hd, int causal, float scale, void* stream) {
     using namespace vaa;
     if (!q || !k || !v || !o || !lse) {
         set_error("vaa_model_attention_fwd: null pointer argument");
@@ -569,6 +597,7 @@ extern "C" int vaa_model_attention_fwd(const uint16_t* q, const int64_t* q_str, 
     AttnFwdArgs a;
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
     a.sq = mk(q_str); a.sk = mk(k_str); a.sv = mk(v_str); a.so = mk(o_str);
+    a.cu = cu_seqlens;
     a.B = B; a.H = H; a.T = T; a.hd = hd;
     a.scale_log2 = scale * 1.4426950408889634f;
     return causal ? launch_fwd<true>(a, (hipStream_t)stream) : launch_fwd<false>(a, (hipStream_t)stream);
@@ -578,7 +607,7 @@ extern "C" int vaa_model_attention_bwd(const uint16_t* q, const int64_t* q_str, 
                                        const int64_t* v_str, const uint16_t* o, const int64_t* o_str, const uint16_t* dout,
                                        const int64_t* do_str, const float* lse, float* dsum, uint16_t* dq, const int64_t* dq_str, uint16_t* dk,
                                        const int64_t* dk_str, uint16_t* dv, const int64_t* dv_str, const float* rope_cos, const float* rope_sin,
-                                       int B, int H, int T, int hd, int causal, float scale, void* stream) {
+                                       const int32_t* cu_seqlens, int B, int H, int T, int hd, int causal, float scale, void* stream) {
     using namespace vaa;
     if (!q || !k || !v || !o || !dout || !lse || !dsum || !dq || !dk || !dv) {
         set_error("vaa_model_attention_bwd: null pointer argument");
@@ -598,6 +627,7 @@ extern "C" int vaa_model_attention_bwd(const uint16_t* q, const int64_t* q_str, 
         return VAA_E_UNSUPPORTED;
     }
     a.rope_cos = rope_cos; a.rope_sin = rope_sin;
+    a.cu = cu_seqlens;
     a.B = B; a.H = H; a.T = T; a.hd = hd;
     a.scale = scale;
     a.scale_log2 = scale * 1.4426950408889634f;

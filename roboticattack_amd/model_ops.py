@@ -185,37 +185,42 @@ def _str3(x: torch.Tensor):
     return (ctypes.c_int64 * 3)(x.stride(0), x.stride(1), x.stride(2))
 
 
-def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool, scale: float | None = None):
+def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool, scale: float | None = None, cu_seqlens=None, max_len: int = 0):
     """softmax(scale * q k^T [causal]) v for bf16 [B,T,H,hd] views (any batch/token/head strides); returns (o [B,T,H,hd]
-    contiguous, lse float32 [B,H,T])."""
-    B, T, H, hd = q.shape
+    contiguous, lse float32 [B,H,T]). Packed form: q/k/v are [1,sumT,H,hd], cu_seqlens int32 [B+1] on the device, max_len = longest
+    sequence; o is [1,sumT,H,hd] and lse [B,H,max_len]."""
+    Bq, T, H, hd = q.shape
     scale = float(hd) ** -0.5 if scale is None else float(scale)
-    o = torch.empty((B, T, H, hd), dtype=torch.bfloat16, device=q.device)
-    lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    o = torch.empty((Bq, T, H, hd), dtype=torch.bfloat16, device=q.device)
+    B, Tm = (int(cu_seqlens.numel()) - 1, int(max_len)) if cu_seqlens is not None else (Bq, T)
+    lse = torch.empty((B, H, Tm), dtype=torch.float32, device=q.device)
     rc = _lib.lib().vaa_model_attention_fwd(q.data_ptr(), _str3(q), k.data_ptr(), _str3(k), v.data_ptr(), _str3(v), o.data_ptr(), _str3(o),
-                                            lse.data_ptr(), B, H, T, hd, int(bool(causal)), scale, _stream())
+                                            lse.data_ptr(), cu_seqlens.data_ptr() if cu_seqlens is not None else None, B, H, Tm, hd,
+                                            int(bool(causal)), scale, _stream())
     _lib.check(rc, "vaa_model_attention_fwd")
     return o, lse
 
 
-def attention_bwd(q, k, v, o, lse, dout, causal: bool, scale: float, packed_grad: bool = False, rope=None):
+def attention_bwd(q, k, v, o, lse, dout, causal: bool, scale: float, packed_grad: bool = False, rope=None, cu_seqlens=None, max_len: int = 0):
     """Gradients of attention_fwd. packed_grad=True returns one [B,T,3,H,hd] buffer (dq|dk|dv slices) — the layout of a fused
     qkv projection's output gradient — instead of three [B,T,H,hd] tensors. rope=(cos, sin) float32 [T,hd/2]: q and k are the
     ROTATED tensors and dq/dk come back w.r.t. the un-rotated ones (adjoint rotation fused into the kernels' epilogues)."""
-    B, T, H, hd = q.shape
+    Bq, T, H, hd = q.shape
+    B, Tm = (int(cu_seqlens.numel()) - 1, int(max_len)) if cu_seqlens is not None else (Bq, T)
     if dout.stride(3) != 1:
         dout = dout.contiguous()
     if packed_grad:
-        buf = torch.empty((B, T, 3, H, hd), dtype=torch.bfloat16, device=q.device)
+        buf = torch.empty((Bq, T, 3, H, hd), dtype=torch.bfloat16, device=q.device)
         dq, dk, dv = buf[:, :, 0], buf[:, :, 1], buf[:, :, 2]
     else:
         buf = None
-        dq, dk, dv = (torch.empty((B, T, H, hd), dtype=torch.bfloat16, device=q.device) for _ in range(3))
-    dsum = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+        dq, dk, dv = (torch.empty((Bq, T, H, hd), dtype=torch.bfloat16, device=q.device) for _ in range(3))
+    dsum = torch.empty((B, H, Tm), dtype=torch.float32, device=q.device)
     rc = _lib.lib().vaa_model_attention_bwd(q.data_ptr(), _str3(q), k.data_ptr(), _str3(k), v.data_ptr(), _str3(v), o.data_ptr(), _str3(o),
                                             dout.data_ptr(), _str3(dout), lse.data_ptr(), dsum.data_ptr(), dq.data_ptr(), _str3(dq),
                                             dk.data_ptr(), _str3(dk), dv.data_ptr(), _str3(dv), rope[0].data_ptr() if rope else None,
-                                            rope[1].data_ptr() if rope else None, B, H, T, hd, int(bool(causal)), float(scale), _stream())
+                                            rope[1].data_ptr() if rope else None, cu_seqlens.data_ptr() if cu_seqlens is not None else None,
+                                            B, H, Tm, hd, int(bool(causal)), float(scale), _stream())
     _lib.check(rc, "vaa_model_attention_bwd")
     return buf if packed_grad else (dq, dk, dv)
 
@@ -243,19 +248,21 @@ class RopeAttentionFn(torch.autograd.Function):
     (saves two full passes over [B,T,H,hd] per layer). q, k, v: [B,T,H,hd] bf16 views; cos/sin: float32 [T,hd/2]."""
 
     @staticmethod
-    def forward(ctx, q, k, v, cos, sin, causal, scale):
+    def forward(ctx, q, k, v, cos, sin, causal, scale, cu_seqlens=None, max_len=0):
+        """Packed form (cu_seqlens given): q/k/v are [1,sumT,H,hd] and cos/sin hold one row PER PACKED TOKEN (gathered by position id)."""
         scale = float(q.shape[-1]) ** -0.5 if scale is None else float(scale)
         qr, kr = _rope_launch(q, cos, sin, 1.0), _rope_launch(k, cos, sin, 1.0)
-        o, lse = attention_fwd(qr, kr, v, causal, scale)
-        ctx.save_for_backward(qr, kr, v, o, lse, cos, sin)
-        ctx.causal, ctx.scale = bool(causal), scale
+        o, lse = attention_fwd(qr, kr, v, causal, scale, cu_seqlens, max_len)
+        ctx.save_for_backward(qr, kr, v, o, lse, cos, sin, *([cu_seqlens] if cu_seqlens is not None else []))
+        ctx.causal, ctx.scale, ctx.max_len = bool(causal), scale, int(max_len)
         return o
 
     @staticmethod
     def backward(ctx, dout):
-        qr, kr, v, o, lse, cos, sin = ctx.saved_tensors
-        dq, dk, dv = attention_bwd(qr, kr, v, o, lse, dout, ctx.causal, ctx.scale, rope=(cos, sin))
-        return dq, dk, dv, None, None, None, None
+        qr, kr, v, o, lse, cos, sin, *cu = ctx.saved_tensors
+        dq, dk, dv = attention_bwd(qr, kr, v, o, lse, dout, ctx.causal, ctx.scale, rope=(cos, sin), cu_seqlens=cu[0] if cu else None,
+                                   max_len=ctx.max_len)
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 class PackedAttentionFn(torch.autograd.Function):

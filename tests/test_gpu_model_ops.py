@@ -248,3 +248,42 @@ def test_residual_layernorm_fwd_bwd_matches_eager(D):
     assert torch.equal(xo, x)
     assert (h.float() - hr).abs().max() <= 2 ** -7 * hr.abs().max()
     assert (xa.grad.float() - xb.grad).abs().max() <= 2 ** -6 * xb.grad.abs().max()
+
+
+@pytest.mark.parametrize("hd,causal", [(128, True), (64, False)])
+def test_attention_packed_sequences_match_per_sample(hd, causal):
+    """cu_seqlens form (sequences packed back to back, no padding rows) == running every sample on its own, forward and backward,
+    including the fused rotary adjoint with per-token tables."""
+    from roboticattack_amd import model_ops
+
+    lens = [37, 64, 101, 1, 130]
+    H = 2
+    g = torch.Generator(device=DEV).manual_seed(hd)
+    tot = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    q, k, v, go = [torch.randn(1, tot, H, hd, device=DEV, generator=g).to(torch.bfloat16) for _ in range(4)]
+    pos = torch.cat([torch.arange(n, device=DEV) for n in lens])
+    ang = torch.outer(torch.arange(max(lens), device=DEV, dtype=torch.float32), 1.0 / (10000 ** (torch.arange(0, hd, 2, device=DEV, dtype=torch.float32) / hd)))
+    cos, sin = ang.cos().to(torch.bfloat16).float().contiguous(), ang.sin().to(torch.bfloat16).float().contiguous()
+    cos_p, sin_p = cos.index_select(0, pos).contiguous(), sin.index_select(0, pos).contiguous()
+    qa, ka, va = [x.clone().requires_grad_(True) for x in (q, k, v)]
+    if causal:
+        o = model_ops.RopeAttentionFn.apply(qa, ka, va, cos_p, sin_p, True, None, cu, max(lens))
+    else:
+        o, lse = model_ops.attention_fwd(qa, ka, va, False, None, cu, max(lens))
+    outs, grads = [], []
+    for i, n in enumerate(lens):
+        s0 = int(cu[i])
+        qi, ki, vi = [x[:, s0:s0 + n].clone().requires_grad_(True) for x in (q, k, v)]
+        if causal:
+            oi = model_ops.RopeAttentionFn.apply(qi, ki, vi, cos[:n].contiguous(), sin[:n].contiguous(), True, None)
+            oi.backward(go[:, s0:s0 + n])
+            grads.append((qi.grad, ki.grad, vi.grad))
+        else:
+            oi, _ = model_ops.attention_fwd(qi, ki, vi, False, None)
+        outs.append(oi.detach())
+    assert torch.equal(o.detach(), torch.cat(outs, dim=1))
+    if causal:
+        o.backward(go)
+        for j, ga in enumerate((qa.grad, ka.grad, va.grad)):
+            assert torch.equal(ga, torch.cat([gr[j] for gr in grads], dim=1))
