@@ -181,15 +181,16 @@ def main():
     inv_world = 1.0 / world
     scal = torch.zeros(8, device=dev)
     row_index = model.label_row_index(labels) if use_rows else None  # once per outer iteration, as the attack loops do
+    pack = model.make_pack(attn) if hasattr(model, "make_pack") else None  # padding rows of the right-padded prompts are never computed
 
     def step():
         opt.zero_grad()
         pix = tr.apply_random_patch_batch(img, patch, mean, std, geometry=True)  # host RNG draws + K1
         if use_rows:
             if isinstance(pix, ops.PatchEmbeds):
-                logits = model.forward_rows(input_ids, None, labels, row_index, patch_embeds=pix)
+                logits = model.forward_rows(input_ids, None, labels, row_index, patch_embeds=pix, pack=pack)
             else:
-                logits = model.forward_rows(input_ids, pix, labels, row_index)
+                logits = model.forward_rows(input_ids, pix, labels, row_index, pack=pack)
             total, scalars, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
         else:
             out = model(input_ids=input_ids, attention_mask=attn, pixel_values=pix, labels=None)

@@ -64,10 +64,15 @@ class AttackBase:
             # cache holds a reference, so identity cannot be recycled by the allocator, and in-place edits bump _version
             if getattr(self, "_row_ref", None) is not labels or self._row_ver != labels._version:
                 self._row_ref, self._row_ver, self._row_index = labels, labels._version, self.vla.label_row_index(labels)
+            pack = None
+            if hasattr(self.vla, "make_pack") and attention_mask is not None:  # drop the padding rows (cached like the row index)
+                if getattr(self, "_pack_ref", None) is not attention_mask or self._pack_ver != attention_mask._version:
+                    self._pack_ref, self._pack_ver, self._pack = attention_mask, attention_mask._version, self.vla.make_pack(attention_mask)
+                pack = self._pack
             if isinstance(pix, ops.PatchEmbeds):  # patched batch handed over as patch-embed outputs (pixel gradient never built)
-                logits = self.vla.forward_rows(input_ids, None, labels, self._row_index, patch_embeds=pix)
+                logits = self.vla.forward_rows(input_ids, None, labels, self._row_index, patch_embeds=pix, pack=pack)
             else:
-                logits = self.vla.forward_rows(input_ids, pix, labels, self._row_index)
+                logits = self.vla.forward_rows(input_ids, pix, labels, self._row_index, pack=pack)
             layout = ops.LAYOUT_ROWS
         else:
             out = self.vla(input_ids=input_ids, attention_mask=attention_mask, pixel_values=pix, labels=None)

@@ -202,7 +202,7 @@ class LlamaLayer(nn.Module):
             ws += [getattr(self, n).weight, self._wt(n)]
         return model_ops.FrozenLinearsFn.apply(x, res, *ws)
 
-    def forward(self, x, cos, sin, rope_tab=None, rows=None):
+    def forward(self, x, cos, sin, rope_tab=None, rows=None, pack=None):
         """`rows` (flat indices into the B*T positions): everything after the attention — o_proj, residual, MLP — is evaluated
         for those rows only and [R,D] is returned (last layer of `forward_rows`: no other position reaches the loss)."""
         from . import model_ops
@@ -222,7 +222,8 @@ class LlamaLayer(nn.Module):
         if fused and model_ops.attention_enabled(q.view(B, T, self.heads, hd)):
             sh = (B, T, self.heads, hd)
             if hd in (64, 128):  # rotary adjoint of dq/dk runs in the attention backward's epilogues
-                a = model_ops.RopeAttentionFn.apply(q.view(sh), k.view(sh), v.view(sh), *rope_tab, True, None).view(B, T, D)
+                a = model_ops.RopeAttentionFn.apply(q.view(sh), k.view(sh), v.view(sh), *rope_tab, True, None,
+                                                    pack.cu if pack is not None else None, pack.max_len if pack is not None else 0).view(B, T, D)
             else:
                 q = model_ops.RopeFn.apply(q.view(sh), *rope_tab)
                 k = model_ops.RopeFn.apply(k.view(sh), *rope_tab)
@@ -263,6 +264,43 @@ class LlamaLayer(nn.Module):
         else:
             x = x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
         return x[0] if rows is not None else x
+
+
+class SeqPack:
+    """Right-padded batch -> packed token axis for the Llama stack: the padding rows (8 of 300 tokens per sample on BridgeData-like
+    prompts) are never computed. Built once per outer iteration from `attention_mask` (one host sync for the lengths); the multimodal
+    sequence of sample b is [BOS, 256 image tokens, text 1..len_b-1], i.e. 256 + len_b tokens of the padded 256 + L."""
+
+    def __init__(self, attention_mask: torch.Tensor):
+        B, L = attention_mask.shape
+        self.T_pad = N_IMG_TOKENS + L
+        lens = (attention_mask.sum(1).to(torch.int64) + N_IMG_TOKENS).tolist()
+        dev = attention_mask.device
+        cu = [0]
+        for n in lens:
+            cu.append(cu[-1] + int(n))
+        self.total = cu[-1]  # real tokens
+        fill = (-cu[-1]) % 256  # GEMM row count kept a multiple of the 256-row MFMA macro tile: a dummy sequence of `fill` tokens
+        if fill:                # (copies of token 0, attended only by itself, never selected, zero gradient)
+            lens = lens + [fill]
+            cu.append(cu[-1] + fill)
+        self.lens, self.max_len = lens, max(lens)
+        self.cu = torch.tensor(cu, dtype=torch.int32, device=dev)
+        self.pos = torch.cat([torch.arange(n, device=dev) for n in lens])                                   # position id of every packed token
+        self.gather = torch.cat([torch.arange(n, device=dev) + b * self.T_pad if b < B else torch.zeros(n, dtype=torch.int64, device=dev)
+                                 for b, n in enumerate(lens)])  # packed <- padded flat index
+        self._rope = None
+
+    def rows(self, row_index_padded: torch.Tensor) -> torch.Tensor:
+        """Padded flat indices b*T_pad + t -> packed indices cu[b] + t."""
+        b = torch.div(row_index_padded, self.T_pad, rounding_mode="floor")
+        return self.cu.to(torch.int64).index_select(0, b) + (row_index_padded - b * self.T_pad)
+
+    def rope_tab(self, cos_half: torch.Tensor, sin_half: torch.Tensor):
+        """One rotary row per packed token (gathered by position id), cached."""
+        if self._rope is None:
+            self._rope = (cos_half.index_select(0, self.pos).contiguous(), sin_half.index_select(0, self.pos).contiguous())
+        return self._rope
 
 
 class OpenVLAShaped(nn.Module):
@@ -309,9 +347,11 @@ class OpenVLAShaped(nn.Module):
             return None
         return (*self.featurizer.embed_params(), *self.fused_featurizer.embed_params())
 
-    def hidden_states(self, input_ids, pixel_values, rows=None, patch_embeds=None):
+    def hidden_states(self, input_ids, pixel_values, rows=None, patch_embeds=None, pack=None):
         """[B, 1+256+(L-1), D] final-norm hidden states of the multimodal sequence (modeling_prismatic.py:366-415); with
-        `rows` (flat position indices) only those positions of the LAST layer are evaluated and [R,D] is returned."""
+        `rows` (flat position indices into the PADDED [B*T] layout) only those positions of the LAST layer are evaluated and
+        [R,D] is returned. `pack` (SeqPack): the Llama stack runs on the packed token axis ([1, sum T_b, D] is returned unless
+        `rows` is given)."""
         if patch_embeds is not None:
             feats = torch.cat([self.featurizer(None, embedded=patch_embeds[0]), self.fused_featurizer(None, embedded=patch_embeds[1])], dim=2)
         else:
@@ -329,10 +369,31 @@ class OpenVLAShaped(nn.Module):
         half = ang[:, : hd // 2]
         # fused path: HF rounds cos/sin to the activation dtype before use (modeling_llama rotary) — keep that rounding
         rope_tab = (half.cos().to(x.dtype).float().contiguous(), half.sin().to(x.dtype).float().contiguous())
+        from . import model_ops
+
+        if pack is not None and model_ops.enabled(x) and model_ops.attention_enabled(x.view(x.shape[0], T, self.cfg.llm_heads, hd)) and hd in (64, 128):
+            # packed token axis [1, sum T_b, D]: no padding rows through the 32 layers (rows = packed indices, see SeqPack.rows)
+            x = x.reshape(-1, x.shape[-1]).index_select(0, pack.gather)[None]
+            rope_tab = pack.rope_tab(*rope_tab)
+            rows = pack.rows(rows) if rows is not None else None
+        else:
+            pack = None
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
-            x = layer(x, cos, sin, rope_tab, rows if i == last else None)
+            x = layer(x, cos, sin, rope_tab, rows if i == last else None, pack)
         return self.norm(x)
+
+    @staticmethod
+    def make_pack(attention_mask):
+        """SeqPack of a right-padded batch when packing is asked for (VAA_SEQ_PACK=1) and there is something to drop, else None.
+        OPT-IN: the packed row count (e.g. 18 688 instead of 19 200 at bs=64) falls outside the shipped hipBLASLt selections, and the
+        default heuristics cost more (476 -> 511 ms/step measured) than the 2.7 % of rows saved; it pays once those shapes are tuned."""
+        import os
+
+        if not os.environ.get("VAA_SEQ_PACK") or attention_mask is None or not attention_mask.is_cuda:
+            return None
+        p = SeqPack(attention_mask)
+        return p if p.total < attention_mask.shape[0] * p.T_pad else None
 
     @staticmethod
     def label_row_index(labels):
@@ -343,13 +404,13 @@ class OpenVLAShaped(nn.Module):
         bk = (labels[:, 1:] != IGNORE_INDEX).nonzero(as_tuple=False)  # [R,2] sorted row-major
         return bk[:, 0] * S + N_IMG_TOKENS + bk[:, 1]
 
-    def forward_rows(self, input_ids, pixel_values, labels, row_index=None, patch_embeds=None):
+    def forward_rows(self, input_ids, pixel_values, labels, row_index=None, patch_embeds=None, pack=None):
         """Logits [R,V] of the labelled rows only, in (b,k) row-major order of labels[b,k+1] != -100 (VAA_LAYOUT_ROWS):
         row (b,k) is model position S-L+k = 256+k, the position whose next-token target is labels[b,k+1].
         Pass `row_index=label_row_index(labels)` to keep the step free of host synchronisation."""
         if row_index is None:
             row_index = self.label_row_index(labels)
-        return self.lm_head(self.hidden_states(input_ids, pixel_values, rows=row_index, patch_embeds=patch_embeds))  # [R, D] -> [R, V]
+        return self.lm_head(self.hidden_states(input_ids, pixel_values, rows=row_index, patch_embeds=patch_embeds, pack=pack))  # [R, D] -> [R, V]
 
     def forward(self, input_ids, attention_mask=None, pixel_values=None, labels=None, **_):
         """Drop-in contract of PrismaticForConditionalGeneration.forward: full fp32 logits and HF's mean CE."""

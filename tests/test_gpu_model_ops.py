@@ -287,3 +287,32 @@ def test_attention_packed_sequences_match_per_sample(hd, causal):
         o.backward(go)
         for j, ga in enumerate((qa.grad, ka.grad, va.grad)):
             assert torch.equal(ga, torch.cat([gr[j] for gr in grads], dim=1))
+
+
+def test_model_sequence_packing_matches_padded(monkeypatch):
+    """SeqPack (padding rows never computed) gives the same labelled-row logits and the same pixel gradient as the padded batch."""
+    from roboticattack_amd import synthetic
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+
+    cfg = OpenVLACfg(dino=VitCfg(32, 3, 2, 64, 5, True, True), siglip=VitCfg(48, 3, 2, 80, 0, False, False),
+                     llm_dim=256, llm_layers=3, llm_heads=2, llm_mlp=512)
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=12)
+    batch = synthetic.synth_batch(11, 5, "noise", as_pil=False)
+    ids, attn = batch["input_ids"].to(DEV), batch["attention_mask"].to(DEV)
+    labels = mask_labels(batch["labels"].clone(), [0, 3]).to(DEV)
+    assert int(attn.sum()) < attn.numel()  # there IS padding to drop
+    assert m.make_pack(attn) is None  # opt-in
+    monkeypatch.setenv("VAA_SEQ_PACK", "1")
+    pack = m.make_pack(attn)
+    assert pack is not None and pack.total == int(attn.sum()) + 5 * 256
+    pix0 = torch.randn(5, 6, 224, 224, device=DEV).to(torch.bfloat16)
+    res = []
+    for p in (pack, None):
+        pix = pix0.clone().requires_grad_(True)
+        rows = m.forward_rows(ids, pix, labels, pack=p)
+        rows.float().square().mean().backward()
+        res.append((rows.detach().float(), pix.grad.detach().float()))
+    (r1, g1), (r2, g2) = res
+    assert (r1 - r2).abs().max() <= 2e-2 * r2.abs().max() + 1e-3   # same math; GEMM row count differs -> different kernel selections
+    assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.999
