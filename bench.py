@@ -44,6 +44,17 @@ def parse():
     return ap.parse_args()
 
 
+def _tunable_entries() -> int:
+    """hipBLASLt/rocBLAS selections in effect (roboticattack_amd/tunableop/*.csv; 0 = the file was rejected by a validator mismatch or
+    TunableOp is off -> the GEMMs run on default heuristics, ~6 % slower)."""
+    try:
+        import torch.cuda.tunable as tunable
+
+        return len(tunable.get_results()) if tunable.is_enabled() else 0
+    except Exception:
+        return -1
+
+
 def build_model(kind, dev):
     from roboticattack_amd.openvla_model import build_openvla, openvla_7b_cfg, tiny_cfg
 
@@ -300,7 +311,7 @@ def main():
         "config": {"workload": f"UADA_wrapper_ddp inner step: bs={B} per rank (global {B * world}), patch {args.patch}, geometry=True, maskidx=[0], "
                                f"{model_desc}; frames resident in HBM as u8",
                    "global_batch": B * world, "images_per_s": B * world * args.steps / dt, "parallelism": f"dp{world}",
-                   "labelled_rows_per_rank": R, "lm_head": "labelled rows only" if use_rows else "full logits",
+                   "labelled_rows_per_rank": R, "tunableop_entries_loaded": _tunable_entries(), "lm_head": "labelled rows only" if use_rows else "full logits",
                    "h2d_stage_ms_per_outer_iteration": stage_ms,
                    "pcie_inclusive_value_if_restaged_every_step": world * args.steps / (dt + args.steps * stage_ms * 1e-3)},
         "roofline": roofline, "roofline_kernels": kern, "cpu_baseline": cpu,
