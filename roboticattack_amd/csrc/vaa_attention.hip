@@ -346,7 +346,7 @@ __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 
 template <int KS, int NT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     constexpr int HDP = KS * 32;
-    constexpr int SK = HDP + 8, SV = HDP + 8;
+    constexpr int SK = HDP + 16, SV = HDP + 8;  // K is read by rows (16) AND transposed (32 reads): its stride favours the transpose reads
     __shared__ __attribute__((aligned(16))) uint16_t sK[kTile * SK];
     __shared__ __attribute__((aligned(16))) uint16_t sV[kTile * SV];
 
