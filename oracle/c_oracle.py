@@ -112,3 +112,61 @@ def patch_apply_eval(img_u8, patch, xy, theta, geometry):
     lib().vaa_oracle_patch_apply_eval(_p(img_u8, C.c_uint8), _p(patch, C.c_float), _p(xy, C.c_int32), _p(theta, C.c_float), img_u8.shape[0],
                                       patch.shape[1], patch.shape[2], _p(geo, C.c_int32), _p(out, C.c_uint8))
     return out
+
+
+# ---- resize_patch=True (config 5): per-image patches --------------------------------------------------------------
+def make_pdesc(sizes, align=4):
+    """sizes [B,2] (h,w) -> pdesc int32 [B,4] = {h, w, offset (floats, multiple of `align`), 0} and the packed length."""
+    sizes = np.asarray(sizes, np.int32).reshape(-1, 2)
+    pdesc = np.zeros((sizes.shape[0], 4), np.int32)
+    off = 0
+    for b, (h, w) in enumerate(sizes):
+        pdesc[b] = (h, w, off, 0)
+        off += (3 * int(h) * int(w) + align - 1) // align * align
+    return pdesc, off
+
+
+def patch_resize_fwd(patch, pdesc, total):
+    patch = np.ascontiguousarray(patch, np.float32)
+    pdesc = np.ascontiguousarray(pdesc, np.int32)
+    packed = np.zeros(total, np.float32)
+    lib().vaa_oracle_patch_resize_fwd(_p(patch, C.c_float), patch.shape[1], patch.shape[2], _p(pdesc, C.c_int32), pdesc.shape[0],
+                                      _p(packed, C.c_float))
+    return packed
+
+
+def patch_resize_bwd(gpacked, pdesc, ph, pw):
+    gpacked = np.ascontiguousarray(gpacked, np.float32)
+    pdesc = np.ascontiguousarray(pdesc, np.int32)
+    out = np.empty((3, ph, pw), np.float32)
+    lib().vaa_oracle_patch_resize_bwd(_p(gpacked, C.c_float), ph, pw, _p(pdesc, C.c_int32), pdesc.shape[0], _p(out, C.c_float))
+    return out
+
+
+def patch_apply_fwd_multi(img_u8, packed, pdesc, xy, theta, geometry, mask_mode=0, want_f32=True, want_bf16=True, want_keep=True):
+    img_u8 = np.ascontiguousarray(img_u8, np.uint8)
+    packed = np.ascontiguousarray(packed, np.float32)
+    pdesc = np.ascontiguousarray(pdesc, np.int32)
+    xy = np.ascontiguousarray(xy, np.int32)
+    theta = np.ascontiguousarray(theta, np.float32).reshape(-1, 6)
+    B = img_u8.shape[0]
+    out = np.empty((B, 6, 224, 224), np.float32) if want_f32 else None
+    ob = np.empty((B, 6, 224, 224), np.uint16) if want_bf16 else None
+    keep = np.empty((B, 3, 224 * 224), np.uint8) if want_keep else None
+    lib().vaa_oracle_patch_apply_fwd_multi(_p(img_u8, C.c_uint8), _p(packed, C.c_float), _p(pdesc, C.c_int32), _p(xy, C.c_int32),
+                                           _p(theta, C.c_float), B, int(geometry), int(mask_mode), _p(MEAN6, C.c_float),
+                                           _p(STD6, C.c_float), _p(out, C.c_float), _p(ob, C.c_uint16), _p(keep, C.c_uint8))
+    return out, ob, keep
+
+
+def patch_grad_multi(gout_bf16_bits, packed, pdesc, xy, theta, geometry, mask_mode=0):
+    g = np.ascontiguousarray(gout_bf16_bits, np.uint16)
+    packed = np.ascontiguousarray(packed, np.float32)
+    pdesc = np.ascontiguousarray(pdesc, np.int32)
+    xy = np.ascontiguousarray(xy, np.int32)
+    theta = np.ascontiguousarray(theta, np.float32).reshape(-1, 6)
+    out = np.zeros_like(packed)
+    lib().vaa_oracle_patch_grad_multi(_p(g, C.c_uint16), _p(packed, C.c_float), _p(pdesc, C.c_int32), _p(xy, C.c_int32),
+                                      _p(theta, C.c_float), g.shape[0], int(geometry), int(mask_mode), _p(STD6, C.c_float),
+                                      _p(out, C.c_float))
+    return out

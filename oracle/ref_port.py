@@ -133,6 +133,52 @@ def patch_grad_via_autograd(images_u8, patch, xy, theta, geometry, gout_bf16, th
 
 
 # --------------------------------------------------------------------------------------------
+# a-1 with resize_patch=True (BASELINE config 5): appply_random_transform.py:113-118, Appendix A-D2 semantics
+# --------------------------------------------------------------------------------------------
+def resize_patch(patch: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """`transforms.Resize((h, w))(patch)` (:116) [3p torchvision 0.17 on a tensor: bilinear, antialias=True]."""
+    return F.interpolate(patch[None], size=(h, w), mode="bilinear", antialias=True, align_corners=False)[0]
+
+
+def draw_params_resized(batch: int, ph: int, pw: int, geometry: bool, img: int = 224):
+    """Draw order per image with resize_patch=True (:114, :123-128): random.uniform(0.61, 1.39) (scale), then randint(x),
+    randint(y) against the RESIZED size, then (geometry) the transform matrix. Returns sizes [B,2] (h,w), xy, theta."""
+    sizes = np.zeros((batch, 2), dtype=np.int32)
+    xy = np.zeros((batch, 2), dtype=np.int32)
+    theta = np.zeros((batch, 2, 3), dtype=np.float32)
+    for b in range(batch):
+        scale = random.uniform(0.61, 1.39)  # :114
+        h, w = int(ph * scale), int(pw * scale)  # :115 (base patch size: A-D2)
+        sizes[b] = (h, w)
+        xy[b] = (random.randint(0, img - w), random.randint(0, img - h))
+        m = combined_transform_matrix() if geometry else np.eye(3, dtype=np.float32)
+        theta[b] = m[:2, :]
+    return sizes, xy, theta
+
+
+def apply_random_patch_batch_resized(images_u8, patch, sizes, xy, theta, geometry: bool, return_keep=False):
+    """:104-136 with resize_patch=True and the draws hoisted out: image b pastes resize(base patch, sizes[b])."""
+    outs, keeps = [], []
+    for b in range(len(images_u8)):
+        pb = resize_patch(patch, int(sizes[b][0]), int(sizes[b][1]))
+        o = apply_random_patch_batch(images_u8[b : b + 1], pb, xy[b : b + 1], theta[b : b + 1], geometry, "lt-20", return_keep=return_keep)
+        if return_keep:
+            outs.append(o[0])
+            keeps.append(o[1])
+        else:
+            outs.append(o)
+    out = torch.cat(outs, dim=0)
+    return (out, torch.cat(keeps, dim=0)) if return_keep else out
+
+
+def patch_grad_resized_via_autograd(images_u8, patch, sizes, xy, theta, geometry, gout_bf16):
+    p = patch.detach().clone().requires_grad_(True)
+    out = apply_random_patch_batch_resized(images_u8, p, sizes, xy, theta, geometry)
+    out.to(torch.bfloat16).backward(gradient=gout_bf16)
+    return p.grad.detach()
+
+
+# --------------------------------------------------------------------------------------------
 # a-6  label masking
 # --------------------------------------------------------------------------------------------
 def mask_labels(labels: torch.Tensor, maskidx) -> torch.Tensor:

@@ -376,3 +376,143 @@ void vaa_oracle_patch_apply_eval(const uint8_t* img_u8, const float* patch, cons
     }
     free(q);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * resize_patch=True (BASELINE config 5): appply_random_transform.py:113-116 with the Appendix A-D2 semantics
+ * (every image scales the BASE patch): `transforms.Resize((h, w))(patch)` [3p torchvision 0.17 -> torch
+ * F.interpolate(mode='bilinear', antialias=True, align_corners=False)]. The restatement below follows torch's CPU kernel
+ * (ATen UpSampleKernel.cpp: _compute_indices_min_size_weights_aa + separable horizontal-then-vertical passes, each
+ * output = src[0]*w[0] then fma(src[j], w[j], acc)); tests/test_oracle_golden.py checks it BIT-EXACT against
+ * F.interpolate for a sweep of sizes.
+ * pdesc [B,4] int32 = {h_b, w_b, offset_b (in floats into `packed`), 0}; packed holds [3,h_b,w_b] per image.
+ * --------------------------------------------------------------------------------------------- */
+static int aa_weights(int i, int in_size, float scale, float support, int max_interp, float* wt, int* xmin_o) {
+    float center = (float)((double)scale * ((double)i + 0.5));
+    float total_w = 0.0f;
+    float invscale = (scale >= 1.0f) ? (float)(1.0 / (double)scale) : 1.0f;
+    int64_t xmin = (int64_t)((double)(center - support) + 0.5);
+    if (xmin < 0) xmin = 0;
+    int64_t xe = (int64_t)((double)(center + support) + 0.5);
+    if (xe > in_size) xe = in_size;
+    int64_t xsize = xe - xmin;
+    if (xsize < 0) xsize = 0;
+    if (xsize > max_interp) xsize = max_interp;
+    for (int j = 0; j < xsize; ++j) {
+        float x = (float)(((double)((float)(j + xmin) - center) + 0.5) * (double)invscale);
+        x = fabsf(x);
+        float w = (x < 1.0f) ? (float)(1.0 - (double)x) : 0.0f; /* HelperInterpLinear::aa_filter */
+        wt[j] = w;
+        total_w += w;
+    }
+    if (total_w != 0.0f)
+        for (int j = 0; j < xsize; ++j) wt[j] /= total_w;
+    *xmin_o = (int)xmin;
+    return (int)xsize;
+}
+
+static void aa_axis(int in_size, int out_size, float* scale, float* support, int* max_interp) {
+    *scale = (float)in_size / (float)out_size; /* area_pixel_compute_scale, align_corners=False, no scale_factor */
+    *support = (*scale >= 1.0f) ? *scale : 1.0f;
+    *max_interp = (int)ceilf(*support) * 2 + 1;
+}
+
+static void resize_plane_fwd(const float* src, int ih, int iw, float* dst, int oh, int ow) {
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)ih * ow);
+    const float* hsrc = src;
+    if (ow != iw) { /* horizontal pass (skipped when the width is unchanged, as torch does) */
+        float scale, support;
+        int mi;
+        aa_axis(iw, ow, &scale, &support, &mi);
+        float* wt = (float*)malloc(sizeof(float) * mi);
+        for (int x = 0; x < ow; ++x) {
+            int xmin, n = aa_weights(x, iw, scale, support, mi, wt, &xmin);
+            for (int y = 0; y < ih; ++y) {
+                const float* s = src + (size_t)y * iw + xmin;
+                float o = s[0] * wt[0];
+                for (int j = 1; j < n; ++j) o = fmaf(s[j], wt[j], o);
+                tmp[(size_t)y * ow + x] = o;
+            }
+        }
+        free(wt);
+        hsrc = tmp;
+    }
+    if (oh != ih) { /* vertical pass */
+        float scale, support;
+        int mi;
+        aa_axis(ih, oh, &scale, &support, &mi);
+        float* wt = (float*)malloc(sizeof(float) * mi);
+        for (int y = 0; y < oh; ++y) {
+            int ymin, n = aa_weights(y, ih, scale, support, mi, wt, &ymin);
+            for (int x = 0; x < ow; ++x) {
+                const float* s = hsrc + (size_t)ymin * ow + x;
+                float o = s[0] * wt[0];
+                for (int j = 1; j < n; ++j) o = fmaf(s[(size_t)j * ow], wt[j], o);
+                dst[(size_t)y * ow + x] = o;
+            }
+        }
+        free(wt);
+    } else {
+        memcpy(dst, hsrc, sizeof(float) * (size_t)oh * ow);
+    }
+    free(tmp);
+}
+
+void vaa_oracle_patch_resize_fwd(const float* patch, int ph, int pw, const int32_t* pdesc, int B, float* packed) {
+    for (int b = 0; b < B; ++b) {
+        const int h = pdesc[4 * b], w = pdesc[4 * b + 1];
+        float* dst = packed + pdesc[4 * b + 2];
+        for (int c = 0; c < 3; ++c) resize_plane_fwd(patch + (size_t)c * ph * pw, ph, pw, dst + (size_t)c * h * w, h, w);
+    }
+}
+
+/* autograd backward of the resize to the base patch (torch cpu_upsample_genNd_backward_aa: grad_in[ymin+y][xmin+x] +=
+ * wx[x]*wy[y]*g in (oh, ow) scan order), summed over the images last-created-first like autograd does. */
+void vaa_oracle_patch_resize_bwd(const float* gpacked, int ph, int pw, const int32_t* pdesc, int B, float* gpatch) {
+    const size_t n = (size_t)3 * ph * pw;
+    float* acc = (float*)malloc(sizeof(float) * n);
+    memset(gpatch, 0, sizeof(float) * n);
+    for (int b = B - 1; b >= 0; --b) {
+        const int h = pdesc[4 * b], w = pdesc[4 * b + 1];
+        const float* g = gpacked + pdesc[4 * b + 2];
+        memset(acc, 0, sizeof(float) * n);
+        float sh, sw, suph, supw;
+        int mih, miw;
+        aa_axis(ph, h, &sh, &suph, &mih);
+        aa_axis(pw, w, &sw, &supw, &miw);
+        float* wy = (float*)malloc(sizeof(float) * mih);
+        float* wx = (float*)malloc(sizeof(float) * miw);
+        for (int oh = 0; oh < h; ++oh) {
+            int ymin, ysize = aa_weights(oh, ph, sh, suph, mih, wy, &ymin);
+            for (int ow = 0; ow < w; ++ow) {
+                int xmin, xsize = aa_weights(ow, pw, sw, supw, miw, wx, &xmin);
+                for (int c = 0; c < 3; ++c) {
+                    const float gv = g[((size_t)c * h + oh) * w + ow];
+                    for (int y = 0; y < ysize; ++y)
+                        for (int x = 0; x < xsize; ++x) acc[((size_t)c * ph + ymin + y) * pw + xmin + x] += wx[x] * wy[y] * gv;
+                }
+            }
+        }
+        free(wy);
+        free(wx);
+        for (size_t k = 0; k < n; ++k) gpatch[k] += acc[k];
+    }
+    free(acc);
+}
+
+/* K1 / K2 with one patch PER IMAGE (the resized patches of config 5): image b uses packed + offset_b as [3,h_b,w_b]. */
+void vaa_oracle_patch_apply_fwd_multi(const uint8_t* img_u8, const float* packed, const int32_t* pdesc, const int32_t* xy,
+                                      const float* theta, int B, int geometry, int mask_mode, const float* mean6, const float* std6,
+                                      float* out_f32, uint16_t* out_bf16, uint8_t* keep) {
+    for (int b = 0; b < B; ++b)
+        vaa_oracle_patch_apply_fwd(img_u8 + (size_t)b * NPIX * 3, packed + pdesc[4 * b + 2], xy + 2 * b, theta + 6 * b, 1, pdesc[4 * b],
+                                   pdesc[4 * b + 1], geometry, mask_mode, mean6, std6, out_f32 ? out_f32 + (size_t)b * 6 * NPIX : NULL,
+                                   out_bf16 ? out_bf16 + (size_t)b * 6 * NPIX : NULL, keep ? keep + (size_t)b * 3 * NPIX : NULL);
+}
+
+/* gpacked: d L / d packed (every image's own resized patch), same layout as packed; regions between patches untouched. */
+void vaa_oracle_patch_grad_multi(const uint16_t* gout_bf16, const float* packed, const int32_t* pdesc, const int32_t* xy,
+                                 const float* theta, int B, int geometry, int mask_mode, const float* std6, float* gpacked) {
+    for (int b = 0; b < B; ++b)
+        vaa_oracle_patch_grad(gout_bf16 + (size_t)b * 6 * NPIX, packed + pdesc[4 * b + 2], xy + 2 * b, theta + 6 * b, 1, pdesc[4 * b],
+                              pdesc[4 * b + 1], geometry, mask_mode, std6, gpacked + pdesc[4 * b + 2]);
+}

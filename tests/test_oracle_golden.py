@@ -59,6 +59,65 @@ def test_torch_port_k1_k2(f):
     assert np.abs(pg - d["patch_grad"]).max() <= 2e-6 * np.abs(d["patch_grad"]).max()
 
 
+RESIZE = golden_files("resize_")
+assert len(RESIZE) >= 2
+
+
+@pytest.mark.parametrize("f", RESIZE, ids=[os.path.basename(f)[:-4] for f in RESIZE])
+def test_resize_patch_config5_vs_reference_golden(f):
+    """BASELINE config 5 (resize_patch=True): the reference (with the A-D2 repair of tools/ref_import.py) vs both oracles:
+    RNG draw order and consumption, per-image sizes, mask bits, whole bf16 tensor, gradient to the BASE patch."""
+    d = np.load(f)
+    B = int(d["batch"])
+    imgs = synthetic.synth_images(int(d["img_seed"]), B, str(d["img_kind"]))
+    g = synthetic.synth_upstream_grad(int(d["grad_seed"]), B)
+    patch = d["patch"]
+    ph, pw = patch.shape[1:]
+    random.seed(int(d["rng_seed"]))
+    np.random.seed(int(d["rng_seed"]))
+    sizes, xy, theta = ref_port.draw_params_resized(B, ph, pw, True)
+    assert np.array_equal(sizes, d["sizes"]) and np.array_equal(xy, d["xy"]) and np.array_equal(theta, d["theta"])
+    assert (random.random(), float(np.random.rand())) == tuple(d["rng_after"]), "RNG consumption differs from the reference"
+    kb = np.unpackbits(d["keep_bits"], axis=-1)[:, :, : 224 * 224]
+    si = d["sample_idx"].astype(int)
+    # torch port
+    out, keep = ref_port.apply_random_patch_batch_resized(imgs, torch.from_numpy(patch), sizes, xy, theta, True, return_keep=True)
+    assert np.array_equal(kb, keep.reshape(B, 3, -1).numpy().astype(np.uint8))
+    assert zlib.crc32(out.to(torch.bfloat16).view(torch.int16).numpy().tobytes()) == int(d["bf16_crc32"])
+    pg = ref_port.patch_grad_resized_via_autograd(imgs, torch.from_numpy(patch), sizes, xy, theta, True, g).numpy()
+    assert np.abs(pg - d["patch_grad"]).max() <= 1e-6 * np.abs(d["patch_grad"]).max()
+    # C oracle: resize -> per-image paste -> gradient of every resized patch -> adjoint of the resize
+    pdesc, total = c_oracle.make_pdesc(sizes)
+    packed = c_oracle.patch_resize_fwd(patch, pdesc, total)
+    o32, ob, ck = c_oracle.patch_apply_fwd_multi(imgs, packed, pdesc, xy, theta, 1, 0)
+    assert np.array_equal(kb, ck), "paste/warp mask indices must be bit-exact"
+    assert np.array_equal(o32[:, 0:3].reshape(B, 3, -1)[ck.astype(bool)][::8], d["kept_vals_stride8"])
+    assert np.array_equal(o32[si[:, 0], si[:, 1], si[:, 2], si[:, 3]], d["samples"])
+    assert zlib.crc32(ob.view(np.int16).tobytes()) == int(d["bf16_crc32"]), "whole bf16 model input identical"
+    gp = c_oracle.patch_grad_multi(g.view(torch.int16).numpy().view(np.uint16), packed, pdesc, xy, theta, 1, 0)
+    pg_c = c_oracle.patch_resize_bwd(gp, pdesc, ph, pw)
+    assert np.abs(pg_c - d["patch_grad"]).max() <= 2e-6 * np.abs(d["patch_grad"]).max()
+
+
+@pytest.mark.parametrize("ih,iw,oh,ow", [(100, 100, 61, 61), (100, 100, 139, 139), (100, 100, 100, 100), (50, 50, 30, 69), (37, 61, 22, 84),
+                                         (50, 50, 1, 1), (3, 5, 7, 2), (100, 100, 110, 82)])
+def test_c_oracle_resize_bit_exact_vs_torch(ih, iw, oh, ow):
+    """The restated antialias-bilinear resize equals torch's CPU kernel bit for bit (forward); adjoint vs autograd."""
+    torch.manual_seed(ih * 7 + ow)
+    x = torch.rand(3, ih, iw)
+    ref = ref_port.resize_patch(x, oh, ow).numpy()
+    pdesc, total = c_oracle.make_pdesc([[oh, ow]])
+    got = c_oracle.patch_resize_fwd(x.numpy(), pdesc, total)[: 3 * oh * ow].reshape(3, oh, ow)
+    assert np.array_equal(got, ref)
+    xg = x.clone().requires_grad_(True)
+    gy = torch.rand(3, oh, ow)
+    ref_port.resize_patch(xg, oh, ow).backward(gy)
+    gpk = np.zeros(total, np.float32)
+    gpk[: 3 * oh * ow] = gy.numpy().ravel()
+    gb = c_oracle.patch_resize_bwd(gpk, pdesc, ih, iw)
+    assert np.abs(gb - xg.grad.numpy()).max() <= 1e-6 * np.abs(xg.grad.numpy()).max()
+
+
 def test_rng_stream_seed42():
     """Draw order of a-2: randint(x), randint(y), rand, [uniform x3] per image (appply_random_transform.py:120-128)."""
     d = np.load(os.path.join(GOLDEN, "rng_stream_seed42.npz"))

@@ -199,6 +199,68 @@ def gen_k1k2():
 
 
 # ------------------------------------------------------------------------------------------------
+# resize_patch=True (BASELINE config 5; reference lines :113-118 with the A-D2 repair of ref_import)
+# ------------------------------------------------------------------------------------------------
+def gen_resize():
+    TR2 = ref_import.load_transform_d2_repaired()
+    for name, batch, shape, img_kind, img_seed, rng_seed in (("base100", 4, (3, 100, 100), "smooth", 71, 42),
+                                                             ("base50", 3, (3, 50, 50), "noise", 72, 5)):
+        imgs = synthetic.synth_images(img_seed, batch, img_kind)
+        pil = synthetic.to_pil_list(imgs)
+        patch = _make_patch(42, shape).requires_grad_(True)
+        t = TR2.RandomPatchTransform(torch.device("cpu"), True)
+        proxy = _TorchProxy()
+        TR2.torch = proxy
+        random.seed(rng_seed)
+        np.random.seed(rng_seed)
+        st_r, st_n = random.getstate(), np.random.get_state()
+        try:
+            out = t.apply_random_patch_batch(pil, patch, MEAN, STD, True)
+        finally:
+            TR2.torch = torch
+        after = (random.random(), float(np.random.rand()))  # RNG consumption probe: the next draws after the call
+        # replay the draws: per image uniform(scale), randint(x), randint(y), combined_transform_matrix (:114,:123-128)
+        random.setstate(st_r)
+        np.random.set_state(st_n)
+        scales = np.zeros(batch, np.float64)
+        sizes = np.zeros((batch, 2), np.int32)
+        xy = np.zeros((batch, 2), np.int32)
+        theta = np.zeros((batch, 2, 3), np.float32)
+        t2 = TR2.RandomPatchTransform(torch.device("cpu"), True)
+        for b in range(batch):
+            scales[b] = random.uniform(0.61, 1.39)
+            h, w = int(shape[1] * scales[b]), int(shape[2] * scales[b])
+            sizes[b] = (h, w)
+            xy[b] = (random.randint(0, 224 - w), random.randint(0, 224 - h))
+            theta[b] = t2.combined_transform_matrix().numpy()[:2]
+        assert after == (random.random(), float(np.random.rand()))
+        cond = torch.cat([c.reshape(1, 3, 224, 224) for c in proxy.conds], 0)
+        keep_np = (~cond).numpy()
+        out_d = out.detach()
+        kept_vals = out_d[:, 0:3][~cond].numpy()
+        rs = np.random.RandomState(991)
+        n_s = 2048
+        sb, sc = rs.randint(0, batch, n_s), rs.randint(0, 6, n_s)
+        si, sj = rs.randint(0, 224, n_s), rs.randint(0, 224, n_s)
+        out_bf16 = out_d.to(torch.bfloat16)
+        crc = zlib.crc32(out_bf16.view(torch.int16).numpy().tobytes())
+        gout = synthetic.synth_upstream_grad(777, batch)
+        out.to(torch.bfloat16).backward(gradient=gout)
+        pgrad = patch.grad.detach().numpy().copy()
+        np.savez_compressed(
+            os.path.join(GOLD, f"resize_{name}.npz"),
+            batch=batch, img_kind=img_kind, img_seed=img_seed, grad_seed=777, rng_seed=rng_seed,
+            patch=patch.detach().numpy(), scales=scales, sizes=sizes, xy=xy, theta=theta,
+            keep_bits=np.packbits(keep_np.reshape(batch, 3, -1), axis=-1), n_keep=int(keep_np.sum()),
+            kept_vals_stride8=kept_vals[::8],  # every 8th kept fp32 value in canonical (b, c, i, j) order (fixture size)
+            sample_idx=np.stack([sb, sc, si, sj], 1).astype(np.int16), samples=out_d[sb, sc, si, sj].numpy(),
+            bf16_crc32=np.uint32(crc), bf16_sum=np.float64(out_bf16.double().sum().item()), patch_grad=pgrad,
+            rng_after=np.array(after, np.float64),
+        )
+        print(f"resize_{name}: sizes={sizes.tolist()} keep={int(keep_np.sum())} crc={crc:#x} |g|max={np.abs(pgrad).max():.3e}")
+
+
+# ------------------------------------------------------------------------------------------------
 # RNG parameter stream (a-2) for seed 42
 # ------------------------------------------------------------------------------------------------
 def gen_rng_stream():
@@ -569,8 +631,8 @@ def gen_sim():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1k2", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "sim"]
-    fns = dict(k1k2=gen_k1k2, rng=gen_rng_stream, labels=gen_labels_tokenizer, k3=gen_k3, sched=gen_sched, fmt=gen_patch_format,
+    which = sys.argv[1:] or ["k1k2", "resize", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "sim"]
+    fns = dict(k1k2=gen_k1k2, resize=gen_resize, rng=gen_rng_stream, labels=gen_labels_tokenizer, k3=gen_k3, sched=gen_sched, fmt=gen_patch_format,
                traj=gen_trajectory, traj2=gen_trajectory_tma_upa, sim=gen_sim)
     for w in which:
         fns[w]()

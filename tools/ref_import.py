@@ -133,6 +133,28 @@ def load_reference():
     return ns
 
 
+def load_transform_d2_repaired():
+    """A second, independent module object of the reference transform with D1 + D2 repaired in memory (see the header).
+    `load_reference()` must have been called first (it installs the torchvision stubs)."""
+    path = f"{REF}/VLAAttacker/white_patch/appply_random_transform.py"
+    src = open(path).read().split("\n")
+    assert src[42].startswith("   def simulation_random_patch"), src[42]
+    src[42] = " " + src[42]
+    # D2: lines 104-118 (1-based). Assert the shipped text before touching it so a changed reference is noticed.
+    assert src[104].strip() == "modified_images = []", src[104]
+    assert src[106].strip() == "for im in images:", src[106]
+    assert "int(patch_height * scale), int(patch_width * scale)" in src[114], src[114]
+    assert src[115].strip() == "patch = transforms.Resize((height, width))(patch)", src[115]
+    src[104] = src[104] + "; base_patch = patch"
+    src[114] = src[114].replace("int(patch_height * scale), int(patch_width * scale)",
+                                "int(base_patch.shape[1] * scale), int(base_patch.shape[2] * scale)")
+    src[115] = src[115].replace("(patch)", "(base_patch)")
+    tr = types.ModuleType("appply_random_transform_d2")
+    tr.__spec__ = importlib.machinery.ModuleSpec("appply_random_transform_d2", None)
+    exec(compile("\n".join(src), path, "exec"), tr.__dict__)
+    return tr
+
+
 class FakeTokenizer:
     """Stands in for the Llama tokenizer: only vocab_size is used by ActionTokenizer's numeric paths."""
 
