@@ -95,6 +95,31 @@ int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* patch, const i
                           float* gpatch, void* ws, size_t ws_bytes, void* stream);
 
 /*
+ * resize_patch=True (BASELINE config 5) — replaces, for the whole batch at once, `patch = transforms.Resize((height, width))(patch)`
+ * with `scale = random.uniform(0.61, 1.39)` (appply_random_transform.py:113-116; semantics of SURVEY.md Appendix A-D2: every image
+ * scales the BASE patch), the paste/warp of every image's own resized patch (:118-136) and their autograd backward.
+ * The draws stay on the host; their results travel as a per-image descriptor:
+ *   pdesc    dev  [B,4] int32 = {h_b, w_b, offset_b, 0}: image b's patch is [3,h_b,w_b] float32 at packed + offset_b
+ *             (offsets in floats; regions must not overlap; vaa_patch_*_multi read sizes from here, max_h/max_w bound them)
+ * vaa_patch_resize_fwd: packed[offset_b ...] = antialiased bilinear resize of patch [3,ph,pw] to (h_b, w_b) — torchvision Resize on a
+ *             tensor == torch F.interpolate(mode='bilinear', antialias=True, align_corners=False); bit-exact against torch's CPU kernel.
+ * vaa_patch_resize_bwd: gpatch [3,ph,pw] = sum_b adjoint(resize_b)(gpacked_b), overwritten; ws >= vaa_patch_resize_ws_bytes(B,ph,pw).
+ * vaa_patch_apply_fwd_multi / vaa_patch_grad_gather_multi: K1 / K2 with per-image patches. K2's output gpacked has the layout of
+ *             packed and holds d L / d (every image's own resized patch); elements between the patches are not written.
+ * Launch counts do not depend on B: forward = resize + K1, backward = K2 + resize adjoint + fixed-order sum over the images.
+ */
+int vaa_patch_resize_fwd(const float* patch, int ph, int pw, const int32_t* pdesc, int B, float* packed, void* stream);
+size_t vaa_patch_resize_ws_bytes(int B, int ph, int pw);
+int vaa_patch_resize_bwd(const float* gpacked, int ph, int pw, const int32_t* pdesc, int B, float* gpatch, void* ws, size_t ws_bytes,
+                         void* stream);
+int vaa_patch_apply_fwd_multi(const uint8_t* img_u8, const float* packed, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                              int B, int max_h, int max_w, int geometry, int mask_mode, const float* mean6, const float* std6,
+                              uint16_t* out_bf16, uint8_t* keep_bits, void* stream);
+int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const float* packed, const int32_t* pdesc, const int32_t* xy,
+                                const float* theta, const uint8_t* keep_bits, int B, int max_h, int max_w, int geometry, int mask_mode,
+                                const float* std6, float* gpacked, void* stream);
+
+/*
  * K3 — replaces HF Llama's `.loss` (via modeling_prismatic.py:404-415) + OpenVLAAttacker.weighted_loss
  * (UADA.py:381-406, UADA_ddp.py:99-124, UPA.py:367-387) and their autograd backward to the logits.
  *   logits   dev  f32|bf16, layout FULL [B,S,V] or ROWS [R,V]. For ROWS pass S = R (the number of rows, which must equal the number

@@ -34,6 +34,11 @@ EXPORTS = (
     "vaa_patch_apply_eval",
     "vaa_patch_embed_grad_ws_bytes",
     "vaa_patch_embed_grad_gather",
+    "vaa_patch_resize_fwd",
+    "vaa_patch_resize_ws_bytes",
+    "vaa_patch_resize_bwd",
+    "vaa_patch_apply_fwd_multi",
+    "vaa_patch_grad_gather_multi",
 )
 
 
@@ -46,10 +51,17 @@ _lib = None
 
 def build(verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    import fcntl
     import subprocess
 
     script = os.path.join(_HERE, "csrc", "build.sh")
-    out = subprocess.run(["bash", script], capture_output=True, text=True)
+    # rank-safe under torchrun: one process compiles (exclusive file lock), build.sh renames the finished file into place
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            out = subprocess.run(["bash", script], capture_output=True, text=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     if out.returncode != 0:
         raise VaaError(f"building libvaa_hip.so failed:\n{out.stdout}\n{out.stderr}")
     if verbose:
@@ -62,7 +74,13 @@ def lib() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH) and not os.environ.get("VAA_LIB_PATH") and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
-        build()  # compiling the HIP extension is not a fallback: the product still runs only through libvaa_hip.so
+        import fcntl
+
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:  # wait for a build another rank may be running
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            fcntl.flock(lock, fcntl.LOCK_UN)
+        if not os.path.exists(LIB_PATH):
+            build()  # compiling the HIP extension is not a fallback: the product still runs only through libvaa_hip.so
     if not os.path.exists(LIB_PATH):
         raise VaaError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
@@ -84,6 +102,16 @@ def lib() -> C.CDLL:
     L.vaa_patch_embed_grad_ws_bytes.argtypes = [i32, i32, i32]
     L.vaa_patch_embed_grad_gather.restype = i32
     L.vaa_patch_embed_grad_gather.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
+    L.vaa_patch_resize_fwd.restype = i32
+    L.vaa_patch_resize_fwd.argtypes = [vp, i32, i32, vp, i32, vp, vp]
+    L.vaa_patch_resize_ws_bytes.restype = sz
+    L.vaa_patch_resize_ws_bytes.argtypes = [i32, i32, i32]
+    L.vaa_patch_resize_bwd.restype = i32
+    L.vaa_patch_resize_bwd.argtypes = [vp, i32, i32, vp, i32, vp, vp, sz, vp]
+    L.vaa_patch_apply_fwd_multi.restype = i32
+    L.vaa_patch_apply_fwd_multi.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, vp]
+    L.vaa_patch_grad_gather_multi.restype = i32
+    L.vaa_patch_grad_gather_multi.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp]
     L.vaa_loss_ws_bytes.restype = sz
     L.vaa_loss_ws_bytes.argtypes = [i32, i32]
     L.vaa_loss_fwd_bwd.restype = i32

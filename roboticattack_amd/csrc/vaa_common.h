@@ -18,6 +18,8 @@ namespace vaa {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// vaa_patch_grad.hip: gpatch[e] = sum_p partial[p][e] (p < nparts, e < n) in a fixed order with fp64 accumulation
+int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts, hipStream_t st, const char* who);
 
 struct Norm6 {
     float mean[6];
@@ -67,6 +69,30 @@ __device__ __forceinline__ Samp sample_pos(float bx, float by, const float* th) 
     s.ne = so * w;
     s.sw = n * e;
     s.se = n * w;
+    return s;
+}
+
+// The same coordinates with the fractional parts kept (K2 stores {x0, y0, w, n} per pixel and forms the four corner weights
+// when it scatters: so*e, so*w, n*e, n*w with e = 1-w, so = 1-n — the products of sample_pos above, bit for bit).
+__device__ __forceinline__ void sample_pos_frac(float bx, float by, const float* th, int& x0, int& y0, float& w, float& n) {
+    float gx = __builtin_fmaf(by, th[1], bx * th[0]) + th[2];
+    float gy = __builtin_fmaf(by, th[4], bx * th[3]) + th[5];
+    float ix = __builtin_fmaf(gx + 1.0f, 112.0f, -0.5f);
+    float iy = __builtin_fmaf(gy + 1.0f, 112.0f, -0.5f);
+    ix = fminf(223.0f, fmaxf(ix, 0.0f));
+    iy = fminf(223.0f, fmaxf(iy, 0.0f));
+    float xw = floorf(ix), yn = floorf(iy);
+    w = ix - xw;
+    n = iy - yn;
+    x0 = (int)xw;
+    y0 = (int)yn;
+}
+
+__device__ __forceinline__ Samp samp_from_frac(int x0, int y0, float w, float n) {
+    Samp s;
+    const float e = 1.0f - w, so = 1.0f - n;
+    s.x0 = x0; s.y0 = y0;
+    s.nw = so * e; s.ne = so * w; s.sw = n * e; s.se = n * w;
     return s;
 }
 

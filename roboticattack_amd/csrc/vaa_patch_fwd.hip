@@ -25,9 +25,18 @@ struct FwdArgs {
     const float* theta;
     uint16_t* out;
     uint8_t* keep;
+    const int32_t* pdesc;  // nullptr: one patch [3,ph,pw] for the batch; else [B,4] = {h_b, w_b, offset_b, 0}: image b pastes patch + offset_b
     int B, ph, pw, geometry, mask_mode;
     Norm6 nrm;
 };
+
+__device__ __forceinline__ void patch_of(const FwdArgs& a, int b, int& ph, int& pw, const float*& p) {
+    if (a.pdesc) {  // resize_patch=True (appply_random_transform.py:113-118): every image has its own resized patch
+        ph = a.pdesc[4 * b]; pw = a.pdesc[4 * b + 1]; p = a.patch + a.pdesc[4 * b + 2];
+    } else {
+        ph = a.ph; pw = a.pw; p = a.patch;
+    }
+}
 
 constexpr int kPix = 16;                                  // pixels per item: 48 B in (3 x 16 B), 2 x 16 B out per plane
 constexpr int kItemsPerRow = VAA_IMG / kPix;              // 14
@@ -56,6 +65,9 @@ __host__ __device__ inline uint32_t norm_pack(float v, const Norm6& n, int c) {
 // is what makes their ownership of items disjoint and complete.
 __device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it_lo, int& it_hi) {
     const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
+    int ph, pw;
+    const float* unused;
+    patch_of(a, b, ph, pw, unused);
     int jlo = 0, jhi = -1;
     if (a.geometry) {
         float th[6];
@@ -63,9 +75,9 @@ __device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it
         for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
         const PixAffine pa = pix_affine(th);
         const float xlo = (px == 0) ? -1e30f : (float)(px - 1);
-        const float xhi = (px + a.pw == VAA_IMG) ? 1e30f : (float)(px + a.pw);
+        const float xhi = (px + pw == VAA_IMG) ? 1e30f : (float)(px + pw);
         const float ylo = (py == 0) ? -1e30f : (float)(py - 1);
-        const float yhi = (py + a.ph == VAA_IMG) ? 1e30f : (float)(py + a.ph);
+        const float yhi = (py + ph == VAA_IMG) ? 1e30f : (float)(py + ph);
         float jl = -1e30f, jh = 1e30f;
         solve_interval(pa.a00, pa.a01 * (float)i + pa.c0, xlo, xhi, jl, jh);
         solve_interval(pa.a10, pa.a11 * (float)i + pa.c1, ylo, yhi, jl, jh);
@@ -73,9 +85,9 @@ __device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it
             jlo = (int)fmaxf(0.0f, floorf(jl) - 1.0f);
             jhi = (int)fminf((float)(VAA_IMG - 1), ceilf(jh) + 1.0f);
         }
-    } else if (i >= py && i < py + a.ph) {
+    } else if (i >= py && i < py + ph) {
         jlo = px;
-        jhi = px + a.pw - 1;
+        jhi = px + pw - 1;
     }
     it_lo = jlo >> 4;
     it_hi = (jhi < jlo) ? -1 : (jhi >> 4);
@@ -192,7 +204,10 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
     const int nslots = nrows * nseg;
     const int hw = (chunk * kFwdThreads + tid) >> 5, nhw = fsplit * (kFwdThreads >> 5), hlane = tid & 31;
     const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
-    const int plane = a.ph * a.pw;
+    int ph, pw;
+    const float* patch;
+    patch_of(a, b, ph, pw, patch);
+    const int plane = ph * pw;
     float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
     if (a.geometry) {
 #pragma unroll
@@ -219,18 +234,18 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
             if (a.geometry) {
                 const Samp s = sample_pos(bgrid[j], bgrid[i], th);
                 const int u0 = s.x0 - px, v0 = s.y0 - py;
-                inside = !(u0 < -1 || u0 >= a.pw || v0 < -1 || v0 >= a.ph);
-                const int uc0 = min(max(u0, 0), a.pw - 1), uc1 = min(max(u0 + 1, 0), a.pw - 1);
-                const int vc0 = min(max(v0, 0), a.ph - 1), vc1 = min(max(v0 + 1, 0), a.ph - 1);
+                inside = !(u0 < -1 || u0 >= pw || v0 < -1 || v0 >= ph);
+                const int uc0 = min(max(u0, 0), pw - 1), uc1 = min(max(u0 + 1, 0), pw - 1);
+                const int vc0 = min(max(v0, 0), ph - 1), vc1 = min(max(v0 + 1, 0), ph - 1);
                 float t[3][4];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float* pc = a.patch + c * plane;
-                    t[c][0] = pc[vc0 * a.pw + uc0]; t[c][1] = pc[vc0 * a.pw + uc1];
-                    t[c][2] = pc[vc1 * a.pw + uc0]; t[c][3] = pc[vc1 * a.pw + uc1];
+                    const float* pc = patch + c * plane;
+                    t[c][0] = pc[vc0 * pw + uc0]; t[c][1] = pc[vc0 * pw + uc1];
+                    t[c][2] = pc[vc1 * pw + uc0]; t[c][3] = pc[vc1 * pw + uc1];
                 }
-                const bool ux0 = (unsigned)u0 < (unsigned)a.pw, ux1 = (unsigned)(u0 + 1) < (unsigned)a.pw;
-                const bool vy0 = (unsigned)v0 < (unsigned)a.ph, vy1 = (unsigned)(v0 + 1) < (unsigned)a.ph;
+                const bool ux0 = (unsigned)u0 < (unsigned)pw, ux1 = (unsigned)(u0 + 1) < (unsigned)pw;
+                const bool vy0 = (unsigned)v0 < (unsigned)ph, vy1 = (unsigned)(v0 + 1) < (unsigned)ph;
                 const bool fx1 = s.x0 + 1 < VAA_IMG, fy1 = s.y0 + 1 < VAA_IMG;  // (x0, y0) itself is always inside the frame
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -242,10 +257,10 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
                 }
             } else {
                 const int u = j - px, v = i - py;
-                inside = (unsigned)u < (unsigned)a.pw && (unsigned)v < (unsigned)a.ph;
-                const int uc = min(max(u, 0), a.pw - 1), vc = min(max(v, 0), a.ph - 1);
+                inside = (unsigned)u < (unsigned)pw && (unsigned)v < (unsigned)ph;
+                const int uc = min(max(u, 0), pw - 1), vc = min(max(v, 0), ph - 1);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) cv[c] = a.patch[c * plane + vc * a.pw + uc];
+                for (int c = 0; c < 3; ++c) cv[c] = patch[c * plane + vc * pw + uc];
             }
             L[0] = lut[by0]; L[1] = lut[256 + by1]; L[2] = lut[512 + by2];
             if (inside) {
@@ -276,25 +291,26 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
 
 }  // namespace vaa
 
-extern "C" int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, const int32_t* xy, const float* theta, int B,
-                                   int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
-                                   uint16_t* out_bf16, uint8_t* keep_bits, void* stream) {
-    using namespace vaa;
+namespace vaa {
+
+static int launch_patch_apply(const char* who, const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy,
+                              const float* theta, int B, int ph, int pw, int geometry, int mask_mode, const float* mean6,
+                              const float* std6, uint16_t* out_bf16, uint8_t* keep_bits, void* stream) {
     if (B == 0) return VAA_OK;  // empty batch: nothing to read or write (pointers may be null)
     if (!img_u8 || !patch || !xy || !out_bf16 || !mean6 || !std6 || (geometry && !theta)) {
-        set_error("vaa_patch_apply_fwd: null pointer argument");
+        set_error("%s: null pointer argument", who);
         return VAA_E_INVALID;
     }
     if (B < 0 || ph <= 0 || pw <= 0 || (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100)) {
-        set_error("vaa_patch_apply_fwd: bad sizes/mode (B=%d ph=%d pw=%d mask_mode=%d)", B, ph, pw, mask_mode);
+        set_error("%s: bad sizes/mode (B=%d ph=%d pw=%d mask_mode=%d)", who, B, ph, pw, mask_mode);
         return VAA_E_INVALID;
     }
     if (ph > VAA_IMG || pw > VAA_IMG) {
-        set_error("vaa_patch_apply_fwd: patch %dx%d larger than the %dx%d frame", ph, pw, VAA_IMG, VAA_IMG);
+        set_error("%s: patch %dx%d larger than the %dx%d frame", who, ph, pw, VAA_IMG, VAA_IMG);
         return VAA_E_UNSUPPORTED;
     }
     FwdArgs a;
-    a.img = img_u8; a.patch = patch; a.xy = xy; a.theta = theta; a.out = out_bf16; a.keep = keep_bits;
+    a.img = img_u8; a.patch = patch; a.xy = xy; a.theta = theta; a.out = out_bf16; a.keep = keep_bits; a.pdesc = pdesc;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) { a.nrm.mean[q] = mean6[q]; a.nrm.stdv[q] = std6[q]; }
     const long total = (long)B * kItemsPerImg;
@@ -304,5 +320,26 @@ extern "C" int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, co
     const long n_fp = (long)B * fsplit;
     hipLaunchKernelGGL(patch_apply_fwd_kernel, dim3((unsigned)(n_fp + n_bg)), dim3(kFwdThreads), 0, (hipStream_t)stream, a,
                        (int)n_fp, fsplit);
-    return check_launch("vaa_patch_apply_fwd");
+    return check_launch(who);
+}
+
+}  // namespace vaa
+
+extern "C" int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, const int32_t* xy, const float* theta, int B,
+                                   int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
+                                   uint16_t* out_bf16, uint8_t* keep_bits, void* stream) {
+    return vaa::launch_patch_apply("vaa_patch_apply_fwd", img_u8, patch, nullptr, xy, theta, B, ph, pw, geometry, mask_mode, mean6, std6,
+                                   out_bf16, keep_bits, stream);
+}
+
+// K1 with one patch per image (resize_patch=True): image b pastes packed + pdesc[b].offset as [3,h_b,w_b]; max_h/max_w bound the sizes.
+extern "C" int vaa_patch_apply_fwd_multi(const uint8_t* img_u8, const float* packed, const int32_t* pdesc, const int32_t* xy,
+                                         const float* theta, int B, int max_h, int max_w, int geometry, int mask_mode,
+                                         const float* mean6, const float* std6, uint16_t* out_bf16, uint8_t* keep_bits, void* stream) {
+    if (B > 0 && !pdesc) {
+        vaa::set_error("vaa_patch_apply_fwd_multi: null pdesc");
+        return VAA_E_INVALID;
+    }
+    return vaa::launch_patch_apply("vaa_patch_apply_fwd_multi", img_u8, packed, pdesc, xy, theta, B, max_h, max_w, geometry, mask_mode, mean6,
+                                   std6, out_bf16, keep_bits, stream);
 }

@@ -5,19 +5,27 @@
 // grid_sample backward (bilinear scatter, padding 'border'), canvas slice, sum over the batch.
 //
 // Design for gfx950:
-//   * only the warped footprint of the patch is touched: per image and output row the kernel bounds the
-//     columns whose source point can land on the pasted rectangle (inverse of the pixel-space affine,
-//     +-1 px margin), prefix-sums the 224 row lengths in LDS and walks the flattened footprint with all
-//     256 lanes busy; the exact forward coordinates are then recomputed per pixel, so bounds only need to
-//     be conservative.
-//   * each output pixel scatters G*w into a patch-shaped accumulator tile in LDS (ds_add_f64). fp64
-//     accumulation makes the sum independent of arrival order to ~1e-16, i.e. the fp32 result is
-//     run-to-run reproducible without serialising the scatter (the reference's CUDA path is not).
-//   * workgroups are persistent over images (b = blockIdx.x, += gridDim.x) and accumulate every image they
-//     own into the same tile (the tile is in patch coordinates), then write ONE fp32 partial; a second tiny
-//     kernel adds the <=512 partials in fixed order. No global atomics anywhere.
-//   * border padding: out-of-frame source points clamp onto frame-edge canvas pixels; when the patch touches
-//     the frame edge the row bounds are opened to infinity on that side, everything else is unchanged.
+//   * only the warped footprint of the patch is touched: per image and output row the kernel bounds the columns whose
+//     source point can land on the pasted rectangle (inverse of the pixel-space affine, +-1 px margin); footprint rows are
+//     cut into 32-column segments that are dealt round-robin to half-waves, so consecutive lanes read consecutive pixels
+//     of a row of each gradient plane. The exact forward coordinates are recomputed per pixel: bounds only need to be
+//     conservative.
+//   * a workgroup works in ROUNDS of K slots per thread: every load of a round (6 gradient values + 3 keep bytes per pixel)
+//     is in flight before the first is consumed (memory-level parallelism instead of occupancy), then the round's largest
+//     |G| is reduced over the workgroup.
+//   * accumulation is INTEGER: each bilinear contribution G*w is rounded to a 32-bit fixed-point number whose quantum is a
+//     power of two tied to the workgroup's gradient scale (2^-26 of the largest |G| seen, re-scaled lazily when a later
+//     image is > 16x larger) and added into a patch-shaped int64 tile in LDS with ds_add_u64. Integer sums do not depend
+//     on arrival order, so the result is bitwise reproducible for every patch size without serialising the scatter (the
+//     reference's CUDA grid_sample backward is not), and ds_add_u64 measured 12.7 cycles per wave-instruction on the
+//     footprint access pattern against 21 for ds_add_f64 (tools/probe/lds_atomic_probe.hip). The quantisation error per
+//     contribution is <= 2^-26 of the largest gradient, below fp32's own rounding of the same sum.
+//   * workgroups are persistent over images and keep accumulating into the same tile (the tile is in patch coordinates),
+//     then write ONE fp32 partial; a second small kernel adds the partials in fixed order. No global atomics.
+//   * patches whose int64 plane exceeds the LDS are cut into row bands (grid.z), so every size up to 224x224 is covered.
+//   * border padding: out-of-frame source points clamp onto frame-edge canvas pixels; when the patch touches the frame edge
+//     the row bounds are opened to infinity on that side, everything else is unchanged.
+//   * MULTI (resize_patch=True, config 5): one patch PER IMAGE (pdesc), the output is every image's own gradient.
 #include "vaa_common.h"
 
 namespace vaa {
@@ -28,9 +36,11 @@ struct GradArgs {
     const int32_t* xy;
     const float* theta;
     const uint8_t* keep;
-    float* partial;
-    int B, ph, pw, geometry, mask_mode;
-    float istd6[6];  // 1/std, rounded from double on the host
+    float* partial;          // uniform patch: [workgroups][3*ph*pw] partial tiles; MULTI: gpacked (same layout as `patch`)
+    const int32_t* pdesc;    // MULTI: [B,4] = {h, w, offset in floats, 0}
+    int B, ph, pw, geometry, mask_mode;  // MULTI: ph/pw are upper bounds (LDS sizing)
+    int band_rows;           // patch rows per row band (== ph when the whole plane fits the LDS)
+    float istd6[6];          // 1/std, rounded from double on the host
     // TILED source (vaa_patch_embed_grad_gather): instead of the 6-plane bf16 pixel gradient `g`, the already combined and
     // scaled gradient of the tiles that carry kept pixels: geff[b][slot][c*196 + y*14 + x], slot = tile_slot[b][ty*16 + tx]
     const float* geff;
@@ -39,8 +49,14 @@ struct GradArgs {
 
 constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTilePx;  // ViT patch-embed tiling of the 224x224 frame
 
-constexpr int kGradThreads = 1024;  // 16 waves: two workgroups per CU with the 60 KB fp64 tile
-constexpr int kImgsPerPass = 8;      // images whose row tables are built together (one barrier set per pass)
+constexpr int kImgsPerPass = 8;   // images whose row tables are built together (one barrier set per pass)
+constexpr int kFracBits = 26;     // |contribution| < 2^26 when the exponent is set, < 2^30 before a re-scale is forced
+constexpr int kGrowBits = 4;
+constexpr int kExpUnset = -100000;
+
+__device__ __forceinline__ long long shift_round(long long v, int d) {  // v / 2^d, round half up; d in [1, 62]
+    return (v + (1ll << (d - 1))) >> d;
+}
 
 // Schedule: image b is owned by workgroup-row (b % gx); each workgroup-row is `split` workgroups that share the image's
 // footprint slots. Small batches use split > 1 to fill the chip.
@@ -48,22 +64,30 @@ constexpr int kImgsPerPass = 8;      // images whose row tables are built togeth
 // Footprint walk without any per-pixel search: the footprint rows [rmin, rmax] of an image are cut into 32-column
 // segments; one half-wave owns one (row, segment) slot at a time, so a lane needs ONE LDS read (packed {jlo,len} of its
 // row) to know its pixel. Slots are dealt round-robin to the half-waves of the workgroup-row.
-template <typename ACC, int NCH, bool TILED = false>
-__global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradArgs a, int gx, int split) {
+template <int NCH, bool TILED, bool MULTI, int THREADS>
+__global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a, int gx, int split) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    ACC* acc = reinterpret_cast<ACC*>(smem_raw);  // [NCH][ph][pw]
+    long long* tile = reinterpret_cast<long long*>(smem_raw);  // [NCH][band_rows][pw]
     __shared__ float bgrid[VAA_IMG];
     __shared__ uint32_t row_word[kImgsPerPass][VAA_IMG];  // (jlo << 16) | len
     __shared__ int row_min[kImgsPerPass], row_max[kImgsPerPass], len_max[kImgsPerPass];
+    __shared__ uint32_t round_max[3];  // max |G| bits of a round, three slots in rotation (see the reset below)
+    __shared__ int nonfinite;
+    constexpr int K = (NCH == 3) ? 4 : 8;   // slots (pixels) a thread holds per round
+    constexpr int HWS = THREADS / 32;       // half-waves per workgroup
 
     const int tid = threadIdx.x;
-    const int plane = a.ph * a.pw;
     const int c_base = (NCH == 1) ? blockIdx.y : 0;
+    const int v_lo = blockIdx.z * a.band_rows;  // first patch row of this workgroup's band
     const int wg_row = blockIdx.x / split, chunk = blockIdx.x - wg_row * split;
-    const int hw = (chunk * kGradThreads + tid) >> 5, nhw = split * (kGradThreads >> 5), hl = tid & 31;
-    for (int e = tid; e < NCH * plane; e += kGradThreads) acc[e] = (ACC)0;
+    const int hw = chunk * HWS + (tid >> 5), nhw = split * HWS, hl = tid & 31;
+    const int tile_elems = NCH * a.band_rows * a.pw;
+    for (int e = tid; e < tile_elems; e += THREADS) tile[e] = 0ll;
     if (tid < VAA_IMG) bgrid[tid] = base_coord(tid);
-
+    if (tid < 3) round_max[tid] = 0u;
+    if (tid == 0) nonfinite = 0;
+    int E = kExpUnset;  // exponent of the tile's fixed-point format (workgroup-uniform): quantum = 2^(E + 1 - kFracBits)
+    int rnd = 0;        // round counter (workgroup-uniform)
 
     for (int b0 = wg_row; b0 < a.B; b0 += gx * kImgsPerPass) {
         int nimg = (a.B - b0 + gx - 1) / gx;  // images of this pass: b0, b0+gx, ...
@@ -72,15 +96,16 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
         if (tid < kImgsPerPass) { row_min[tid] = VAA_IMG; row_max[tid] = -1; len_max[tid] = 0; }
         __syncthreads();
         // ---- per-row column bounds of each footprint (conservative) ----
-        // 1024 threads cover 4 images x 256 row slots per round (rows 224..255 idle), so a wave never straddles two images
-        // and the extent reduction is one shuffle tree + 3 LDS atomics per wave instead of 3 same-address atomics per row
-        for (int r0 = 0; r0 < nimg * 256; r0 += kGradThreads) {
+        // threads cover images x 256 row slots (rows 224..255 idle), so a wave never straddles two images and the extent
+        // reduction is one shuffle tree + 3 LDS atomics per wave instead of 3 same-address atomics per row
+        for (int r0 = 0; r0 < nimg * 256; r0 += THREADS) {
             const int r = r0 + tid;
             const int q = r >> 8, i = r & 255;
             int len = 0;
             if (q < nimg && i < VAA_IMG) {
                 const int b = b0 + q * gx;
                 const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
+                const int ph = MULTI ? a.pdesc[4 * b] : a.ph, pw = MULTI ? a.pdesc[4 * b + 1] : a.pw;
                 int jlo = 0, jhi = -1;
                 if (a.geometry) {
                     float th[6];
@@ -90,9 +115,9 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
                     // source x must fall in [px-1, px+pw) (corner x0 or x0+1 on the patch); a side that lies on the
                     // frame edge also receives every clamped out-of-frame sample (padding_mode='border').
                     const float xlo = (px == 0) ? -1e30f : (float)(px - 1);
-                    const float xhi = (px + a.pw == VAA_IMG) ? 1e30f : (float)(px + a.pw);
+                    const float xhi = (px + pw == VAA_IMG) ? 1e30f : (float)(px + pw);
                     const float ylo = (py == 0) ? -1e30f : (float)(py - 1);
-                    const float yhi = (py + a.ph == VAA_IMG) ? 1e30f : (float)(py + a.ph);
+                    const float yhi = (py + ph == VAA_IMG) ? 1e30f : (float)(py + ph);
                     float jl = -1e30f, jh = 1e30f;
                     solve_interval(pa.a00, pa.a01 * (float)i + pa.c0, xlo, xhi, jl, jh);
                     solve_interval(pa.a10, pa.a11 * (float)i + pa.c1, ylo, yhi, jl, jh);
@@ -100,9 +125,9 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
                         jlo = (int)fmaxf(0.0f, floorf(jl) - 1.0f);
                         jhi = (int)fminf((float)(VAA_IMG - 1), ceilf(jh) + 1.0f);
                     }
-                } else if (i >= py && i < py + a.ph) {
+                } else if (i >= py && i < py + ph) {
                     jlo = px;
-                    jhi = px + a.pw - 1;
+                    jhi = px + pw - 1;
                 }
                 len = max(0, jhi - jlo + 1);
                 row_word[q][i] = ((uint32_t)jlo << 16) | (uint32_t)len;
@@ -117,119 +142,219 @@ __global__ __launch_bounds__(kGradThreads) void patch_grad_scatter_kernel(GradAr
         __syncthreads();
 
         for (int q = 0; q < nimg; ++q) {
-            const int rmin = row_min[q], nrows = row_max[q] - rmin + 1;
-            if (nrows <= 0) continue;
-            const int nseg = (len_max[q] + 31) >> 5;                   // <= 7
-            const uint32_t inv_nseg = (65536u + nseg - 1) / nseg;      // exact floor(s/nseg) for s < 9362
-            const int nslots = nrows * nseg;
             const int b = b0 + q * gx;
-            const int px = a.xy[2 * b], py = a.xy[2 * b + 1];          // workgroup-uniform -> scalar loads
-            float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
-            if (a.geometry) {
-#pragma unroll
-                for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
-            }
-            const uint16_t* gimg = a.g + (size_t)b * 6 * VAA_NPIX;
-            const uint8_t* kimg = a.keep ? a.keep + (size_t)b * 3 * (VAA_NPIX / 8) : nullptr;
-            for (int sidx = hw; sidx < nslots; sidx += nhw) {
-                const int r = (int)(((uint32_t)sidx * inv_nseg) >> 16);
-                const int k = sidx - r * nseg;
-                const int i = rmin + r;
-                const uint32_t w = row_word[q][i];
-                const int off = (k << 5) + hl;
-                if (off >= (int)(w & 0xffffu)) continue;
-                const int j = (int)(w >> 16) + off;
-                Samp s;
+            const int rmin = row_min[q], nrows = row_max[q] - rmin + 1;
+            const int ph = MULTI ? a.pdesc[4 * b] : a.ph, pw = MULTI ? a.pdesc[4 * b + 1] : a.pw;
+            const int plane = ph * pw;
+            const int v_hi = min(ph, v_lo + a.band_rows);
+            const int tplane = a.band_rows * pw;  // elements of one channel of the tile
+            if (nrows > 0 && v_lo < ph) {
+                const int nseg = (len_max[q] + 31) >> 5;                   // <= 7
+                const uint32_t inv_nseg = (65536u + nseg - 1) / nseg;      // exact floor(s/nseg) for s < 9362
+                const int nslots = nrows * nseg;
+                const int px = a.xy[2 * b], py = a.xy[2 * b + 1];          // workgroup-uniform -> scalar loads
+                float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
                 if (a.geometry) {
-                    s = sample_pos(bgrid[j], bgrid[i], th);
-                } else {
-                    s.x0 = j; s.y0 = i; s.nw = 1.0f; s.ne = 0.0f; s.sw = 0.0f; s.se = 0.0f;
-                }
-                const int u0 = s.x0 - px, v0 = s.y0 - py;
-                if (u0 < -1 || u0 >= a.pw || v0 < -1 || v0 >= a.ph) continue;
-                // corners that fall off the patch (or off the frame) get weight 0 and are redirected to an in-tile cell:
-                // x + 0.0 is exact, so the four LDS adds need no per-corner branch.
-                const bool uin0 = u0 >= 0, uin1 = (u0 + 1 < a.pw) && (s.x0 + 1 < VAA_IMG);
-                const bool vin0 = v0 >= 0, vin1 = (v0 + 1 < a.ph) && (s.y0 + 1 < VAA_IMG);
-                const int uc0 = uin0 ? u0 : u0 + 1, uc1 = uin1 ? u0 + 1 : u0;   // at least one of each pair is inside
-                const int vc0 = vin0 ? v0 : v0 + 1, vc1 = vin1 ? v0 + 1 : v0;
-                const float wnw = (vin0 && uin0) ? s.nw : 0.0f, wne = (vin0 && uin1) ? s.ne : 0.0f;
-                const float wsw = (vin1 && uin0) ? s.sw : 0.0f, wse = (vin1 && uin1) ? s.se : 0.0f;
-                const int o_nw = vc0 * a.pw + uc0, o_ne = vc0 * a.pw + uc1, o_sw = vc1 * a.pw + uc0, o_se = vc1 * a.pw + uc1;
-                const int pix = i * VAA_IMG + j;
-                const uint16_t* gb = gimg + pix;
-                // issue every load of this pixel before the first use
-                uint32_t kbyte[NCH], g0[NCH], g1[NCH];
-                float gt[NCH];
-                const float* gtile = nullptr;
-                if (TILED) {
-                    const int ty = i / kTilePx, tx = j / kTilePx;
-                    const int slot = a.tile_slot[b * (kTilesPerSide * kTilesPerSide) + ty * kTilesPerSide + tx];
-                    // slot < 0 only for pixels without any kept channel (their tile was not evaluated): read slot 0, never used
-                    gtile = a.geff + ((size_t)b * (kTilesPerSide * kTilesPerSide) + (slot < 0 ? 0 : slot)) * kTileElems +
-                            (i - ty * kTilePx) * kTilePx + (j - tx * kTilePx);
-                }
 #pragma unroll
-                for (int cc = 0; cc < NCH; ++cc) {
-                    const int c = c_base + cc;
-                    kbyte[cc] = kimg ? kimg[(size_t)c * (VAA_NPIX / 8) + (pix >> 3)] : 0u;
-                    if (TILED) {
-                        gt[cc] = gtile[c * (kTilePx * kTilePx)];
-                    } else {
-                        g0[cc] = gb[(size_t)c * VAA_NPIX];
-                        g1[cc] = gb[(size_t)(c + 3) * VAA_NPIX];
+                    for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
+                }
+                const float* pimg = MULTI ? a.patch + a.pdesc[4 * b + 2] : a.patch;
+                const uint16_t* gimg = a.g + (size_t)b * 6 * VAA_NPIX;
+                const uint8_t* kimg = a.keep ? a.keep + (size_t)b * 3 * (VAA_NPIX / 8) : nullptr;
+
+                for (int s0 = 0; s0 < nslots; s0 += nhw * K, ++rnd) {
+                    // ======== phase 1: K pixels per thread, every load issued before the first use ========
+                    // per pixel a thread keeps {w, n, tile offset + corner validity bits, G per channel}; the four corner weights
+                    // are formed again when it scatters
+                    float G[K][NCH], fw[K], fn[K];
+                    int t0v[K];           // nw corner in tile coordinates (can be out of range: validity bits decide)
+                    uint32_t flg[K];      // bit 0 active, 1..4 corner nw/ne/sw/se usable, 5..7 pixel-bit index, 8..10 kept (no-mask path)
+                    uint32_t kb[K][NCH], g0[K][NCH], g1[K][NCH];
+                    float gt[K][NCH];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int sidx = s0 + hw + k * nhw;
+                        const int sc = min(sidx, nslots - 1);
+                        const int r = (int)(((uint32_t)sc * inv_nseg) >> 16);
+                        const int ks = sc - r * nseg;
+                        const int i = rmin + r;
+                        const uint32_t w = row_word[q][i];
+                        const int off = (ks << 5) + hl;
+                        const int j = min((int)(w >> 16) + off, VAA_IMG - 1);
+                        int x0 = j, y0 = i;
+                        float wf = 0.0f, nf = 0.0f;
+                        if (a.geometry) sample_pos_frac(bgrid[j], bgrid[i], th, x0, y0, wf, nf);
+                        fw[k] = wf; fn[k] = nf;
+                        const int u0 = x0 - px, v0 = y0 - py;
+                        const bool act = sidx < nslots && off < (int)(w & 0xffffu) && !(u0 < -1 || u0 >= pw || v0 < -1 || v0 >= ph);
+                        // corners off the patch, off this workgroup's row band or off the frame are never added
+                        const bool uin0 = u0 >= 0, uin1 = (u0 + 1 < pw) && (x0 + 1 < VAA_IMG);
+                        const bool vin0 = v0 >= v_lo && v0 < v_hi, vin1 = (v0 + 1 >= v_lo) && (v0 + 1 < v_hi) && (y0 + 1 < VAA_IMG);
+                        const int pix = i * VAA_IMG + j;
+                        uint32_t f = (act ? 1u : 0u) | ((vin0 && uin0) ? 2u : 0u) | ((vin0 && uin1) ? 4u : 0u) | ((vin1 && uin0) ? 8u : 0u) |
+                                     ((vin1 && uin1) ? 16u : 0u) | ((uint32_t)(pix & 7) << 5);
+                        t0v[k] = (v0 - v_lo) * pw + u0;
+                        if (act) {
+                            const uint16_t* gb = gimg + pix;
+                            const float* gtile = nullptr;
+                            if (TILED) {
+                                const int ty = i / kTilePx, tx = j / kTilePx;
+                                const int slot = a.tile_slot[b * (kTilesPerSide * kTilesPerSide) + ty * kTilesPerSide + tx];
+                                // slot < 0 only for pixels without any kept channel (their tile was not evaluated): read slot 0, never used
+                                gtile = a.geff + ((size_t)b * (kTilesPerSide * kTilesPerSide) + (slot < 0 ? 0 : slot)) * kTileElems +
+                                        (i - ty * kTilePx) * kTilePx + (j - tx * kTilePx);
+                            }
+#pragma unroll
+                            for (int cc = 0; cc < NCH; ++cc) {
+                                const int c = c_base + cc;
+                                if (kimg) {
+                                    kb[k][cc] = kimg[(size_t)c * (VAA_NPIX / 8) + (pix >> 3)];
+                                } else {  // no stored mask: recompute it from the patch (test / stand-alone use)
+                                    const Samp s = samp_from_frac(x0, y0, wf, nf);
+                                    const float cv = a.geometry ? sample_canvas(pimg + c * plane, ph, pw, px, py, s)
+                                                                : canvas_at(pimg + c * plane, ph, pw, px, py, j, i);
+                                    if (keep_rule(cv, a.mask_mode)) f |= 256u << cc;
+                                }
+                                if (TILED) {
+                                    gt[k][cc] = gtile[c * (kTilePx * kTilePx)];
+                                } else {
+                                    g0[k][cc] = gb[(size_t)c * VAA_NPIX];
+                                    g1[k][cc] = gb[(size_t)(c + 3) * VAA_NPIX];
+                                }
+                            }
+                        }
+                        flg[k] = f;
+                    }
+                    float lmax = 0.0f;
+                    bool bad = false;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+#pragma unroll
+                        for (int cc = 0; cc < NCH; ++cc) {
+                            const int c = c_base + cc;
+                            float Gv = 0.0f;
+                            if (flg[k] & 1u) {
+                                const bool kept = kimg ? ((kb[k][cc] >> ((flg[k] >> 5) & 7u)) & 1u) : ((flg[k] >> (8 + cc)) & 1u);
+                                // d/d(im) of (im-mean)/std for both normalisations, fp32 exactly like autograd. Reciprocals are
+                                // rounded once on the host (exact for the 0.5 of the second normalisation, <= 1 ulp for the first).
+                                if (kept)
+                                    Gv = TILED ? gt[k][cc] : bf16_bits_to_f32(g0[k][cc]) * a.istd6[c] + bf16_bits_to_f32(g1[k][cc]) * a.istd6[c + 3];
+                            }
+                            if ((__float_as_uint(Gv) & 0x7fffffffu) >= 0x7f800000u) { bad = true; Gv = 0.0f; }  // inf / nan upstream: poisons the output
+                            G[k][cc] = Gv;
+                            lmax = fmaxf(lmax, fabsf(Gv));
+                        }
+                    }
+                    lmax = wave_max(lmax);
+                    if ((tid & 63) == 0 && lmax > 0.0f) atomicMax(&round_max[rnd % 3], __float_as_uint(lmax));
+                    if (bad) nonfinite = 1;
+                    // slot (rnd+1)%3 was last read after the barrier of round rnd-2, i.e. before every thread arrived at the barrier
+                    // of round rnd-1, and is next written after this round's barrier: resetting it here races with neither
+                    if (tid == 0) round_max[(rnd + 1) % 3] = 0u;
+                    __syncthreads();
+                    const uint32_t mbits = round_max[rnd % 3];
+                    if (mbits == 0u) continue;  // nothing kept in this round (workgroup-uniform)
+                    int e = (int)(mbits >> 23) - 127;  // floor(log2(max |G|)) (denormals: -127)
+                    e = max(e, -100);                  // keeps 2^(kFracBits - 1 - E) a normal float; such gradients are ~1e-30
+                    if (E == kExpUnset) {
+                        E = e;
+                    } else if (e > E + kGrowBits) {  // a much larger image: re-scale what the tile holds (rare; deterministic)
+                        const int d = min(e - E, 62);
+                        for (int el = tid; el < tile_elems; el += THREADS) tile[el] = shift_round(tile[el], d);
+                        E = e;
+                        __syncthreads();
+                    }
+                    // ======== phase 2: integer scatter ========
+                    const float scale = __uint_as_float((uint32_t)(kFracBits - 1 - E + 127) << 23);  // 2^(kFracBits-1-E)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const Samp s = samp_from_frac(0, 0, fw[k], fn[k]);
+                        const float wq[4] = {s.nw, s.ne, s.sw, s.se};
+                        const int offs[4] = {t0v[k], t0v[k] + 1, t0v[k] + pw, t0v[k] + pw + 1};
+#pragma unroll
+                        for (int cc = 0; cc < NCH; ++cc) {
+                            unsigned long long* tb = reinterpret_cast<unsigned long long*>(tile) + cc * tplane;
+#pragma unroll
+                            for (int cn = 0; cn < 4; ++cn) {
+                                const float prod = G[k][cc] * wq[cn];                    // fp32 product, as grid_sample's backward forms it
+                                const int ci = __float2int_rn(prod * scale);             // |.| < 2^30
+                                if (ci != 0 && ((flg[k] >> (1 + cn)) & 1u)) atomicAdd(tb + offs[cn], (unsigned long long)(long long)ci);
+                            }
+                        }
                     }
                 }
-#pragma unroll
-                for (int cc = 0; cc < NCH; ++cc) {
-                    const int c = c_base + cc;
-                    bool kept;
-                    if (kimg) {
-                        kept = (kbyte[cc] >> (pix & 7)) & 1u;
-                    } else {
-                        const float cv = a.geometry ? sample_canvas(a.patch + c * plane, a.ph, a.pw, px, py, s)
-                                                    : canvas_at(a.patch + c * plane, a.ph, a.pw, px, py, j, i);
-                        kept = keep_rule(cv, a.mask_mode);
-                    }
-                    if (!kept) continue;
-                    // d/d(im) of (im-mean)/std for both normalisations. Reciprocals are rounded once on the host (exact for
-                    // the 0.5 of the second normalisation, <= 1 ulp for the first); only the ACCUMULATION is fp64, which
-                    // makes the sum independent of arrival order.
-                    const float G = TILED ? gt[cc] : bf16_bits_to_f32(g0[cc]) * a.istd6[c] + bf16_bits_to_f32(g1[cc]) * a.istd6[c + 3];
-                    ACC* tb = acc + cc * plane;
-                    atomicAdd(tb + o_nw, (ACC)(G * wnw));
-                    atomicAdd(tb + o_ne, (ACC)(G * wne));
-                    atomicAdd(tb + o_sw, (ACC)(G * wsw));
-                    atomicAdd(tb + o_se, (ACC)(G * wse));
+            }
+            if (MULTI) {  // per-image output: write this image's band of d L / d (its own patch), reset the tile
+                __syncthreads();
+                const double quantum = (E == kExpUnset) ? 0.0 : __longlong_as_double((long long)(E + 1 - kFracBits + 1023) << 52);
+                const bool poison = nonfinite != 0;
+                if (v_lo < ph) {
+                    float* dst = a.partial + a.pdesc[4 * b + 2];
+                    const int rows = v_hi - v_lo;
+#pragma unroll 1
+                    for (int cc = 0; cc < NCH; ++cc)
+                        for (int el = tid; el < rows * pw; el += THREADS) {
+                            const float v = (float)((double)tile[cc * tplane + el] * quantum);
+                            dst[(size_t)(c_base + cc) * plane + v_lo * pw + el] = poison ? __uint_as_float(0x7fc00000u) : v;
+                            tile[cc * tplane + el] = 0ll;
+                        }
                 }
+                __syncthreads();
+                E = kExpUnset;
+                if (tid == 0) nonfinite = 0;
             }
         }
     }
+    if (MULTI) return;
     __syncthreads();
-    float* dst = a.partial + ((size_t)blockIdx.x * 3 + c_base) * plane;
-    for (int e = tid; e < NCH * plane; e += kGradThreads) dst[e] = (float)acc[e];
+    const double quantum = (E == kExpUnset) ? 0.0 : __longlong_as_double((long long)(E + 1 - kFracBits + 1023) << 52);
+    const bool poison = nonfinite != 0;
+    const int plane = a.ph * a.pw, rows = min(a.ph, v_lo + a.band_rows) - v_lo;
+    float* dst = a.partial + (size_t)blockIdx.x * 3 * plane;
+    for (int cc = 0; cc < NCH; ++cc)
+        for (int el = tid; el < rows * a.pw; el += THREADS) {
+            const float v = (float)((double)tile[cc * a.band_rows * a.pw + el] * quantum);
+            dst[(size_t)(c_base + cc) * plane + v_lo * a.pw + el] = poison ? __uint_as_float(0x7fc00000u) : v;
+        }
 }
 
 // gpatch[e] = sum_p partial[p][e] in a fixed two-level order (16 interleaved slices, then slice 0..15), fp64.
-// Workgroup = 64 elements x 16 slices.
+// A thread owns four consecutive elements (16 B loads); workgroup = 64 element-quads x 16 slices.
 __global__ __launch_bounds__(1024) void patch_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gpatch,
                                                                   int n, int nparts) {
-    __shared__ double sl[16][64];
+    __shared__ double sl[16][64][4];
     const int el = threadIdx.x & 63, s = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
-    double acc = 0.0;
-    if (e < n) {
-#pragma unroll 8
-        for (int p = s; p < nparts; p += 16) acc += (double)partial[(size_t)p * n + e];
-    }
-    sl[s][el] = acc;
-    __syncthreads();
-    if (s == 0 && e < n) {
-        double t = 0.0;
+    const int e = (blockIdx.x * 64 + el) * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (e + 3 < n && (n & 3) == 0) {
+#pragma unroll 4
+        for (int p = s; p < nparts; p += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)p * n + e);
+            acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
+        }
+    } else {
+        for (int p = s; p < nparts; p += 16)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t += sl[q][el];
-        gpatch[e] = (float)t;
+            for (int z = 0; z < 4; ++z)
+                if (e + z < n) acc[z] += (double)partial[(size_t)p * n + e + z];
     }
+#pragma unroll
+    for (int z = 0; z < 4; ++z) sl[s][el][z] = acc[z];
+    __syncthreads();
+    if (s < 4) {  // slice s of the second level sums element z = s of every quad
+        const int z = s;
+        if (e + z < n) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += sl[q][el][z];
+            gpatch[e + z] = (float)t;
+        }
+    }
+}
+
+int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts, hipStream_t st, const char* who) {
+    hipLaunchKernelGGL(patch_grad_reduce_kernel, dim3((n + 255) / 256), dim3(1024), 0, st, partial, gpatch, n, nparts);
+    return check_launch(who);
 }
 
 struct GradSched {
@@ -239,35 +364,38 @@ struct GradSched {
 static GradSched grad_sched(int B) {
     GradSched g;
     g.gx = B < 512 ? B : 512;
-    // two workgroups per image while the batch alone cannot fill the chip: measured 12.7 us (split 2) vs 19.1 us (split 1)
-    // at B=64; split 4 is no faster (12.4 us) and doubles the partial-tile traffic.
+    // two workgroups per image while the batch alone cannot fill the chip
     g.split = (B <= 256) ? 2 : 1;
     return g;
 }
 
+constexpr size_t kLdsBudget = 144 * 1024;  // 160 KiB per CU minus the static row tables (~9 KB)
+
+static int band_rows_for(int ph, int pw) {  // patch rows whose int64 plane fits the LDS
+    const size_t row_bytes = (size_t)pw * sizeof(long long);
+    int rows = (int)(kLdsBudget / row_bytes);
+    return rows >= ph ? ph : rows;
+}
+
 template <bool TILED>
-static int launch_scatter_reduce(const GradArgs& a, float* gpatch, hipStream_t st, const char* who) {
+static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t st, const char* who) {
+    GradArgs a = a0;
     const int B = a.B, ph = a.ph, pw = a.pw, n = 3 * ph * pw;
     const GradSched gs = grad_sched(B);
     const int G = gs.gx * gs.split;  // workgroups (x) == partial tiles
     const size_t plane = (size_t)ph * pw;
-    const size_t lds_budget = 144 * 1024;  // 160 KiB per CU minus the static row tables (~13 KB)
     hipError_t e = hipSuccess;
-    if (3 * plane * sizeof(double) <= 64 * 1024) {  // e.g. 50x50: 60,000 B, two workgroups per CU
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 3, TILED>), dim3(G), dim3(kGradThreads), 3 * plane * sizeof(double), st, a, gs.gx, gs.split);
-    } else if (plane * sizeof(double) <= lds_budget) {  // up to ~138x138: one channel per workgroup
-        const size_t bytes = plane * sizeof(double);
+    if (3 * plane * sizeof(long long) <= 64 * 1024) {  // e.g. 50x50: 60,000 B
+        a.band_rows = ph;
+        hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, 1024>), dim3(G), dim3(1024), 3 * plane * sizeof(long long), st, a, gs.gx, gs.split);
+    } else {  // one channel per workgroup (grid.y), row bands (grid.z) when even one plane exceeds the LDS (> 135x135)
+        a.band_rows = band_rows_for(ph, pw);
+        const int nbands = (ph + a.band_rows - 1) / a.band_rows;
+        const size_t bytes = (size_t)a.band_rows * pw * sizeof(long long);
         if (bytes > 64 * 1024)
-            e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<double, 1, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<double, 1, TILED>), dim3(G, 3), dim3(kGradThreads), bytes, st, a, gs.gx, gs.split);
-    } else if (plane * sizeof(float) <= lds_budget) {  // up to ~195x195: fp32 accumulation
-        const size_t bytes = plane * sizeof(float);
-        if (bytes > 64 * 1024)
-            e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<float, 1, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e == hipSuccess) hipLaunchKernelGGL((patch_grad_scatter_kernel<float, 1, TILED>), dim3(G, 3), dim3(kGradThreads), bytes, st, a, gs.gx, gs.split);
-    } else {
-        set_error("%s: patch %dx%d does not fit the LDS accumulator", who, ph, pw);
-        return VAA_E_UNSUPPORTED;
+            e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<1, TILED, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, 1024>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx, gs.split);
     }
     if (e != hipSuccess) {
         set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
@@ -275,8 +403,7 @@ static int launch_scatter_reduce(const GradArgs& a, float* gpatch, hipStream_t s
     }
     int rc = check_launch(who);
     if (rc != VAA_OK) return rc;
-    hipLaunchKernelGGL(patch_grad_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, (const float*)a.partial, gpatch, n, G);
-    return check_launch(who);
+    return launch_partial_reduce((const float*)a.partial, gpatch, n, G, st, who);
 }
 
 }  // namespace vaa
@@ -314,11 +441,47 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
         return VAA_E_WORKSPACE;
     }
     GradArgs a;
-    a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws;
-    a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
+    a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
+    a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode; a.band_rows = ph;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
     a.geff = nullptr; a.tile_slot = nullptr;
     return launch_scatter_reduce<false>(a, gpatch, st, "vaa_patch_grad_gather");
+}
+
+// K2 with one patch per image (resize_patch=True, appply_random_transform.py:113-118): image b's patch is packed + offset_b,
+// [3,h_b,w_b]; gpacked receives d L / d (that patch) in the same layout. One workgroup per (image, channel, row band).
+extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const float* packed, const int32_t* pdesc, const int32_t* xy,
+                                           const float* theta, const uint8_t* keep_bits, int B, int max_h, int max_w, int geometry,
+                                           int mask_mode, const float* std6, float* gpacked, void* stream) {
+    using namespace vaa;
+    if (B == 0) return VAA_OK;
+    if (!gout_bf16 || !pdesc || !xy || !std6 || !gpacked || (geometry && !theta) || (!keep_bits && !packed)) {
+        set_error("vaa_patch_grad_gather_multi: null pointer argument");
+        return VAA_E_INVALID;
+    }
+    if (B < 0 || max_h <= 0 || max_w <= 0 || (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100)) {
+        set_error("vaa_patch_grad_gather_multi: bad sizes/mode (B=%d max_h=%d max_w=%d mask_mode=%d)", B, max_h, max_w, mask_mode);
+        return VAA_E_INVALID;
+    }
+    if (max_h > VAA_IMG || max_w > VAA_IMG) {
+        set_error("vaa_patch_grad_gather_multi: patch bound %dx%d larger than the frame", max_h, max_w);
+        return VAA_E_UNSUPPORTED;
+    }
+    GradArgs a;
+    a.g = gout_bf16; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
+    a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
+    for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
+    a.geff = nullptr; a.tile_slot = nullptr;
+    a.band_rows = band_rows_for(max_h, max_w);
+    const int nbands = (max_h + a.band_rows - 1) / a.band_rows;
+    const size_t bytes = (size_t)a.band_rows * max_w * sizeof(long long);
+    if (bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<1, false, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        set_error("vaa_patch_grad_gather_multi: hipFuncSetAttribute failed");
+        return VAA_E_LAUNCH;
+    }
+    hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, 1024>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B, 1);
+    return check_launch("vaa_patch_grad_gather_multi");
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

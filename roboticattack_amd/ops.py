@@ -65,8 +65,11 @@ def _need(t: torch.Tensor, dtype, name: str, shape=None) -> torch.Tensor:
     return t
 
 
-def _workspace(device, nbytes: int) -> torch.Tensor:
-    key = (device.index if device.index is not None else torch.cuda.current_device(), "ws")
+def _workspace(device, nbytes: int, kind: str = "k2") -> torch.Tensor:
+    """Scratch for one operator KIND on the current stream: K2's partial tiles, K3's row statistics and the resize adjoint each have
+    their own buffer per (device, stream), so a caller that overlaps them on different streams never shares scratch (vaa.h: the
+    library is re-entrant per stream, the workspace is the caller's)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, kind)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -146,7 +149,7 @@ def patch_embed_grad_gather(dy0, dy1, wt0, wt1, patch, xy, theta, keep_bits, geo
     _need(keep_bits, torch.uint8, "keep_bits", (B, 3, IMG * IMG // 8))
     ph, pw = int(patch.shape[1]), int(patch.shape[2])
     L = _lib.lib()
-    ws = _workspace(patch.device, L.vaa_patch_embed_grad_ws_bytes(B, ph, pw))
+    ws = _workspace(patch.device, L.vaa_patch_embed_grad_ws_bytes(B, ph, pw), "k2e")
     gpatch = torch.empty_like(patch)
     std_c = _STD if std6 is None else _lib.f32x(std6)
     with _timed("K2_patch_embed_grad_gather", B=B, ph=ph, pw=pw):
@@ -174,6 +177,121 @@ class PatchApply(torch.autograd.Function):
         g = patch_grad_gather(gout.to(torch.bfloat16).contiguous(), patch, xy, theta if ctx.geometry else None, keep,
                               ctx.geometry, ctx.mask_mode, std6=ctx.std6)
         return g, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# resize_patch=True (config 5): per-image patches
+# ------------------------------------------------------------------------------------------------------
+def make_pdesc(sizes, align: int = 4):
+    """sizes [B,2] (h,w) host ints -> (pdesc int32 numpy [B,4] = {h, w, offset, 0}, packed length in floats)."""
+    import numpy as np
+
+    sizes = np.asarray(sizes, np.int32).reshape(-1, 2)
+    pdesc = np.zeros((sizes.shape[0], 4), np.int32)
+    off = 0
+    for b, (h, w) in enumerate(sizes):
+        if h <= 0 or w <= 0 or h > IMG or w > IMG:
+            raise _lib.VaaError(f"resized patch {h}x{w} of image {b} does not fit the {IMG}x{IMG} frame")
+        pdesc[b] = (h, w, off, 0)
+        off += (3 * int(h) * int(w) + align - 1) // align * align
+    return pdesc, off
+
+
+def patch_resize_fwd(patch, pdesc, total: int):
+    """Base patch [3,ph,pw] f32 -> packed f32 [total]: image b's antialias-bilinear resized patch [3,h_b,w_b] at pdesc[b].offset."""
+    _need(patch, torch.float32, "patch")
+    B = int(pdesc.shape[0])
+    _need(pdesc, torch.int32, "pdesc", (B, 4))
+    packed = torch.zeros(int(total), dtype=torch.float32, device=patch.device)
+    with _timed("K0_patch_resize_fwd", B=B):
+        rc = _lib.lib().vaa_patch_resize_fwd(patch.data_ptr(), int(patch.shape[1]), int(patch.shape[2]), pdesc.data_ptr(), B, packed.data_ptr(), _stream())
+    _lib.check(rc, "vaa_patch_resize_fwd")
+    return packed
+
+
+def patch_resize_bwd(gpacked, pdesc, ph: int, pw: int):
+    """Adjoint of patch_resize_fwd summed over the images: gpacked f32 [total] -> d L / d base patch [3,ph,pw]."""
+    _need(gpacked, torch.float32, "gpacked")
+    B = int(pdesc.shape[0])
+    _need(pdesc, torch.int32, "pdesc", (B, 4))
+    L = _lib.lib()
+    ws = _workspace(gpacked.device, L.vaa_patch_resize_ws_bytes(B, ph, pw), "resize")
+    g = torch.empty((3, ph, pw), dtype=torch.float32, device=gpacked.device)
+    with _timed("K0_patch_resize_bwd", B=B):
+        rc = L.vaa_patch_resize_bwd(gpacked.data_ptr(), ph, pw, pdesc.data_ptr(), B, g.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "vaa_patch_resize_bwd")
+    return g
+
+
+def patch_apply_fwd_multi(img_u8, packed, pdesc, max_hw, xy, theta, geometry: bool, mask_mode: int = MASK_LT_M20, want_keep: bool = True,
+                          mean6=None, std6=None):
+    """K1 with one patch per image (packed/pdesc from patch_resize_fwd). max_hw = (max h, max w) over the batch (host ints)."""
+    B = img_u8.shape[0]
+    _need(img_u8, torch.uint8, "img_u8", (B, IMG, IMG, 3))
+    _need(packed, torch.float32, "packed")
+    _need(pdesc, torch.int32, "pdesc", (B, 4))
+    _need(xy, torch.int32, "xy", (B, 2))
+    if geometry:
+        _need(theta, torch.float32, "theta", (B, 6))
+    out = torch.empty((B, 6, IMG, IMG), dtype=torch.bfloat16, device=img_u8.device)
+    keep = torch.empty((B, 3, IMG * IMG // 8), dtype=torch.uint8, device=img_u8.device) if want_keep else None
+    mean_c = _MEAN if mean6 is None else _lib.f32x(mean6)
+    std_c = _STD if std6 is None else _lib.f32x(std6)
+    with _timed("K1_patch_apply_fwd_multi", B=B, ph=int(max_hw[0]), pw=int(max_hw[1])):
+        rc = _lib.lib().vaa_patch_apply_fwd_multi(
+            img_u8.data_ptr(), packed.data_ptr(), pdesc.data_ptr(), xy.data_ptr(), theta.data_ptr() if geometry else None, B,
+            int(max_hw[0]), int(max_hw[1]), int(bool(geometry)), int(mask_mode), mean_c, std_c, out.data_ptr(),
+            keep.data_ptr() if want_keep else None, _stream())
+    _lib.check(rc, "vaa_patch_apply_fwd_multi")
+    return out, keep
+
+
+def patch_grad_gather_multi(gout_bf16, packed, pdesc, max_hw, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None):
+    """K2 with one patch per image: returns gpacked (layout of `packed`): d L / d (every image's own patch)."""
+    B = gout_bf16.shape[0]
+    _need(gout_bf16, torch.bfloat16, "gout_bf16", (B, 6, IMG, IMG))
+    _need(packed, torch.float32, "packed")
+    _need(pdesc, torch.int32, "pdesc", (B, 4))
+    _need(xy, torch.int32, "xy", (B, 2))
+    if geometry:
+        _need(theta, torch.float32, "theta", (B, 6))
+    if keep_bits is not None:
+        _need(keep_bits, torch.uint8, "keep_bits", (B, 3, IMG * IMG // 8))
+    gpacked = torch.zeros_like(packed)
+    std_c = _STD if std6 is None else _lib.f32x(std6)
+    with _timed("K2_patch_grad_gather_multi", B=B, ph=int(max_hw[0]), pw=int(max_hw[1])):
+        rc = _lib.lib().vaa_patch_grad_gather_multi(
+            gout_bf16.data_ptr(), packed.data_ptr(), pdesc.data_ptr(), xy.data_ptr(), theta.data_ptr() if geometry else None,
+            keep_bits.data_ptr() if keep_bits is not None else None, B, int(max_hw[0]), int(max_hw[1]), int(bool(geometry)), int(mask_mode),
+            std_c, gpacked.data_ptr(), _stream())
+    _lib.check(rc, "vaa_patch_grad_gather_multi")
+    return gpacked
+
+
+class PatchApplyResized(torch.autograd.Function):
+    """resize_patch=True: resize (K0) + K1 with per-image patches forward; K2 (per-image gradients) + resize adjoint backward.
+    `sizes` is a host int array [B,2] (h,w); four launches + one fixed-order reduce per step, independent of B."""
+
+    @staticmethod
+    def forward(ctx, patch, img_u8, sizes, xy, theta, geometry, mask_mode, mean6=None, std6=None):
+        p = patch.detach().contiguous()
+        pdesc_np, total = make_pdesc(sizes)
+        pdesc = torch.from_numpy(pdesc_np).to(p.device, non_blocking=True)
+        max_hw = (int(pdesc_np[:, 0].max()), int(pdesc_np[:, 1].max()))
+        packed = patch_resize_fwd(p, pdesc, total)
+        out, keep = patch_apply_fwd_multi(img_u8, packed, pdesc, max_hw, xy, theta, geometry, mask_mode, want_keep=True, mean6=mean6, std6=std6)
+        ctx.save_for_backward(packed, pdesc, xy, theta if geometry else xy, keep)
+        ctx.geometry, ctx.mask_mode, ctx.std6, ctx.max_hw = bool(geometry), int(mask_mode), std6, max_hw
+        ctx.base_hw = (int(p.shape[1]), int(p.shape[2]))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        packed, pdesc, xy, theta, keep = ctx.saved_tensors
+        gp = patch_grad_gather_multi(gout.to(torch.bfloat16).contiguous(), packed, pdesc, ctx.max_hw, xy, theta if ctx.geometry else None, keep,
+                                     ctx.geometry, ctx.mask_mode, std6=ctx.std6)
+        g = patch_resize_bwd(gp, pdesc, *ctx.base_hw)
+        return g, None, None, None, None, None, None, None, None
 
 
 class PatchEmbeds(tuple):
@@ -235,7 +353,7 @@ def loss_fwd_bwd(logits, labels, mode: int, w: float = 5.0, alpha: float = 0.8, 
             raise _lib.VaaError(f"logits: ROWS layout expects [R,V], got {tuple(logits.shape)}")
         S, V = int(logits.shape[0]), int(logits.shape[1])  # ROWS: S carries the row count R (row-indexed schedule)
     L = _lib.lib()
-    ws = _workspace(logits.device, L.vaa_loss_ws_bytes(B, Lt))
+    ws = _workspace(logits.device, L.vaa_loss_ws_bytes(B, Lt), "k3")
     scalars = torch.empty(8, dtype=torch.float32, device=logits.device)
     pred = torch.empty((B, Lt - 1), dtype=torch.int32, device=logits.device) if want_pred else None
     if want_grad and glogits is None:

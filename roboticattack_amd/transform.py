@@ -19,7 +19,6 @@ import random
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .constants import IMG, MAX_ANGLE_DEG, MAX_SHEAR, P_IDENTITY
@@ -44,6 +43,7 @@ class RandomPatchTransform:
         self._staged = None
         self.embed_with = None  # a model exposing patch_embed_params(): training calls then return ops.PatchEmbeds
         self.last_params = None  # (xy, theta) of the most recent call, host numpy (tests / logging)
+        self.last_sizes = None   # resize_patch=True: per-image (h, w) of the most recent call
 
     # ---- small tensor helpers kept for API compatibility (:16-24) ----
     def normalize(self, images, mean, std):
@@ -79,14 +79,14 @@ class RandomPatchTransform:
             if t.dtype != torch.uint8 or t.dim() != 4 or tuple(t.shape[1:]) != (IMG, IMG, 3):
                 raise ValueError("image tensor must be uint8 [B,224,224,3] (HWC)")
             return t.to(self.device).contiguous()
-        key = (id(images), len(images))
-        if self._staged_key == key and self._staged is not None:
+        # the cache holds the list object itself and compares by identity (an id() alone can be recycled by a new list)
+        if self._staged_key is images and self._staged is not None and self._staged.shape[0] == len(images):
             return self._staged
         arr = np.stack([np.asarray(im, dtype=np.uint8) for im in images])
         if arr.shape[1:] != (IMG, IMG, 3):
             raise ValueError(f"images must be 224x224 RGB, got {arr.shape[1:]}")
         t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device, non_blocking=True)
-        self._staged_key, self._staged = key, t
+        self._staged_key, self._staged = images, t
         return t
 
     def _draw(self, batch, ph, pw, geometry):
@@ -127,22 +127,28 @@ class RandomPatchTransform:
             return None
         return self.embed_with.patch_embed_params()
 
-    def _apply_resized(self, img, patch, mean6, std6, geometry, out_dtype):
-        """resize_patch=True (:113-116, Appendix A-D2): per image s~U(0.61,1.39) drawn BEFORE the position; the base
-        patch is resized (bilinear, antialias) to (int(ph*s), int(pw*s)). One launch per image (sizes differ)."""
-        outs, xs, ts = [], [], []
-        ph0, pw0 = int(patch.shape[1]), int(patch.shape[2])
-        for b in range(img.shape[0]):
+    def _draw_resized(self, batch, ph0, pw0, geometry):
+        """Draw order per image with resize_patch=True (:114, :123-128): uniform (scale) BEFORE the position, the position against
+        the resized size, then the transform matrix."""
+        sizes = np.empty((batch, 2), np.int32)
+        xy = np.empty((batch, 2), np.int32)
+        theta = np.empty((batch, 6), np.float32)
+        for b in range(batch):
             scale = random.uniform(0.61, 1.39)
             h, w = max(1, int(ph0 * scale)), max(1, int(pw0 * scale))
-            p = F.interpolate(patch[None], size=(h, w), mode="bilinear", antialias=True, align_corners=False)[0].contiguous()
-            xy, theta = self._draw(1, h, w, geometry)
-            xs.append(xy)
-            ts.append(theta)
-            outs.append(ops.PatchApply.apply(p, img[b : b + 1], torch.from_numpy(xy).to(self.device),
-                                             torch.from_numpy(theta).to(self.device), bool(geometry), ops.MASK_LT_M20, mean6, std6))
-        self.last_params = (np.concatenate(xs), np.concatenate(ts))
-        out = torch.cat(outs, dim=0)
+            sizes[b] = (h, w)
+            xy1, th1 = self._draw(1, h, w, geometry)
+            xy[b], theta[b] = xy1[0], th1[0]
+        return sizes, xy, theta
+
+    def _apply_resized(self, img, patch, mean6, std6, geometry, out_dtype):
+        """resize_patch=True (:113-116, Appendix A-D2): per image s~U(0.61,1.39); the BASE patch is resized (bilinear, antialias)
+        to (int(ph*s), int(pw*s)). The whole batch is one resize launch + one K1 launch with per-image patches
+        (`ops.PatchApplyResized`); the backward is K2 with per-image outputs + the resize adjoint."""
+        sizes, xy_n, theta_n = self._draw_resized(img.shape[0], int(patch.shape[1]), int(patch.shape[2]), geometry)
+        self.last_sizes = sizes
+        xy, theta = self._to_dev(xy_n, theta_n)
+        out = ops.PatchApplyResized.apply(patch, img, sizes, xy, theta, bool(geometry), ops.MASK_LT_M20, mean6, std6)
         return out if out_dtype == torch.bfloat16 else out.to(out_dtype)
 
     def _paste(self, images, patch, mean, std, out_dtype):

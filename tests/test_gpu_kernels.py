@@ -185,6 +185,195 @@ def test_k1_k2_empty_and_large_batch(ops):
     assert (whole - parts).abs().max() <= 1e-6 * whole.abs().max()
 
 
+@pytest.mark.parametrize("ph,pw,B", [(50, 50, 64), (100, 100, 8), (139, 139, 4), (195, 200, 2), (224, 224, 2)])
+def test_k2_bitwise_repeatable_every_size(ops, ph, pw, B):
+    """Integer (fixed-point) LDS accumulation + fixed-order partial sums: identical bits run after run for every patch size,
+    including the row-banded sizes whose int64 plane exceeds the LDS (> 135 px) — and still the oracle's numbers."""
+    rs = np.random.RandomState(ph + B)
+    imgs = _t(synthetic.synth_images(3, B, "noise"))
+    patch_n = rs.rand(3, ph, pw).astype(np.float32)
+    xy_n, th_n = _random_case(rs, B, ph, pw)
+    patch, xy, th = _t(patch_n), _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6))
+    _, keep = ops.patch_apply_fwd(imgs, patch, xy, th, True, 0)
+    g = synthetic.synth_upstream_grad(11, B)
+    a = ops.patch_grad_gather(g.to(DEV), patch, xy, th, keep, True, 0)
+    for _ in range(4):
+        assert torch.equal(a, ops.patch_grad_gather(g.to(DEV), patch, xy, th, keep, True, 0))
+    og = c_oracle.patch_grad(_bits(g), patch_n, xy_n, th_n, 1, 0)
+    assert np.abs(a.cpu().numpy() - og).max() <= 3e-6 * np.abs(og).max()
+
+
+def test_k2_gradient_scale_range_and_nonfinite(ops):
+    """The fixed-point format follows the data: images whose gradients differ by 2^40 in one batch (forces the lazy re-scale),
+    tiny (1e-27 after the 1e-3 of the generator; the format bottoms out at 2^-100) and huge (1e27) gradients keep fp32-level relative accuracy; an inf/nan upstream gradient poisons the output."""
+    B, rs = 12, np.random.RandomState(5)
+    imgs = _t(synthetic.synth_images(4, B, "smooth"))
+    patch_n = rs.rand(3, 50, 50).astype(np.float32)
+    xy_n, th_n = _random_case(rs, B, 50, 50)
+    patch, xy, th = _t(patch_n), _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6))
+    _, keep = ops.patch_apply_fwd(imgs, patch, xy, th, True, 0)
+    g = synthetic.synth_upstream_grad(21, B).float()
+    for scales in ([2.0 ** (-20 + 4 * b) for b in range(B)], [1e-24] * B, [1e30] * B, [2.0 ** (24 - 4 * b) for b in range(B)]):
+        gs = (g * torch.tensor(scales).view(B, 1, 1, 1)).to(torch.bfloat16)
+        og = c_oracle.patch_grad(_bits(gs), patch_n, xy_n, th_n, 1, 0)
+        got = ops.patch_grad_gather(gs.to(DEV), patch, xy, th, keep, True, 0).cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - og).max() <= 3e-6 * np.abs(og).max(), scales[:2]
+    gbad = g.clone()
+    ys, xs = np.nonzero(_keep_unpack(keep)[3, 0].reshape(224, 224))
+    gbad[3, 0, ys[0], xs[0]] = float("inf")
+    assert torch.isnan(ops.patch_grad_gather(gbad.to(torch.bfloat16).to(DEV), patch, xy, th, keep, True, 0)).all()
+
+
+RESIZE = golden_files("resize_")
+
+
+@pytest.mark.parametrize("f", RESIZE, ids=[os.path.basename(f)[:-4] for f in RESIZE])
+def test_resize_patch_config5_vs_reference_golden(ops, f):
+    """BASELINE config 5 (resize_patch=True) against what the REFERENCE computed (A-D2 repair, tools/gen_golden.py:gen_resize):
+    draws, RNG consumption, mask bits and the whole bf16 tensor bit-exact; gradient to the base patch <= 2e-6; every stage against
+    the C oracle; launches do not depend on B."""
+    import random
+
+    from roboticattack_amd import ops as O
+    from roboticattack_amd.transform import RandomPatchTransform
+
+    d = np.load(f)
+    B = int(d["batch"])
+    imgs = synthetic.synth_images(int(d["img_seed"]), B, str(d["img_kind"]))
+    g = synthetic.synth_upstream_grad(int(d["grad_seed"]), B)
+    patch_n = d["patch"]
+    ph, pw = patch_n.shape[1:]
+    # ---- the operator as the attack loops call it ----
+    t = RandomPatchTransform(DEV, resize_patch=True)
+    random.seed(int(d["rng_seed"]))
+    np.random.seed(int(d["rng_seed"]))
+    patch = _t(patch_n).requires_grad_(True)
+    O.TIMER = []
+    out = t.apply_random_patch_batch(synthetic.to_pil_list(imgs), patch, ref_port.MEAN, ref_port.STD, True)
+    assert (random.random(), float(np.random.rand())) == tuple(d["rng_after"]), "RNG consumption differs from the reference"
+    assert np.array_equal(t.last_sizes, d["sizes"]) and np.array_equal(t.last_params[0], d["xy"])
+    assert np.array_equal(t.last_params[1].reshape(B, 2, 3), d["theta"])
+    assert zlib.crc32(_bits(out).view(np.int16).tobytes()) == int(d["bf16_crc32"]), "whole bf16 model input identical to the reference's"
+    si = d["sample_idx"].astype(int)
+    assert np.array_equal(out.detach().float().cpu().numpy()[si[:, 0], si[:, 1], si[:, 2], si[:, 3]],
+                          torch.from_numpy(d["samples"]).to(torch.bfloat16).float().numpy())
+    out.backward(gradient=g.to(DEV))
+    torch.cuda.synchronize()
+    launches = [n for (n, *_r) in O.TIMER]
+    O.TIMER = None
+    assert launches == ["K0_patch_resize_fwd", "K1_patch_apply_fwd_multi", "K2_patch_grad_gather_multi", "K0_patch_resize_bwd"], launches
+    ref = d["patch_grad"]
+    assert np.abs(patch.grad.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+    # ---- stage by stage against the C oracle ----
+    pdesc_n, total = O.make_pdesc(d["sizes"])
+    o_pdesc, o_total = c_oracle.make_pdesc(d["sizes"])
+    assert np.array_equal(pdesc_n, o_pdesc) and total == o_total
+    pdesc = _t(pdesc_n)
+    packed = O.patch_resize_fwd(_t(patch_n), pdesc, total)
+    o_packed = c_oracle.patch_resize_fwd(patch_n, pdesc_n, total)
+    assert np.array_equal(packed.cpu().numpy(), o_packed), "antialias-bilinear resize must equal torch's CPU kernel bit for bit"
+    max_hw = (int(pdesc_n[:, 0].max()), int(pdesc_n[:, 1].max()))
+    xy, th = _t(d["xy"], torch.int32), _t(d["theta"].reshape(-1, 6))
+    o2, keep = O.patch_apply_fwd_multi(_t(imgs), packed, pdesc, max_hw, xy, th, True, 0)
+    kb = np.unpackbits(d["keep_bits"], axis=-1)[:, :, : 224 * 224]
+    assert np.array_equal(_keep_unpack(keep), kb), "paste/warp mask indices must be bit-exact"
+    assert torch.equal(o2, out.detach())
+    for kp in (keep, None):  # stored mask / mask recomputed from the resized patches
+        gp = O.patch_grad_gather_multi(g.to(DEV), packed, pdesc, max_hw, xy, th, kp, True, 0)
+        o_gp = c_oracle.patch_grad_multi(_bits(g), o_packed, pdesc_n, d["xy"], d["theta"], 1, 0)
+        assert np.abs(gp.cpu().numpy() - o_gp).max() <= 3e-6 * np.abs(o_gp).max()
+    assert torch.equal(gp, O.patch_grad_gather_multi(g.to(DEV), packed, pdesc, max_hw, xy, th, keep, True, 0))  # bitwise repeatable
+    gb = O.patch_resize_bwd(_t(o_gp), pdesc, ph, pw).cpu().numpy()
+    o_gb = c_oracle.patch_resize_bwd(o_gp, pdesc_n, ph, pw)
+    assert np.abs(gb - o_gb).max() <= 1e-6 * np.abs(o_gb).max()
+
+
+@pytest.mark.parametrize("ph,pw,sizes", [(100, 100, [(61, 61), (139, 139), (100, 100), (100, 61), (139, 100), (1, 1), (224, 224)]),
+                                         (50, 50, [(30, 69), (50, 50), (19, 19), (69, 69)]), (37, 61, [(22, 84), (51, 37)])])
+def test_patch_resize_kernel_vs_torch_cpu(ops, ph, pw, sizes):
+    """The HIP resize equals torch's CPU antialias-bilinear kernel bit for bit (up- and down-scaling, unchanged axes, extremes);
+    its adjoint equals torch autograd to fp32 summation order."""
+    torch.manual_seed(ph + pw)
+    x = torch.rand(3, ph, pw)
+    pdesc_n, total = ops.make_pdesc(sizes)
+    pdesc = _t(pdesc_n)
+    packed = ops.patch_resize_fwd(x.to(DEV), pdesc, total).cpu().numpy()
+    gy = torch.rand(total)
+    xg = x.clone().requires_grad_(True)
+    acc = 0
+    for (h, w, off, _z) in pdesc_n:
+        ref = ref_port.resize_patch(xg, int(h), int(w))
+        assert np.array_equal(packed[off : off + 3 * h * w].reshape(3, h, w), ref.detach().numpy()), (h, w)
+        acc = acc + (ref * gy[off : off + 3 * h * w].view(3, h, w)).sum()
+    acc.backward()
+    gb = ops.patch_resize_bwd(gy.to(DEV), pdesc, ph, pw).cpu().numpy()
+    assert np.abs(gb - xg.grad.numpy()).max() <= 2e-6 * np.abs(xg.grad.numpy()).max()
+
+
+def test_resize_patch_config5_upa_step_vs_ref_port(ops):
+    """Config 5 as a workload: 3x100x100 base patch, B=4, geometry on, UPA loss (maskidx sweep) through the fp32 surrogate.
+    The product path (RandomPatchTransform(resize_patch=True) -> model -> K3 UPA -> K2 multi -> resize adjoint) against the
+    restated reference ops (oracle/ref_port.py + autograd on CPU) driven by the same draws."""
+    import random
+
+    from roboticattack_amd.surrogate import SurrogateVLA
+    from roboticattack_amd.transform import RandomPatchTransform
+
+    B = 4
+    imgs = synthetic.synth_images(505, B, "smooth")
+    input_ids, labels, attn = synthetic.synth_text_batch(55, B)
+    torch.manual_seed(42)
+    patch0 = torch.rand(3, 100, 100)
+    cpu_model, gpu_model = SurrogateVLA(seed=9), SurrogateVLA(seed=9).to(DEV)
+    # ---- reference ops on CPU ----
+    random.seed(7)
+    np.random.seed(7)
+    sizes, xy, theta = ref_port.draw_params_resized(B, 100, 100, True)
+    after = (random.random(), float(np.random.rand()))
+    pc = patch0.clone().requires_grad_(True)
+    pix_c = ref_port.apply_random_patch_batch_resized(imgs, pc, sizes, xy, theta, True).to(torch.bfloat16)
+    pix_c.retain_grad()
+    logits_c = cpu_model(input_ids, attn, pix_c, labels).logits
+    loss_c, _, _ = ref_port.upa_weighted_loss(logits_c, labels, 0.8, 0.2)
+    loss_c.backward()
+    # ---- product path on the GPU ----
+    random.seed(7)
+    np.random.seed(7)
+    t = RandomPatchTransform(DEV, resize_patch=True)
+    pg = patch0.clone().to(DEV).requires_grad_(True)
+    pix_g = t.apply_random_patch_batch(synthetic.to_pil_list(imgs), pg, ref_port.MEAN, ref_port.STD, True)
+    assert (random.random(), float(np.random.rand())) == after, "RNG consumption"
+    assert np.array_equal(t.last_sizes, sizes) and np.array_equal(t.last_params[0], xy)
+    # bit-exact against the C oracle (pinned to the reference's own output by the resize_* goldens). torch's CPU grid_sample on the
+    # test host can differ from the golden-producing host in the last fp32 bit (MKL / vector path; a `canvas < -20` flip at a
+    # boundary pixel is then possible), so against ref_port-on-this-host only the fraction of differing values is bounded.
+    pdesc_n, total = c_oracle.make_pdesc(sizes)
+    o_packed = c_oracle.patch_resize_fwd(patch0.numpy(), pdesc_n, total)
+    _, o_bf16, _ = c_oracle.patch_apply_fwd_multi(imgs, o_packed, pdesc_n, xy, theta, 1, 0)
+    assert np.array_equal(_bits(pix_g.detach()), o_bf16), "model input identical to the oracle's"
+    assert float((pix_g.detach().float().cpu() != pix_c.detach().float()).float().mean()) < 1e-3
+    # the whole step on the GPU: surrogate model + K3 (UPA) + K2 with per-image patches + resize adjoint
+    pix_g.retain_grad()
+    out = gpu_model(input_ids.to(DEV), attn.to(DEV), pix_g, labels.to(DEV))
+    total_l, sc, _ = ops.DiscrepancyLoss.apply(out.logits, labels.to(DEV), ops.LOSS_UPA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
+    total_l.backward()
+    # K3 against the restated UPA loss on the very same logits
+    l_ref, a_ref, d_ref = ref_port.upa_weighted_loss(out.logits.detach().float().cpu(), labels, 0.8, 0.2)
+    assert abs(float(total_l) - float(l_ref)) <= 3e-5 * abs(float(l_ref))
+    assert abs(float(sc[3]) - float(a_ref)) <= 3e-5 and abs(float(sc[4]) - float(d_ref)) <= 3e-5 * float(d_ref)
+    # K2 (per-image gradients) + resize adjoint against the oracle chain fed with the same upstream bf16 gradient
+    gup = pix_g.grad.detach()
+    o_gp = c_oracle.patch_grad_multi(_bits(gup), o_packed, pdesc_n, xy, theta, 1, 0)
+    o_g = c_oracle.patch_resize_bwd(o_gp, pdesc_n, 100, 100)
+    assert np.abs(pg.grad.cpu().numpy() - o_g).max() <= 3e-6 * np.abs(o_g).max()
+    # and the complete CPU autograd of the restated reference ops (different GEMM order in the model, possible mask flips): direction
+    ref = pc.grad.numpy().ravel()
+    got = pg.grad.cpu().numpy().ravel()
+    assert abs(float(total_l) - float(loss_c)) <= 1e-3 * abs(float(loss_c))
+    assert float(np.dot(ref, got) / (np.linalg.norm(ref) * np.linalg.norm(got))) > 0.999
+
+
 def test_patch_apply_autograd_function(ops):
     """PyTorch-ROCm autograd drives K2 through PatchApply.backward exactly like the attack loop does."""
     d = np.load(os.path.join(GOLDEN, "k1k2_geo50_rand.npz"))
