@@ -26,6 +26,8 @@
 //   * border padding: out-of-frame source points clamp onto frame-edge canvas pixels; when the patch touches the frame edge
 //     the row bounds are opened to infinity on that side, everything else is unchanged.
 //   * MULTI (resize_patch=True, config 5): one patch PER IMAGE (pdesc), the output is every image's own gradient.
+#include <stdlib.h>
+
 #include "vaa_common.h"
 
 namespace vaa {
@@ -49,32 +51,46 @@ struct GradArgs {
 
 constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTilePx;  // ViT patch-embed tiling of the 224x224 frame
 
+#ifdef VAA_K2_TIMING
+__device__ long long* vaa_k2_dbg = nullptr;
+#endif
 constexpr int kImgsPerPass = 8;   // images whose row tables are built together (one barrier set per pass)
-constexpr int kFracBits = 26;     // |contribution| < 2^26 when the exponent is set, < 2^30 before a re-scale is forced
-constexpr int kGrowBits = 4;
+constexpr int kGBits = 22;        // |G| is quantised to 22 bits + sign relative to the workgroup's exponent, weights to 2^-22
 constexpr int kExpUnset = -100000;
+constexpr long kFlushPixels = 1l << 17;  // footprint pixels a tile may absorb before it is flushed (int64 headroom: 2^63 / 2^44 / 4)
 
 __device__ __forceinline__ long long shift_round(long long v, int d) {  // v / 2^d, round half up; d in [1, 62]
     return (v + (1ll << (d - 1))) >> d;
 }
 
+// round-to-nearest-even of x (|x| <= 2^22) to an integer through the fp32 adder: the low mantissa bits of x + 1.5*2^23 hold it
+__device__ __forceinline__ int rint_small(float x_times_scale_plus_magic) { return (int)(__float_as_uint(x_times_scale_plus_magic) - 0x4B400000u); }
+
+__device__ __forceinline__ unsigned long long mul_i24_i24(int a, int b) {  // exact 48-bit product of two 24-bit signed integers, two full-rate VALU ops
+    int lo, hi;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_mul_hi_i32_i24 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
 // Schedule: image b is owned by workgroup-row (b % gx); each workgroup-row is `split` workgroups that share the image's
 // footprint slots. Small batches use split > 1 to fill the chip.
 //
-// Footprint walk without any per-pixel search: the footprint rows [rmin, rmax] of an image are cut into 32-column
-// segments; one half-wave owns one (row, segment) slot at a time, so a lane needs ONE LDS read (packed {jlo,len} of its
-// row) to know its pixel. Slots are dealt round-robin to the half-waves of the workgroup-row.
-template <int NCH, bool TILED, bool MULTI, int THREADS>
+// Footprint walk without any per-pixel search: the footprint rows [rmin, rmax] of an image are cut into 64-column
+// segments starting at an even column; one half-wave owns one (row, segment) slot at a time and a lane owns TWO adjacent
+// pixels of it (one 4-byte load per gradient plane, one keep byte), so a lane needs ONE LDS read (packed {jlo,len} of its
+// row) to know its pixels. Slots are dealt round-robin to the half-waves of the workgroup-row.
+template <int NCH, bool TILED, bool MULTI, bool HASK, int THREADS, int K>
 __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a, int gx, int split) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    long long* tile = reinterpret_cast<long long*>(smem_raw);  // [NCH][band_rows][pw]
+    unsigned long long* tile = reinterpret_cast<unsigned long long*>(smem_raw);  // [band_rows*pw][NCH] (channels interleaved)
     __shared__ float bgrid[VAA_IMG];
-    __shared__ uint32_t row_word[kImgsPerPass][VAA_IMG];  // (jlo << 16) | len
+    __shared__ uint32_t row_word[kImgsPerPass][VAA_IMG];  // (jlo << 16) | len, jlo even
     __shared__ int row_min[kImgsPerPass], row_max[kImgsPerPass], len_max[kImgsPerPass];
     __shared__ uint32_t round_max[3];  // max |G| bits of a round, three slots in rotation (see the reset below)
     __shared__ int nonfinite;
-    constexpr int K = (NCH == 3) ? 4 : 8;   // slots (pixels) a thread holds per round
-    constexpr int HWS = THREADS / 32;       // half-waves per workgroup
+    constexpr int HWS = THREADS / 32;  // half-waves per workgroup
+    constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23
 
     const int tid = threadIdx.x;
     const int c_base = (NCH == 1) ? blockIdx.y : 0;
@@ -82,12 +98,42 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
     const int wg_row = blockIdx.x / split, chunk = blockIdx.x - wg_row * split;
     const int hw = chunk * HWS + (tid >> 5), nhw = split * HWS, hl = tid & 31;
     const int tile_elems = NCH * a.band_rows * a.pw;
-    for (int e = tid; e < tile_elems; e += THREADS) tile[e] = 0ll;
+    for (int e = tid; e < tile_elems; e += THREADS) tile[e] = 0ull;
     if (tid < VAA_IMG) bgrid[tid] = base_coord(tid);
     if (tid < 3) round_max[tid] = 0u;
     if (tid == 0) nonfinite = 0;
-    int E = kExpUnset;  // exponent of the tile's fixed-point format (workgroup-uniform): quantum = 2^(E + 1 - kFracBits)
+#ifdef VAA_K2_TIMING
+    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    long long tlast = wall_clock64();
+#define K2_STAMP(i) { const long long tn = wall_clock64(); tacc[i] += tn - tlast; tlast = tn; }
+#else
+#define K2_STAMP(i)
+#endif
+    int E = kExpUnset;  // exponent of the tile's fixed-point format (workgroup-uniform): quantum = 2^(E - 2*kGBits + 1)
     int rnd = 0;        // round counter (workgroup-uniform)
+    long absorbed = 0;  // footprint pixels added into the tile since the last flush (workgroup-uniform)
+    bool flushed = false;
+
+    // tile -> fp32 (this workgroup's partial, or in MULTI mode the image's own gradient), optionally accumulating, then zero the tile
+    auto drain = [&](float* dst, int ph, int pw, bool accumulate, bool rezero) {
+        // value = tile * quantum, formed as (hi * 2^32 + lo) * 2^q in fp64 (exact), then rounded once to fp32
+        const double quantum = (E == kExpUnset) ? 0.0 : __longlong_as_double((long long)(E - 2 * kGBits + 1 + 1023) << 52);
+        const bool poison = nonfinite != 0;
+        const int plane = ph * pw, rows = min(ph, v_lo + a.band_rows) - v_lo;
+        const int tp = rows * pw;
+        for (int el = tid; el < tp * NCH; el += THREADS) {  // channel-major walk: consecutive threads store consecutive floats of one plane
+            const int cc = (NCH == 1) ? 0 : el / tp, t = el - cc * tp;
+            float* o = dst + (size_t)(c_base + cc) * plane + v_lo * pw + t;
+            const unsigned long long raw = tile[t * NCH + cc];
+            const double d = __builtin_fma((double)(int)(raw >> 32), 4294967296.0, (double)(unsigned)raw);
+            const float v = (float)(d * quantum) + (accumulate ? *o : 0.0f);
+            *o = poison ? __uint_as_float(0x7fc00000u) : v;
+        }
+        if (rezero) {
+            __syncthreads();
+            for (int el = tid; el < tp * NCH; el += THREADS) tile[el] = 0ull;
+        }
+    };
 
     for (int b0 = wg_row; b0 < a.B; b0 += gx * kImgsPerPass) {
         int nimg = (a.B - b0 + gx - 1) / gx;  // images of this pass: b0, b0+gx, ...
@@ -129,6 +175,7 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
                     jlo = px;
                     jhi = px + pw - 1;
                 }
+                jlo &= ~1;  // a lane's pixel pair starts at an even column: one aligned 4-byte load per plane
                 len = max(0, jhi - jlo + 1);
                 row_word[q][i] = ((uint32_t)jlo << 16) | (uint32_t)len;
             }
@@ -140,6 +187,7 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
             }
         }
         __syncthreads();
+        K2_STAMP(0)
 
         for (int q = 0; q < nimg; ++q) {
             const int b = b0 + q * gx;
@@ -147,9 +195,8 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
             const int ph = MULTI ? a.pdesc[4 * b] : a.ph, pw = MULTI ? a.pdesc[4 * b + 1] : a.pw;
             const int plane = ph * pw;
             const int v_hi = min(ph, v_lo + a.band_rows);
-            const int tplane = a.band_rows * pw;  // elements of one channel of the tile
             if (nrows > 0 && v_lo < ph) {
-                const int nseg = (len_max[q] + 31) >> 5;                   // <= 7
+                const int nseg = (len_max[q] + 63) >> 6;                   // <= 4
                 const uint32_t inv_nseg = (65536u + nseg - 1) / nseg;      // exact floor(s/nseg) for s < 9362
                 const int nslots = nrows * nseg;
                 const int px = a.xy[2 * b], py = a.xy[2 * b + 1];          // workgroup-uniform -> scalar loads
@@ -160,145 +207,186 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
                 }
                 const float* pimg = MULTI ? a.patch + a.pdesc[4 * b + 2] : a.patch;
                 const uint16_t* gimg = a.g + (size_t)b * 6 * VAA_NPIX;
-                const uint8_t* kimg = a.keep ? a.keep + (size_t)b * 3 * (VAA_NPIX / 8) : nullptr;
+                const uint8_t* kimg = HASK ? a.keep + (size_t)b * 3 * (VAA_NPIX / 8) : nullptr;  // HASK: K1's keep bits are given
+                if (!MULTI && absorbed + (long)nslots * 64 > kFlushPixels) {  // int64 headroom (pathological zoom-outs / huge batches only)
+                    __syncthreads();
+                    drain(a.partial + (size_t)blockIdx.x * 3 * plane, ph, pw, flushed, true);
+                    flushed = true;
+                    absorbed = 0;
+                    __syncthreads();
+                }
+                absorbed += (long)nslots * 64;
 
                 for (int s0 = 0; s0 < nslots; s0 += nhw * K, ++rnd) {
-                    // ======== phase 1: K pixels per thread, every load issued before the first use ========
-                    // per pixel a thread keeps {w, n, tile offset + corner validity bits, G per channel}; the four corner weights
-                    // are formed again when it scatters
-                    float G[K][NCH], fw[K], fn[K];
-                    int t0v[K];           // nw corner in tile coordinates (can be out of range: validity bits decide)
-                    uint32_t flg[K];      // bit 0 active, 1..4 corner nw/ne/sw/se usable, 5..7 pixel-bit index, 8..10 kept (no-mask path)
+                    // ======== phase 1: K slots x 2 pixels per thread, every load issued before the first use ========
+                    // per pixel a thread keeps {w, n, tile offset, G per channel}; the four corner weights are formed again when it scatters
+                    float G[K][2][NCH], fw[K][2], fn[K][2];
+                    int t0v[K][2];      // nw corner in tile coordinates, {row - v_lo + 256, col + 256} packed (can be out of range: the validity bits decide)
+                    uint32_t flg[K];    // per pixel p (shift 8p): bit 0 inside, 1 uin0, 2 uin1, 3 vin0, 4 vin1, 5..7 kept per channel (no-mask path); bits 16..18 pix0 & 7
                     uint32_t kb[K][NCH], g0[K][NCH], g1[K][NCH];
-                    float gt[K][NCH];
+                    float gt[K][2][NCH];
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const int sidx = s0 + hw + k * nhw;
+                        flg[k] = 0u;
+                        if (s0 + (hw & ~1) + k * nhw >= nslots) continue;  // wave-uniform: neither half-wave has a slot left in this round
                         const int sc = min(sidx, nslots - 1);
                         const int r = (int)(((uint32_t)sc * inv_nseg) >> 16);
                         const int ks = sc - r * nseg;
                         const int i = rmin + r;
                         const uint32_t w = row_word[q][i];
-                        const int off = (ks << 5) + hl;
-                        const int j = min((int)(w >> 16) + off, VAA_IMG - 1);
-                        int x0 = j, y0 = i;
-                        float wf = 0.0f, nf = 0.0f;
-                        if (a.geometry) sample_pos_frac(bgrid[j], bgrid[i], th, x0, y0, wf, nf);
-                        fw[k] = wf; fn[k] = nf;
-                        const int u0 = x0 - px, v0 = y0 - py;
-                        const bool act = sidx < nslots && off < (int)(w & 0xffffu) && !(u0 < -1 || u0 >= pw || v0 < -1 || v0 >= ph);
-                        // corners off the patch, off this workgroup's row band or off the frame are never added
-                        const bool uin0 = u0 >= 0, uin1 = (u0 + 1 < pw) && (x0 + 1 < VAA_IMG);
-                        const bool vin0 = v0 >= v_lo && v0 < v_hi, vin1 = (v0 + 1 >= v_lo) && (v0 + 1 < v_hi) && (y0 + 1 < VAA_IMG);
-                        const int pix = i * VAA_IMG + j;
-                        uint32_t f = (act ? 1u : 0u) | ((vin0 && uin0) ? 2u : 0u) | ((vin0 && uin1) ? 4u : 0u) | ((vin1 && uin0) ? 8u : 0u) |
-                                     ((vin1 && uin1) ? 16u : 0u) | ((uint32_t)(pix & 7) << 5);
-                        t0v[k] = (v0 - v_lo) * pw + u0;
-                        if (act) {
-                            const uint16_t* gb = gimg + pix;
-                            const float* gtile = nullptr;
-                            if (TILED) {
+                        const int off = (ks << 6) + 2 * hl, len = (int)(w & 0xffffu);
+                        const bool lane_in = sidx < nslots && off < len;
+                        const int j0 = min((int)(w >> 16) + off, VAA_IMG - 2);  // even
+                        const int pix0 = i * VAA_IMG + j0;
+                        uint32_t f = (uint32_t)(pix0 & 7) << 16;
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const int j = j0 + p;
+                            int x0 = j, y0 = i;
+                            float wf = 0.0f, nf = 0.0f;
+                            if (a.geometry) sample_pos_frac(bgrid[j], bgrid[i], th, x0, y0, wf, nf);
+                            fw[k][p] = wf; fn[k][p] = nf;
+                            const int u0 = x0 - px, v0 = y0 - py;
+                            const bool inside = lane_in && (off + p < len) && !(u0 < -1 || u0 >= pw || v0 < -1 || v0 >= ph);
+                            // corners off the patch, off this workgroup's row band or off the frame get weight 0
+                            const bool uin0 = u0 >= 0, uin1 = (u0 + 1 < pw) && (x0 + 1 < VAA_IMG);
+                            const bool vin0 = v0 >= v_lo && v0 < v_hi, vin1 = (v0 + 1 >= v_lo) && (v0 + 1 < v_hi) && (y0 + 1 < VAA_IMG);
+                            uint32_t fp = (inside ? 1u : 0u) | (uin0 ? 2u : 0u) | (uin1 ? 4u : 0u) | (vin0 ? 8u : 0u) | (vin1 ? 16u : 0u);
+                            t0v[k][p] = ((min(max(v0 - v_lo, -255), 255) + 256) << 16) | (min(max(u0, -255), 255) + 256);
+                            if (!HASK && inside) {  // no stored mask: recompute it from the patch (test / stand-alone use)
+                                const Samp s = samp_from_frac(x0, y0, wf, nf);
+#pragma unroll
+                                for (int cc = 0; cc < NCH; ++cc) {
+                                    const int c = c_base + cc;
+                                    const float cv = a.geometry ? sample_canvas(pimg + c * plane, ph, pw, px, py, s)
+                                                                : canvas_at(pimg + c * plane, ph, pw, px, py, j, i);
+                                    if (keep_rule(cv, a.mask_mode)) fp |= 32u << cc;
+                                }
+                            }
+                            f |= fp << (8 * p);
+                            if (TILED && inside) {
                                 const int ty = i / kTilePx, tx = j / kTilePx;
                                 const int slot = a.tile_slot[b * (kTilesPerSide * kTilesPerSide) + ty * kTilesPerSide + tx];
                                 // slot < 0 only for pixels without any kept channel (their tile was not evaluated): read slot 0, never used
-                                gtile = a.geff + ((size_t)b * (kTilesPerSide * kTilesPerSide) + (slot < 0 ? 0 : slot)) * kTileElems +
-                                        (i - ty * kTilePx) * kTilePx + (j - tx * kTilePx);
-                            }
+                                const float* gtile = a.geff + ((size_t)b * (kTilesPerSide * kTilesPerSide) + (slot < 0 ? 0 : slot)) * kTileElems +
+                                                     (i - ty * kTilePx) * kTilePx + (j - tx * kTilePx);
 #pragma unroll
-                            for (int cc = 0; cc < NCH; ++cc) {
-                                const int c = c_base + cc;
-                                if (kimg) {
-                                    kb[k][cc] = kimg[(size_t)c * (VAA_NPIX / 8) + (pix >> 3)];
-                                } else {  // no stored mask: recompute it from the patch (test / stand-alone use)
-                                    const Samp s = samp_from_frac(x0, y0, wf, nf);
-                                    const float cv = a.geometry ? sample_canvas(pimg + c * plane, ph, pw, px, py, s)
-                                                                : canvas_at(pimg + c * plane, ph, pw, px, py, j, i);
-                                    if (keep_rule(cv, a.mask_mode)) f |= 256u << cc;
-                                }
-                                if (TILED) {
-                                    gt[k][cc] = gtile[c * (kTilePx * kTilePx)];
-                                } else {
-                                    g0[k][cc] = gb[(size_t)c * VAA_NPIX];
-                                    g1[k][cc] = gb[(size_t)(c + 3) * VAA_NPIX];
-                                }
+                                for (int cc = 0; cc < NCH; ++cc) gt[k][p][cc] = gtile[(c_base + cc) * (kTilePx * kTilePx)];
                             }
                         }
                         flg[k] = f;
+                        if (lane_in) {
+#pragma unroll
+                            for (int cc = 0; cc < NCH; ++cc) {
+                                const int c = c_base + cc;
+#ifndef VAA_K2_ABLATE_NO_LOADS
+                                if (HASK) kb[k][cc] = kimg[(size_t)c * (VAA_NPIX / 8) + (pix0 >> 3)];
+                                if (!TILED) {
+                                    g0[k][cc] = *reinterpret_cast<const uint32_t*>(gimg + (size_t)c * VAA_NPIX + pix0);
+                                    g1[k][cc] = *reinterpret_cast<const uint32_t*>(gimg + (size_t)(c + 3) * VAA_NPIX + pix0);
+                                }
+#else
+                                kb[k][cc] = 0xffu; g0[k][cc] = 0x3c003c00u + pix0; g1[k][cc] = 0x3c003c00u + c;  // ablation: no global loads
+#endif
+                            }
+                        }
                     }
+                    K2_STAMP(1)
                     float lmax = 0.0f;
                     bool bad = false;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
+                    for (int k = 0; k < K; ++k)
 #pragma unroll
-                        for (int cc = 0; cc < NCH; ++cc) {
-                            const int c = c_base + cc;
-                            float Gv = 0.0f;
-                            if (flg[k] & 1u) {
-                                const bool kept = kimg ? ((kb[k][cc] >> ((flg[k] >> 5) & 7u)) & 1u) : ((flg[k] >> (8 + cc)) & 1u);
-                                // d/d(im) of (im-mean)/std for both normalisations, fp32 exactly like autograd. Reciprocals are
-                                // rounded once on the host (exact for the 0.5 of the second normalisation, <= 1 ulp for the first).
-                                if (kept)
-                                    Gv = TILED ? gt[k][cc] : bf16_bits_to_f32(g0[k][cc]) * a.istd6[c] + bf16_bits_to_f32(g1[k][cc]) * a.istd6[c + 3];
+                        for (int p = 0; p < 2; ++p) {
+                            const uint32_t fp = flg[k] >> (8 * p);
+#pragma unroll
+                            for (int cc = 0; cc < NCH; ++cc) G[k][p][cc] = 0.0f;
+                            if (s0 + (hw & ~1) + k * nhw >= nslots) continue;  // wave-uniform
+#pragma unroll
+                            for (int cc = 0; cc < NCH; ++cc) {
+                                const int c = c_base + cc;
+                                float Gv = 0.0f;
+                                if (fp & 1u) {
+                                    const bool kept = HASK ? ((kb[k][cc] >> (((flg[k] >> 16) & 7u) + p)) & 1u) : ((fp >> (5 + cc)) & 1u);
+                                    // d/d(im) of (im-mean)/std for both normalisations, fp32 exactly like autograd. Reciprocals are
+                                    // rounded once on the host (exact for the 0.5 of the second normalisation, <= 1 ulp for the first).
+                                    if (kept) {
+                                        const float ga = __uint_as_float(p ? (g0[k][cc] & 0xffff0000u) : (g0[k][cc] << 16));
+                                        const float gb = __uint_as_float(p ? (g1[k][cc] & 0xffff0000u) : (g1[k][cc] << 16));
+                                        Gv = TILED ? gt[k][p][cc] : ga * a.istd6[c] + gb * a.istd6[c + 3];
+                                    }
+                                }
+                                if ((__float_as_uint(Gv) & 0x7fffffffu) >= 0x7f800000u) { bad = true; Gv = 0.0f; }  // inf / nan upstream: poisons the output
+                                G[k][p][cc] = Gv;
+                                lmax = fmaxf(lmax, fabsf(Gv));
                             }
-                            if ((__float_as_uint(Gv) & 0x7fffffffu) >= 0x7f800000u) { bad = true; Gv = 0.0f; }  // inf / nan upstream: poisons the output
-                            G[k][cc] = Gv;
-                            lmax = fmaxf(lmax, fabsf(Gv));
                         }
-                    }
                     lmax = wave_max(lmax);
                     if ((tid & 63) == 0 && lmax > 0.0f) atomicMax(&round_max[rnd % 3], __float_as_uint(lmax));
                     if (bad) nonfinite = 1;
                     // slot (rnd+1)%3 was last read after the barrier of round rnd-2, i.e. before every thread arrived at the barrier
                     // of round rnd-1, and is next written after this round's barrier: resetting it here races with neither
                     if (tid == 0) round_max[(rnd + 1) % 3] = 0u;
+                    K2_STAMP(2)
                     __syncthreads();
+                    K2_STAMP(3)
                     const uint32_t mbits = round_max[rnd % 3];
                     if (mbits == 0u) continue;  // nothing kept in this round (workgroup-uniform)
                     int e = (int)(mbits >> 23) - 127;  // floor(log2(max |G|)) (denormals: -127)
-                    e = max(e, -100);                  // keeps 2^(kFracBits - 1 - E) a normal float; such gradients are ~1e-30
+                    e = max(e, -100);                  // keeps 2^(kGBits - 1 - E) a normal float; such gradients are ~1e-30
                     if (E == kExpUnset) {
                         E = e;
-                    } else if (e > E + kGrowBits) {  // a much larger image: re-scale what the tile holds (rare; deterministic)
+                    } else if (e > E) {  // a larger image than any before: re-scale what the tile holds (rare; deterministic)
                         const int d = min(e - E, 62);
-                        for (int el = tid; el < tile_elems; el += THREADS) tile[el] = shift_round(tile[el], d);
+                        for (int el = tid; el < tile_elems; el += THREADS) tile[el] = (unsigned long long)shift_round((long long)tile[el], d);
                         E = e;
                         __syncthreads();
                     }
-                    // ======== phase 2: integer scatter ========
-                    const float scale = __uint_as_float((uint32_t)(kFracBits - 1 - E + 127) << 23);  // 2^(kFracBits-1-E)
+                    // ======== phase 2: integer scatter. contribution = rint(G*2^(21-E)) * rint(weight*2^22), exact 48-bit product ========
+                    const float gscale = __uint_as_float((uint32_t)(kGBits - 1 - E + 127) << 23);  // |G * gscale| < 2^22
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const Samp s = samp_from_frac(0, 0, fw[k], fn[k]);
-                        const float wq[4] = {s.nw, s.ne, s.sw, s.se};
-                        const int offs[4] = {t0v[k], t0v[k] + 1, t0v[k] + pw, t0v[k] + pw + 1};
+                    for (int k = 0; k < K; ++k)
 #pragma unroll
-                        for (int cc = 0; cc < NCH; ++cc) {
-                            unsigned long long* tb = reinterpret_cast<unsigned long long*>(tile) + cc * tplane;
+                        for (int p = 0; p < 2; ++p) {
+                            const uint32_t fp = flg[k] >> (8 * p);
+                            if (!(fp & 1u)) continue;  // pixel outside the footprint / the slot: nothing to add
+                            const float wf = fw[k][p], nf = fn[k][p];
+                            const float ee = 1.0f - wf, so = 1.0f - nf;
+                            const float wx0 = (fp & 2u) ? ee : 0.0f, wx1 = (fp & 4u) ? wf : 0.0f;
+                            const float wy0 = (fp & 8u) ? so : 0.0f, wy1 = (fp & 16u) ? nf : 0.0f;
+                            const float wt[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};  // the fp32 products grid_sample's backward forms
+                            // zero-weight corners (off the patch / band / frame) add 0 to a cell of the pixel's own neighbourhood: the
+                            // coordinates are clamped per axis, so lanes keep distinct addresses (a shared dummy cell would serialise)
+                            const int vr = (t0v[k][p] >> 16) - 256, uc = (t0v[k][p] & 0xffff) - 256;
+                            const int vmaxr = v_hi - v_lo - 1;
+                            const int u0c = min(max(uc, 0), pw - 1), u1c = min(max(uc + 1, 0), pw - 1);
+                            const int v0c = min(max(vr, 0), vmaxr) * pw, v1c = min(max(vr + 1, 0), vmaxr) * pw;
+                            const int offs[4] = {v0c + u0c, v0c + u1c, v1c + u0c, v1c + u1c};
+                            int wi[4];
+                            unsigned long long* tp[4];
 #pragma unroll
                             for (int cn = 0; cn < 4; ++cn) {
-                                const float prod = G[k][cc] * wq[cn];                    // fp32 product, as grid_sample's backward forms it
-                                const int ci = __float2int_rn(prod * scale);             // |.| < 2^30
-                                if (ci != 0 && ((flg[k] >> (1 + cn)) & 1u)) atomicAdd(tb + offs[cn], (unsigned long long)(long long)ci);
+                                wi[cn] = rint_small(__builtin_fmaf(wt[cn], 4194304.0f, kMagic));
+                                tp[cn] = tile + offs[cn] * NCH;
+                            }
+#pragma unroll
+                            for (int cc = 0; cc < NCH; ++cc) {
+                                const int Gi = rint_small(__builtin_fmaf(G[k][p][cc], gscale, kMagic));
+#pragma unroll
+#ifndef VAA_K2_ABLATE_NO_ATOMICS
+                                for (int cn = 0; cn < 4; ++cn) atomicAdd(tp[cn] + cc, mul_i24_i24(Gi, wi[cn]));
+#else
+                                for (int cn = 0; cn < 4; ++cn) if (mul_i24_i24(Gi, wi[cn]) == 0x123456789ull) tp[cn][cc] = 1ull;  // ablation: keep the arithmetic, drop the LDS atomics
+#endif
                             }
                         }
-                    }
+                    K2_STAMP(4)
                 }
             }
             if (MULTI) {  // per-image output: write this image's band of d L / d (its own patch), reset the tile
                 __syncthreads();
-                const double quantum = (E == kExpUnset) ? 0.0 : __longlong_as_double((long long)(E + 1 - kFracBits + 1023) << 52);
-                const bool poison = nonfinite != 0;
-                if (v_lo < ph) {
-                    float* dst = a.partial + a.pdesc[4 * b + 2];
-                    const int rows = v_hi - v_lo;
-#pragma unroll 1
-                    for (int cc = 0; cc < NCH; ++cc)
-                        for (int el = tid; el < rows * pw; el += THREADS) {
-                            const float v = (float)((double)tile[cc * tplane + el] * quantum);
-                            dst[(size_t)(c_base + cc) * plane + v_lo * pw + el] = poison ? __uint_as_float(0x7fc00000u) : v;
-                            tile[cc * tplane + el] = 0ll;
-                        }
-                }
+                if (v_lo < ph) drain(a.partial + a.pdesc[4 * b + 2], ph, pw, false, true);
                 __syncthreads();
                 E = kExpUnset;
                 if (tid == 0) nonfinite = 0;
@@ -307,27 +395,25 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
     }
     if (MULTI) return;
     __syncthreads();
-    const double quantum = (E == kExpUnset) ? 0.0 : __longlong_as_double((long long)(E + 1 - kFracBits + 1023) << 52);
-    const bool poison = nonfinite != 0;
-    const int plane = a.ph * a.pw, rows = min(a.ph, v_lo + a.band_rows) - v_lo;
-    float* dst = a.partial + (size_t)blockIdx.x * 3 * plane;
-    for (int cc = 0; cc < NCH; ++cc)
-        for (int el = tid; el < rows * a.pw; el += THREADS) {
-            const float v = (float)((double)tile[cc * a.band_rows * a.pw + el] * quantum);
-            dst[(size_t)(c_base + cc) * plane + v_lo * a.pw + el] = poison ? __uint_as_float(0x7fc00000u) : v;
-        }
+    drain(a.partial + (size_t)blockIdx.x * 3 * a.ph * a.pw, a.ph, a.pw, flushed, false);
+#ifdef VAA_K2_TIMING
+    K2_STAMP(5)
+    if ((tid & 63) == 0 && a.geff == nullptr && vaa_k2_dbg)
+        for (int z = 0; z < 6; ++z) vaa_k2_dbg[((size_t)blockIdx.x * 16 + (tid >> 6)) * 6 + z] = tacc[z];
+#endif
 }
 
 // gpatch[e] = sum_p partial[p][e] in a fixed two-level order (16 interleaved slices, then slice 0..15), fp64.
-// A thread owns four consecutive elements (16 B loads); workgroup = 64 element-quads x 16 slices.
-__global__ __launch_bounds__(1024) void patch_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gpatch,
-                                                                  int n, int nparts) {
-    __shared__ double sl[16][64][4];
-    const int el = threadIdx.x & 63, s = threadIdx.x >> 6;
-    const int e = (blockIdx.x * 64 + el) * 4;
+// A thread owns four consecutive elements (16 B loads); workgroup = 16 element-quads x 16 slices (64 elements), so a 3x50x50
+// gradient is 118 workgroups and the partial tiles are pulled by that many CUs at once.
+__global__ __launch_bounds__(256) void patch_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gpatch,
+                                                                 int n, int nparts) {
+    __shared__ double sl[16][16][4];
+    const int el = threadIdx.x & 15, s = threadIdx.x >> 4;
+    const int e = (blockIdx.x * 16 + el) * 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     if (e + 3 < n && (n & 3) == 0) {
-#pragma unroll 4
+#pragma unroll 8
         for (int p = s; p < nparts; p += 16) {
             const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)p * n + e);
             acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
@@ -341,7 +427,7 @@ __global__ __launch_bounds__(1024) void patch_grad_reduce_kernel(const float* __
 #pragma unroll
     for (int z = 0; z < 4; ++z) sl[s][el][z] = acc[z];
     __syncthreads();
-    if (s < 4) {  // slice s of the second level sums element z = s of every quad
+    if (s < 4) {  // thread (s, el) of the second level sums element z = s of quad el
         const int z = s;
         if (e + z < n) {
             double t = 0.0;
@@ -353,7 +439,7 @@ __global__ __launch_bounds__(1024) void patch_grad_reduce_kernel(const float* __
 }
 
 int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts, hipStream_t st, const char* who) {
-    hipLaunchKernelGGL(patch_grad_reduce_kernel, dim3((n + 255) / 256), dim3(1024), 0, st, partial, gpatch, n, nparts);
+    hipLaunchKernelGGL(patch_grad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, partial, gpatch, n, nparts);
     return check_launch(who);
 }
 
@@ -366,6 +452,7 @@ static GradSched grad_sched(int B) {
     g.gx = B < 512 ? B : 512;
     // two workgroups per image while the batch alone cannot fill the chip
     g.split = (B <= 256) ? 2 : 1;
+    if (const char* e = getenv("VAA_K2_SPLIT")) g.split = atoi(e) > 0 ? atoi(e) : g.split;  // tuning experiments only
     return g;
 }
 
@@ -387,15 +474,23 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
     hipError_t e = hipSuccess;
     if (3 * plane * sizeof(long long) <= 64 * 1024) {  // e.g. 50x50: 60,000 B
         a.band_rows = ph;
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, 1024>), dim3(G), dim3(1024), 3 * plane * sizeof(long long), st, a, gs.gx, gs.split);
+        if (a.keep)
+            hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, true, 1024, 3>), dim3(G), dim3(1024), 3 * plane * sizeof(long long), st, a, gs.gx, gs.split);
+        else
+            hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, false, 1024, 3>), dim3(G), dim3(1024), 3 * plane * sizeof(long long), st, a, gs.gx, gs.split);
     } else {  // one channel per workgroup (grid.y), row bands (grid.z) when even one plane exceeds the LDS (> 135x135)
         a.band_rows = band_rows_for(ph, pw);
         const int nbands = (ph + a.band_rows - 1) / a.band_rows;
         const size_t bytes = (size_t)a.band_rows * pw * sizeof(long long);
-        if (bytes > 64 * 1024)
-            e = hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<1, TILED, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e == hipSuccess)
-            hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, 1024>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx, gs.split);
+        const void* fn = a.keep ? (const void*)patch_grad_scatter_kernel<1, TILED, false, true, 1024, 3>
+                                : (const void*)patch_grad_scatter_kernel<1, TILED, false, false, 1024, 3>;
+        if (bytes > 64 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) {
+            if (a.keep)
+                hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, true, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx, gs.split);
+            else
+                hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, false, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx, gs.split);
+        }
     }
     if (e != hipSuccess) {
         set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
@@ -407,6 +502,10 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
 }
 
 }  // namespace vaa
+
+#ifdef VAA_K2_TIMING
+extern "C" int vaa_k2_set_debug(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(vaa::vaa_k2_dbg), &p, sizeof(p)); }
+#endif
 
 extern "C" size_t vaa_patch_grad_ws_bytes(int B, int ph, int pw) {
     if (B <= 0 || ph <= 0 || pw <= 0) return 0;
@@ -475,12 +574,16 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.band_rows = band_rows_for(max_h, max_w);
     const int nbands = (max_h + a.band_rows - 1) / a.band_rows;
     const size_t bytes = (size_t)a.band_rows * max_w * sizeof(long long);
-    if (bytes > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)patch_grad_scatter_kernel<1, false, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    const void* fn = keep_bits ? (const void*)patch_grad_scatter_kernel<1, false, true, true, 1024, 3>
+                               : (const void*)patch_grad_scatter_kernel<1, false, true, false, 1024, 3>;
+    if (bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
         set_error("vaa_patch_grad_gather_multi: hipFuncSetAttribute failed");
         return VAA_E_LAUNCH;
     }
-    hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, 1024>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B, 1);
+    if (keep_bits)
+        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, true, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B, 1);
+    else
+        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, false, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B, 1);
     return check_launch("vaa_patch_grad_gather_multi");
 }
 
