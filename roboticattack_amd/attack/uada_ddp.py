@@ -107,15 +107,15 @@ class OpenVLAAttacker(AttackBase):
 
             self._tma_target = tma_target_tokens(float(self.target_action) * torch.ones(7).numpy(), self.maskidx, self.action_tokenizer).to(dev)
         sync = vdist.PatchGradSync(patch.numel(), 4, dev)
+        pick = torch.tensor([1, 2, 7], dtype=torch.int64, device=dev)  # CE, w^2*MSE (or the attack loss), UAD of K3's scalars
         inv_world = 1.0 / world_size
-        log_max_grad = 0.0
+        inv_n = 1.0 / patch.numel()
 
         for i, data in enumerate(self.train_loader):
             if i == self.num_iter:
                 break
             pixel_values, labels, attention_mask, input_ids = to_dev(data, dev)
             labels = self._prepare_labels(labels)
-            local_stats = None
             for inner_loop in range(self.innerLoop):
                 optimizer.zero_grad()
                 pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
@@ -123,13 +123,13 @@ class OpenVLAAttacker(AttackBase):
                 total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, self._loss_mode(), w=float(self.MSE_weights),
                                                        alpha=self.alpha, beta=self.belta)
                 total.backward()  # K2 inside
-                local_stats = (patch.grad.mean(), scalars)
-                # C3 + C4 in one message: [grad | CE, MSE, UAD, mean-grad]
-                g_sum, s_sum = sync.allreduce(patch.grad, torch.stack([scalars[1], scalars[2], scalars[7], patch.grad.mean()]))
+                local_grad_sum = patch.grad.sum() if inner_loop == self.innerLoop - 1 else None  # logged once per outer iteration
+                # C3 + C4 in one message: [grad | CE, MSE, UAD, sum(grad)]
+                g_sum, s_sum = sync.allreduce_step(patch.grad, scalars, pick)
                 optimizer.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4, DDP mean folded in
             scheduler.step()
             s = (s_sum * inv_world).cpu().numpy()
-            log_patch_grad = vdist.allreduce_scalar(float(local_stats[0].item()), "MAX", dev)  # UADA_ddp.py:216-217
+            log_patch_grad = vdist.allreduce_scalar(float(local_grad_sum.item()) * inv_n, "MAX", dev)  # UADA_ddp.py:216-217
             train_logdata = {"TRAIN_attack_loss(CE)": float(s[0]), "TRAIN_patch_gradient": log_patch_grad,
                              "TRAIN_LR": optimizer.param_groups[0]["lr"], "TRAIN_attack_loss (MSE_Distance)": float(s[1]),
                              "TRAIN_UAD": float(s[2])}

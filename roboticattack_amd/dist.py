@@ -25,7 +25,9 @@ def init_process_group(backend: str | None = None, device: torch.device | None =
     rank, world, local = env_rank_world()
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # VAA_DIST_BACKEND=gloo runs the same loop with gloo moving the (GPU-resident) buffers through the host: several ranks
+            # can then share ONE GPU, which is how the N > 1 path is tested on a single-GPU box (tests/test_gpu_attack.py)
+            backend = os.environ.get("VAA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -56,6 +58,18 @@ class PatchGradSync:
         self.buf[: self.n_grad].copy_(grad.reshape(-1))
         if scalars is not None and self.n_scalars:
             self.buf[self.n_grad :].copy_(scalars.reshape(-1)[: self.n_scalars])
+        if self.world > 1:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+        return self.buf[: self.n_grad], self.buf[self.n_grad :]
+
+    def allreduce_step(self, grad: torch.Tensor, loss_scalars: torch.Tensor, pick: torch.Tensor):
+        """One inner step's message [grad | loss_scalars[pick] | sum(grad)] packed with three small launches (copy, gather, sum)
+        instead of the copy/copy/stack/mean chain, then ONE all-reduce(sum). `pick` is an int64 device index of n_scalars-1 entries;
+        the last slot carries sum(grad) (the caller divides by numel for the logged mean gradient)."""
+        g = grad.reshape(-1)
+        self.buf[: self.n_grad].copy_(g)
+        torch.index_select(loss_scalars, 0, pick, out=self.buf[self.n_grad : self.n_grad + pick.numel()])
+        torch.sum(g.view(1, -1), dim=1, out=self.buf[self.n_grad + pick.numel() : self.n_grad + pick.numel() + 1])
         if self.world > 1:
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
         return self.buf[: self.n_grad], self.buf[self.n_grad :]

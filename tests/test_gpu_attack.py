@@ -285,6 +285,115 @@ def test_ddp_attacker_single_rank(tmp_path, attack, monkeypatch):
     assert os.path.exists(os.path.join(str(tmp_path), "0", "patch.pt"))
 
 
+def _two_rank_worker(rank, world, port, out_dir, attack, num_iter, inner, bs):
+    """One rank of the PRODUCT data-parallel attacker; both ranks share cuda:0, gloo carries the all-reduce through the host."""
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      VAA_DIST_BACKEND="gloo")
+    from roboticattack_amd import optim
+    from roboticattack_amd.attack.uada_ddp import OpenVLAAttacker
+
+    _seed()  # UADA_wrapper_ddp.py:53: every rank seeds 42
+    snaps = []
+    orig = optim.PatchOptimizer.step
+
+    def rec(self, *a, **k):
+        r = orig(self, *a, **k)
+        snaps.append(self.patch.detach().cpu().numpy().copy())
+        return r
+
+    optim.PatchOptimizer.step = rec
+    OpenVLAAttacker.val_batches = 1
+    params = dict(vla_path="surrogate:3", dataset_name="synthetic", save_dir=os.path.join(out_dir, f"rank{rank}"), resize_patch=False,
+                  patch_size=[3, 50, 50], lr=0.03, bs=bs, warmup=1, num_iter=num_iter, maskidx=[0] if attack == "UADA" else [0, 1, 2],
+                  innerLoop=inner, geometry=True, use_wandb=False, MSE_weights=5, device=torch.device("cuda:0"))
+    if attack != "UADA":
+        params.update(attack_type=attack, target_action=0.25)
+    att = OpenVLAAttacker(**params)
+    patch = att.attack(rank, world)
+    np.savez(os.path.join(out_dir, f"ddp_r{rank}.npz"), snaps=np.stack(snaps), final=patch.detach().cpu().numpy(),
+             log=np.array([att.last_train_log[k] for k in sorted(att.last_train_log)], np.float64))
+
+
+def _single_process_two_shard_reference(attack, num_iter, inner, bs, world=2):
+    """What N ranks must equal: ONE process computes every rank's shard gradient with that rank's data
+    and the rank-identical RNG stream (every rank seeds 42), sums them in rank order, and applies the mean through K4."""
+    import random
+
+    from roboticattack_amd import ops
+    from roboticattack_amd.attack.engine import AttackBase, to_dev
+    from roboticattack_amd.attack.uada_ddp import default_dataset_factory
+    from roboticattack_amd.labels import mask_labels, tma_target_labels, tma_target_tokens
+    from roboticattack_amd.optim import CosineWarmupSchedule, PatchOptimizer
+    from roboticattack_amd.surrogate import SurrogateVLA
+
+    _seed()
+    base = AttackBase(SurrogateVLA(seed=3).to(DEV), None, "", "adamW", False)
+    t = base.randomPatchTransform
+    patch = torch.rand([3, 50, 50]).to(DEV).requires_grad_(True)
+    opt = PatchOptimizer(patch, 0.03, "adamW", l1_clip=1e-3 if attack == "UPA" else 0.0)
+    sched = CosineWarmupSchedule(opt, 1, num_iter, 0.5)
+    mode = {"UADA": ops.LOSS_UADA_DDP, "UPA": ops.LOSS_UPA, "TMA": ops.LOSS_CE}[attack]
+    maskidx = [0] if attack == "UADA" else [0, 1, 2]
+    tgt = tma_target_tokens(0.25 * np.ones(7), maskidx, base.action_tokenizer).to(DEV) if attack == "TMA" else None
+    loaders = [default_dataset_factory("synthetic", bs, r, world) for r in range(world)]
+    its = [iter(l[0]) for l in loaders]
+    snaps = []
+    for i in range(num_iter):
+        shards = []
+        for r in range(world):
+            pv, labels, am, ids = to_dev(next(its[r]), DEV)
+            labels = mask_labels(labels, maskidx) if attack == "UADA" else (tma_target_labels(labels, tgt) if attack == "TMA" else labels)
+            shards.append((list(pv), labels, am, ids))  # a fresh list per shard: the transform stages frames per list object
+        for _ in range(inner):
+            st = (random.getstate(), np.random.get_state())
+            gsum = torch.zeros_like(patch)
+            for (pv, labels, am, ids) in shards:
+                random.setstate(st[0])
+                np.random.set_state(st[1])  # every rank consumes the same draws
+                opt.zero_grad()
+                pix = t.apply_random_patch_batch(pv, patch, mean=base.mean, std=base.std, geometry=True)
+                total, _, _ = base.model_loss(ids, am, pix, labels, mode, w=5.0, alpha=0.8, beta=0.2)
+                total.backward()
+                gsum += patch.grad
+            opt.step(grad=gsum, grad_scale=1.0 / world)
+            snaps.append(patch.detach().cpu().numpy().copy())
+        sched.step()
+        if i % 200 == 0:  # the validation pass of UADA_ddp.py:233 draws placements too (val_batches = 1 in this test)
+            t._draw(bs, 50, 50, True)
+    return np.stack(snaps)
+
+
+@pytest.mark.parametrize("attack", ["UADA", "UPA", "TMA"])
+def test_ddp_attacker_two_ranks_vs_single_process(tmp_path, attack):
+    """The product data-parallel loop (UADA_ddp.py:138-221 mirror) with WORLD_SIZE = 2: two processes share the one GPU of the test box
+    (VAA_DIST_BACKEND=gloo). After EVERY inner step both ranks hold bit-identical patches, and the trajectory equals the single-process
+    run that averages the two shard gradients (<= 1e-4, north-star tolerance). UPA / TMA are the extensions of SURVEY.md section 8e."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    num_iter, inner, bs = 3, 3, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), attack, num_iter, inner, bs), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "ddp_r0.npz"), np.load(tmp_path / "ddp_r1.npz")
+    assert r0["snaps"].shape == (num_iter * inner, 3, 50, 50)
+    assert np.array_equal(r0["snaps"], r1["snaps"]), "ranks must stay bit-identical after every inner step"
+    assert np.array_equal(r0["final"], r1["final"]) and np.array_equal(r0["log"], r1["log"])
+    ref = _single_process_two_shard_reference(attack, num_iter, inner, bs)
+    err = np.abs(r0["snaps"] - ref).reshape(len(ref), -1).max(1)
+    assert err.max() <= 1e-4, err
+    assert np.abs(ref[-1] - ref[inner - 1]).max() > 1e-3  # the patch really moved (lr = 0 only during outer iteration 0)
+    assert os.path.exists(tmp_path / "rank0" / "last" / "patch.pt") and not os.path.exists(tmp_path / "rank1" / "last")  # rank 0 writes
+
+
 def test_patch_embed_grad_path_matches_pixel_grad_path(monkeypatch):
     """SURVEY.md 8f-3 end to end: one UADA step with the patch-embed backward restricted to the kept tiles (K2') gives the same loss and
     the same patch gradient as the path through the dense bf16 pixel gradient (K2)."""
