@@ -202,10 +202,10 @@ def main():
                 logits = model.forward_rows(input_ids, None, labels, row_index, patch_embeds=pix, pack=pack)
             else:
                 logits = model.forward_rows(input_ids, pix, labels, row_index, pack=pack)
-            total, scalars, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
+            total, scalars, _, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
         else:
             out = model(input_ids=input_ids, attention_mask=attn, pixel_values=pix, labels=None)
-            total, scalars, _ = ops.DiscrepancyLoss.apply(out.logits.contiguous(), labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
+            total, scalars, _, _ = ops.DiscrepancyLoss.apply(out.logits.contiguous(), labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
         total.backward()  # ... -> K2 (or K2' fed by the patch-embed output gradients)
         g_sum, _ = sync.allreduce(patch.grad, torch.stack([scalars[1], scalars[2], scalars[7], patch.grad.mean()]))
         opt.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4

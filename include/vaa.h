@@ -53,6 +53,10 @@ extern "C" {
 #define VAA_LAYOUT_FULL 0 /* [B,S,V], S = 256 + L: row (b, S-L+k) predicts labels[b,k+1] (HF shift; UADA.py:385) */
 #define VAA_LAYOUT_ROWS 1 /* [R,V]: only the labelled rows, in (b,k) row-major order of labels[b,k+1] != -100 */
 
+/* gradient storage of vaa_loss_rows_fwd_bwd */
+#define VAA_GRAD_FULL 0  /* [R,V], the logits' dtype */
+#define VAA_GRAD_SLICE 1 /* [R,256]: the action columns 31744..31999 only (UADA_DDP / UPA: the gradient is zero elsewhere) */
+
 /* optimiser modes (K4) */
 #define VAA_OPT_ADAMW_HF 0 /* transformers==4.40.1 AdamW.step (eps outside bias correction) + clamp(0,1)  UADA.py:155-156 */
 #define VAA_OPT_PGD_SIGN 1 /* p = clamp(p - lr*sign(g), 0, 1)                                            TMA.py:171-175 */
@@ -123,8 +127,8 @@ int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const float* packed, 
  * K3 — replaces HF Llama's `.loss` (via modeling_prismatic.py:404-415) + OpenVLAAttacker.weighted_loss
  * (UADA.py:381-406, UADA_ddp.py:99-124, UPA.py:367-387) and their autograd backward to the logits.
  *   logits   dev  f32|bf16, layout FULL [B,S,V] or ROWS [R,V]. For ROWS pass S = R (the number of rows, which must equal the number
- *             of labelled positions) to get the row-indexed schedule (one workgroup per row, loads issued before the labels are
- *             consulted); S = 0 (unknown) keeps the label-driven schedule
+ *             of labelled positions): the call then builds the row map in `ws` and runs vaa_loss_rows_fwd_bwd (below); S = 0 (unknown)
+ *             keeps the label-driven schedule
  *   labels   dev  [B,L] int64, already masked by the caller (mask_labels, UADA.py:371-379)
  *   params   host [4] float32: {w (MSE weight: 5 or --MSE_weights), alpha, beta, scale (1/accumulate_steps)}
  *   scalars  dev  [8] float32 out: {total, CE, w^2*MSE, aux0 (UPA angle), aux1 (UPA dist), #CE rows, #action rows, UAD}
@@ -138,6 +142,34 @@ size_t vaa_loss_ws_bytes(int B, int L);
 int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const int64_t* labels, int B, int S, int L, int V, int mode,
                      const float* params, float* scalars, int32_t* pred_tokens, void* glogits, void* ws, size_t ws_bytes,
                      void* stream);
+/* The same with one more output: pred_full_tokens dev [B*(L-1)] or NULL = argmax over ALL V logits of every labelled row
+ * (`action_logits.argmax(dim=2)`, UADA.py:165-167, TMA.py:148-149: what the reference's relative-distance / L1 / ASR metrics and the
+ * best-patch selection read), -1 on unlabelled positions. pred_tokens stays the action-slice argmax that feeds UAD (UADA.py:395). */
+int vaa_loss_fwd_bwd_ex(const void* logits, int dtype, int layout, const int64_t* labels, int B, int S, int L, int V, int mode,
+                        const float* params, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, void* glogits, void* ws,
+                        size_t ws_bytes, void* stream);
+
+/*
+ * K3 on the labelled rows with a prebuilt row map (LM head + loss on labelled rows only) — what the attack
+ * loops use: labels are fixed during the innerLoop steps of an outer iteration (UADA.py:130-133), so the map is built once per outer
+ * iteration and a step never touches the label matrix.
+ *   vaa_loss_rowmap_build: rowmap dev (>= vaa_loss_rowmap_bytes(B,L)) = int32 {R, #action rows, 0, 0} followed by {b, k, label, ord}
+ *             per labelled position in (b,k) row-major order of labels[b,k+1] != -100 (the order of VAA_LAYOUT_ROWS).
+ *   vaa_loss_rows_fwd_bwd: logits dev [R,V] f32|bf16 in that order; R (host) must equal the map's count (else scalars[0] = NaN).
+ *             pred_tokens      dev [B*(L-1)] or NULL: 31744 + argmax of the 256 action logits (UADA.py:395, feeds UAD); -1 elsewhere
+ *             pred_full_tokens dev [B*(L-1)] or NULL: argmax over ALL V logits (`action_logits.argmax(dim=2)`, UADA.py:165-167,
+ *                              TMA.py:148-149: relative distance, L1 / ASR metrics, best-patch selection); -1 on unlabelled positions
+ *             grad dev or NULL, grad_kind VAA_GRAD_FULL [R,V] | VAA_GRAD_SLICE [R,256] (only for UADA_DDP / UPA, whose gradient is
+ *                              confined to the action columns: the LM-head backward then contracts over 256 columns, not 32,064)
+ *             ws >= vaa_loss_rows_ws_bytes(R). Rows are split over 2-4 workgroups so that 128 rows fill the 256 CUs; in UADA_DDP
+ *             mode the gradient is written by the same pass that reads the logits.
+ */
+size_t vaa_loss_rowmap_bytes(int B, int L);
+int vaa_loss_rowmap_build(const int64_t* labels, int B, int L, void* rowmap, size_t rowmap_bytes, void* stream);
+size_t vaa_loss_rows_ws_bytes(int R);
+int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int R, int B, int L, int V, int mode, const float* params,
+                          float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, void* grad, int grad_kind, void* ws,
+                          size_t ws_bytes, void* stream);
 
 /*
  * K2' (optional) — K2 fed by the gradient of the ViT patch-embed OUTPUTS instead of the pixel gradient: the

@@ -16,6 +16,7 @@ MASK_LT_M20, MASK_NE_M100 = 0, 1
 LOSS_UADA, LOSS_UADA_DDP, LOSS_UPA, LOSS_CE = 0, 1, 2, 3
 DTYPE_F32, DTYPE_BF16 = 0, 1
 LAYOUT_FULL, LAYOUT_ROWS = 0, 1
+GRAD_FULL, GRAD_SLICE = 0, 1
 OPT_ADAMW_HF, OPT_PGD_SIGN = 0, 1
 
 MODEL_OP_EXPORTS = ("vaa_model_rope", "vaa_model_swiglu_fwd", "vaa_model_swiglu_bwd", "vaa_model_rmsnorm_fwd", "vaa_model_rmsnorm_bwd",
@@ -30,6 +31,7 @@ EXPORTS = (
     "vaa_patch_grad_gather",
     "vaa_loss_ws_bytes",
     "vaa_loss_fwd_bwd",
+    "vaa_loss_fwd_bwd_ex",
     "vaa_patch_update",
     "vaa_patch_apply_eval",
     "vaa_patch_embed_grad_ws_bytes",
@@ -39,6 +41,10 @@ EXPORTS = (
     "vaa_patch_resize_bwd",
     "vaa_patch_apply_fwd_multi",
     "vaa_patch_grad_gather_multi",
+    "vaa_loss_rowmap_bytes",
+    "vaa_loss_rowmap_build",
+    "vaa_loss_rows_ws_bytes",
+    "vaa_loss_rows_fwd_bwd",
 )
 
 
@@ -116,6 +122,16 @@ def lib() -> C.CDLL:
     L.vaa_loss_ws_bytes.argtypes = [i32, i32]
     L.vaa_loss_fwd_bwd.restype = i32
     L.vaa_loss_fwd_bwd.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, vp, vp, sz, vp]
+    L.vaa_loss_fwd_bwd_ex.restype = i32
+    L.vaa_loss_fwd_bwd_ex.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, vp, vp, vp, sz, vp]
+    L.vaa_loss_rowmap_bytes.restype = sz
+    L.vaa_loss_rowmap_bytes.argtypes = [i32, i32]
+    L.vaa_loss_rowmap_build.restype = i32
+    L.vaa_loss_rowmap_build.argtypes = [vp, i32, i32, vp, sz, vp]
+    L.vaa_loss_rows_ws_bytes.restype = sz
+    L.vaa_loss_rows_ws_bytes.argtypes = [i32]
+    L.vaa_loss_rows_fwd_bwd.restype = i32
+    L.vaa_loss_rows_fwd_bwd.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, vp, vp, i32, vp, sz, vp]
     L.vaa_patch_update.restype = i32
     L.vaa_patch_update.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp, vp]
     L.vaa_patch_apply_eval.restype = i32

@@ -58,30 +58,43 @@ class AttackBase:
 
     # ---- the model + loss leg of a step ----
     def model_loss(self, input_ids, attention_mask, pix, labels, mode, w=5.0, alpha=0.8, beta=0.2, scale=1.0, need_grad=True):
-        """Returns (total [autograd scalar or None], scalars f32[8] device, pred i32 [B,L-1] device)."""
+        """Returns (total [autograd scalar or None], scalars f32[8] device, pred i32 [B,L-1] device).
+
+        `pred` is the argmax over the WHOLE vocabulary at every labelled position (-1 elsewhere), i.e. the reference's
+        `action_logits.argmax(dim=2)` (UADA.py:165-167, TMA.py:148-149) that its relative-distance / L1 / ASR metrics and the
+        best-patch selection read; the action-slice argmax of UADA.py:395 only feeds UAD, which K3 reports in scalars[7]."""
         if self.use_rows:
-            # labels are fixed during an outer iteration: the row index (one host sync) is cached per tensor OBJECT; the
-            # cache holds a reference, so identity cannot be recycled by the allocator, and in-place edits bump _version
+            # labels are fixed during an outer iteration: the row index (one host sync) and the device row map of K3 are cached per
+            # tensor OBJECT; the cache holds a reference, so identity cannot be recycled by the allocator, and in-place edits bump _version
             if getattr(self, "_row_ref", None) is not labels or self._row_ver != labels._version:
                 self._row_ref, self._row_ver, self._row_index = labels, labels._version, self.vla.label_row_index(labels)
+                self._row_map = ops.LossRowMap(labels)
             pack = None
             if hasattr(self.vla, "make_pack") and attention_mask is not None:  # drop the padding rows (cached like the row index)
                 if getattr(self, "_pack_ref", None) is not attention_mask or self._pack_ver != attention_mask._version:
                     self._pack_ref, self._pack_ver, self._pack = attention_mask, attention_mask._version, self.vla.make_pack(attention_mask)
                 pack = self._pack
-            if isinstance(pix, ops.PatchEmbeds):  # patched batch handed over as patch-embed outputs (pixel gradient never built)
-                logits = self.vla.forward_rows(input_ids, None, labels, self._row_index, patch_embeds=pix, pack=pack)
-            else:
-                logits = self.vla.forward_rows(input_ids, pix, labels, self._row_index, pack=pack)
-            layout = ops.LAYOUT_ROWS
-        else:
-            out = self.vla(input_ids=input_ids, attention_mask=attention_mask, pixel_values=pix, labels=None)
-            logits = out.logits
-            layout = ops.LAYOUT_FULL
+            pe = pix if isinstance(pix, ops.PatchEmbeds) else None  # patched batch handed over as patch-embed outputs (pixel gradient never built)
+            if need_grad and hasattr(self.vla, "hidden_rows"):
+                # LM head + loss on the labelled rows (SURVEY.md section 8f-2): the head's backward contracts over the 256 action
+                # columns when the loss lives there (UADA_DDP, UPA)
+                h = self.vla.hidden_rows(input_ids, None if pe is not None else pix, self._row_index, patch_embeds=pe, pack=pack)
+                total, scalars, _, pred_full = ops.HeadLossRows.apply(h, self.vla.lm_head.weight, self._row_map, mode, w, alpha, beta, scale)
+                return total, scalars, pred_full
+            logits = self.vla.forward_rows(input_ids, None if pe is not None else pix, labels, self._row_index, patch_embeds=pe, pack=pack)
+            if need_grad:
+                total, scalars, _, pred_full = ops.DiscrepancyLossRows.apply(logits.contiguous(), self._row_map, mode, w, alpha, beta, scale)
+                return total, scalars, pred_full
+            scalars, _, pred_full, _ = ops.loss_rows_fwd_bwd(logits.detach().contiguous(), self._row_map, mode, w, alpha, beta, scale, want_grad=False)
+            return None, scalars, pred_full
+        out = self.vla(input_ids=input_ids, attention_mask=attention_mask, pixel_values=pix, labels=None)
+        logits = out.logits
         if need_grad:
-            return ops.DiscrepancyLoss.apply(logits.contiguous(), labels, mode, w, alpha, beta, scale, layout)
-        scalars, pred, _ = ops.loss_fwd_bwd(logits.detach().contiguous(), labels, mode, w, alpha, beta, scale, layout, want_grad=False)
-        return None, scalars, pred
+            total, scalars, _, pred_full = ops.DiscrepancyLoss.apply(logits.contiguous(), labels, mode, w, alpha, beta, scale, ops.LAYOUT_FULL)
+            return total, scalars, pred_full
+        scalars, _, _, pred_full = ops.loss_fwd_bwd(logits.detach().contiguous(), labels, mode, w, alpha, beta, scale, ops.LAYOUT_FULL,
+                                                    want_grad=False, want_pred_full=True)
+        return None, scalars, pred_full
 
     # ---- metrics (host, once per outer iteration) ----
     def decode_pred_gt(self, pred: torch.Tensor, labels: torch.Tensor):

@@ -27,6 +27,7 @@ struct RowStat {  // one per LABELLED row, stored compactly at its row-major ran
     int pos;     // position p = b*(L-1)+k
     int lab;     // the label (token id)
     int ord;     // rank of this position among its sample's labelled positions (0 = first)
+    int predf;   // argmax over ALL V classes (lowest index on ties, torch.argmax)
 };
 
 struct LossArgs {
@@ -36,6 +37,7 @@ struct LossArgs {
     void* glogits;
     float* scalars;
     int32_t* pred_tokens;
+    int32_t* pred_full;
     int B, S, L, V, mode, layout;
     float w, alpha, beta, scale;
 };
@@ -165,116 +167,72 @@ __device__ __forceinline__ void count_labelled(const Labels& lb, int B, int L, i
 }
 
 
-// Row-indexed schedule (VAA_LAYOUT_ROWS with the row count known on the host): workgroup r owns row r of the [R,V] logits, so its
-// loads are issued before the labels are even staged; this routine then finds which (sample b, position k) row r is — the r-th
-// labelled position in row-major order — from the label matrix in LDS: per-sample counts, a block scan, one ballot search.
-// Needs B <= NT and the labels in LDS. Returns false if r is not a labelled rank (R_dev <= r); R_dev = total labelled count.
-template <int NT>
-__device__ __forceinline__ bool locate_row(const Labels& lb, int B, int L, int r, int& b, int& k, int& jj, int& R_dev, int* sh_i) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int cnt = 0;
-    if (tid < B)
-        for (int e = 1; e < L; ++e) cnt += (lb.at(tid * L + e) != -100) ? 1 : 0;
-    // inclusive scan over threads (wave scan + wave totals)
-    int inc = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += up;
-    }
-    __syncthreads();
-    if (lane == 63) sh_i[wv] = inc;
-    if (tid == 0) { sh_i[NT / 64] = -1; sh_i[NT / 64 + 1] = 0; }
-    __syncthreads();
-    int base = 0, total = 0;
-    for (int q = 0; q < NT / 64; ++q) { if (q < wv) base += sh_i[q]; total += sh_i[q]; }
-    inc += base;
-    if (tid < B && r >= inc - cnt && r < inc) { sh_i[NT / 64] = tid; sh_i[NT / 64 + 1] = r - (inc - cnt); }
-    __syncthreads();
-    R_dev = total;
-    b = sh_i[NT / 64];
-    jj = sh_i[NT / 64 + 1];
-    if (b < 0) return false;
-    k = nth_labelled(lb, b, L, jj);
-    return k >= 0;
-}
-
 // ---- kernel A: per labelled row: compact rank, logsumexp, label logit, action-slice soft-argmax / argmax ----
-template <typename T, bool ROWMAP = false>
+template <typename T>
 __global__ __launch_bounds__(kRowThreads) void loss_stats_kernel(LossArgs a, int J) {
-    // legacy map: workgroup (j, b) owns the j-th, (j+J)-th, ... labelled position of sample b (usually exactly one row, or none);
+    // workgroup (j, b) owns the j-th, (j+J)-th, ... labelled position of sample b (usually exactly one row, or none);
     // sample index fastest: consecutive blocks (dealt round-robin to the 8 XCDs) are all active.
-    // ROWMAP (ROWS layout, row count known on the host): workgroup r owns row r; its loads are issued first, see locate_row().
-    const int j = ROWMAP ? 0 : blockIdx.x / a.B;
-    int b = ROWMAP ? 0 : blockIdx.x - j * a.B;
+    const int j = blockIdx.x / a.B;
+    const int b = blockIdx.x - j * a.B;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     __shared__ int16_t lab16[kLabLds];
     __shared__ float red[16];
+    __shared__ int redi[16];
     __shared__ int shi[16][2];
-    __shared__ int shl[kRowThreads / 64 + 2];
     __shared__ float bmax;
+    __shared__ int bidx;
     constexpr int N = Vec<T>::N;
     const int nvec = a.V / N;  // V = 32064 is a multiple of 8
     // one streaming pass: this thread's elements stay in registers (8 f32 or 4 bf16 16-byte vectors = 32 logits)
     constexpr int MAXV = 32 / N;
     float v[MAXV][N];
-    if (ROWMAP) {
-        const T* z0 = reinterpret_cast<const T*>(a.logits) + (size_t)blockIdx.x * a.V;
-#pragma unroll
-        for (int c = 0; c < MAXV; ++c) {
-            const int q = tid + c * kRowThreads;
-            if (q < nvec) {
-                Vec<T>::load(z0 + (size_t)q * N, v[c]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < N; ++e) v[c][e] = -INFINITY;
-            }
-        }
-    }
     const Labels lb = stage_labels(a, lab16);
   for (int jj = j;; jj += J) {
-    int k, rowidx, total;
-    if (ROWMAP) {
-        if (jj != j) return;  // exactly one row per workgroup
-        rowidx = blockIdx.x;
-        if (!locate_row<kRowThreads>(lb, a.B, a.L, rowidx, b, k, jj, total, shl)) return;
-    } else {
-        k = nth_labelled(lb, b, a.L, jj);
-        if (k < 0) return;
-    }
+    int rowidx, total;
+    const int k = nth_labelled(lb, b, a.L, jj);
+    if (k < 0) return;
     const int lab = lb.at(b * a.L + k + 1);
-    if (!ROWMAP) count_labelled(lb, a.B, a.L, b * a.L + k + 1, rowidx, total, shi);
+    count_labelled(lb, a.B, a.L, b * a.L + k + 1, rowidx, total, shi);
 
     const T* z = reinterpret_cast<const T*>(a.logits) + row_offset(a, b, k, rowidx);
     float m = -INFINITY;
+    int mi = 0x7fffffff;  // argmax over the vocabulary, lowest index on ties (within a thread columns are visited in increasing order)
 #pragma unroll
     for (int c = 0; c < MAXV; ++c) {
         const int q = tid + c * kRowThreads;
-        if (!ROWMAP) {
-            if (q < nvec) {
-                Vec<T>::load(z + (size_t)q * N, v[c]);
-            } else {
+        if (q < nvec) {
+            Vec<T>::load(z + (size_t)q * N, v[c]);
+        } else {
 #pragma unroll
-                for (int e = 0; e < N; ++e) v[c][e] = -INFINITY;
-            }
+            for (int e = 0; e < N; ++e) v[c][e] = -INFINITY;
         }
 #pragma unroll
-        for (int e = 0; e < N; ++e) m = fmaxf(m, v[c][e]);
+        for (int e = 0; e < N; ++e)
+            if (v[c][e] > m) { m = v[c][e]; mi = q * N + e; }
     }
     for (int q = tid + MAXV * kRowThreads; q < nvec; q += kRowThreads) {  // generic tail for larger vocabularies (re-read from L2)
         float t[N];
         Vec<T>::load(z + (size_t)q * N, t);
 #pragma unroll
-        for (int e = 0; e < N; ++e) m = fmaxf(m, t[e]);
+        for (int e = 0; e < N; ++e)
+            if (t[e] > m) { m = t[e]; mi = q * N + e; }
     }
-    m = wave_max(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
     __syncthreads();
-    if (lane == 0) red[wv] = m;
+    if (lane == 0) { red[wv] = m; redi[wv] = mi; }
     __syncthreads();
     if (tid == 0) {
         float mm = red[0];
-        for (int q = 1; q < kRowThreads / 64; ++q) mm = fmaxf(mm, red[q]);
+        int ii = redi[0];
+        for (int q = 1; q < kRowThreads / 64; ++q)
+            if (red[q] > mm || (red[q] == mm && redi[q] < ii)) { mm = red[q]; ii = redi[q]; }
         bmax = mm;
+        bidx = ii;
     }
     __syncthreads();
     const float M = bmax;
@@ -344,6 +302,7 @@ __global__ __launch_bounds__(kRowThreads) void loss_stats_kernel(LossArgs a, int
         r.pos = b * (a.L - 1) + k;
         r.lab = lab;
         r.ord = jj;
+        r.predf = bidx;
         a.st[rowidx] = r;
     }
   }
@@ -377,35 +336,22 @@ struct Upa3 {
 //      when nothing is labelled) publishes the scalars and the predicted tokens. ----
 constexpr int kGradT = 512;  // 64 logits per thread stay in registers (256-VGPR budget), fp64 reductions do not spill
 
-template <typename T, bool ROWMAP = false>
+template <typename T>
 __global__ __launch_bounds__(kGradT) void loss_grad_kernel(LossArgs a, int J) {
-    // ROWMAP (ROWS layout, row count R = a.S known on the host): workgroup r owns row r; everything it needs about the row (label,
-    // rank within its sample) is in the compact statistics the first kernel left at rank r, so no label is read here at all and the
-    // fold over the R statistics starts at once.
-    const int j = ROWMAP ? 0 : blockIdx.x / a.B, b = ROWMAP ? 0 : blockIdx.x - j * a.B;
+    const int j = blockIdx.x / a.B, b = blockIdx.x - j * a.B;
     const int tid = threadIdx.x;
     __shared__ int16_t lab16[kLabLds];
     __shared__ int shi[kGradT / 64][2];
     __shared__ double sh[kGradT / 64][7];
-    Labels lb;
-    lb.g = a.labels;
-    lb.l = nullptr;
-    if (!ROWMAP) lb = stage_labels<kGradT>(a, lab16);
+    const Labels lb = stage_labels<kGradT>(a, lab16);
   for (int jj = j;; jj += J) {
-    if (ROWMAP && jj != j) return;
-    const int k = ROWMAP ? 0 : nth_labelled(lb, b, a.L, jj);
+    const int k = nth_labelled(lb, b, a.L, jj);
     if (k < 0 && !(blockIdx.x == 0 && jj == j)) return;  // workgroup 0 always runs once: it publishes zeros when nothing is labelled
     int rowidx, R;
     RowStat me;
     me.lse = me.alse = me.E = 0.0f; me.ord = 0; me.lab = -100;
-    if (ROWMAP) {
-        rowidx = blockIdx.x;
-        R = a.S;
-        me = a.st[rowidx];
-    } else {
-        count_labelled<kGradT>(lb, a.B, a.L, k < 0 ? 0 : b * a.L + k + 1, rowidx, R, shi);
-    }
-    const int lab = ROWMAP ? me.lab : (k < 0 ? -100 : lb.at(b * a.L + k + 1));
+    count_labelled<kGradT>(lb, a.B, a.L, k < 0 ? 0 : b * a.L + k + 1, rowidx, R, shi);
+    const int lab = k < 0 ? -100 : lb.at(b * a.L + k + 1);
 
     // this row's logits: issue the loads now, use them after the reductions (addresses do not depend on the statistics)
     constexpr int N = Vec<T>::N;
@@ -444,7 +390,7 @@ __global__ __launch_bounds__(kGradT) void loss_grad_kernel(LossArgs a, int J) {
 
     double total = 0.0, aux0 = 0.0, aux1 = 0.0;
     float kce = 0.0f, kE = 0.0f;
-    if (!ROWMAP && k >= 0) me = a.st[rowidx];
+    if (k >= 0) me = a.st[rowidx];
     if (a.mode == VAA_LOSS_UPA) {
         aux0 = acc[5] / a.B;
         aux1 = 1.0 / (acc[6] / a.B + 1e-3);  // UPA.py:384
@@ -472,13 +418,17 @@ __global__ __launch_bounds__(kGradT) void loss_grad_kernel(LossArgs a, int J) {
         a.scalars[0] = (float)total; a.scalars[1] = (float)CE; a.scalars[2] = (float)MSE; a.scalars[3] = (float)aux0;
         a.scalars[4] = (float)aux1; a.scalars[5] = (float)nrow; a.scalars[6] = (float)nact; a.scalars[7] = (float)UAD;
     }
-    if (first && a.pred_tokens) {
+    if (first && (a.pred_tokens || a.pred_full)) {
         const int P = a.B * (a.L - 1);
-        for (int q = tid; q < P; q += kGradT) a.pred_tokens[q] = -1;
+        for (int q = tid; q < P; q += kGradT) {
+            if (a.pred_tokens) a.pred_tokens[q] = -1;
+            if (a.pred_full) a.pred_full[q] = -1;
+        }
         __syncthreads();
         for (int r = tid; r < R; r += kGradT) {
             const RowStat s = a.st[r];
-            if (s.lab > 2) a.pred_tokens[s.pos] = s.pred;
+            if (a.pred_tokens && s.lab > 2) a.pred_tokens[s.pos] = s.pred;
+            if (a.pred_full) a.pred_full[s.pos] = s.predf;
         }
     }
     if (k < 0) return;
@@ -523,16 +473,423 @@ __global__ __launch_bounds__(kGradT) void loss_grad_kernel(LossArgs a, int J) {
   }
 }
 
+// =====================================================================================================================
+// ROWS fast path (what forward_rows feeds): logits [R,V] of the labelled rows only, with a ROW MAP built once per outer
+// iteration (labels do not change during the innerLoop steps: UADA.py:130-133), so a step never touches the label matrix.
+//   * rows_stats_kernel : grid = R x SPLIT workgroups of 512 threads; workgroup (r, h) streams 1/SPLIT of row r (so R' = 128
+//     rows fill all 256 CUs), reduces {max, argmax, sum-exp, label logit} of its part; the part that holds the 256 action
+//     logits also produces the soft-argmax statistics and — in UADA_DDP mode, whose gradient needs nothing from other rows —
+//     writes the row's gradient slice at once.
+//   * rows_finish_kernel: combines the parts, folds the R compact statistics into the scalars (fixed order -> deterministic),
+//     publishes scalars + predicted tokens (slice argmax for UAD, UADA.py:395, and full-vocabulary argmax for the metrics of
+//     UADA.py:165-167 / TMA.py:148-149) and writes the gradients that depend on global scalars (1/CE, CE, UPA).
+//   Gradient storage: VAA_GRAD_FULL [R,V] or VAA_GRAD_SLICE [R,256] (UADA_DDP / UPA: the gradient is zero outside the action
+//   columns, so the LM-head backward contracts over 256 columns instead of 32,064).
+// =====================================================================================================================
+struct RowMap {
+    int b, k, lab, ord;
+};
+struct PartStat {  // one per (row, part)
+    float m, s;    // max and sum exp(z - m) over the part
+    float zlab;    // logit of the label if it lies in this part, else -inf
+    int amax;      // argmax over the part (global column index), lowest index on ties
+};
+struct SliceStat {  // one per row
+    float alse, E;
+    int pred;
+    int pad;
+};
+
+constexpr int kRowsT = 512;
+
+__global__ __launch_bounds__(1024) void loss_rowmap_kernel(const int64_t* __restrict__ labels, int B, int L, int* __restrict__ out) {
+    // out: int hdr[4] = {R, n_action_rows, 0, 0}, then RowMap[R] in (b,k) row-major order of labels[b,k+1] != -100
+    __shared__ int wsum[16][2];
+    __shared__ int carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    RowMap* rm = reinterpret_cast<RowMap*>(out + 4);
+    if (tid == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        const int b = b0 + tid;
+        int cnt = 0, act = 0;
+        if (b < B)
+            for (int e = 1; e < L; ++e) {
+                const long v = labels[(size_t)b * L + e];
+                cnt += (v != -100) ? 1 : 0;
+                act += (v > 2) ? 1 : 0;
+            }
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        const int wact = wave_sum(act);
+        if (lane == 63) wsum[wv][0] = inc;
+        if (lane == 0) wsum[wv][1] = wact;
+        __syncthreads();
+        int base = carry[0], tot = 0, tact = 0;
+        for (int q = 0; q < 16; ++q) { if (q < wv) base += wsum[q][0]; tot += wsum[q][0]; tact += wsum[q][1]; }
+        if (b < B) {
+            int r = base + inc - cnt, ord = 0;
+            for (int e = 1; e < L; ++e) {
+                const long v = labels[(size_t)b * L + e];
+                if (v != -100) { RowMap m; m.b = b; m.k = e - 1; m.lab = (int)v; m.ord = ord++; rm[r++] = m; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { carry[0] += tot; carry[1] += tact; }
+        __syncthreads();
+    }
+    if (tid == 0) { out[0] = carry[0]; out[1] = carry[1]; out[2] = 0; out[3] = 0; }
+}
+
+struct RowsArgs {
+    const void* logits;
+    const int* rowmap;  // hdr[4] + RowMap[R]
+    PartStat* part;     // [R][split]
+    SliceStat* slice;   // [R]
+    void* grad;
+    float* scalars;
+    int32_t* pred_tokens;
+    int32_t* pred_full;
+    int R, B, L, V, mode, split, grad_slice;
+    float w, alpha, beta, scale;
+};
+
+template <typename T>
+__device__ __forceinline__ void store_slice_or_row(const RowsArgs& a, int r, int col0, const float* o) {  // Vec<T>::N values at column col0
+    T* g = reinterpret_cast<T*>(a.grad);
+    if (a.grad_slice) Vec<T>::store(g + (size_t)r * kNA + (col0 - kA0), o);
+    else Vec<T>::store(g + (size_t)r * a.V + col0, o);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a) {
+    constexpr int N = Vec<T>::N;
+    constexpr int MAXV = 32 / N;  // 32 logits per thread in registers: covers V/split <= 16384
+    const int r = blockIdx.x / a.split, h = blockIdx.x - r * a.split;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nvec = a.V / N, pvec = (nvec + a.split - 1) / a.split;  // vectors per part
+    const int v_lo = h * pvec, v_hi = min(nvec, v_lo + pvec);
+    const T* z = reinterpret_cast<const T*>(a.logits) + (size_t)r * a.V;
+    __shared__ float redf[kRowsT / 64];
+    __shared__ int redi[kRowsT / 64];
+    __shared__ float bmax;
+    __shared__ int bidx;
+    float v[MAXV][N];
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int q = v_lo + tid + c * kRowsT;
+        if (q < v_hi) {
+            Vec<T>::load(z + (size_t)q * N, v[c]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[c][e] = -INFINITY;
+        }
+    }
+    // the action slice, for the part that holds it: one extra 16-byte load per lane of wave 0 (L1/L2 hit)
+    const bool has_slice = (kA0 / N) >= v_lo && (kA0 / N) < v_hi;
+    constexpr int nthr = kNA / N;
+    float x[N];
+    if (has_slice && wv == 0 && lane < nthr) Vec<T>::load(z + kA0 + lane * N, x);
+    const RowMap me = reinterpret_cast<const RowMap*>(a.rowmap + 4)[r];
+    const int nact = a.rowmap[1];
+
+    // ---- max + argmax (lowest index on ties, torch.argmax) ----
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int q = v_lo + tid + c * kRowsT;
+#pragma unroll
+        for (int e = 0; e < N; ++e)
+            if (v[c][e] > m) { m = v[c][e]; mi = q * N + e; }  // within a thread columns are visited in increasing order
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    if (lane == 0) { redf[wv] = m; redi[wv] = mi; }
+    __syncthreads();
+    if (tid == 0) {
+        float mm = redf[0];
+        int ii = redi[0];
+        for (int q = 1; q < kRowsT / 64; ++q)
+            if (redf[q] > mm || (redf[q] == mm && redi[q] < ii)) { mm = redf[q]; ii = redi[q]; }
+        bmax = mm;
+        bidx = ii;
+    }
+    __syncthreads();
+    const float M = bmax;
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c)
+#pragma unroll
+        for (int e = 0; e < N; ++e) s += expf(v[c][e] - M);  // exp(-inf) = 0 for the padding
+    s = wave_sum(s);
+    __syncthreads();
+    if (lane == 0) redf[wv] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.0f;
+        for (int q = 0; q < kRowsT / 64; ++q) tot += redf[q];
+        PartStat ps;
+        ps.m = M;
+        ps.s = tot;
+        ps.amax = bidx;
+        const int lv = me.lab / N;
+        ps.zlab = (me.lab >= 0 && lv >= v_lo && lv < v_hi) ? Vec<T>::get(z + me.lab) : -INFINITY;
+        a.part[(size_t)r * a.split + h] = ps;
+    }
+    if (!(has_slice && wv == 0)) return;
+    // ---- action slice: soft-argmax statistics by one wave (UADA.py:384-389, UPA.py:370-374) ----
+    const bool own = lane < nthr;
+    if (!own) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) x[e] = -INFINITY;
+    }
+    int ai = 0;
+#pragma unroll
+    for (int e = 1; e < N; ++e) if (x[e] > x[ai]) ai = e;
+    float bestv = x[ai], am = x[ai];
+    int besti = lane * N + ai;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bestv, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+    }
+    am = wave_max(am);
+    float ex[N], es = 0.0f, ew = 0.0f;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        ex[e] = expf(x[e] - am);
+        es += ex[e];
+        ew += ex[e] * (float)(lane * N + e + 1);
+    }
+    es = wave_sum(es);
+    ew = wave_sum(ew);
+    const float E = ew / es;
+    if (lane == 0) {
+        SliceStat ss;
+        ss.alse = am + logf(es);
+        ss.E = E;
+        ss.pred = kA0 + besti;
+        ss.pad = 0;
+        a.slice[r] = ss;
+    }
+    if (a.mode == VAA_LOSS_UADA_DDP && a.grad && own) {  // gradient of w^2*mean((E/256 - t)^2): needs this row and the row COUNT only
+        float o[N];
+        float kE = 0.0f;
+        if (me.lab > 2 && nact > 0) {
+            const double rr = (double)E / 256.0, t = (me.lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10)
+            kE = (float)((double)a.w * a.w * 2.0 * (rr - t) / nact / 256.0);
+        }
+        const float alse = am + logf(es);
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] = kE * expf(x[e] - alse) * ((float)(lane * N + e + 1) - E);
+        store_slice_or_row<T>(a, r, kA0 + lane * N, o);
+    }
+}
+
+// grid = R x split (full-row gradients) or R (slice / no gradient); every workgroup folds the statistics in the same fixed order.
+template <typename T>
+__global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsplit) {
+    constexpr int N = Vec<T>::N;
+    const int r = blockIdx.x / gsplit, h = blockIdx.x - r * gsplit;
+    const int tid = threadIdx.x;
+    __shared__ double sh[kRowsT / 64][7];
+    const RowMap* rm = reinterpret_cast<const RowMap*>(a.rowmap + 4);
+    const int Rdev = a.rowmap[0];
+    // this workgroup's part of its row: issue the loads before the fold (addresses do not depend on it)
+    const bool full_grad = a.grad && !a.grad_slice && (a.mode == VAA_LOSS_UADA || a.mode == VAA_LOSS_CE);
+    const bool zero_fill = a.grad && !a.grad_slice && !full_grad;  // FULL storage asked for a slice-only mode: zeros outside the slice
+    constexpr int MAXV = 32 / N;
+    const int nvec = a.V / N, pvec = (nvec + gsplit - 1) / gsplit;
+    const int v_lo = h * pvec, v_hi = min(nvec, v_lo + pvec);
+    const T* z = reinterpret_cast<const T*>(a.logits) + (size_t)r * a.V;
+    float v[MAXV][N];
+    if (full_grad && r < a.R) {
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c) {
+            const int q = v_lo + tid + c * kRowsT;
+            if (q < v_hi) Vec<T>::load(z + (size_t)q * N, v[c]);
+        }
+    }
+    auto row_lse = [&](int rr, float& zlab, int& amax) {  // combine the parts of row rr
+        float M = -INFINITY;
+        for (int q = 0; q < a.split; ++q) M = fmaxf(M, a.part[(size_t)rr * a.split + q].m);
+        float tot = 0.0f, best = -INFINITY;
+        zlab = -INFINITY;
+        amax = 0x7fffffff;
+        for (int q = 0; q < a.split; ++q) {
+            const PartStat p = a.part[(size_t)rr * a.split + q];
+            tot += p.s * expf(p.m - M);
+            zlab = fmaxf(zlab, p.zlab);
+            if (p.m > best || (p.m == best && p.amax < amax)) { best = p.m; amax = p.amax; }
+        }
+        return M + logf(tot);
+    };
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // ce, mse, uad, nrow, nact, upa sum(cos+1), upa sum ||e'-l'||
+    auto upa_of = [&](int r0, Upa3& u) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            RowStat t;
+            t.E = a.slice[r0 + q].E;
+            t.lab = rm[r0 + q].lab;
+            u.set(q, t);
+        }
+    };
+    for (int rr = tid; rr < a.R; rr += kRowsT) {
+        const RowMap m = rm[rr];
+        float zl;
+        int am;
+        const float lse = row_lse(rr, zl, am);
+        acc[3] += 1.0;
+        acc[0] += (double)lse - (double)zl;
+        if (m.lab > 2) {
+            const SliceStat ss = a.slice[rr];
+            acc[4] += 1.0;
+            const double q = (double)ss.E / 256.0, t = (m.lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10: 1/256 -> 0)
+            acc[1] += (q - t) * (q - t);
+            const double ag = bin_center(m.lab), ap = bin_center(ss.pred);  // cal_UAD, UADA.py:408-418
+            acc[2] += fabs(ap - ag) / (ag > 0 ? fabs(ag + 1.0) : fabs(ag - 1.0));
+        }
+        if (a.mode == VAA_LOSS_UPA && m.ord == 0 && rr + 2 < a.R) {  // first three labelled rows of a sample are consecutive ranks
+            Upa3 u;
+            upa_of(rr, u);
+            double c1, nd;
+            u.terms(c1, nd);
+            acc[5] += c1;
+            acc[6] += nd;
+        }
+    }
+    block_sums<7, kRowsT>(acc, sh);
+    const double nrow = acc[3], nact = acc[4];
+    const double CE = nrow > 0 ? acc[0] / nrow : 0.0;
+    const double MSE = nact > 0 ? (double)a.w * a.w * acc[1] / nact : 0.0;
+    const double UAD = nact > 0 ? acc[2] / nact : 0.0;
+    double total = 0.0, aux0 = 0.0, aux1 = 0.0, dce = 0.0;
+    if (a.mode == VAA_LOSS_UPA) {
+        aux0 = acc[5] / a.B;
+        aux1 = 1.0 / (acc[6] / a.B + 1e-3);  // UPA.py:384
+        total = (double)a.alpha * aux0 + (double)a.beta * aux1;
+    } else if (a.mode == VAA_LOSS_UADA) { total = MSE + 1.0 / CE; dce = -1.0 / (CE * CE); }  // UADA.py:147
+    else if (a.mode == VAA_LOSS_UADA_DDP) { total = MSE; }                                     // UADA_ddp.py:203-206
+    else { total = (double)a.scale * CE; dce = (double)a.scale; }                             // TMA.py:148
+    if (blockIdx.x == 0) {  // publication
+        if (tid == 0) {
+            const bool ok = Rdev == a.R;  // the caller's row count must be the row map's
+            a.scalars[0] = ok ? (float)total : __uint_as_float(0x7fc00000u);
+            a.scalars[1] = (float)CE; a.scalars[2] = (float)MSE; a.scalars[3] = (float)aux0;
+            a.scalars[4] = (float)aux1; a.scalars[5] = (float)nrow; a.scalars[6] = (float)nact; a.scalars[7] = (float)UAD;
+        }
+        const int P = a.B * (a.L - 1);
+        if (a.pred_tokens) for (int q = tid; q < P; q += kRowsT) a.pred_tokens[q] = -1;
+        if (a.pred_full) for (int q = tid; q < P; q += kRowsT) a.pred_full[q] = -1;
+        __syncthreads();
+        for (int rr = tid; rr < a.R; rr += kRowsT) {
+            const RowMap m = rm[rr];
+            const int pos = m.b * (a.L - 1) + m.k;
+            if (a.pred_tokens && m.lab > 2) a.pred_tokens[pos] = a.slice[rr].pred;
+            if (a.pred_full) {
+                float zl;
+                int am;
+                row_lse(rr, zl, am);
+                a.pred_full[pos] = am;
+            }
+        }
+    }
+    if (!a.grad || r >= a.R) return;
+    const RowMap me = rm[r];
+    if (a.mode == VAA_LOSS_UADA_DDP && !zero_fill) return;  // slice already written by the statistics kernel
+    // ---- gradient of this row (part h) ----
+    const SliceStat ms = a.slice[r];
+    float kce = nrow > 0 ? (float)(dce / nrow) : 0.0f, kE = 0.0f;
+    if (a.mode == VAA_LOSS_UPA) {
+        kce = 0.0f;
+        if (me.ord < 3 && r - me.ord + 2 < a.R) {
+            Upa3 u;
+            upa_of(r - me.ord, u);
+            kE = (float)(u.dE(me.ord, (double)a.alpha, (double)a.beta, aux1, a.B) / 255.0);
+        }
+    } else if (a.mode != VAA_LOSS_CE && me.lab > 2) {
+        const double q = (double)ms.E / 256.0, t = (me.lab > 31872) ? 0.0 : 1.0;
+        kE = (float)((double)a.w * a.w * 2.0 * (q - t) / nact / 256.0);
+    }
+    if (!full_grad) {  // slice-only modes (UPA; UADA_DDP only when FULL storage was asked for)
+        constexpr int nthr = kNA / N;
+        if (zero_fill) {
+            float o[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) o[e] = 0.0f;
+            for (int q = v_lo + tid; q < v_hi; q += kRowsT)
+                if (q * N < kA0 || q * N >= kA0 + kNA) Vec<T>::store(reinterpret_cast<T*>(a.grad) + (size_t)r * a.V + (size_t)q * N, o);
+        }
+        const bool owns_slice = (kA0 / N) >= v_lo && (kA0 / N) < v_hi;
+        if (owns_slice && tid < nthr) {
+            float x[N], o[N];
+            Vec<T>::load(z + kA0 + tid * N, x);
+#pragma unroll
+            for (int e = 0; e < N; ++e) o[e] = kE * expf(x[e] - ms.alse) * ((float)(tid * N + e + 1) - ms.E);
+            store_slice_or_row<T>(a, r, kA0 + tid * N, o);
+        }
+        return;
+    }
+    float zl;
+    int am;
+    const float lse = row_lse(r, zl, am);
+    T* g = reinterpret_cast<T*>(a.grad) + (size_t)r * a.V;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int q = v_lo + tid + c * kRowsT;
+        if (q >= v_hi) continue;
+        const int v0 = q * N;
+        const bool in_slice = (v0 >= kA0 && v0 < kA0 + kNA);
+        float o[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            float gv = 0.0f;
+            if (kce != 0.0f) gv = kce * (expf(v[c][e] - lse) - ((v0 + e) == me.lab ? 1.0f : 0.0f));
+            if (in_slice && kE != 0.0f) gv += kE * expf(v[c][e] - ms.alse) * ((float)(v0 + e - kA0 + 1) - ms.E);
+            o[e] = gv;
+        }
+        Vec<T>::store(g + (size_t)v0, o);
+    }
+}
+
+static int rows_split(int R, int V) {  // parts per row so that >= 256 workgroups are resident; a part must fit 512 threads x 32 logits
+    int s = 1;
+    while (s < 4 && R * s < 256) s <<= 1;
+    while ((V + s - 1) / s > kRowsT * 32) s <<= 1;
+    return s;
+}
+
 }  // namespace vaa
+
+extern "C" size_t vaa_loss_rowmap_bytes(int B, int L);
+extern "C" size_t vaa_loss_rows_ws_bytes(int R);
+extern "C" int vaa_loss_rowmap_build(const int64_t* labels, int B, int L, void* rowmap, size_t rowmap_bytes, void* stream);
+extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int R, int B, int L, int V, int mode,
+                                     const float* params, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, void* grad,
+                                     int grad_kind, void* ws, size_t ws_bytes, void* stream);
+
+static size_t align256(size_t n) { return (n + 255) / 256 * 256; }
 
 extern "C" size_t vaa_loss_ws_bytes(int B, int L) {
     if (B <= 0 || L <= 1) return 0;
-    return (size_t)B * (size_t)(L - 1) * sizeof(vaa::RowStat);
+    const size_t legacy = (size_t)B * (size_t)(L - 1) * sizeof(vaa::RowStat);
+    const size_t rows = align256(vaa_loss_rowmap_bytes(B, L)) + vaa_loss_rows_ws_bytes(B * (L - 1));  // ROWS layout: row map + row statistics
+    return legacy > rows ? legacy : rows;
 }
 
-extern "C" int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const int64_t* labels, int B, int S, int L, int V,
-                                int mode, const float* params, float* scalars, int32_t* pred_tokens, void* glogits, void* ws,
-                                size_t ws_bytes, void* stream) {
+extern "C" int vaa_loss_fwd_bwd_ex(const void* logits, int dtype, int layout, const int64_t* labels, int B, int S, int L, int V,
+                                   int mode, const float* params, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens,
+                                   void* glogits, void* ws, size_t ws_bytes, void* stream) {
     using namespace vaa;
     if (!logits || !labels || !params || !scalars) {
         set_error("vaa_loss_fwd_bwd: null pointer argument");
@@ -552,22 +909,22 @@ extern "C" int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const
         return VAA_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (layout == VAA_LAYOUT_ROWS && S > 0) {
+        // row count given: build the row map in the workspace and take the row-split path (callers that keep the labels for many
+        // steps build the map once with vaa_loss_rowmap_build and call vaa_loss_rows_fwd_bwd directly)
+        const size_t map_bytes = align256(vaa_loss_rowmap_bytes(B, L));
+        int rc0 = vaa_loss_rowmap_build(labels, B, L, ws, map_bytes, stream);
+        if (rc0 != VAA_OK) return rc0;
+        return vaa_loss_rows_fwd_bwd(logits, dtype, ws, S, B, L, V, mode, params, scalars, pred_tokens, pred_full_tokens, glogits, VAA_GRAD_FULL,
+                                     (char*)ws + map_bytes, ws_bytes - map_bytes, stream);
+    }
     LossArgs a;
     a.logits = logits; a.labels = labels; a.st = (RowStat*)ws; a.glogits = glogits; a.scalars = scalars; a.pred_tokens = pred_tokens;
+    a.pred_full = pred_full_tokens;
     a.B = B; a.S = S; a.L = L; a.V = V; a.mode = mode; a.layout = layout;
     a.w = params[0]; a.alpha = params[1]; a.beta = params[2]; a.scale = params[3];
     const int J = (L - 1) < 8 ? (L - 1) : 8;  // workgroups per sample; the attacks label at most 8 positions per sample
     const unsigned G = (unsigned)B * (unsigned)J;
-    if (layout == VAA_LAYOUT_ROWS && S > 0 && B <= kRowThreads && (long)B * L <= kLabLds) {
-        // row count known on the host: one workgroup per row, loads issued before the labels are looked at (locate_row)
-        if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL((loss_stats_kernel<float, true>), dim3((unsigned)S), dim3(kRowThreads), 0, st, a, 1);
-        else hipLaunchKernelGGL((loss_stats_kernel<uint16_t, true>), dim3((unsigned)S), dim3(kRowThreads), 0, st, a, 1);
-        int rc0 = check_launch("vaa_loss_fwd_bwd(stats)");
-        if (rc0 != VAA_OK) return rc0;
-        if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL((loss_grad_kernel<float, true>), dim3((unsigned)S), dim3(kGradT), 0, st, a, 1);
-        else hipLaunchKernelGGL((loss_grad_kernel<uint16_t, true>), dim3((unsigned)S), dim3(kGradT), 0, st, a, 1);
-        return check_launch("vaa_loss_fwd_bwd(grad)");
-    }
     if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(loss_stats_kernel<float>, dim3(G), dim3(kRowThreads), 0, st, a, J);
     else hipLaunchKernelGGL(loss_stats_kernel<uint16_t>, dim3(G), dim3(kRowThreads), 0, st, a, J);
     int rc = check_launch("vaa_loss_fwd_bwd(stats)");
@@ -576,4 +933,79 @@ extern "C" int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const
     else hipLaunchKernelGGL(loss_grad_kernel<uint16_t>, dim3(G), dim3(kGradT), 0, st, a, J);
     rc = check_launch("vaa_loss_fwd_bwd(grad)");
     return rc;
+}
+
+extern "C" int vaa_loss_fwd_bwd(const void* logits, int dtype, int layout, const int64_t* labels, int B, int S, int L, int V,
+                                int mode, const float* params, float* scalars, int32_t* pred_tokens, void* glogits, void* ws,
+                                size_t ws_bytes, void* stream) {
+    return vaa_loss_fwd_bwd_ex(logits, dtype, layout, labels, B, S, L, V, mode, params, scalars, pred_tokens, nullptr, glogits, ws, ws_bytes, stream);
+}
+
+extern "C" size_t vaa_loss_rowmap_bytes(int B, int L) {
+    if (B <= 0 || L <= 1) return 0;
+    return 16 + (size_t)B * (size_t)(L - 1) * sizeof(vaa::RowMap);
+}
+
+extern "C" int vaa_loss_rowmap_build(const int64_t* labels, int B, int L, void* rowmap, size_t rowmap_bytes, void* stream) {
+    using namespace vaa;
+    if (!labels || !rowmap || B <= 0 || L <= 1) {
+        set_error("vaa_loss_rowmap_build: bad arguments (B=%d L=%d)", B, L);
+        return VAA_E_INVALID;
+    }
+    if (rowmap_bytes < vaa_loss_rowmap_bytes(B, L)) {
+        set_error("vaa_loss_rowmap_build: buffer %zu B < required %zu B", rowmap_bytes, vaa_loss_rowmap_bytes(B, L));
+        return VAA_E_WORKSPACE;
+    }
+    hipLaunchKernelGGL(loss_rowmap_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, B, L, (int*)rowmap);
+    return check_launch("vaa_loss_rowmap_build");
+}
+
+extern "C" size_t vaa_loss_rows_ws_bytes(int R) {
+    if (R <= 0) return 0;
+    return (size_t)R * (4 * sizeof(vaa::PartStat) + sizeof(vaa::SliceStat));
+}
+
+extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int R, int B, int L, int V, int mode,
+                                     const float* params, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, void* grad,
+                                     int grad_kind, void* ws, size_t ws_bytes, void* stream) {
+    using namespace vaa;
+    if (!logits || !rowmap || !params || !scalars) {
+        set_error("vaa_loss_rows_fwd_bwd: null pointer argument");
+        return VAA_E_INVALID;
+    }
+    if (R <= 0 || B <= 0 || L <= 1 || V < kA0 + kNA || (V % 8) != 0 || mode < 0 || mode > VAA_LOSS_CE ||
+        (dtype != VAA_DTYPE_F32 && dtype != VAA_DTYPE_BF16) || (grad_kind != VAA_GRAD_FULL && grad_kind != VAA_GRAD_SLICE)) {
+        set_error("vaa_loss_rows_fwd_bwd: bad sizes/mode (R=%d B=%d L=%d V=%d mode=%d dtype=%d grad_kind=%d)", R, B, L, V, mode, dtype, grad_kind);
+        return VAA_E_INVALID;
+    }
+    if (grad && grad_kind == VAA_GRAD_SLICE && (mode == VAA_LOSS_UADA || mode == VAA_LOSS_CE)) {
+        set_error("vaa_loss_rows_fwd_bwd: mode %d has a cross-entropy term, its gradient is not confined to the action slice", mode);
+        return VAA_E_INVALID;
+    }
+    if (V > 4 * kRowsT * 32) {
+        set_error("vaa_loss_rows_fwd_bwd: vocabulary %d exceeds the %d columns the row kernels keep in registers", V, 4 * kRowsT * 32);
+        return VAA_E_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < vaa_loss_rows_ws_bytes(R)) {
+        set_error("vaa_loss_rows_fwd_bwd: workspace %zu B < required %zu B", ws_bytes, vaa_loss_rows_ws_bytes(R));
+        return VAA_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    RowsArgs a;
+    a.logits = logits; a.rowmap = (const int*)rowmap; a.part = (PartStat*)ws; a.slice = (SliceStat*)((char*)ws + (size_t)R * 4 * sizeof(PartStat));
+    a.grad = grad; a.scalars = scalars; a.pred_tokens = pred_tokens; a.pred_full = pred_full_tokens;
+    a.R = R; a.B = B; a.L = L; a.V = V; a.mode = mode; a.split = rows_split(R, V); a.grad_slice = (grad_kind == VAA_GRAD_SLICE) ? 1 : 0;
+    a.w = params[0]; a.alpha = params[1]; a.beta = params[2]; a.scale = params[3];
+    if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(rows_stats_kernel<float>, dim3((unsigned)(R * a.split)), dim3(kRowsT), 0, st, a);
+    else hipLaunchKernelGGL(rows_stats_kernel<uint16_t>, dim3((unsigned)(R * a.split)), dim3(kRowsT), 0, st, a);
+    int rc = check_launch("vaa_loss_rows_fwd_bwd(stats)");
+    if (rc != VAA_OK) return rc;
+    // the finishing pass: per (row, part) when a full-row gradient (or a zero fill) has to be written, else one workgroup per row
+    // (UPA slice) or a single workgroup (UADA_DDP slice: only the scalars are left to do)
+    const bool full_rows = grad && grad_kind == VAA_GRAD_FULL;
+    const int gsplit = full_rows ? a.split : 1;
+    const unsigned G = full_rows ? (unsigned)(R * gsplit) : ((grad && mode == VAA_LOSS_UPA) ? (unsigned)R : 1u);
+    if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(rows_finish_kernel<float>, dim3(G), dim3(kRowsT), 0, st, a, gsplit);
+    else hipLaunchKernelGGL(rows_finish_kernel<uint16_t>, dim3(G), dim3(kRowsT), 0, st, a, gsplit);
+    return check_launch("vaa_loss_rows_fwd_bwd(finish)");
 }

@@ -412,6 +412,11 @@ class OpenVLAShaped(nn.Module):
             row_index = self.label_row_index(labels)
         return self.lm_head(self.hidden_states(input_ids, pixel_values, rows=row_index, patch_embeds=patch_embeds, pack=pack))  # [R, D] -> [R, V]
 
+    def hidden_rows(self, input_ids, pixel_values, row_index, patch_embeds=None, pack=None):
+        """Final-norm hidden states [R,D] of the rows `row_index` (label_row_index): the input of the LM head. `ops.HeadLossRows` applies the
+        head and the loss to them so that the head's backward can contract over the action columns only."""
+        return self.hidden_states(input_ids, pixel_values, rows=row_index, patch_embeds=patch_embeds, pack=pack)
+
     def forward(self, input_ids, attention_mask=None, pixel_values=None, labels=None, **_):
         """Drop-in contract of PrismaticForConditionalGeneration.forward: full fp32 logits and HF's mean CE."""
         from .surrogate import hf_causal_ce

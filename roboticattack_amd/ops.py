@@ -9,6 +9,8 @@ import torch
 
 from . import _lib
 from ._lib import (  # noqa: F401  (re-exported)
+    GRAD_FULL,
+    GRAD_SLICE,
     LAYOUT_FULL,
     LAYOUT_ROWS,
     LOSS_CE,
@@ -331,10 +333,11 @@ class PatchApplyEmbed(torch.autograd.Function):
 # K3
 # ------------------------------------------------------------------------------------------------------
 def loss_fwd_bwd(logits, labels, mode: int, w: float = 5.0, alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0,
-                 layout: int = LAYOUT_FULL, want_grad: bool = True, want_pred: bool = True, glogits=None):
-    """K3. Returns (scalars f32[8] on device, pred_tokens i32 [B,L-1] or None, glogits or None).
+                 layout: int = LAYOUT_FULL, want_grad: bool = True, want_pred: bool = True, glogits=None, want_pred_full: bool = False):
+    """K3. Returns (scalars f32[8] on device, pred_tokens i32 [B,L-1] or None, glogits or None[, pred_full i32 [B,L-1]]).
 
-    scalars = [total, CE, w^2*MSE, UPA angle, UPA dist, #CE rows, #action rows, UAD]."""
+    scalars = [total, CE, w^2*MSE, UPA angle, UPA dist, #CE rows, #action rows, UAD]. pred_tokens = 31744 + argmax of the action
+    slice (what UAD uses, UADA.py:395); pred_full (want_pred_full) = argmax over the whole vocabulary (UADA.py:165-167 metrics)."""
     if logits.dtype == torch.float32:
         dt = _lib.DTYPE_F32
     elif logits.dtype == torch.bfloat16:
@@ -351,36 +354,129 @@ def loss_fwd_bwd(logits, labels, mode: int, w: float = 5.0, alpha: float = 0.8, 
     else:
         if logits.dim() != 2:
             raise _lib.VaaError(f"logits: ROWS layout expects [R,V], got {tuple(logits.shape)}")
-        S, V = int(logits.shape[0]), int(logits.shape[1])  # ROWS: S carries the row count R (row-indexed schedule)
+        S, V = int(logits.shape[0]), int(logits.shape[1])  # ROWS: S carries the row count R
     L = _lib.lib()
     ws = _workspace(logits.device, L.vaa_loss_ws_bytes(B, Lt), "k3")
     scalars = torch.empty(8, dtype=torch.float32, device=logits.device)
     pred = torch.empty((B, Lt - 1), dtype=torch.int32, device=logits.device) if want_pred else None
+    pred_full = torch.empty((B, Lt - 1), dtype=torch.int32, device=logits.device) if want_pred_full else None
     if want_grad and glogits is None:
         glogits = torch.zeros_like(logits) if layout == LAYOUT_FULL else torch.empty_like(logits)
     with _timed("K3_loss_fwd_bwd", B=B, L=Lt, V=V, dtype=str(logits.dtype), rows=(int(logits.shape[0]) if layout == LAYOUT_ROWS else -1)):
-        rc = L.vaa_loss_fwd_bwd(
+        rc = L.vaa_loss_fwd_bwd_ex(
             logits.data_ptr(), dt, int(layout), labels.data_ptr(), B, S, Lt, V, int(mode), _lib.f32x([w, alpha, beta, scale]),
-            scalars.data_ptr(), pred.data_ptr() if want_pred else None, glogits.data_ptr() if want_grad else None,
-            ws.data_ptr(), ws.numel(), _stream())
+            scalars.data_ptr(), pred.data_ptr() if want_pred else None, pred_full.data_ptr() if want_pred_full else None,
+            glogits.data_ptr() if want_grad else None, ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "vaa_loss_fwd_bwd")
+    if want_pred_full:
+        return scalars, pred, (glogits if want_grad else None), pred_full
     return scalars, pred, (glogits if want_grad else None)
 
 
 class DiscrepancyLoss(torch.autograd.Function):
-    """total = loss(logits, labels) with d total/d logits produced by the same fused launch sequence."""
+    """total = loss(logits, labels) with d total/d logits produced by the same fused launch sequence.
+    Returns (total, scalars f32[8], pred_slice i32 [B,L-1], pred_full i32 [B,L-1])."""
 
     @staticmethod
     def forward(ctx, logits, labels, mode, w, alpha, beta, scale, layout):
-        scalars, pred, g = loss_fwd_bwd(logits.detach(), labels, mode, w, alpha, beta, scale, layout, want_grad=True)
+        scalars, pred, g, pred_full = loss_fwd_bwd(logits.detach(), labels, mode, w, alpha, beta, scale, layout, want_grad=True,
+                                                   want_pred_full=True)
         ctx.save_for_backward(g)
-        ctx.mark_non_differentiable(scalars, pred)
-        return scalars[0].clone(), scalars, pred
+        ctx.mark_non_differentiable(scalars, pred, pred_full)
+        return scalars[0].clone(), scalars, pred, pred_full
 
     @staticmethod
-    def backward(ctx, gtotal, _gs, _gp):
+    def backward(ctx, gtotal, _gs, _gp, _gf):
         (g,) = ctx.saved_tensors
         return g * gtotal.to(g.dtype), None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# K3 on the labelled rows with a prebuilt row map (what the attack loops use)
+# ------------------------------------------------------------------------------------------------------
+ACTION_LO, N_ACTION = 31744, 256
+SLICE_MODES = (LOSS_UADA_DDP, LOSS_UPA)  # gradient confined to the 256 action columns
+
+
+class LossRowMap:
+    """Device row map of a label matrix [B,L] (vaa_loss_rowmap_build): built once per outer iteration, reused by every inner step."""
+
+    def __init__(self, labels: torch.Tensor):
+        _need(labels, torch.int64, "labels")
+        self.B, self.L = int(labels.shape[0]), int(labels.shape[1])
+        L = _lib.lib()
+        self.buf = torch.empty(L.vaa_loss_rowmap_bytes(self.B, self.L), dtype=torch.uint8, device=labels.device)
+        _lib.check(L.vaa_loss_rowmap_build(labels.data_ptr(), self.B, self.L, self.buf.data_ptr(), self.buf.numel(), _stream()), "vaa_loss_rowmap_build")
+
+
+def loss_rows_fwd_bwd(logits, rowmap: LossRowMap, mode: int, w: float = 5.0, alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0,
+                      want_grad: bool = True, grad_kind: int = GRAD_FULL, want_pred: bool = True, grad=None):
+    """K3 on logits [R,V] of the labelled rows. Returns (scalars f32[8], pred_slice i32 [B,L-1] | None, pred_full i32 [B,L-1] | None,
+    grad [R,V] | [R,256] | None). pred_slice = 31744 + argmax of the action logits (UAD), pred_full = argmax over the vocabulary."""
+    if logits.dtype == torch.float32:
+        dt = _lib.DTYPE_F32
+    elif logits.dtype == torch.bfloat16:
+        dt = _lib.DTYPE_BF16
+    else:
+        raise _lib.VaaError(f"logits: unsupported dtype {logits.dtype}")
+    _need(logits, logits.dtype, "logits")
+    if logits.dim() != 2:
+        raise _lib.VaaError(f"logits: expected [R,V], got {tuple(logits.shape)}")
+    R, V = int(logits.shape[0]), int(logits.shape[1])
+    B, Lt = rowmap.B, rowmap.L
+    L = _lib.lib()
+    ws = _workspace(logits.device, L.vaa_loss_rows_ws_bytes(R), "k3")
+    scalars = torch.empty(8, dtype=torch.float32, device=logits.device)
+    pred = torch.empty((B, Lt - 1), dtype=torch.int32, device=logits.device) if want_pred else None
+    pred_full = torch.empty((B, Lt - 1), dtype=torch.int32, device=logits.device) if want_pred else None
+    if want_grad and grad is None:
+        grad = torch.empty((R, N_ACTION if grad_kind == GRAD_SLICE else V), dtype=logits.dtype, device=logits.device)
+    with _timed("K3_loss_rows_fwd_bwd", B=B, L=Lt, V=V, dtype=str(logits.dtype), rows=R, grad_kind=grad_kind):
+        rc = L.vaa_loss_rows_fwd_bwd(logits.data_ptr(), dt, rowmap.buf.data_ptr(), R, B, Lt, V, int(mode), _lib.f32x([w, alpha, beta, scale]),
+                                     scalars.data_ptr(), pred.data_ptr() if want_pred else None, pred_full.data_ptr() if want_pred else None,
+                                     grad.data_ptr() if want_grad else None, int(grad_kind), ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "vaa_loss_rows_fwd_bwd")
+    return scalars, pred, pred_full, (grad if want_grad else None)
+
+
+class DiscrepancyLossRows(torch.autograd.Function):
+    """total = loss(logits [R,V], row map); d total / d logits by the same launch sequence (full-row gradient storage)."""
+
+    @staticmethod
+    def forward(ctx, logits, rowmap, mode, w, alpha, beta, scale):
+        scalars, pred, pred_full, g = loss_rows_fwd_bwd(logits.detach(), rowmap, mode, w, alpha, beta, scale, want_grad=True, grad_kind=GRAD_FULL)
+        ctx.save_for_backward(g)
+        ctx.mark_non_differentiable(scalars, pred, pred_full)
+        return scalars[0].clone(), scalars, pred, pred_full
+
+    @staticmethod
+    def backward(ctx, gtotal, _gs, _gp, _gf):
+        (g,) = ctx.saved_tensors
+        return g * gtotal.to(g.dtype), None, None, None, None, None, None
+
+
+class HeadLossRows(torch.autograd.Function):
+    """LM head + loss on the labelled rows: logits = hidden [R,D] @ W^T [V,D] through hipBLASLt, K3 on them, and
+    for the modes whose gradient lives in the 256 action columns (UADA_DDP, UPA) the backward is dh = g_slice [R,256] @ W[31744:32000]
+    — a contraction over 256 columns instead of the 32,064 of the generic head backward; other modes contract over the full rows."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, rowmap, mode, w, alpha, beta, scale):
+        logits = torch.nn.functional.linear(hidden.detach(), weight)
+        sliced = mode in SLICE_MODES
+        scalars, pred, pred_full, g = loss_rows_fwd_bwd(logits, rowmap, mode, w, alpha, beta, scale, want_grad=True,
+                                                        grad_kind=GRAD_SLICE if sliced else GRAD_FULL)
+        ctx.save_for_backward(g, weight)
+        ctx.sliced = sliced
+        ctx.mark_non_differentiable(scalars, pred, pred_full)
+        return scalars[0].clone(), scalars, pred, pred_full
+
+    @staticmethod
+    def backward(ctx, gtotal, _gs, _gp, _gf):
+        g, weight = ctx.saved_tensors
+        wsel = weight[ACTION_LO : ACTION_LO + N_ACTION] if ctx.sliced else weight
+        dh = (g * gtotal.to(g.dtype)) @ wsel
+        return dh, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -247,7 +247,7 @@ def test_tiny_openvla_shaped_model_step():
     pix = ops.PatchApply.apply(patch, torch.from_numpy(b["pixel_values"]).to(DEV), torch.from_numpy(xy).to(DEV), torch.from_numpy(th).to(DEV), True, 0)
     logits = m.forward_rows(b["input_ids"].to(DEV), pix, labels)
     assert logits.shape == (8, 32064) and logits.dtype == torch.bfloat16
-    total, scalars, pred = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
+    total, scalars, pred, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
     total.backward()
     assert bool(torch.isfinite(patch.grad).all()) and float(patch.grad.abs().max()) > 0
 
@@ -423,7 +423,7 @@ def test_patch_embed_grad_path_matches_pixel_grad_path(monkeypatch):
         pix = tr.apply_random_patch_batch(img, patch, mean, std, geometry=True)
         assert isinstance(pix, ops.PatchEmbeds) == fused
         logits = m.forward_rows(ids, None, labels, patch_embeds=pix) if fused else m.forward_rows(ids, pix, labels)
-        total, scalars, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
+        total, scalars, _, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
         total.backward()
         res.append((scalars.clone(), patch.grad.clone()))
     (s1, g1), (s2, g2) = res

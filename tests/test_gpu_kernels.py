@@ -356,7 +356,7 @@ def test_resize_patch_config5_upa_step_vs_ref_port(ops):
     # the whole step on the GPU: surrogate model + K3 (UPA) + K2 with per-image patches + resize adjoint
     pix_g.retain_grad()
     out = gpu_model(input_ids.to(DEV), attn.to(DEV), pix_g, labels.to(DEV))
-    total_l, sc, _ = ops.DiscrepancyLoss.apply(out.logits, labels.to(DEV), ops.LOSS_UPA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
+    total_l, sc, _, _ = ops.DiscrepancyLoss.apply(out.logits, labels.to(DEV), ops.LOSS_UPA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
     total_l.backward()
     # K3 against the restated UPA loss on the very same logits
     l_ref, a_ref, d_ref = ref_port.upa_weighted_loss(out.logits.detach().float().cpu(), labels, 0.8, 0.2)
@@ -491,7 +491,7 @@ def test_k3_bs64_vs_oracle(ops):
 
 def DiscrepancyCheck(ops, logits, labels):
     lg = logits.clone().requires_grad_(True)
-    total, scalars, pred = ops.DiscrepancyLoss.apply(lg, labels, ops.LOSS_UADA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
+    total, scalars, pred, _ = ops.DiscrepancyLoss.apply(lg, labels, ops.LOSS_UADA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
     (total * 2.0).backward()
     _, _, g = ops.loss_fwd_bwd(logits, labels, ops.LOSS_UADA, w=5.0)
     assert torch.allclose(lg.grad, 2.0 * g)
@@ -542,6 +542,97 @@ def test_k4_adamw_pgd_clip_vs_oracle(ops):
     pg = _t(p0)
     ops.patch_update(pg, _t(g), None, None, ops.OPT_PGD_SIGN, 0.05, 1)
     assert np.allclose(pg.cpu().numpy(), ref_port.pgd_step(torch.from_numpy(p0), torch.from_numpy(g), 0.05).numpy(), atol=1e-7)
+
+
+@pytest.mark.parametrize("mode,maskidx,dtype", [("UADA_DDP", [0], torch.bfloat16), ("UADA_DDP", [0, 1, 2], torch.float32), ("UADA", [0], torch.float32),
+                                                ("UPA", None, torch.float32), ("UPA", None, torch.bfloat16), ("CE", [0, 2, 5], torch.float32),
+                                                ("CE", list(range(7)), torch.bfloat16)])
+@pytest.mark.parametrize("B", [3, 64])
+def test_k3_rows_path_vs_oracle(ops, mode, maskidx, dtype, B):
+    """K3 on the labelled rows with a prebuilt row map (what the attack loops run): rows split over 2-4 workgroups, gradient confined
+    to the action slice for UADA_DDP / UPA, slice argmax AND full-vocabulary argmax — all against the C oracle on the same logits."""
+    from roboticattack_amd.labels import mask_labels, tma_target_labels, tma_target_tokens
+
+    rs = np.random.RandomState(B * 7 + len(mode))
+    _, labels, _ = synthetic.synth_text_batch(77 + B, B)
+    if mode == "CE":
+        labels = tma_target_labels(labels, tma_target_tokens(np.zeros(7), maskidx))
+    elif mode != "UPA":
+        labels = mask_labels(labels, maskidx)
+    L = labels.shape[1]
+    rows = _rows(labels.numpy())
+    R = len(rows)
+    rb, rp = np.array([r[0] for r in rows]), np.array([r[1] for r in rows])
+    z = (rs.standard_normal((R, 32064)) * 2).astype(np.float32)
+    z[:, 31744:32000] += (rs.standard_normal((R, 256)) * 3).astype(np.float32)
+    z[::3, 1234] = 40.0  # rows whose top-1 token is NOT an action token: slice argmax and full argmax must differ there
+    zt = torch.from_numpy(z).to(dtype)
+    full = torch.zeros((B, 256 + L, 32064), dtype=torch.float32)
+    full[torch.from_numpy(rb), torch.from_numpy(rp)] = zt.float()
+    omode = {"UADA": c_oracle.MODE_UADA, "UADA_DDP": c_oracle.MODE_UADA_DDP, "CE": c_oracle.MODE_CE, "UPA": c_oracle.MODE_UPA}[mode]
+    kmode = {"UADA": ops.LOSS_UADA, "UADA_DDP": ops.LOSS_UADA_DDP, "CE": ops.LOSS_CE, "UPA": ops.LOSS_UPA}[mode]
+    so, go = c_oracle.loss(full.numpy(), labels.numpy(), omode, w=5.0)
+    gor = go[rb, rp]
+    rm = ops.LossRowMap(labels.to(DEV))
+    hdr = rm.buf[:16].view(torch.int32).cpu().numpy()
+    assert hdr[0] == R and hdr[1] == int((labels[:, 1:] > 2).sum())
+    gtol = (1e-2 if dtype == torch.bfloat16 else 2e-4) * max(np.abs(gor).max(), 1e-30)
+    sliced = mode in ("UADA_DDP", "UPA")
+    for kind in ([ops.GRAD_SLICE, ops.GRAD_FULL] if sliced else [ops.GRAD_FULL]):
+        sc, pred, pred_full, g = ops.loss_rows_fwd_bwd(zt.to(DEV), rm, kmode, w=5.0, grad_kind=kind)
+        assert np.allclose(sc.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5), (sc.cpu().numpy(), so)
+        gg = g.float().cpu().numpy()
+        if kind == ops.GRAD_SLICE:
+            assert gg.shape == (R, 256)
+            assert np.abs(gg - gor[:, 31744:32000]).max() <= gtol
+            assert np.abs(np.delete(gor, np.s_[31744:32000], axis=1)).max() == 0.0  # the oracle agrees: nothing outside the slice
+        else:
+            assert np.abs(gg - gor).max() <= gtol
+    # predictions: slice argmax (feeds UAD) and full-vocabulary argmax (UADA.py:165-167), -1 on positions without a label
+    zf = zt.float().numpy()
+    pf = pred_full.cpu().numpy().reshape(B, L - 1)
+    ps = pred.cpu().numpy().reshape(B, L - 1)
+    exp_full = np.full((B, L - 1), -1)
+    exp_slice = np.full((B, L - 1), -1)
+    for i, (b, p) in enumerate(rows):
+        k = p - 256
+        exp_full[b, k] = int(zf[i].argmax())
+        if labels[b, k + 1] > 2:
+            exp_slice[b, k] = 31744 + int(zf[i, 31744:32000].argmax())
+    assert np.array_equal(pf, exp_full) and np.array_equal(ps, exp_slice)
+    assert (pf[exp_slice >= 0] != ps[exp_slice >= 0]).any()
+    # the generic entry point with LAYOUT_ROWS builds the map itself and must agree bit for bit
+    sc2, pred2, g2, pf2 = ops.loss_fwd_bwd(zt.to(DEV), labels.to(DEV), kmode, w=5.0, layout=ops.LAYOUT_ROWS, want_pred_full=True)
+    assert torch.equal(sc2, sc) and torch.equal(pred2, pred) and torch.equal(pf2, pred_full) and torch.equal(g2, g)
+    # and the FULL layout (black-box model path) reports the same full-vocabulary argmax
+    sc3, pred3, _, pf3 = ops.loss_fwd_bwd(full.to(DEV), labels.to(DEV), kmode, w=5.0, want_grad=False, want_pred_full=True)
+    if dtype == torch.float32:
+        assert torch.equal(pf3, pred_full) and torch.equal(pred3, pred)
+        assert np.allclose(sc3.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5)
+
+
+def test_head_loss_rows_matches_generic_head_backward(ops):
+    """LM head + loss on the labelled rows with the backward contracting over the 256 action columns (UADA_DDP / UPA)
+    equals the generic path (full [R,V] gradient @ W) to bf16 GEMM rounding; CE modes take the full-row route inside the same op."""
+    from roboticattack_amd.labels import mask_labels
+
+    B, D = 8, 512
+    g = torch.Generator(device=DEV).manual_seed(3)
+    W = (torch.randn(32064, D, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    _, labels, _ = synthetic.synth_text_batch(5, B)
+    for mode, lab in ((ops.LOSS_UADA_DDP, mask_labels(labels.clone(), [0, 1])), (ops.LOSS_UPA, labels), (ops.LOSS_UADA, mask_labels(labels.clone(), [0]))):
+        lab = lab.to(DEV)
+        rm = ops.LossRowMap(lab)
+        R = int((lab[:, 1:] != -100).sum())
+        h = (torch.randn(R, D, device=DEV, generator=g)).to(torch.bfloat16)
+        h1 = h.clone().requires_grad_(True)
+        t1, s1, _, _ = ops.HeadLossRows.apply(h1, W, rm, mode, 5.0, 0.8, 0.2, 1.0)
+        t1.backward()
+        h2 = h.clone().requires_grad_(True)
+        t2, s2, _, _ = ops.DiscrepancyLossRows.apply(torch.nn.functional.linear(h2, W), rm, mode, 5.0, 0.8, 0.2, 1.0)
+        t2.backward()
+        assert torch.equal(s1, s2)
+        assert (h1.grad.float() - h2.grad.float()).abs().max() <= 2e-2 * h2.grad.float().abs().max() + 1e-12
 
 
 def test_capi_error_paths_on_gpu(ops):
