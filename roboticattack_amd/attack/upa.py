@@ -31,14 +31,17 @@ class OpenVLAAttacker(AttackBase):
         return _mask_labels(labels, maskidx)
 
     def change_target(self, gt):
-        """UPA.py:358-364 — flip every action label to the opposite extreme (ties at 31872 broken at random)."""
+        """UPA.py:358-364, reproduced statement by statement. The reference assigns SEQUENTIALLY on the tensor it is rewriting: ties at
+        31872 are first broken at random (one torch.randint draw, kept so the RNG stream matches), then every label > 31872 becomes
+        31744, then every label < 31872 — which by now includes all the 31744s just written and the EOS token 2 — becomes 31999. The
+        net effect of the shipped code is therefore "every non-ignored label -> 31999"; kept as is for parity (guide mode is off by
+        default: UPA_wrapper.py passes guide=False)."""
         mask = gt != -100
         mid = mask & (gt == 31872)
         r = torch.randint(0, 2, gt[mid].shape, dtype=torch.bool).to(gt.device)
-        hi, lo = mask & (gt > 31872), mask & (gt < 31872)
         gt[mid] = torch.where(r, torch.tensor(31744, dtype=gt.dtype, device=gt.device), torch.tensor(31999, dtype=gt.dtype, device=gt.device))
-        gt[hi] = 31744
-        gt[lo] = 31999
+        gt[mask & (gt > 31872)] = 31744
+        gt[mask & (gt < 31872)] = 31999
         return gt
 
     def _mode(self, guide, reverse_direction):

@@ -36,7 +36,7 @@ class VitCfg:
     heads: int
     mlp: int
     n_prefix: int  # cls + register tokens
-    cls_pos: bool  # cls token carries a position embedding (DINOv2); register tokens never do
+    cls_pos: bool  # the class token has its own position-embedding slot (timm models WITHOUT no_embed_class); register tokens never do
     layerscale: bool
 
 
@@ -55,7 +55,9 @@ class OpenVLACfg:
 
 def openvla_7b_cfg() -> OpenVLACfg:
     return OpenVLACfg(
-        dino=VitCfg(1024, 24, 16, 4096, 5, True, True),
+        # timm vit_large_patch14_reg4_dinov2.lvd142m is a `no_embed_class` model: pos_embed is [1,256,1024] over the PATCH tokens only,
+        # cls + 4 register tokens are concatenated afterwards (the checkpoint holds pos_embed 256, cls_token 1, reg_token 4)
+        dino=VitCfg(1024, 24, 16, 4096, 5, False, True),
         siglip=VitCfg(1152, 27, 16, 4304, 0, False, False),
     )
 
@@ -63,7 +65,7 @@ def openvla_7b_cfg() -> OpenVLACfg:
 def tiny_cfg() -> OpenVLACfg:
     """Same topology, toy widths: CPU-runnable plumbing tests."""
     return OpenVLACfg(
-        dino=VitCfg(32, 3, 2, 64, 5, True, True),
+        dino=VitCfg(32, 3, 2, 64, 5, False, True),
         siglip=VitCfg(48, 3, 2, 80, 0, False, False),
         llm_dim=64, llm_layers=2, llm_heads=4, llm_mlp=128,
     )
@@ -138,12 +140,16 @@ class Vit(nn.Module):
             B0 = img.shape[0]
             tiles = img.reshape(B0, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(B0, 256, 588)
             x = F.linear(tiles, self.patch_embed.weight.reshape(self.c.dim, 588), self.patch_embed.bias)  # [B,256,D]
-        if self.prefix is not None:
+        if self.prefix is not None and self.c.cls_pos:
             B = x.shape[0]
             cls = self.prefix[:, :1].expand(B, -1, -1)
             reg = self.prefix[:, 1:].expand(B, -1, -1)
-            x = torch.cat([cls, x], dim=1) + self.pos_embed  # timm: pos-embed over [cls, patches], then registers
+            x = torch.cat([cls, x], dim=1) + self.pos_embed  # timm without no_embed_class: pos-embed over [cls, patches], then registers
             x = torch.cat([x[:, :1], reg, x[:, 1:]], dim=1)
+        elif self.prefix is not None:
+            # timm `no_embed_class` (DINOv2 reg4, VisionTransformer._pos_embed): position embedding on the patch tokens only, then
+            # [cls, registers] are prepended
+            x = torch.cat([self.prefix.expand(x.shape[0], -1, -1), x + self.pos_embed], dim=1)
         else:
             x = x + self.pos_embed
         for blk in self.blocks:

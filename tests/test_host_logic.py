@@ -150,6 +150,19 @@ def test_tiny_model_rows_equal_full_logits():
     assert all(not p.requires_grad for p in m.parameters())
 
 
+def test_upa_change_target_matches_reference():
+    """UPA.py:358-364 (guide mode): the reference's sequential in-place assignment and its single torch.randint draw."""
+    import types
+
+    from roboticattack_amd.attack.upa import OpenVLAAttacker
+
+    d = np.load(os.path.join(GOLDEN, "labels_tokenizer.npz"))
+    torch.manual_seed(5)
+    got = OpenVLAAttacker.change_target(types.SimpleNamespace(), torch.from_numpy(d["change_target_in"]).clone())
+    assert np.array_equal(got.numpy(), d["change_target_out"])
+    assert np.array_equal(torch.rand(1).numpy(), d["change_target_rng_after"]), "RNG consumption differs from the reference"
+
+
 def test_hf_checkpoint_name_mapping_roundtrip(tmp_path):
     """`load_hf_openvla` maps an HF-OpenVLA-named safetensors checkpoint (modeling_prismatic.py module tree: vision_backbone.
     {featurizer,fused_featurizer}.blocks.N.attn.qkv ..., projector.fcK, language_model.model.layers.N.self_attn.q_proj ...) onto the
@@ -192,6 +205,37 @@ def test_hf_checkpoint_name_mapping_roundtrip(tmp_path):
     ids, labels, attn = synthetic.synth_text_batch(2, 2, 18, 20)
     pix = torch.randn(2, 6, 224, 224)
     assert torch.equal(src(ids, attn, pix, labels).logits, dst(ids, attn, pix, labels).logits)
+    # the shapes a real openvla-7b checkpoint holds for the DINOv2-reg4 tower (timm no_embed_class): pos_embed over the 256 patch tokens
+    # only, a 1-token cls_token and a 4-token reg_token; SigLIP: pos_embed 256, no prefix tokens
+    assert tuple(hf["vision_backbone.featurizer.pos_embed"].shape) == (1, 256, 32)
+    assert tuple(hf["vision_backbone.featurizer.cls_token"].shape) == (1, 1, 32) and tuple(hf["vision_backbone.featurizer.reg_token"].shape) == (1, 4, 32)
+    assert tuple(hf["vision_backbone.fused_featurizer.pos_embed"].shape) == (1, 256, 48)
+    from roboticattack_amd.openvla_model import openvla_7b_cfg
+
+    c7 = openvla_7b_cfg()
+    assert (c7.dino.n_prefix, c7.dino.cls_pos, c7.siglip.n_prefix) == (5, False, 0)
+
+
+def test_dinov2_reg4_prefix_and_pos_embed_order():
+    """timm `no_embed_class` semantics of the DINOv2-reg4 tower: x = cat([cls, reg x4, patches + pos_embed]) — the position embedding
+    never touches the prefix tokens (a 257-entry pos_embed cannot load the real checkpoint)."""
+    from roboticattack_amd.openvla_model import Vit, VitCfg
+
+    torch.manual_seed(0)
+    v = Vit(VitCfg(16, 2, 2, 32, 5, False, True)).eval()
+    with torch.no_grad():
+        v.pos_embed.normal_()
+        v.prefix.normal_()
+    assert tuple(v.pos_embed.shape) == (1, 256, 16)
+    img = torch.randn(2, 3, 224, 224)
+    seen = {}
+    v.blocks[0].register_forward_pre_hook(lambda m, a: seen.setdefault("x", a[0].detach().clone()))
+    v(img)
+    x = seen["x"]
+    tiles = img.reshape(2, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(2, 256, 588)
+    emb = torch.nn.functional.linear(tiles, v.patch_embed.weight.reshape(16, 588), v.patch_embed.bias)
+    assert x.shape == (2, 261, 16)
+    assert torch.equal(x[:, :5], v.prefix.expand(2, -1, -1)) and torch.allclose(x[:, 5:], emb + v.pos_embed, atol=1e-6)
 
 
 def test_frozen_linears_fn_matches_autograd():

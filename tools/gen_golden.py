@@ -305,6 +305,13 @@ def gen_labels_tokenizer():
     rd = ref.UADA.OpenVLAAttacker.calculate_relative_distance(ns, pred, gt, [0, 3], {"0": [], "3": []})
     out["rd_pred"], out["rd_gt"] = pred.numpy(), gt.numpy()
     out["rd_0"], out["rd_3"] = np.array(rd["0"]), np.array(rd["3"])
+    # UPA guide-mode target flip (UPA.py:358-364): sequential in-place assignment, one torch.randint draw for the ties at 31872
+    lab_ct = labels.clone()
+    lab_ct[0, -3] = 31872  # a tie, so the random branch is exercised
+    torch.manual_seed(5)
+    out["change_target_in"] = lab_ct.numpy().copy()
+    out["change_target_out"] = ref.UPA.OpenVLAAttacker.change_target(ns, lab_ct.clone()).numpy()
+    out["change_target_rng_after"] = torch.rand(1).numpy()
     np.savez_compressed(os.path.join(GOLD, "labels_tokenizer.npz"), **out)
     print("labels_tokenizer ok")
 
