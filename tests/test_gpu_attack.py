@@ -394,6 +394,71 @@ def test_ddp_attacker_two_ranks_vs_single_process(tmp_path, attack):
     assert os.path.exists(tmp_path / "rank0" / "last" / "patch.pt") and not os.path.exists(tmp_path / "rank1" / "last")  # rank 0 writes
 
 
+def test_integration_md_stub_runs_verbatim():
+    """INTEGRATION.md sections 1-2 — the ctypes stub a reference maintainer would paste into appply_random_transform.py / UADA.py — is
+    executed AS WRITTEN against a black-box model that returns fp32 [B,S,V] logits (VAA_LAYOUT_FULL): one UADA step and one DDP-style
+    step give the same loss scalars, predictions, patch gradient and updated patch as this repository's own binding, and the loss
+    matches the oracle."""
+    import random
+    import re
+
+    from conftest import ROOT
+    from oracle import c_oracle
+    from roboticattack_amd import _lib, ops
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.optim import PatchOptimizer
+    from roboticattack_amd.surrogate import SurrogateVLA
+    from roboticattack_amd.transform import RandomPatchTransform as OwnTransform
+
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = md[md.index("## 1."):md.index("## 3.")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 3
+    ns = {}
+    src = "\n".join(blocks).replace('ctypes.CDLL("libvaa_hip.so")', f'ctypes.CDLL({_lib.LIB_PATH!r})')  # only the library path is local
+    exec(compile(src, "INTEGRATION.md", "exec"), ns)
+
+    class Transform(ns["RandomPatchTransform"], OwnTransform):  # the stub class + what the reference class already has around it
+        def __init__(self, device):
+            OwnTransform.__init__(self, device, False)
+
+        apply_random_patch_batch = ns["RandomPatchTransform"].apply_random_patch_batch
+
+    B = 3
+    batch = synthetic.synth_batch(31, B, "smooth")
+    labels = mask_labels(batch["labels"].clone(), [0]).to(DEV)
+    ids, attn = batch["input_ids"].to(DEV), batch["attention_mask"].to(DEV)
+    vla = SurrogateVLA(seed=4).to(DEV)  # black box: forward(input_ids, attention_mask, pixel_values, labels) -> .logits fp32 [B,S,V]
+    mean = [torch.tensor([0.484375, 0.455078125, 0.40625]), torch.tensor([0.5, 0.5, 0.5])]
+    std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
+    torch.manual_seed(1)
+    p0 = torch.rand(3, 50, 50, device=DEV)
+    for ddp in (False, True):
+        # --- the stub ---
+        random.seed(9)
+        np.random.seed(9)
+        patch = p0.clone().requires_grad_(True)
+        opt = ns["_PatchAdamW"](patch, 2e-3)
+        scalars, pred_full = ns["uada_inner_step"](vla, Transform(DEV), opt, batch["pixel_values"], patch, ids, attn, labels, mean, std, True, ddp=ddp)
+        g_stub = patch.grad.clone()
+        # --- this repository's binding on the same draws ---
+        random.seed(9)
+        np.random.seed(9)
+        patch2 = p0.clone().requires_grad_(True)
+        opt2 = PatchOptimizer(patch2, 2e-3, "adamW")
+        pix = OwnTransform(DEV).apply_random_patch_batch(batch["pixel_values"], patch2, mean, std, True)
+        out = vla(input_ids=ids, attention_mask=attn, pixel_values=pix, labels=None)
+        assert out.logits.dtype == torch.float32 and out.logits.dim() == 3
+        total, sc2, _, pf2 = ops.DiscrepancyLoss.apply(out.logits, labels, ops.LOSS_UADA_DDP if ddp else ops.LOSS_UADA, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
+        total.backward()
+        opt2.step()
+        assert torch.equal(scalars, sc2) and torch.equal(pred_full, pf2)
+        assert torch.equal(g_stub, patch2.grad) and torch.equal(patch.detach(), patch2.detach())
+        so, _ = c_oracle.loss(out.logits.detach().cpu().numpy(), labels.cpu().numpy(), c_oracle.MODE_UADA_DDP if ddp else c_oracle.MODE_UADA, w=5.0, want_grad=False)
+        assert np.allclose(scalars.cpu().numpy()[:3], so[:3], rtol=3e-5, atol=3e-5)
+        assert float((patch.detach() - p0).abs().max()) > 0
+
+
 def test_patch_embed_grad_path_matches_pixel_grad_path(monkeypatch):
     """SURVEY.md 8f-3 end to end: one UADA step with the patch-embed backward restricted to the kept tiles (K2') gives the same loss and
     the same patch gradient as the path through the dense bf16 pixel gradient (K2)."""

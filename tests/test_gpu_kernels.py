@@ -635,6 +635,38 @@ def test_head_loss_rows_matches_generic_head_backward(ops):
         assert (h1.grad.float() - h2.grad.float()).abs().max() <= 2e-2 * h2.grad.float().abs().max() + 1e-12
 
 
+def test_two_streams_overlap_k2_and_k3(ops):
+    """include/vaa.h: re-entrant per stream, scratch is the caller's. The binding keys its scratch by (device, stream, operator), so
+    the loss of one step and the gather of another can overlap on two streams; results equal the serial ones bit for bit."""
+    from roboticattack_amd.labels import mask_labels
+
+    B = 64
+    rs = np.random.RandomState(2)
+    imgs = _t(synthetic.synth_images(8, B, "noise"))
+    patch = _t(rs.rand(3, 50, 50).astype(np.float32))
+    xy_n, th_n = _random_case(rs, B, 50, 50)
+    xy, th = _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6))
+    _, keep = ops.patch_apply_fwd(imgs, patch, xy, th, True, 0)
+    g = synthetic.synth_upstream_grad(3, B).to(DEV)
+    _, labels, _ = synthetic.synth_text_batch(12, B)
+    labels = mask_labels(labels, [0]).to(DEV)
+    R = int((labels[:, 1:] != -100).sum())
+    logits = (torch.randn(R, 32064, device=DEV) * 2).to(torch.bfloat16)
+    rm = ops.LossRowMap(labels)
+    ref_g = ops.patch_grad_gather(g, patch, xy, th, keep, True, 0)
+    ref_sc, _, _, ref_gl = ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            g1 = ops.patch_grad_gather(g, patch, xy, th, keep, True, 0)
+        with torch.cuda.stream(s2):
+            sc2, _, _, gl2 = ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0)
+        torch.cuda.synchronize()
+        assert torch.equal(g1, ref_g) and torch.equal(sc2, ref_sc) and torch.equal(gl2, ref_gl)
+    assert len({k for k in ops._ws_cache if k[1] in (s1.cuda_stream, s2.cuda_stream)}) == 2  # one scratch buffer per (stream, operator)
+
+
 def test_capi_error_paths_on_gpu(ops):
     from roboticattack_amd import _lib
 
