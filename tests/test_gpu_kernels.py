@@ -791,3 +791,14 @@ def test_patch_embed_grad_gather_vs_unfused(ops, B, ph, pw, geo, D0, D1):
     exact = ops.patch_embed_grad_gather(dy0, dy1, w0.t().contiguous(), w1.t().contiguous(), patch, xy, th if geo else None, keep, bool(geo),
                                         round_bf16=False)
     assert (exact - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-7
+    # ORACLE leg (no HIP code on this side): the patch-embed backward as an fp32 matmul on the host, folded to pixel layout, rounded to
+    # bf16 per tower like the model's own backward hands it over, then the plain-C gather (oracle/vaa_oracle.c:vaa_oracle_patch_grad)
+    def fold_cpu(dy, w):
+        t = (dy.float().cpu() @ w.float().cpu()).to(torch.bfloat16)
+        return t.view(B, 16, 16, 3, 14, 14).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 224, 224)
+
+    gout_cpu = torch.cat([fold_cpu(dy0, w0), fold_cpu(dy1, w1)], dim=1).contiguous()
+    theta_o = th_n.reshape(B, 2, 3) if geo else np.tile(np.eye(3, dtype=np.float32)[:2], (B, 1, 1))
+    og = c_oracle.patch_grad(_bits(gout_cpu), patch.cpu().numpy(), xy_n, theta_o, int(geo), 0)
+    assert np.abs(got.cpu().numpy() - og).max() <= 2e-3 * np.abs(og).max() + 1e-7  # bf16 rounding flips of the tile gradients (GEMM order)
+    assert np.abs(ref.cpu().numpy() - og).max() <= 2e-3 * np.abs(og).max() + 1e-7
