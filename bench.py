@@ -10,7 +10,7 @@ One step = one inner-loop iteration of UADA_wrapper_ddp (UADA_ddp.py:189-209):
 Workload: bs=64 PER RANK (reference semantics, UADA_ddp.py:158 -> weak scaling), 3x50x50 patch, geometry=True, maskidx=[0],
 synthetic BridgeData-shaped frames resident in HBM as u8, random-init weights of the OpenVLA-7B architecture.
 Prints ONE JSON line on rank 0. `roofline` is the dominant hand-written kernel of the path — K1's `patch_apply_fwd_kernel`, which
-moves 73 % of the path's algorithmic bytes and is the longest launch of the default path (K1-K4) in profiles/r01_kbench_kernel_stats_*.csv —
+moves 73 % of the path's algorithmic bytes and is the longest launch of the default path (K1-K4) in profiles/r02_kbench_kernel_stats.csv —
 timed inside the timed region (HIP events on the launch stream); `roofline_kernels`/`k2_sweep` carry every op and the K2 batch sweep; `cpu_baseline` is the reference's
 PyTorch-CPU op sequence for the same replaced ops (oracle/ref_port.py) timed on this box's host cores.
 """
@@ -68,13 +68,12 @@ def build_model(kind, dev):
 
 
 def cpu_baseline(bs, patch_shape, budget_s=25.0):
-    """The reference's CPU path for the replaced ops at the same shapes: per-image PyTorch op chain + autograd (K1,K2),
-    HF-style CE + weighted_loss on fp32 logits [B,S,32064] + backward (K3), HF AdamW + clamp (K4).
+    """The reference's CPU path for the replaced ops (oracle/ref_port.py: per-image PyTorch op chain + autograd for K1/K2, HF-style CE +
+    weighted_loss on fp32 logits [B,S,32064] + backward for K3, HF AdamW + clamp for K4), timed on this box's host cores with ONE thread
+    and with ALL logical cores: 2 warm-ups, then >= 5 timed iterations, min and median reported.
 
-    Bounded sample: torch's default (all host cores) thrashes on the reference's many tiny per-image ops, so a short
-    probe at bs=8 picks the fastest intra-op thread count out of {1, 8, 16, 32} for the patch ops (K1,K2,K4) and
-    out of {16, 32, 64} for the big-tensor loss (K3) — i.e. the CPU path is timed at ITS best setting — then the full
-    bs is timed (min over the iterations that fit the budget, at least one after a warm-up)."""
+    Bounded sample (about 25 s of CPU work in total): every leg times a slice of the per-rank batch whose size a 2-image probe picks so
+    that 2 + 5 iterations fit the leg's budget, and scales linearly to bs (one K3 iteration at bs=64 on one thread takes ~40 s)."""
     from oracle import ref_port
     from roboticattack_amd import synthetic
     from roboticattack_amd.benchmarks import random_params
@@ -84,6 +83,10 @@ def cpu_baseline(bs, patch_shape, budget_s=25.0):
     imgs_all = synthetic.synth_images(1234, bs, "noise")
     xy_all, th_all = random_params(bs, patch_shape[1], patch_shape[2], 42)
     th_all = th_all.reshape(bs, 2, 3)
+    _, labels_all, _ = synthetic.synth_text_batch(4242, bs)
+    labels_all = ref_port.mask_labels(labels_all, [0])
+    S = 256 + labels_all.shape[1]
+    logits4 = torch.randn(4, S, 32064)
 
     def patch_ops(n):
         patch = torch.nn.Parameter(torch.rand(*patch_shape))
@@ -92,53 +95,48 @@ def cpu_baseline(bs, patch_shape, budget_s=25.0):
         ref_port.cpu_patch_step(imgs_all[:n], patch, opt, xy_all[:n], th_all[:n], True, gout_all[:n])
         return time.perf_counter() - t0
 
-    def pick(fn, cands):
-        best, best_t = None, 1e30
-        cands = sorted({min(c, ncores) for c in cands})
-        for th in cands:
-            torch.set_num_threads(th)
-            fn()
-            t = min(fn(), fn())
-            if t < best_t:
-                best, best_t = th, t
-        return best
-
-    t_start = time.perf_counter()
-    th_patch = pick(lambda: patch_ops(8), (1, 8, 16, 32))
-    torch.set_num_threads(th_patch)
-    patch_ops(bs)
-    t12 = [patch_ops(bs)]
-    while time.perf_counter() - t_start < budget_s * 0.4 and len(t12) < 5:
-        t12.append(patch_ops(bs))
-
-    _, labels, _ = synthetic.synth_text_batch(4242, bs)
-    labels = ref_port.mask_labels(labels, [0])
-    S = 256 + labels.shape[1]
-    logits_small = torch.randn(4, S, 32064)
-
-    def loss_ops(lg0, lab):
-        lg = lg0.detach().requires_grad_(True)
+    def loss_ops(n):
+        lg = logits4.repeat((n + 3) // 4, 1, 1)[:n].contiguous().requires_grad_(True)  # values do not affect timing
         t0 = time.perf_counter()
-        mse, _ = ref_port.uada_weighted_loss(lg, lab, 5.0)
-        ce = ref_port.hf_ce(lg, lab)  # HF computes `.loss` whenever labels are passed (UADA_ddp.py:196-201)
+        mse, _ = ref_port.uada_weighted_loss(lg, labels_all[:n], 5.0)
+        ce = ref_port.hf_ce(lg, labels_all[:n])  # HF computes `.loss` whenever labels are passed (UADA_ddp.py:196-201)
         (mse + 0.0 * ce).backward()
         return time.perf_counter() - t0
 
-    th_loss = pick(lambda: loss_ops(logits_small, labels[:4]), (16, 32, 64))
-    torch.set_num_threads(th_loss)
-    logits = logits_small.repeat((bs + 3) // 4, 1, 1)[:bs].contiguous()  # values do not affect timing
-    loss_ops(logits, labels)
-    t3 = [loss_ops(logits, labels)]
-    while time.perf_counter() - t_start < budget_s and len(t3) < 5:
-        t3.append(loss_ops(logits, labels))
-    k124, k3 = float(np.min(t12)), float(np.min(t3))
+    def timed(fn, n_max, t_budget, warm=2, iters=5):
+        """2 warm-ups + 5 timed iterations that FIT the budget: a 2-image probe sizes the sample (every op of the path is linear in the
+        batch), so a slow host (or a thread count that thrashes on the reference's many tiny ops) cannot stretch the run."""
+        n0 = min(2, n_max)
+        fn(n0)
+        per_img = fn(n0) / n0
+        n = max(1, min(n_max, int(0.6 * t_budget / (warm + iters) / max(per_img, 1e-9))))
+        t_end = time.perf_counter() + 2.0 * t_budget  # hard stop: never fewer than 3 timed iterations, never far beyond the budget
+        for _ in range(warm):
+            fn(n)
+        ts = []
+        while len(ts) < iters and (len(ts) < 3 or time.perf_counter() < t_end):
+            ts.append(fn(n))
+        return float(np.min(ts)), float(np.median(ts)), n
+
+    legs = {}
+    for tag, threads, n_max, b_patch, b_loss in (("1_thread", 1, min(8, bs), 2.0, 8.0), ("all_cores", ncores, bs, 4.0, 11.0)):
+        torch.set_num_threads(threads)
+        p_min, p_med, p_n = timed(patch_ops, n_max, budget_s / 25.0 * b_patch)
+        l_min, l_med, l_n = timed(loss_ops, n_max, budget_s / 25.0 * b_loss)
+        legs[tag] = {"threads": threads, "sample_bs_K1_K2_K4": p_n, "sample_bs_K3": l_n, "scaled_to_bs": bs,
+                     "ms_K1_K2_K4_min": p_min * bs / p_n * 1e3, "ms_K1_K2_K4_median": p_med * bs / p_n * 1e3,
+                     "ms_K3_min": l_min * bs / l_n * 1e3, "ms_K3_median": l_med * bs / l_n * 1e3,
+                     "steps_per_s_min_time": 1.0 / (p_min * bs / p_n + l_min * bs / l_n),
+                     "steps_per_s_median_time": 1.0 / (p_med * bs / p_n + l_med * bs / l_n)}
+    best = max(legs, key=lambda k: legs[k]["steps_per_s_min_time"])
     return {
-        "value": 1.0 / (k124 + k3), "unit": "patch-path steps/s on host CPU (K1+K2+K3+K4 only, model excluded)",
-        "cores": max(th_patch, th_loss), "kind": "port",
-        "sample": f"oracle/ref_port.py (PyTorch-CPU restatement of the reference op sequence), bs={bs}, patch {patch_shape}, geometry=True, "
-                  f"fp32 logits [{bs},{S},32064]; min of {len(t12)}/{len(t3)} timed iterations after a warm-up; intra-op threads picked by a "
-                  f"bs=8 probe: {th_patch} for K1/K2/K4, {th_loss} for K3 (host has {ncores} logical cores)",
-        "ms_K1_K2_K4": k124 * 1e3, "ms_K3": k3 * 1e3, "threads_patch_ops": th_patch, "threads_loss": th_loss, "host_logical_cores": ncores,
+        "value": legs[best]["steps_per_s_min_time"], "unit": "patch-path steps/s on host CPU (K1+K2+K3+K4 only, model excluded)",
+        "cores": legs[best]["threads"], "kind": "port",
+        "sample": f"oracle/ref_port.py (PyTorch-CPU restatement of the reference op sequence), patch {patch_shape}, geometry=True, fp32 logits "
+                  f"[bs,{S},32064]; per leg (1 thread; all {ncores} logical cores) 2 warm-ups then 5 timed iterations, min and median, on a slice of "
+                  f"the bs={bs} batch sized by a 2-image probe to fit ~{budget_s:.0f} s in total (sample_bs_* in `legs`), scaled linearly to bs={bs}; "
+                  f"value = the faster leg's min",
+        "legs": legs, "host_logical_cores": ncores,
     }
 
 
@@ -192,22 +190,22 @@ def main():
     inv_world = 1.0 / world
     scal = torch.zeros(8, device=dev)
     row_index = model.label_row_index(labels) if use_rows else None  # once per outer iteration, as the attack loops do
+    row_map = ops.LossRowMap(labels) if use_rows else None               # K3's device row map, same lifetime
     pack = model.make_pack(attn) if hasattr(model, "make_pack") else None  # padding rows of the right-padded prompts are never computed
+    pick = torch.tensor([1, 2, 7], dtype=torch.int64, device=dev)
 
-    def step():
+    def step():  # attack/uada_ddp.py inner step
         opt.zero_grad()
         pix = tr.apply_random_patch_batch(img, patch, mean, std, geometry=True)  # host RNG draws + K1
         if use_rows:
-            if isinstance(pix, ops.PatchEmbeds):
-                logits = model.forward_rows(input_ids, None, labels, row_index, patch_embeds=pix, pack=pack)
-            else:
-                logits = model.forward_rows(input_ids, pix, labels, row_index, pack=pack)
-            total, scalars, _, _ = ops.DiscrepancyLoss.apply(logits, labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_ROWS)
+            pe = pix if isinstance(pix, ops.PatchEmbeds) else None
+            h = model.hidden_rows(input_ids, None if pe is not None else pix, row_index, patch_embeds=pe, pack=pack)
+            total, scalars, _, _ = ops.HeadLossRows.apply(h, model.lm_head.weight, row_map, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0)  # LM head + K3
         else:
             out = model(input_ids=input_ids, attention_mask=attn, pixel_values=pix, labels=None)
             total, scalars, _, _ = ops.DiscrepancyLoss.apply(out.logits.contiguous(), labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
         total.backward()  # ... -> K2 (or K2' fed by the patch-embed output gradients)
-        g_sum, _ = sync.allreduce(patch.grad, torch.stack([scalars[1], scalars[2], scalars[7], patch.grad.mean()]))
+        g_sum, _ = sync.allreduce_step(patch.grad, scalars, pick)  # [grad | CE, MSE, UAD, sum(grad)]: one all-reduce per step
         opt.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4
         scal.copy_(scalars)
 
@@ -232,8 +230,11 @@ def main():
     barrier()
     ops.TIMER = []
     t0 = time.perf_counter()
+    host_enqueue = 0.0
     for _ in range(args.steps):
+        th0 = time.perf_counter()
         step()
+        host_enqueue += time.perf_counter() - th0  # python + launch time of a step; the GPU runs behind it (no sync inside a step)
     barrier()
     dt = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
@@ -258,7 +259,7 @@ def main():
     kern = {}
     esz = 2 if use_rows and args.model == "openvla-7b" else 4
     for name, ts in per.items():
-        key = "K2e" if name.startswith("K2_patch_embed") else name[:2]
+        key = "K2e" if name.startswith("K2_patch_embed") else ("K3_slice" if name.startswith("K3_loss_rows") else name[:2])
         nb = algo_bytes(key, B, patch_shape[1], patch_shape[2], rows=R, esize=esz)
         mean = float(np.mean(ts))
         kern[name] = {"launches": len(ts), "mean_us": mean * 1e6, "algo_bytes": nb, "achieved_GBs": nb / mean / 1e9,
@@ -266,7 +267,8 @@ def main():
     # dominant kernel: most algorithmic bytes (K1, one launch per op -> the event bracket is the kernel); every op is in `roofline_kernels`
     dom = max(kern, key=lambda k: kern[k]["algo_bytes"]) if kern else None
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")  # rocprofv3 --pmc passes of tools/pmc_traffic.py (same kernels, same shapes)
+    tfile = "profiles/traffic_r02.json"  # rocprofv3 --pmc passes of tools/pmc_traffic.py (same kernels, same shapes); NOT measured in this run
+    tpath = os.path.join(ROOT, tfile)
     tr_ops = json.load(open(tpath)).get("ops", {}) if os.path.exists(tpath) else {}
     if dom:
         traffic = tr_ops.get(dom, {}).get("hbm_bytes_per_launch")
@@ -275,17 +277,30 @@ def main():
     roofline = None
     if dom:
         roofline = {"timing": "one start/stop HIP event pair per launch on the launching stream inside the timed region", "kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": kern[dom]["frac"], "traffic": traffic, "mean_us": kern[dom]["mean_us"], "algo_bytes": kern[dom]["algo_bytes"],
+                    "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": tfile + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",
+                    "mean_us": kern[dom]["mean_us"], "algo_bytes": kern[dom]["algo_bytes"],
                     "note": "dominant = the kernel of the default hot path (K1-K4) with the most algorithmic bytes, also its longest single launch in the rocprofv3 kernel stats "
                             "(the opt-in K2' tile GEMM of SURVEY 8f-3 is listed under roofline_kernels_standalone as K2e); "
-                            "traffic = HBM-side bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes (profiles/traffic_r01.json, calibrated in-run)"}
+                            "frac_of_measured_copy_bw = achieved / this box's device-to-device copy rate measured in this run"}
 
-    extra = {}
+    extra = {"host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
+             "host_overhead_note": "python + launch time of one step (no host synchronisation inside a step); ms_per_step - host_enqueue_ms_per_step "
+                                   "is the slack the GPU runs behind the host: the step is GPU-bound while it is positive, and N ranks on one host need N x this host time in parallel"}
     if not args.no_kernel_suite:
         del model
         torch.cuda.empty_cache()
+        from roboticattack_amd.benchmarks import device_copy_bandwidth, k1_sweep, rank_shapes
+
+        copy_bw = device_copy_bandwidth(device=str(dev))
+        extra["measured_device_copy_GBs"] = copy_bw
         extra["roofline_kernels_standalone"] = kernel_suite(B, patch_shape[1], patch_shape[2], device=str(dev))
+        for v in extra["roofline_kernels_standalone"].values():
+            v["frac_of_measured_copy_bw"] = v["achieved_GBs"] / copy_bw
         extra["k2_sweep"] = k2_sweep(device=str(dev))
+        extra["k1_sweep"] = k1_sweep(device=str(dev))
+        extra["rank_shapes"] = rank_shapes(device=str(dev))
+        if roofline:
+            roofline["measured_device_copy_GBs"] = copy_bw
         ks = extra["roofline_kernels_standalone"]
         used_k2 = "K2e_patch_embed_grad_gather" if tr.embed_with is not None else "K2_patch_grad_gather"
         gpu_ops_s = sum(v["mean_us"] for k, v in ks.items() if not k.startswith("K2") or k == used_k2) * 1e-6
@@ -296,8 +311,8 @@ def main():
             # process, HIP events around hipGraph replays of 10 launches) is what agrees with rocprofv3's per-kernel average.
             k = ks[roofline["kernel"]]
             roofline.update({"in_loop_event_bracket_us": roofline["mean_us"], "mean_us": k["mean_us"], "achieved": k["achieved_GBs"],
-                             "frac": k["achieved_GBs"] / HBM_PEAK_GBS,
-                             "timing": "mean_us/achieved/frac: HIP events around hipGraph replays of 10 back-to-back launches of the kernel, same process (agrees with profiles/r01_kbench_kernel_stats_*.csv); "
+                             "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "frac_of_measured_copy_bw": k["achieved_GBs"] / copy_bw,
+                             "timing": "mean_us/achieved/frac: HIP events around hipGraph replays of 10 back-to-back launches of the kernel, same process (agrees with profiles/r02_kbench_kernel_stats.csv); "
                                        "in_loop_event_bracket_us = one start/stop event pair per launch inside the timed region (includes marker packets and gaps)"})
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # host-CPU leg only at N=1 (rank 0), as the bench contract asks

@@ -4,7 +4,8 @@ Algorithmic bytes per launch (restated in DESIGN.md):
   K1 fwd   : B*(150,528 [u8 frame] + 602,112 [bf16 6-ch output]) + 12*ph*pw [patch]
   K2 gather: strict  = B*3*ph*pw*(2*2 [bf16 upstream grad, channels c and c+3, ~ph*pw kept pixels/|det|~1]) + 12*ph*pw
              i.e. ~ B*12*ph*pw + 12*ph*pw  (B*30,000 + 30,000 at 50x50);  full-frame figure B*602,112 reported separately
-  K3 loss  : 2 * R' * V * e   (one read + one write of the labelled rows; e = bytes per logit)
+  K3 loss  : 2 * R' * V * e   (one read + one write of the labelled rows; e = bytes per logit); "K3_slice" (UADA_DDP / UPA, gradient
+             confined to the 256 action columns): R' * V * e read + R' * 256 * e written
   K4 update: 7*4*n  (patch, g, m, v read; patch, m, v written)
 """
 from __future__ import annotations
@@ -30,6 +31,8 @@ def algo_bytes(kernel: str, B: int, ph: int = 50, pw: int = 50, rows: int = 0, V
         return B * 36 * (1024 + 1152) * 2 + 588 * (1024 + 1152) * 2 + 4 * n
     if kernel == "K3":
         return 2.0 * rows * V * esize
+    if kernel == "K3_slice":
+        return rows * V * esize + rows * 256 * esize
     if kernel == "K4":
         return 7 * 4 * n
     raise KeyError(kernel)
@@ -130,9 +133,15 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
     wt1 = (torch.randn(588, 1152, device=dev) * 0.05).to(torch.bfloat16)
     rec("K2e_patch_embed_grad_gather", "K2e", lambda: ops.patch_embed_grad_gather(dy0, dy1, wt0, wt1, patch, xy, th, keep, True),
         algo_bytes("K2e", B, ph, pw), B=B, note="SURVEY 8f-3: patch-embed backward on the kept tiles (MFMA) + gather; replaces 2 dgrad GEMMs + fold + K2")
-    rec("K3_loss_fwd_bwd", "K3",
-        lambda: ops.loss_fwd_bwd(logits, labels, ops.LOSS_UADA_DDP, w=5.0, layout=ops.LAYOUT_ROWS, glogits=glog),
-        algo_bytes("K3", B, rows=R, esize=logits.element_size()), rows=R)
+    rowmap = ops.LossRowMap(labels)
+    gslice = torch.empty((R, 256), dtype=logits_dtype, device=dev)
+    rec("K3_loss_rows_fwd_bwd", "K3_slice",
+        lambda: ops.loss_rows_fwd_bwd(logits, rowmap, ops.LOSS_UADA_DDP, w=5.0, grad_kind=ops.GRAD_SLICE, grad=gslice),
+        algo_bytes("K3_slice", B, rows=R, esize=logits.element_size()), rows=R,
+        note="the bench step's mode (UADA_DDP): row map prebuilt, gradient = the 256 action columns; 16.4 MB figure of SURVEY 8d = full-row storage, see K3_full")
+    rec("K3_full_rows_fwd_bwd", "K3",
+        lambda: ops.loss_rows_fwd_bwd(logits, rowmap, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=glog),
+        algo_bytes("K3", B, rows=R, esize=logits.element_size()), rows=R, note="UADA (1/CE term): full-row gradient, SURVEY 8d's 2*R'*V*e")
     rec("K4_patch_update", "K4", lambda: ops.patch_update(patch, gp, m, v, ops.OPT_ADAMW_HF, 1e-3, 1), algo_bytes("K4", B, ph, pw))
     return res
 
@@ -156,3 +165,85 @@ def k2_sweep(batches=(64, 256, 1024, 4096), ph=50, pw=50, iters=20, device="cuda
                         frac_of_8TBs=nb / mean / 1e9 / HBM_PEAK_GBS, fullframe_GBs=algo_bytes("K2_fullframe", B, ph, pw) / mean / 1e9))
         del g, keep
     return out
+
+
+def k1_sweep(batches=(8, 16, 64, 256), ph=50, pw=50, iters=20, device="cuda:0"):
+    """K1 at the per-rank batch sizes of the BASELINE configs (strong scaling: 64 / 8 ranks = 8; config 2: 16) and beyond."""
+    dev = torch.device(device)
+    out = []
+    patch = torch.rand(3, ph, pw, device=dev)
+    for B in batches:
+        img = torch.from_numpy(synthetic.synth_images(1234, min(B, 64), "noise")).to(dev)
+        if B > img.shape[0]:
+            img = img.repeat((B + 63) // 64, 1, 1, 1)[:B].contiguous()
+        xy_n, th_n = random_params(B, ph, pw, 42)
+        xy, th = torch.from_numpy(xy_n).to(dev), torch.from_numpy(th_n).to(dev)
+        mean, med, mn = _time(lambda: ops.patch_apply_fwd(img, patch, xy, th, True), iters)
+        nb = algo_bytes("K1", B, ph, pw)
+        out.append(dict(B=B, mean_us=mean * 1e6, min_us=mn * 1e6, algo_bytes=nb, achieved_GBs=nb / mean / 1e9, frac_of_8TBs=nb / mean / 1e9 / HBM_PEAK_GBS))
+    return out
+
+
+def rank_shapes(iters=20, device="cuda:0"):
+    """Kernel numbers at the per-rank shapes of the multi-GPU BASELINE configs: config 3 strong scaling (B=8, 50x50, UADA_DDP), config 4
+    (TMA, B=8, all 7 DoF) and config 5 (UPA, resize_patch=True, 3x100x100 base, B=4: resize + K1/K2 with per-image patches)."""
+    import random
+
+    from .transform import RandomPatchTransform
+
+    dev = torch.device(device)
+    res = {}
+    s8 = kernel_suite(8, 50, 50, iters=iters, device=device)
+    res["cfg3_B8_50x50"] = {k: v for k, v in s8.items() if not k.startswith("K2e")}
+    # config 5: the whole resized forward/backward of the patch operator (4 launches + fixed-order reduce), B = 4
+    B = 4
+    img = torch.from_numpy(synthetic.synth_images(5, B, "noise")).to(dev)
+    patch = torch.rand(3, 100, 100, device=dev)
+    st_r, st_n = random.getstate(), np.random.get_state()
+    random.seed(42)
+    np.random.seed(42)
+    sizes, xy_n, th_n = RandomPatchTransform("cpu", True)._draw_resized(B, 100, 100, True)
+    random.setstate(st_r)
+    np.random.set_state(st_n)
+    xy, th = torch.from_numpy(xy_n).to(dev), torch.from_numpy(th_n).to(dev)
+    pdesc_n, total = ops.make_pdesc(sizes)
+    pdesc = torch.from_numpy(pdesc_n).to(dev)
+    max_hw = (int(pdesc_n[:, 0].max()), int(pdesc_n[:, 1].max()))
+    packed = ops.patch_resize_fwd(patch, pdesc, total)
+    _, keep = ops.patch_apply_fwd_multi(img, packed, pdesc, max_hw, xy, th, True)
+    g = synthetic.synth_upstream_grad(7, B).to(dev)
+    gp = ops.patch_grad_gather_multi(g, packed, pdesc, max_hw, xy, th, keep, True)
+    kept_px = int(sum(int(h) * int(w) for h, w in sizes))
+    c5 = {}
+    for name, fn, nb in (
+        ("K0_patch_resize_fwd", lambda: ops.patch_resize_fwd(patch, pdesc, total), 4 * 3 * 100 * 100 + 4 * total),
+        ("K1_patch_apply_fwd_multi", lambda: ops.patch_apply_fwd_multi(img, packed, pdesc, max_hw, xy, th, True), B * (150528 + 602112) + 4 * total),
+        ("K2_patch_grad_gather_multi", lambda: ops.patch_grad_gather_multi(g, packed, pdesc, max_hw, xy, th, keep, True), 12 * kept_px + 4 * total),
+        ("K0_patch_resize_bwd", lambda: ops.patch_resize_bwd(gp, pdesc, 100, 100), 4 * total + 4 * 3 * 100 * 100),
+    ):
+        mean, med, mn = _time(fn, iters)
+        c5[name] = dict(mean_us=mean * 1e6, min_us=mn * 1e6, algo_bytes=nb, achieved_GBs=nb / mean / 1e9, frac_of_8TBs=nb / mean / 1e9 / HBM_PEAK_GBS)
+    c5["sizes"] = [[int(h), int(w)] for h, w in sizes]
+    res["cfg5_B4_resize100"] = c5
+    return res
+
+
+def device_copy_bandwidth(nbytes=512 * 1024 * 1024, iters=5, device="cuda:0"):
+    """Measured device-to-device copy bandwidth (read + write bytes per second) of this box: the practical HBM ceiling the
+    roofline fractions can also be read against. 512 MiB > the 256 MiB Infinity Cache."""
+    dev = torch.device(device)
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        dst.copy_(src)
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) * 1e-3)
+    del src, dst
+    return 2.0 * nbytes / float(np.median(ts)) / 1e9

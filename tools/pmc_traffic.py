@@ -39,7 +39,7 @@ def run_pass(counter):
         if r.get("Counter_Name") != counter:
             continue
         name = r["Kernel_Name"]
-        key = name.split("(")[0][-60:] + "|" + r.get("Grid_Size", r.get("Grid_Size_X", "?"))
+        key = name.split("(")[0][-110:] + "|" + r.get("Grid_Size", r.get("Grid_Size_X", "?"))
         acc[key].append(float(r["Counter_Value"]))
     shutil.rmtree(d, ignore_errors=True)
     return acc
@@ -73,9 +73,13 @@ def main():
         out[k] = {"launches": len(f), "FETCH_SIZE_KiB": fm, "WRITE_SIZE_KiB": wm, "read_bytes": fm * 1024 * f_fac,
                   "write_bytes": wm * 1024 * w_fac, "hbm_bytes_per_launch": fm * 1024 * f_fac + wm * 1024 * w_fac}
     # per hot-path op (what bench.py's event brackets cover): sum over the op's kernels
-    ops = {"K1_patch_apply_fwd": ("patch_apply_fwd_kernel",), "K2_patch_grad_gather": ("patch_grad_scatter_kernel<double, 3, false>", "patch_grad_reduce_kernel"),
-           "K2_patch_embed_grad_gather": ("embed_dgrad_tiles", "patch_grad_scatter_kernel<double, 3, true>", "patch_grad_reduce_kernel"),
-           "K3_loss_fwd_bwd": ("loss_stats_kernel", "loss_grad_kernel"), "K4_patch_update": ("patch_update_kernel",)}
+    ops = {"K1_patch_apply_fwd": ("patch_apply_fwd_kernel",),
+           "K2_patch_grad_gather": ("patch_grad_scatter_kernel<3, false, false", "patch_grad_reduce_kernel|30208"),
+           "K2_patch_embed_grad_gather": ("embed_dgrad_tiles", "patch_grad_scatter_kernel<3, true, false", "patch_grad_reduce_kernel|30208"),
+           "K3_loss_rows_fwd_bwd": ("rows_stats_kernel", "rows_finish_kernel<unsigned short>|512"),        # UADA_DDP: gradient slice, one finishing workgroup
+           "K3_full_rows_fwd_bwd": ("rows_stats_kernel", "rows_finish_kernel<unsigned short>|131072"),      # UADA: full-row gradient, R x split workgroups
+           "K4_patch_update": ("patch_update_kernel",)}
+    # a kernel that belongs to two ops (reduce: K2 and K2'; stats: both K3 modes) ran once per op call, so its per-launch mean is counted once in each
     out["ops"] = {}
     for op, kns in ops.items():
         tot = sum(v["hbm_bytes_per_launch"] for k, v in out.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v and any(kn in k for kn in kns))
