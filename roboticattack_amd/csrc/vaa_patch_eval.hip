@@ -60,6 +60,7 @@ __global__ __launch_bounds__(kEvThreads) void patch_apply_eval_kernel(const Eval
                 jhi = px + a.pw - 1;
             }
         }
+        if (jhi < jlo) { jlo = 0; jhi = -1; }  // an interval wholly beyond the frame (side open to infinity) is an empty row
         rb_lo[tid] = (short)jlo;
         rb_hi[tid] = (short)jhi;
     }

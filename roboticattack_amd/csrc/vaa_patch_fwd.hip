@@ -89,6 +89,10 @@ __device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it
         jlo = px;
         jhi = px + pw - 1;
     }
+    // an interval that lies wholly beyond the frame (possible when a side is open to +-infinity: patch on the frame edge) clamps to
+    // jhi < jlo with jlo > 0; normalise every empty row to [0, -1] so that BOTH roles see "no items" (the background role packs the
+    // count into 8 bits and would otherwise skip items nobody writes)
+    if (jhi < jlo) { jlo = 0; jhi = -1; }
     it_lo = jlo >> 4;
     it_hi = (jhi < jlo) ? -1 : (jhi >> 4);
 }

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
                     jlo = px;
                     jhi = px + pw - 1;
                 }
+                if (jhi < jlo) { jlo = 0; jhi = -1; }  // an interval wholly beyond the frame (side open to infinity) is an empty row
                 jlo &= ~1;  // a lane's pixel pair starts at an even column: one aligned 4-byte load per plane
                 len = max(0, jhi - jlo + 1);
                 row_word[q][i] = ((uint32_t)jlo << 16) | (uint32_t)len;

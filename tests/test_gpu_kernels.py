@@ -111,6 +111,48 @@ def test_k1_k2_random_sweep_vs_oracle(ops, ph, pw, B, geo):
     assert np.abs(gg - og).max() <= 3e-6 * max(np.abs(og).max(), 1e-30)
 
 
+def test_k1_empty_row_beyond_the_frame_regression(ops):
+    """Patch on the right/bottom frame edge with a small rotation: far above/below the patch the conservative column interval of a row
+    lies wholly BEYOND column 223 (the edge side is open to infinity). Such rows must be empty for both kernel roles — round 2 found
+    the streaming role skipping items nobody wrote (seen at bs > 64, image 66 of the bench batch: xy=(174,108))."""
+    xy = np.array([[174, 108], [174, 0], [100, 174], [0, 174], [174, 174]], np.int32)
+    theta = np.array([[[0.9908992, -0.13735135, 0.0], [0.00398219, 1.0131141, 0.0]],
+                      [[0.99, 0.01, 0.0], [-0.004, 1.01, 0.0]],
+                      [[1.0, 0.004, 0.0], [0.14, 0.99, 0.0]],
+                      [[1.01, -0.003, 0.0], [0.1, 0.98, 0.0]],
+                      [[0.995, 0.002, 0.0], [0.003, 1.004, 0.0]]], np.float32)
+    B = len(xy)
+    imgs = synthetic.synth_images(66, B, "noise")
+    patch = np.random.RandomState(1).rand(3, 50, 50).astype(np.float32)
+    out, keep = _run_k1(ops, imgs, patch, xy, theta, 1, 0)
+    _, o_bf16, o_keep = c_oracle.patch_apply_fwd(imgs, patch, xy, theta, 1, 0)
+    assert np.array_equal(_bits(out), o_bf16) and np.array_equal(_keep_unpack(keep), o_keep)
+    g = synthetic.synth_upstream_grad(2, B)
+    og = c_oracle.patch_grad(_bits(g), patch, xy, theta, 1, 0)
+    gg = ops.patch_grad_gather(g.to(DEV), _t(patch), _t(xy, torch.int32), _t(theta.reshape(-1, 6)), keep, True, 0).cpu().numpy()
+    assert np.abs(gg - og).max() <= 3e-6 * np.abs(og).max()
+
+
+@pytest.mark.parametrize("B", [96, 200])
+def test_k1_k2_bench_draws_beyond_bs64_vs_oracle(ops, B):
+    """The seed-42 draws of the bench at batch sizes above 64 (different footprint split per image), every value against the oracle."""
+    from roboticattack_amd.benchmarks import random_params
+
+    imgs = synthetic.synth_images(1234, B, "noise")
+    patch = np.random.RandomState(3).rand(3, 50, 50).astype(np.float32)
+    xy, th = random_params(B, 50, 50, 42)
+    theta = th.reshape(B, 2, 3)
+    out, keep = _run_k1(ops, imgs, patch, xy, theta, 1, 0)
+    out2, keep2 = _run_k1(ops, imgs, patch, xy, theta, 1, 0)
+    assert torch.equal(out, out2) and torch.equal(keep, keep2)
+    _, o_bf16, o_keep = c_oracle.patch_apply_fwd(imgs, patch, xy, theta, 1, 0)
+    assert np.array_equal(_bits(out), o_bf16) and np.array_equal(_keep_unpack(keep), o_keep)
+    g = synthetic.synth_upstream_grad(2, 64).repeat((B + 63) // 64, 1, 1, 1)[:B].contiguous()
+    og = c_oracle.patch_grad(_bits(g), patch, xy, theta, 1, 0)
+    gg = ops.patch_grad_gather(g.to(DEV), _t(patch), _t(xy, torch.int32), _t(theta.reshape(-1, 6)), keep, True, 0).cpu().numpy()
+    assert np.abs(gg - og).max() <= 3e-6 * np.abs(og).max()
+
+
 def test_k1_general_affine_with_translation(ops):
     """The C-ABI takes any 2x3 theta (the reference only draws rotation+shear): scale, translation, near-singular."""
     rs = np.random.RandomState(77)
