@@ -195,6 +195,20 @@ def rank_shapes(iters=20, device="cuda:0"):
     res = {}
     s8 = kernel_suite(8, 50, 50, iters=iters, device=device)
     res["cfg3_B8_50x50"] = {k: v for k, v in s8.items() if not k.startswith("K2e")}
+    # config 4 (TMA, 32 over 4 ranks -> B=8 per rank, all 7 DoF + EOS = 64 labelled rows, CE to the target tokens: full-row gradient)
+    from .labels import tma_target_labels, tma_target_tokens
+
+    _, lab4, _ = synthetic.synth_text_batch(4242, 8)
+    lab4 = tma_target_labels(lab4, tma_target_tokens(np.zeros(7), list(range(7)))).to(dev)
+    R4 = int((lab4[:, 1:] != -100).sum())
+    lg4 = (torch.randn(R4, 32064, device=dev) * 2).to(torch.bfloat16)
+    g4 = torch.empty_like(lg4)
+    rm4 = ops.LossRowMap(lab4)
+    mean, med, mn = _time(lambda: ops.loss_rows_fwd_bwd(lg4, rm4, ops.LOSS_CE, grad_kind=ops.GRAD_FULL, grad=g4), iters)
+    nb = algo_bytes("K3", 8, rows=R4, esize=2)
+    res["cfg4_tma_B8"] = {"K3_full_rows_fwd_bwd": dict(mean_us=mean * 1e6, min_us=mn * 1e6, algo_bytes=nb, achieved_GBs=nb / mean / 1e9,
+                                                       frac_of_8TBs=nb / mean / 1e9 / HBM_PEAK_GBS, rows=R4),
+                         "note": "K1/K2/K4 as in cfg3_B8_50x50 (same per-rank batch and patch)"}
     # config 5: the whole resized forward/backward of the patch operator (4 launches + fixed-order reduce), B = 4
     B = 4
     img = torch.from_numpy(synthetic.synth_images(5, B, "noise")).to(dev)

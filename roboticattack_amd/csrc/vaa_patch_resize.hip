@@ -122,6 +122,26 @@ __global__ __launch_bounds__(256) void patch_resize_bwd_kernel(ResizeArgs a) {
             ox_lo = max(0, (int)floorf(((float)x - ax.support - 1.0f) / ax.scale - 0.5f) - 2);
             ox_hi = min(w - 1, (int)ceilf(((float)x + ax.support + 1.0f) / ax.scale - 0.5f) + 2);
         }
+        // the x taps do not depend on oy: evaluate them once (up to kMaxCand candidates in registers; a wider window — extreme
+        // down-scaling — takes the generic path that recomputes them per row)
+        constexpr int kMaxCand = 12;
+        float wxs[kMaxCand];
+        const int ncx = ox_hi - ox_lo + 1;
+        const bool cached = ncx <= kMaxCand;
+        if (cached) {
+#pragma unroll
+            for (int q = 0; q < kMaxCand; ++q) {
+                float wx = 0.0f;
+                if (q < ncx) {
+                    wx = 1.0f;
+                    if (horiz) {
+                        const Taps tx = make_taps(ax, ox_lo + q);
+                        wx = (x >= tx.lo && x < tx.lo + tx.n) ? tap_weight(ax, tx, x - tx.lo) : 0.0f;
+                    }
+                }
+                wxs[q] = wx;
+            }
+        }
         float acc = 0.0f;
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             float wy = 1.0f;
@@ -130,6 +150,12 @@ __global__ __launch_bounds__(256) void patch_resize_bwd_kernel(ResizeArgs a) {
                 if (y < ty.lo || y >= ty.lo + ty.n) continue;
                 wy = tap_weight(ay, ty, y - ty.lo);
             }
+            if (cached) {
+#pragma unroll
+                for (int q = 0; q < kMaxCand; ++q)
+                    if (q < ncx && wxs[q] != 0.0f) acc += wxs[q] * wy * g[(size_t)oy * w + ox_lo + q];  // torch: grad_in += wx*wy*grad_out, (oh, ow) scan order
+                continue;
+            }
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
                 float wx = 1.0f;
                 if (horiz) {
@@ -137,7 +163,7 @@ __global__ __launch_bounds__(256) void patch_resize_bwd_kernel(ResizeArgs a) {
                     if (x < tx.lo || x >= tx.lo + tx.n) continue;
                     wx = tap_weight(ax, tx, x - tx.lo);
                 }
-                acc += wx * wy * g[(size_t)oy * w + ox];  // torch: grad_in += wx*wy*grad_out, (oh, ow) scan order
+                acc += wx * wy * g[(size_t)oy * w + ox];
             }
         }
         dst[e] = acc;
