@@ -67,29 +67,28 @@ def build_model(kind, dev):
     return SurrogateVLA(seed=0).to(dev), "fp32 surrogate"
 
 
-def cpu_baseline(bs, patch_shape, budget_s=25.0):
-    """The reference's CPU path for the replaced ops (oracle/ref_port.py: per-image PyTorch op chain + autograd for K1/K2, HF-style CE +
-    weighted_loss on fp32 logits [B,S,32064] + backward for K3, HF AdamW + clamp for K4), timed on this box's host cores with ONE thread
-    and with ALL logical cores: 2 warm-ups, then >= 5 timed iterations, min and median reported.
+def _cpu_leg(threads, bs, patch_shape, budget_s, conn):
+    """One leg of the CPU baseline in its own process (so that a thread count that thrashes can be stopped by the parent)."""
+    import numpy as _np
+    import torch as _torch
 
-    Bounded sample (about 25 s of CPU work in total): every leg times a slice of the per-rank batch whose size a 2-image probe picks so
-    that 2 + 5 iterations fit the leg's budget, and scales linearly to bs (one K3 iteration at bs=64 on one thread takes ~40 s)."""
     from oracle import ref_port
     from roboticattack_amd import synthetic
     from roboticattack_amd.benchmarks import random_params
 
-    ncores = os.cpu_count() or 1
-    gout_all = synthetic.synth_upstream_grad(7, bs)
-    imgs_all = synthetic.synth_images(1234, bs, "noise")
-    xy_all, th_all = random_params(bs, patch_shape[1], patch_shape[2], 42)
-    th_all = th_all.reshape(bs, 2, 3)
+    _torch.set_num_threads(threads)
+    n_max = min(8, bs) if threads == 1 else bs
+    gout_all = synthetic.synth_upstream_grad(7, n_max)
+    imgs_all = synthetic.synth_images(1234, n_max, "noise")
+    xy_all, th_all = random_params(n_max, patch_shape[1], patch_shape[2], 42)
+    th_all = th_all.reshape(n_max, 2, 3)
     _, labels_all, _ = synthetic.synth_text_batch(4242, bs)
-    labels_all = ref_port.mask_labels(labels_all, [0])
+    labels_all = ref_port.mask_labels(labels_all, [0])[:n_max]
     S = 256 + labels_all.shape[1]
-    logits4 = torch.randn(4, S, 32064)
+    logits4 = _torch.randn(4, S, 32064)
 
     def patch_ops(n):
-        patch = torch.nn.Parameter(torch.rand(*patch_shape))
+        patch = _torch.nn.Parameter(_torch.rand(*patch_shape))
         opt = ref_port.HFAdamW([patch], lr=1e-3)
         t0 = time.perf_counter()
         ref_port.cpu_patch_step(imgs_all[:n], patch, opt, xy_all[:n], th_all[:n], True, gout_all[:n])
@@ -103,39 +102,71 @@ def cpu_baseline(bs, patch_shape, budget_s=25.0):
         (mse + 0.0 * ce).backward()
         return time.perf_counter() - t0
 
-    def timed(fn, n_max, t_budget, warm=2, iters=5):
-        """2 warm-ups + 5 timed iterations that FIT the budget: a 2-image probe sizes the sample (every op of the path is linear in the
-        batch), so a slow host (or a thread count that thrashes on the reference's many tiny ops) cannot stretch the run."""
+    def timed(fn, t_budget, warm=2, iters=5):
+        """2 warm-ups + 5 timed iterations that fit the budget: a 2-image probe sizes the sample (every op of the path is linear in the batch)."""
         n0 = min(2, n_max)
         fn(n0)
         per_img = fn(n0) / n0
         n = max(1, min(n_max, int(0.6 * t_budget / (warm + iters) / max(per_img, 1e-9))))
-        t_end = time.perf_counter() + 2.0 * t_budget  # hard stop: never fewer than 3 timed iterations, never far beyond the budget
         for _ in range(warm):
             fn(n)
-        ts = []
-        while len(ts) < iters and (len(ts) < 3 or time.perf_counter() < t_end):
-            ts.append(fn(n))
-        return float(np.min(ts)), float(np.median(ts)), n
+        ts = [fn(n) for _ in range(iters)]
+        return float(_np.min(ts)), float(_np.median(ts)), n
 
+    p_min, p_med, p_n = timed(patch_ops, budget_s * 0.2)
+    l_min, l_med, l_n = timed(loss_ops, budget_s * 0.8)
+    conn.send({"threads": threads, "sample_bs_K1_K2_K4": p_n, "sample_bs_K3": l_n, "scaled_to_bs": bs, "logits_S": S,
+               "ms_K1_K2_K4_min": p_min * bs / p_n * 1e3, "ms_K1_K2_K4_median": p_med * bs / p_n * 1e3,
+               "ms_K3_min": l_min * bs / l_n * 1e3, "ms_K3_median": l_med * bs / l_n * 1e3,
+               "steps_per_s_min_time": 1.0 / (p_min * bs / p_n + l_min * bs / l_n),
+               "steps_per_s_median_time": 1.0 / (p_med * bs / p_n + l_med * bs / l_n)})
+    conn.close()
+
+
+def cpu_baseline(bs, patch_shape, budget_s=25.0):
+    """The reference's CPU path for the replaced ops (oracle/ref_port.py: per-image PyTorch op chain + autograd for K1/K2, HF-style CE +
+    weighted_loss on fp32 logits [B,S,32064] + backward for K3, HF AdamW + clamp for K4), timed on this box's host cores with ONE thread
+    and with ALL logical cores: 2 warm-ups, then 5 timed iterations, min and median reported.
+
+    Bounded: every leg times a slice of the per-rank batch whose size a 2-image probe picks so that 2 + 5 iterations fit the leg's
+    budget (one K3 iteration at bs=64 on one thread takes ~30 s) and scales linearly to bs; every leg runs in its own process under a
+    wall-clock guard, because torch.set_num_threads(256) thrashes on the reference's many tiny per-image ops (a single-image iteration
+    was seen to take seconds): a leg that exceeds its guard is reported as timed out. Hosts with more than 32 logical cores also get a
+    32-thread leg (the setting the CPU path ran best at in round 1)."""
+    import multiprocessing as mp
+
+    ncores = os.cpu_count() or 1
+    ctx = mp.get_context("spawn")
+    plan = [("1_thread", 1), ("all_cores", ncores)] + ([("32_threads", 32)] if ncores > 32 else [])
+    leg_budget = budget_s / len(plan)
     legs = {}
-    for tag, threads, n_max, b_patch, b_loss in (("1_thread", 1, min(8, bs), 2.0, 8.0), ("all_cores", ncores, bs, 4.0, 11.0)):
-        torch.set_num_threads(threads)
-        p_min, p_med, p_n = timed(patch_ops, n_max, budget_s / 25.0 * b_patch)
-        l_min, l_med, l_n = timed(loss_ops, n_max, budget_s / 25.0 * b_loss)
-        legs[tag] = {"threads": threads, "sample_bs_K1_K2_K4": p_n, "sample_bs_K3": l_n, "scaled_to_bs": bs,
-                     "ms_K1_K2_K4_min": p_min * bs / p_n * 1e3, "ms_K1_K2_K4_median": p_med * bs / p_n * 1e3,
-                     "ms_K3_min": l_min * bs / l_n * 1e3, "ms_K3_median": l_med * bs / l_n * 1e3,
-                     "steps_per_s_min_time": 1.0 / (p_min * bs / p_n + l_min * bs / l_n),
-                     "steps_per_s_median_time": 1.0 / (p_med * bs / p_n + l_med * bs / l_n)}
-    best = max(legs, key=lambda k: legs[k]["steps_per_s_min_time"])
+    for tag, threads in plan:
+        rx, tx = ctx.Pipe(duplex=False)
+        p = ctx.Process(target=_cpu_leg, args=(threads, bs, patch_shape, leg_budget, tx))
+        p.start()
+        tx.close()
+        guard = 4.0 * leg_budget + 30.0  # import + probe + iterations; generous, but finite
+        try:
+            if rx.poll(guard):
+                legs[tag] = rx.recv()
+                p.join(10)
+            else:
+                legs[tag] = {"threads": threads, "timed_out_after_s": guard}
+        except EOFError:
+            legs[tag] = {"threads": threads, "failed": "the leg's process exited without a result"}
+        if p.is_alive():
+            p.terminate()
+            p.join(5)
+    ok = {k: v for k, v in legs.items() if "steps_per_s_min_time" in v}
+    best = max(ok, key=lambda k: ok[k]["steps_per_s_min_time"]) if ok else None
+    S = ok[best]["logits_S"] if best else 0
     return {
-        "value": legs[best]["steps_per_s_min_time"], "unit": "patch-path steps/s on host CPU (K1+K2+K3+K4 only, model excluded)",
-        "cores": legs[best]["threads"], "kind": "port",
+        "value": ok[best]["steps_per_s_min_time"] if best else None, "unit": "patch-path steps/s on host CPU (K1+K2+K3+K4 only, model excluded)",
+        "cores": ok[best]["threads"] if best else 0, "kind": "port",
         "sample": f"oracle/ref_port.py (PyTorch-CPU restatement of the reference op sequence), patch {patch_shape}, geometry=True, fp32 logits "
-                  f"[bs,{S},32064]; per leg (1 thread; all {ncores} logical cores) 2 warm-ups then 5 timed iterations, min and median, on a slice of "
-                  f"the bs={bs} batch sized by a 2-image probe to fit ~{budget_s:.0f} s in total (sample_bs_* in `legs`), scaled linearly to bs={bs}; "
-                  f"value = the faster leg's min",
+                  f"[bs,{S},32064]; legs: 1 thread, all {ncores} logical cores" + (", 32 threads" if ncores > 32 else "") + "; per leg 2 warm-ups "
+                  f"then 5 timed iterations, min and median, on a slice of the bs={bs} batch sized by a 2-image probe (sample_bs_* in `legs`), "
+                  f"scaled linearly to bs={bs}; each leg in its own process under a wall-clock guard; value = the fastest leg's min",
         "legs": legs, "host_logical_cores": ncores,
     }
 
