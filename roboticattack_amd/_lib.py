@@ -92,6 +92,12 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or roboticattack_amd/csrc/build.sh"
         )
+    try:
+        # PyTorch-ROCm ships its own libamdhip64; if this library pulled in the system copy first, torch would later initialise a second
+        # HIP runtime in the same process and see no GPU. Importing torch first makes both resolve to the one runtime torch loaded.
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - the C-ABI is usable without torch
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     L.vaa_last_error.restype = C.c_char_p
