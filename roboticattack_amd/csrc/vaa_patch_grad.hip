@@ -26,8 +26,6 @@
 //   * border padding: out-of-frame source points clamp onto frame-edge canvas pixels; when the patch touches the frame edge
 //     the row bounds are opened to infinity on that side, everything else is unchanged.
 //   * MULTI (resize_patch=True, config 5): one patch PER IMAGE (pdesc), the output is every image's own gradient.
-#include <stdlib.h>
-
 #include "vaa_common.h"
 
 namespace vaa {
@@ -451,9 +449,9 @@ struct GradSched {
 static GradSched grad_sched(int B) {
     GradSched g;
     g.gx = B < 512 ? B : 512;
-    // two workgroups per image while the batch alone cannot fill the chip
+    // two workgroups per image while the batch alone cannot fill the chip (measured at B=64: split 1 / 2 / 3 / 4 -> 24.4 / 20.8 / 22.8 /
+    // 24.7 us for scatter + reduce; at B=4096 any split > 1 only adds partial tiles)
     g.split = (B <= 256) ? 2 : 1;
-    if (const char* e = getenv("VAA_K2_SPLIT")) g.split = atoi(e) > 0 ? atoi(e) : g.split;  // tuning experiments only
     return g;
 }
 
