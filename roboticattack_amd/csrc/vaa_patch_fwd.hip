@@ -103,12 +103,25 @@ __device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it
 //   blockIdx.x <  n_fp : FOOTPRINT  — owns exactly the skipped items of one image (a 1/fsplit share of them), one LANE per
 //                        pixel: LUT value, exact warp sample, mask, normalise, 2-byte stores; keep bits by wave ballot.
 // The two roles never write the same byte, so no ordering between workgroups is needed.
+#ifdef VAA_K1_TIMING
+__device__ long long* vaa_k1_dbg = nullptr;
+#define K1_T0() long long k1_t = wall_clock64(); const long long k1_start = k1_t; long long k1_acc[6] = {0, 0, 0, 0, 0, 0};
+#define K1_STAMP(i) { const long long tn = wall_clock64(); k1_acc[i] += tn - k1_t; k1_t = tn; }
+#define K1_FLUSH(role) if ((threadIdx.x & 63) == 0 && vaa_k1_dbg) { long long* d = vaa_k1_dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; \
+    for (int z = 0; z < 6; ++z) d[z] = k1_acc[z]; d[6] = role; d[7] = k1_start; }
+#else
+#define K1_T0()
+#define K1_STAMP(i)
+#define K1_FLUSH(role)
+#endif
+
 __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdArgs a, int n_fp, int fsplit) {
     __shared__ uint32_t lut[3 * 256];
     __shared__ float bgrid[VAA_IMG];
     __shared__ uint32_t row_word[VAA_IMG];  // footprint role: (it_lo << 8) | n_items per row; background: first kMaxRows rows
     __shared__ int red_min, red_max, red_n;
     const int tid = threadIdx.x;
+    K1_T0()
     const bool bg = (int)blockIdx.x >= n_fp;
     // Background role: the input bytes of this lane's two half items depend on nothing but the item index, so their loads are
     // issued first and fly while the LUT is built and the placement (xy, theta -> row table) is fetched.
@@ -127,6 +140,8 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
     // camera-pixel LUT: same IEEE arithmetic as the host (true divisions, RNE), 3 entries per thread
 #pragma unroll
     for (int e = tid; e < 768; e += kFwdThreads) lut[e] = norm_pack((float)(e & 255) / 255.0f, a.nrm, e >> 8);
+    // (building this table once on the host and carrying it in the kernel-argument segment was measured: 16.4 vs 15.5 us at bs=64 —
+    // bulk reads from the kernarg segment are slower than nine correctly-rounded divisions per thread)
 
     if (bg) {  // footprint workgroups come FIRST in dispatch order: their latency chain overlaps the stream
         // ------------------------------------------------------------------ background role
@@ -137,7 +152,9 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
             if (gr < (long)a.B * VAA_IMG) row_items(a, (int)(gr / VAA_IMG), (int)(gr % VAA_IMG), lo, hi);
             row_word[tid] = ((uint32_t)(lo & 0xff) << 8) | (uint32_t)((hi - lo + 1) & 0xff);
         }
+        K1_STAMP(0)
         __syncthreads();
+        K1_STAMP(1)
         // A wave owns 64 consecutive items = 1024 pixels. Lane l handles two HALF items: pixels [8l, 8l+8) of the wave's first
         // 512 pixels and the same of its second 512, so that every store instruction writes 64 x 16 B = 1 KB CONTIGUOUS bytes
         // of a plane (a thread storing its own 16 pixels as two 16 B halves leaves every 128 B line to be completed by a
@@ -183,6 +200,8 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
                 for (int c = 0; c < 3; ++c) a.keep[kbase + (size_t)c * (VAA_NPIX / 8)] = (uint8_t)0;
             }
         }
+        K1_STAMP(2)
+        K1_FLUSH(0)
         return;
     }
 
@@ -201,6 +220,7 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
         if ((tid & 63) == 0) { atomicMin(&red_min, wmin); atomicMax(&red_max, wmax); atomicMax(&red_n, wn); }
     }
     __syncthreads();
+    K1_STAMP(0)
     const int rmin = red_min, nrows = red_max - rmin + 1;
     if (nrows <= 0) return;
     const int nseg = (red_n + 1) >> 1;                             // half-wave = 32 pixels = 2 items per slot
@@ -266,7 +286,9 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
 #pragma unroll
                 for (int c = 0; c < 3; ++c) cv[c] = patch[c * plane + vc * pw + uc];
             }
+            K1_STAMP(1)
             L[0] = lut[by0]; L[1] = lut[256 + by1]; L[2] = lut[512 + by2];
+            K1_STAMP(2)
             if (inside) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
@@ -290,7 +312,9 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
                 }
             }
         }
+        K1_STAMP(3)
     }
+    K1_FLUSH(1)
 }
 
 }  // namespace vaa
@@ -328,6 +352,10 @@ static int launch_patch_apply(const char* who, const uint8_t* img_u8, const floa
 }
 
 }  // namespace vaa
+
+#ifdef VAA_K1_TIMING
+extern "C" int vaa_k1_set_debug(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(vaa::vaa_k1_dbg), &p, sizeof(p)); }
+#endif
 
 extern "C" int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, const int32_t* xy, const float* theta, int B,
                                    int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
