@@ -190,7 +190,7 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
-        vdist.init_process_group("nccl", device=dev)
+        vdist.init_process_group(device=dev)  # "nccl" (= RCCL) on GPUs; VAA_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
     random.seed(42)
     np.random.seed(42)
     torch.manual_seed(42)  # UADA_wrapper_ddp.py:53: every rank seeds 42

@@ -459,6 +459,36 @@ def test_integration_md_stub_runs_verbatim():
         assert float((patch.detach() - p0).abs().max()) > 0
 
 
+def test_bench_py_two_ranks_one_gpu(tmp_path):
+    """bench.py's multi-rank path (rank != 0 flow, barriers, max-over-ranks timing, patch broadcast, packed all-reduce) executed with
+    WORLD_SIZE = 2 on the single GPU of the test box (tiny model, gloo through the host): rank 0 prints ONE JSON line with n_gpus = 2
+    and whole-job throughput = 2 x synchronous steps/s."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VAA_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--model", "tiny",
+                                       "--bs", "4", "--no-cpu-baseline", "--no-kernel-suite"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]  # rank 0 prints, exactly once
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["loss_finite"]
+    assert abs(d["value"] - 2 * d["sync_steps_per_s"]) < 1e-9 and d["config"]["global_batch"] == 8
+    assert d["cpu_baseline"] is None and d["roofline"]["kernel"] == "K1_patch_apply_fwd"
+
+
 def test_patch_embed_grad_path_matches_pixel_grad_path(monkeypatch):
     """SURVEY.md 8f-3 end to end: one UADA step with the patch-embed backward restricted to the kept tiles (K2') gives the same loss and
     the same patch gradient as the path through the dense bf16 pixel gradient (K2)."""
