@@ -267,6 +267,76 @@ def test_k2_gradient_scale_range_and_nonfinite(ops):
     assert torch.isnan(ops.patch_grad_gather(gbad.to(torch.bfloat16).to(DEV), patch, xy, th, keep, True, 0)).all()
 
 
+def test_k2_int64_tile_flush_huge_batch(ops):
+    """A workgroup flushes its int64 tile into its fp32 partial before the tile could overflow (2^17 footprint pixels). 16,000 images =
+    the same 64 placements / gradients 250 times (9.6 GB of bf16 gradient, 32 images per workgroup -> one flush each): the result is
+    250 x the 64-image result, which the oracle provides."""
+    B0, rep = 64, 250
+    rs = np.random.RandomState(11)
+    imgs = _t(synthetic.synth_images(5, B0, "noise"))
+    patch_n = rs.rand(3, 50, 50).astype(np.float32)
+    xy_n, th_n = _random_case(rs, B0, 50, 50)
+    patch = _t(patch_n)
+    _, keep0 = ops.patch_apply_fwd(imgs, patch, _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6)), True, 0)
+    g0 = synthetic.synth_upstream_grad(9, B0)
+    og = c_oracle.patch_grad(_bits(g0), patch_n, xy_n, th_n, 1, 0)
+    g = g0.to(DEV).repeat(rep, 1, 1, 1).contiguous()
+    xy, th, keep = _t(xy_n, torch.int32).repeat(rep, 1).contiguous(), _t(th_n.reshape(-1, 6)).repeat(rep, 1).contiguous(), keep0.repeat(rep, 1, 1).contiguous()
+    got = ops.patch_grad_gather(g, patch, xy, th, keep, True, 0)
+    assert torch.equal(got, ops.patch_grad_gather(g, patch, xy, th, keep, True, 0))
+    del g
+    assert np.abs(got.cpu().numpy() / rep - og).max() <= 3e-6 * np.abs(og).max()
+
+
+def test_k1_k2_multi_row_banded_sizes_vs_oracle(ops):
+    """Per-image patches up to 139x139 (config 5's largest scale): the int64 plane of the largest image exceeds the LDS, so K2 `_multi`
+    runs in row bands; smaller images of the same batch fit a single band's worth of rows. Against the oracle, stored and recomputed mask."""
+    sizes = np.array([[139, 139], [61, 61], [100, 139], [139, 70], [224, 3]], np.int32)
+    B = len(sizes)
+    rs = np.random.RandomState(139)
+    imgs = synthetic.synth_images(13, B, "smooth")
+    pdesc_n, total = ops.make_pdesc(sizes)
+    packed_n = rs.rand(total).astype(np.float32)
+    xy_n = np.array([[rs.randint(0, 224 - w + 1), rs.randint(0, 224 - h + 1)] for h, w in sizes], np.int32)
+    xy_n[0] = (85, 0)  # the largest patch on the top edge
+    _, th_n = _random_case(rs, B, 50, 50)
+    pdesc, packed, xy, th = _t(pdesc_n), _t(packed_n), _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6))
+    max_hw = (int(sizes[:, 0].max()), int(sizes[:, 1].max()))
+    out, keep = ops.patch_apply_fwd_multi(_t(imgs), packed, pdesc, max_hw, xy, th, True, 0)
+    _, o_bf16, o_keep = c_oracle.patch_apply_fwd_multi(imgs, packed_n, pdesc_n, xy_n, th_n, 1, 0)
+    assert np.array_equal(_bits(out), o_bf16) and np.array_equal(_keep_unpack(keep), o_keep)
+    g = synthetic.synth_upstream_grad(4, B)
+    o_gp = c_oracle.patch_grad_multi(_bits(g), packed_n, pdesc_n, xy_n, th_n, 1, 0)
+    for kp in (keep, None):
+        gp = ops.patch_grad_gather_multi(g.to(DEV), packed, pdesc, max_hw, xy, th, kp, True, 0)
+        for (h, w, off, _z) in pdesc_n:  # per image: its own gradient scale
+            a, b = gp.cpu().numpy()[off : off + 3 * h * w], o_gp[off : off + 3 * h * w]
+            assert np.abs(a - b).max() <= 3e-6 * max(np.abs(b).max(), 1e-30), (h, w)
+    assert torch.equal(gp, ops.patch_grad_gather_multi(g.to(DEV), packed, pdesc, max_hw, xy, th, None, True, 0))
+
+
+def test_k3_rowmap_large_batch(ops):
+    """vaa_loss_rowmap_build beyond one pass of its 1024 threads (B = 1500): header counts and every {b, k, label, ord} entry."""
+    from roboticattack_amd.labels import mask_labels
+
+    B = 1500
+    _, labels, _ = synthetic.synth_text_batch(3, B)
+    labels = mask_labels(labels, [0, 3])
+    labels[7] = -100  # a sample without any labelled position
+    rm = ops.LossRowMap(labels.to(DEV))
+    raw = rm.buf.cpu().numpy().view(np.int32)
+    lab = labels.numpy()
+    bk = np.argwhere(lab[:, 1:] != -100)
+    R = len(bk)
+    assert raw[0] == R and raw[1] == int((lab[:, 1:] > 2).sum())
+    ent = raw[4 : 4 + 4 * R].reshape(R, 4)
+    assert np.array_equal(ent[:, 0], bk[:, 0]) and np.array_equal(ent[:, 1], bk[:, 1])
+    assert np.array_equal(ent[:, 2], lab[bk[:, 0], bk[:, 1] + 1])
+    first = np.r_[True, bk[1:, 0] != bk[:-1, 0]]
+    ordv = np.arange(R) - np.maximum.accumulate(np.where(first, np.arange(R), 0))
+    assert np.array_equal(ent[:, 3], ordv)
+
+
 RESIZE = golden_files("resize_")
 
 
