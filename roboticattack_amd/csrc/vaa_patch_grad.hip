@@ -119,13 +119,36 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
         const bool poison = nonfinite != 0;
         const int plane = ph * pw, rows = min(ph, v_lo + a.band_rows) - v_lo;
         const int tp = rows * pw;
-        for (int el = tid; el < tp * NCH; el += THREADS) {  // channel-major walk: consecutive threads store consecutive floats of one plane
-            const int cc = (NCH == 1) ? 0 : el / tp, t = el - cc * tp;
-            float* o = dst + (size_t)(c_base + cc) * plane + v_lo * pw + t;
+        auto value = [&](int t, int cc) {
             const unsigned long long raw = tile[t * NCH + cc];
             const double d = __builtin_fma((double)(int)(raw >> 32), 4294967296.0, (double)(unsigned)raw);
-            const float v = (float)(d * quantum) + (accumulate ? *o : 0.0f);
-            *o = poison ? __uint_as_float(0x7fc00000u) : v;
+            return (float)(d * quantum);
+        };
+        const float qnan = __uint_as_float(0x7fc00000u);
+        // channel-major walk, four consecutive elements per thread: one 16-byte store per thread where the destination allows it
+        const int nq = (tp + 3) >> 2;
+        for (int qi = tid; qi < nq * NCH; qi += THREADS) {
+            const int cc = (NCH == 1) ? 0 : qi / nq, t0 = (qi - cc * nq) * 4;
+            float* o = dst + (size_t)(c_base + cc) * plane + v_lo * pw + t0;
+            float v[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) v[z] = (t0 + z < tp) ? value(t0 + z, cc) : 0.0f;
+            if (accumulate) {  // only after a flush (workgroup-uniform): the partial already holds earlier images
+#pragma unroll
+                for (int z = 0; z < 4; ++z)
+                    if (t0 + z < tp) v[z] += o[z];
+            }
+            if (poison) {
+#pragma unroll
+                for (int z = 0; z < 4; ++z) v[z] = qnan;
+            }
+            if (t0 + 3 < tp && (reinterpret_cast<uintptr_t>(o) & 15u) == 0) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int z = 0; z < 4; ++z)
+                    if (t0 + z < tp) o[z] = v[z];
+            }
         }
         if (rezero) {
             __syncthreads();
