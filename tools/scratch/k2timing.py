@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
-os.environ["VAA_LIB_PATH"] = os.path.join(os.getcwd(), "tools/scratch/libvaa_TIMING.so")
+os.environ["VAA_LIB_PATH"] = os.path.join(os.getcwd(), "tools/scratch/libvaa_K2TIMING.so")  # tools/scratch/build_variant.sh K2TIMING -DVAA_K2_TIMING
 import numpy as np, torch
 from roboticattack_amd import benchmarks, ops, synthetic, _lib
 L = _lib.lib()
