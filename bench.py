@@ -261,11 +261,12 @@ def main():
     barrier()
     ops.TIMER = []
     t0 = time.perf_counter()
-    host_enqueue = 0.0
+    host_enqueue, cpu0 = 0.0, time.thread_time()
     for _ in range(args.steps):
         th0 = time.perf_counter()
         step()
-        host_enqueue += time.perf_counter() - th0  # python + launch time of a step; the GPU runs behind it (no sync inside a step)
+        host_enqueue += time.perf_counter() - th0  # wall time the host spends inside step() (no explicit sync inside a step)
+    host_cpu = time.thread_time() - cpu0  # CPU time of the launching thread: the real host cost (enqueue wall time also contains back-pressure waits)
     barrier()
     dt = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
@@ -314,9 +315,10 @@ def main():
                             "(the opt-in K2' tile GEMM of SURVEY 8f-3 is listed under roofline_kernels_standalone as K2e); "
                             "frac_of_measured_copy_bw = achieved / this box's device-to-device copy rate measured in this run"}
 
-    extra = {"host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
-             "host_overhead_note": "python + launch time of one step (no host synchronisation inside a step); ms_per_step - host_enqueue_ms_per_step "
-                                   "is the slack the GPU runs behind the host: the step is GPU-bound while it is positive, and N ranks on one host need N x this host time in parallel"}
+    extra = {"host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "host_cpu_ms_per_step": host_cpu / args.steps * 1e3,
+             "host_overhead_note": "host_cpu = CPU time of the launching thread per step (python + HIP launches): what N ranks on one host need N times in parallel; "
+                                   "host_enqueue = wall time inside step() without an explicit sync (it also contains waits on a full launch queue / staged H2D copies, "
+                                   "so it scales with the GPU work); the step is GPU-bound while ms_per_step exceeds host_cpu"}
     if not args.no_kernel_suite:
         del model
         torch.cuda.empty_cache()
