@@ -37,7 +37,8 @@ extern "C" {
 
 /* paste-mask rule */
 #define VAA_MASK_LT_M20 0 /* keep patch where !(canvas < -20)  : apply_random_patch_batch, appply_random_transform.py:131 */
-#define VAA_MASK_NE_M100 1 /* keep patch where canvas != -100   : paste_patch_fix / random_paste_patch, :153 :179 */
+#define VAA_MASK_NE_M100 1 /* keep patch where canvas != -100   : paste_patch_fix / random_paste_patch, :153 :179; geometry=0 only
+                              (with a warp the rule would hinge on the rounding of -100*(sum of weights): VAA_E_UNSUPPORTED) */
 
 /* loss modes (K3) */
 #define VAA_LOSS_UADA 0     /* w^2*mean((r-t)^2) + 1/CE                       UADA.py:145-148,381-406 */

@@ -53,15 +53,17 @@ def patch_apply_fwd(img_u8, patch, xy, theta, geometry, mask_mode=0, want_f32=Tr
     return out, ob, keep
 
 
-def patch_grad(gout_bf16_bits, patch, xy, theta, geometry, mask_mode=0):
+def patch_grad(gout_bf16_bits, patch, xy, theta, geometry, mask_mode=0, f64=False):
+    """f64=True: the same fp32 products accumulated in fp64 (the exact sum); default = fp32 scan-order accumulation like torch CPU."""
     g = np.ascontiguousarray(gout_bf16_bits, np.uint16)
     patch = np.ascontiguousarray(patch, np.float32)
     xy = np.ascontiguousarray(xy, np.int32)
     theta = np.ascontiguousarray(theta, np.float32).reshape(-1, 6)
     B, ph, pw = g.shape[0], patch.shape[1], patch.shape[2]
     out = np.empty((3, ph, pw), np.float32)
-    lib().vaa_oracle_patch_grad(_p(g, C.c_uint16), _p(patch, C.c_float), _p(xy, C.c_int32), _p(theta, C.c_float), B, ph, pw,
-                                int(geometry), int(mask_mode), _p(STD6, C.c_float), _p(out, C.c_float))
+    fn = lib().vaa_oracle_patch_grad_f64 if f64 else lib().vaa_oracle_patch_grad
+    fn(_p(g, C.c_uint16), _p(patch, C.c_float), _p(xy, C.c_int32), _p(theta, C.c_float), B, ph, pw,
+       int(geometry), int(mask_mode), _p(STD6, C.c_float), _p(out, C.c_float))
     return out
 
 

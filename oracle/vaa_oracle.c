@@ -174,6 +174,52 @@ void vaa_oracle_patch_grad(const uint16_t* gout_bf16, const float* patch, const 
     free(acc);
 }
 
+/* The same gradient with the fp32 PRODUCTS of the reference (G, G*w) but fp64 ACCUMULATION: the exact sum up to 1e-16, used where the
+ * fp32 scan-order accumulation above is itself the dominant error (transforms that map many output pixels onto one texel). */
+void vaa_oracle_patch_grad_f64(const uint16_t* gout_bf16, const float* patch, const int32_t* xy, const float* theta, int B,
+                           int ph, int pw, int geometry, int mask_mode, const float* std6, float* gpatch) {
+    float bgrid[IMG];
+    base_grid(bgrid);
+    const int n = 3 * ph * pw;
+    double* acc = (double*)malloc(sizeof(double) * n);
+    double* tot = (double*)calloc(n, sizeof(double));
+    memset(gpatch, 0, sizeof(float) * n);
+    for (int b = B - 1; b >= 0; --b) { /* autograd visits the last-created branch first */
+        memset(acc, 0, sizeof(double) * n);
+        const int px = xy[2 * b], py = xy[2 * b + 1];
+        const float* th = theta + 6 * b;
+        for (int i = 0; i < IMG; ++i)
+            for (int j = 0; j < IMG; ++j) {
+                samp_t s = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+                if (geometry) s = sample_pos(bgrid, th, i, j);
+                for (int c = 0; c < 3; ++c) {
+                    float cv = geometry ? sample_canvas(patch, c, ph, pw, px, py, &s)
+                                        : canvas_at(patch, c, ph, pw, px, py, j, i);
+                    if (!keep_rule(cv, mask_mode)) continue;
+                    size_t o = ((size_t)(b * 6 + c) * IMG + i) * IMG + j;
+                    float G = bf16_to_f32(gout_bf16[o]) / std6[c] + bf16_to_f32(gout_bf16[o + (size_t)3 * NPIX]) / std6[c + 3];
+                    if (!geometry) {
+                        int u = j - px, v = i - py;
+                        if (u >= 0 && u < pw && v >= 0 && v < ph) acc[(c * ph + v) * pw + u] += (double)G;
+                        continue;
+                    }
+                    const int cx[4] = {s.x0, s.x0 + 1, s.x0, s.x0 + 1};
+                    const int cy[4] = {s.y0, s.y0, s.y0 + 1, s.y0 + 1};
+                    const float wt[4] = {s.nw, s.ne, s.sw, s.se};
+                    for (int q = 0; q < 4; ++q) {
+                        int u = cx[q] - px, v = cy[q] - py;
+                        if (cx[q] >= IMG || cy[q] >= IMG) continue;
+                        if (u >= 0 && u < pw && v >= 0 && v < ph) acc[(c * ph + v) * pw + u] += (double)(G * wt[q]);
+                    }
+                }
+            }
+        for (int k = 0; k < n; ++k) tot[k] += acc[k];
+    }
+    for (int k = 0; k < n; ++k) gpatch[k] = (float)tot[k];
+    free(acc);
+    free(tot);
+}
+
 /* ---------------------------------------------------------------------------------------------
  * K3 losses on the labelled rows of logits [B,S,V] f32 with labels [B,L] (S = 256 + L).
  * Row (b,k), k in [0,L-1): model position p = S-L+k predicts labels[b,k+1] (UADA.py:382-386; HF shift).

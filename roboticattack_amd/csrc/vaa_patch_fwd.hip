@@ -337,6 +337,12 @@ static int launch_patch_apply(const char* who, const uint8_t* img_u8, const floa
         set_error("%s: patch %dx%d larger than the %dx%d frame", who, ph, pw, VAA_IMG, VAA_IMG);
         return VAA_E_UNSUPPORTED;
     }
+    if (geometry && mask_mode == VAA_MASK_NE_M100) {
+        // the reference pairs `canvas != -100` only with the un-warped paste (paste_patch_fix / random_paste_patch, :138-188); after a
+        // warp the all-background blend -100*(nw+ne+sw+se) is not exactly -100, so the rule would depend on rounding over the whole frame
+        set_error("%s: VAA_MASK_NE_M100 is defined for geometry=0 only (appply_random_transform.py:153,179)", who);
+        return VAA_E_UNSUPPORTED;
+    }
     FwdArgs a;
     a.img = img_u8; a.patch = patch; a.xy = xy; a.theta = theta; a.out = out_bf16; a.keep = keep_bits; a.pdesc = pdesc;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;

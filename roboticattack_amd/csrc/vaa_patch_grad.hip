@@ -13,13 +13,14 @@
 //   * a workgroup works in ROUNDS of K slots per thread: every load of a round (6 gradient values + 3 keep bytes per pixel)
 //     is in flight before the first is consumed (memory-level parallelism instead of occupancy), then the round's largest
 //     |G| is reduced over the workgroup.
-//   * accumulation is INTEGER: each bilinear contribution G*w is rounded to a 32-bit fixed-point number whose quantum is a
-//     power of two tied to the workgroup's gradient scale (2^-26 of the largest |G| seen, re-scaled lazily when a later
-//     image is > 16x larger) and added into a patch-shaped int64 tile in LDS with ds_add_u64. Integer sums do not depend
-//     on arrival order, so the result is bitwise reproducible for every patch size without serialising the scatter (the
-//     reference's CUDA grid_sample backward is not), and ds_add_u64 measured 12.7 cycles per wave-instruction on the
-//     footprint access pattern against 21 for ds_add_f64 (tools/probe/lds_atomic_probe.hip). The quantisation error per
-//     contribution is <= 2^-26 of the largest gradient, below fp32's own rounding of the same sum.
+//   * accumulation is INTEGER: each bilinear contribution fl(G*w) — the very fp32 product grid_sample's backward forms — is rounded
+//     to an integer of < 2^30 relative to the workgroup's gradient exponent (one v_cvt_rpi_i32_f32; the power-of-two scale commutes
+//     with the product's rounding; re-scaled lazily when a later image has a larger exponent) and added into a patch-shaped int64 tile
+//     in LDS with ds_add_u64. Integer sums do not depend on arrival order, so the result is bitwise reproducible for every patch size
+//     without serialising the scatter (the reference's CUDA grid_sample backward is not), and ds_add_u64 measured 12.9 cycles per
+//     wave-instruction on the footprint access pattern against 20.9 for ds_add_f64 (tools/probe/lds_atomic_probe.hip). The sum is
+//     exact to 2^-30 of the largest gradient: against the fp64-accumulated sum of the same products the output differs by its own
+//     final fp32 rounding only (7e-8), the reference's fp32 scan-order accumulation by 3e-7 (tools/scratch/k2prec.py).
 //   * workgroups are persistent over images and keep accumulating into the same tile (the tile is in patch coordinates),
 //     then write ONE fp32 partial; a second small kernel adds the partials in fixed order. No global atomics.
 //   * patches whose int64 plane exceeds the LDS are cut into row bands (grid.z), so every size up to 224x224 is covered.
@@ -53,22 +54,20 @@ constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTile
 __device__ long long* vaa_k2_dbg = nullptr;
 #endif
 constexpr int kImgsPerPass = 8;   // images whose row tables are built together (one barrier set per pass)
-constexpr int kGBits = 22;        // |G| is quantised to 22 bits + sign relative to the workgroup's exponent, weights to 2^-22
+constexpr int kCBits = 30;        // a contribution fl(G*w) is rounded to an integer of < 2^30 relative to the workgroup's exponent
 constexpr int kExpUnset = -100000;
-constexpr long kFlushPixels = 1l << 17;  // footprint pixels a tile may absorb before it is flushed (int64 headroom: 2^63 / 2^44 / 4)
+constexpr long kFlushPixels = 1l << 30;  // footprint pixels a tile may absorb before it is flushed (int64 headroom 2^63 / 2^30 / 4: never in practice)
 
 __device__ __forceinline__ long long shift_round(long long v, int d) {  // v / 2^d, round half up; d in [1, 62]
     return (v + (1ll << (d - 1))) >> d;
 }
 
-// round-to-nearest-even of x (|x| <= 2^22) to an integer through the fp32 adder: the low mantissa bits of x + 1.5*2^23 hold it
-__device__ __forceinline__ int rint_small(float x_times_scale_plus_magic) { return (int)(__float_as_uint(x_times_scale_plus_magic) - 0x4B400000u); }
-
-__device__ __forceinline__ unsigned long long mul_i24_i24(int a, int b) {  // exact 48-bit product of two 24-bit signed integers, two full-rate VALU ops
-    int lo, hi;
-    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
-    asm("v_mul_hi_i32_i24 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+// floor(x + 0.5) as int32 in ONE instruction (|x| < 2^31); the tie rule differs from round-to-nearest-even only at exact .5, any fixed
+// rule keeps the sums order-independent
+__device__ __forceinline__ int round_half_up(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 // Schedule: image b is owned by workgroup-row (b % gx); each workgroup-row is `split` workgroups that share the image's
@@ -88,7 +87,6 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
     __shared__ uint32_t round_max[3];  // max |G| bits of a round, three slots in rotation (see the reset below)
     __shared__ int nonfinite;
     constexpr int HWS = THREADS / 32;  // half-waves per workgroup
-    constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23
 
     const int tid = threadIdx.x;
     const int c_base = (NCH == 1) ? blockIdx.y : 0;
@@ -107,7 +105,7 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
 #else
 #define K2_STAMP(i)
 #endif
-    int E = kExpUnset;  // exponent of the tile's fixed-point format (workgroup-uniform): quantum = 2^(E - 2*kGBits + 1)
+    int E = kExpUnset;  // exponent of the tile's fixed-point format (workgroup-uniform): quantum = 2^(E + 1 - kCBits)
     int rnd = 0;        // round counter (workgroup-uniform)
     long absorbed = 0;  // footprint pixels added into the tile since the last flush (workgroup-uniform)
     bool flushed = false;
@@ -115,7 +113,7 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
     // tile -> fp32 (this workgroup's partial, or in MULTI mode the image's own gradient), optionally accumulating, then zero the tile
     auto drain = [&](float* dst, int ph, int pw, bool accumulate, bool rezero) {
         // value = tile * quantum, formed as (hi * 2^32 + lo) * 2^q in fp64 (exact), then rounded once to fp32
-        const double quantum = (E == kExpUnset) ? 0.0 : __longlong_as_double((long long)(E - 2 * kGBits + 1 + 1023) << 52);
+        const double quantum = (E == kExpUnset) ? 0.0 : __longlong_as_double((long long)(E + 1 - kCBits + 1023) << 52);
         const bool poison = nonfinite != 0;
         const int plane = ph * pw, rows = min(ph, v_lo + a.band_rows) - v_lo;
         const int tp = rows * pw;
@@ -356,7 +354,7 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
                     const uint32_t mbits = round_max[rnd % 3];
                     if (mbits == 0u) continue;  // nothing kept in this round (workgroup-uniform)
                     int e = (int)(mbits >> 23) - 127;  // floor(log2(max |G|)) (denormals: -127)
-                    e = max(e, -100);                  // keeps 2^(kGBits - 1 - E) a normal float; such gradients are ~1e-30
+                    e = max(e, -96);                   // keeps 2^(kCBits - 1 - E) a normal float; such gradients are ~1e-29
                     if (E == kExpUnset) {
                         E = e;
                     } else if (e > E) {  // a larger image than any before: re-scale what the tile holds (rare; deterministic)
@@ -365,8 +363,9 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
                         E = e;
                         __syncthreads();
                     }
-                    // ======== phase 2: integer scatter. contribution = rint(G*2^(21-E)) * rint(weight*2^22), exact 48-bit product ========
-                    const float gscale = __uint_as_float((uint32_t)(kGBits - 1 - E + 127) << 23);  // |G * gscale| < 2^22
+                    // ======== phase 2: integer scatter. contribution = round(fl(G*w) * 2^(29-E)): the reference's fp32 product, to 2^-30 of the
+                    //          workgroup's largest |G| (the power-of-two scale commutes with the fp32 rounding of the product) ========
+                    const float gscale = __uint_as_float((uint32_t)(kCBits - 1 - E + 127) << 23);  // |G * gscale| < 2^30
 #pragma unroll
                     for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
                             const float ee = 1.0f - wf, so = 1.0f - nf;
                             const float wx0 = (fp & 2u) ? ee : 0.0f, wx1 = (fp & 4u) ? wf : 0.0f;
                             const float wy0 = (fp & 8u) ? so : 0.0f, wy1 = (fp & 16u) ? nf : 0.0f;
-                            const float wt[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};  // the fp32 products grid_sample's backward forms
+                            const float wt[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};  // the fp32 weights grid_sample's backward uses
                             // zero-weight corners (off the patch / band / frame) add 0 to a cell of the pixel's own neighbourhood: the
                             // coordinates are clamped per axis, so lanes keep distinct addresses (a shared dummy cell would serialise)
                             const int vr = (t0v[k][p] >> 16) - 256, uc = (t0v[k][p] & 0xffff) - 256;
@@ -385,22 +384,21 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
                             const int u0c = min(max(uc, 0), pw - 1), u1c = min(max(uc + 1, 0), pw - 1);
                             const int v0c = min(max(vr, 0), vmaxr) * pw, v1c = min(max(vr + 1, 0), vmaxr) * pw;
                             const int offs[4] = {v0c + u0c, v0c + u1c, v1c + u0c, v1c + u1c};
-                            int wi[4];
                             unsigned long long* tp[4];
 #pragma unroll
-                            for (int cn = 0; cn < 4; ++cn) {
-                                wi[cn] = rint_small(__builtin_fmaf(wt[cn], 4194304.0f, kMagic));
-                                tp[cn] = tile + offs[cn] * NCH;
-                            }
+                            for (int cn = 0; cn < 4; ++cn) tp[cn] = tile + offs[cn] * NCH;
 #pragma unroll
                             for (int cc = 0; cc < NCH; ++cc) {
-                                const int Gi = rint_small(__builtin_fmaf(G[k][p][cc], gscale, kMagic));
+                                const float Gs = G[k][p][cc] * gscale;
 #pragma unroll
+                                for (int cn = 0; cn < 4; ++cn) {
+                                    const int ci = round_half_up(Gs * wt[cn]);
 #ifndef VAA_K2_ABLATE_NO_ATOMICS
-                                for (int cn = 0; cn < 4; ++cn) atomicAdd(tp[cn] + cc, mul_i24_i24(Gi, wi[cn]));
+                                    atomicAdd(tp[cn] + cc, (unsigned long long)(long long)ci);
 #else
-                                for (int cn = 0; cn < 4; ++cn) if (mul_i24_i24(Gi, wi[cn]) == 0x123456789ull) tp[cn][cc] = 1ull;  // ablation: keep the arithmetic, drop the LDS atomics
+                                    if (ci == 0x12345678) tp[cn][cc] = 1ull;  // ablation: keep the arithmetic, drop the LDS atomics
 #endif
+                                }
                             }
                         }
                     K2_STAMP(4)
@@ -556,6 +554,10 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
         set_error("vaa_patch_grad_gather: patch %dx%d larger than the frame", ph, pw);
         return VAA_E_UNSUPPORTED;
     }
+    if (geometry && mask_mode == VAA_MASK_NE_M100) {
+        set_error("vaa_patch_grad_gather: VAA_MASK_NE_M100 is defined for geometry=0 only");
+        return VAA_E_UNSUPPORTED;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (!ws || ws_bytes < vaa_patch_grad_ws_bytes(B, ph, pw)) {
         set_error("vaa_patch_grad_gather: workspace %zu B < required %zu B", ws_bytes, vaa_patch_grad_ws_bytes(B, ph, pw));
@@ -586,6 +588,10 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     }
     if (max_h > VAA_IMG || max_w > VAA_IMG) {
         set_error("vaa_patch_grad_gather_multi: patch bound %dx%d larger than the frame", max_h, max_w);
+        return VAA_E_UNSUPPORTED;
+    }
+    if (geometry && mask_mode == VAA_MASK_NE_M100) {
+        set_error("vaa_patch_grad_gather_multi: VAA_MASK_NE_M100 is defined for geometry=0 only");
         return VAA_E_UNSUPPORTED;
     }
     GradArgs a;
@@ -919,6 +925,10 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     }
     if (ph > VAA_IMG || pw > VAA_IMG) {
         set_error("vaa_patch_embed_grad_gather: patch %dx%d larger than the frame", ph, pw);
+        return VAA_E_UNSUPPORTED;
+    }
+    if (geometry && mask_mode == VAA_MASK_NE_M100) {
+        set_error("vaa_patch_embed_grad_gather: VAA_MASK_NE_M100 is defined for geometry=0 only");
         return VAA_E_UNSUPPORTED;
     }
     if (!ws || ws_bytes < vaa_patch_embed_grad_ws_bytes(B, ph, pw)) {
