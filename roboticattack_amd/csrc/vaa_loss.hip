@@ -973,6 +973,14 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
         set_error("vaa_loss_rows_fwd_bwd: null pointer argument");
         return VAA_E_INVALID;
     }
+    if (R == 0 && B > 0 && L > 1) {  // nothing is labelled: every scalar is 0 (the reference's means over empty sets are not defined), no prediction
+        hipStream_t st0 = (hipStream_t)stream;
+        hipError_t e = hipMemsetAsync(scalars, 0, 8 * sizeof(float), st0);
+        if (e == hipSuccess && pred_tokens) e = hipMemsetAsync(pred_tokens, 0xff, (size_t)B * (L - 1) * sizeof(int32_t), st0);
+        if (e == hipSuccess && pred_full_tokens) e = hipMemsetAsync(pred_full_tokens, 0xff, (size_t)B * (L - 1) * sizeof(int32_t), st0);
+        if (e != hipSuccess) { set_error("vaa_loss_rows_fwd_bwd: %s", hipGetErrorString(e)); return VAA_E_LAUNCH; }
+        return VAA_OK;
+    }
     if (R <= 0 || B <= 0 || L <= 1 || V < kA0 + kNA || (V % 8) != 0 || mode < 0 || mode > VAA_LOSS_CE ||
         (dtype != VAA_DTYPE_F32 && dtype != VAA_DTYPE_BF16) || (grad_kind != VAA_GRAD_FULL && grad_kind != VAA_GRAD_SLICE)) {
         set_error("vaa_loss_rows_fwd_bwd: bad sizes/mode (R=%d B=%d L=%d V=%d mode=%d dtype=%d grad_kind=%d)", R, B, L, V, mode, dtype, grad_kind);

@@ -431,6 +431,7 @@ def loss_rows_fwd_bwd(logits, rowmap: LossRowMap, mode: int, w: float = 5.0, alp
     pred_full = torch.empty((B, Lt - 1), dtype=torch.int32, device=logits.device) if want_pred else None
     if want_grad and grad is None:
         grad = torch.empty((R, N_ACTION if grad_kind == GRAD_SLICE else V), dtype=logits.dtype, device=logits.device)
+    ws = ws if R > 0 else _workspace(logits.device, 256, "k3")
     with _timed("K3_loss_rows_fwd_bwd", B=B, L=Lt, V=V, dtype=str(logits.dtype), rows=R, grad_kind=grad_kind):
         rc = L.vaa_loss_rows_fwd_bwd(logits.data_ptr(), dt, rowmap.buf.data_ptr(), R, B, Lt, V, int(mode), _lib.f32x([w, alpha, beta, scale]),
                                      scalars.data_ptr(), pred.data_ptr() if want_pred else None, pred_full.data_ptr() if want_pred else None,

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Randomised parity soak of K3 (both routes) against the plain-C oracle (GPU box; not part of the test suite).
+
+    python tools/soak_loss.py --seconds 120 --seed 1
+
+Every case draws a batch, a prompt-length range, a labelling pattern (subsets of the 7 action positions, with / without EOS, samples
+without any label), a mode (UADA, UADA_DDP, UPA, CE) and a logits dtype, then checks scalars (3e-5), gradients (2e-4 of the row scale
+for fp32, 1e-2 for bf16 storage), slice-vs-full storage, the action-slice and full-vocabulary argmax, for the rows route (row map) and
+the label-driven route (FULL layout).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import c_oracle  # noqa: E402
+from roboticattack_amd import ops, synthetic  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def one_case(seed):
+    rs = np.random.RandomState(seed)
+    fails = []
+    B = int(rs.choice([1, 2, 3, 5, 8, 12]))
+    lo = int(rs.randint(12, 30))
+    _, labels, _ = synthetic.synth_text_batch(seed % 9973, B, min_len=lo, max_len=lo + int(rs.randint(0, 12)))
+    mode = str(rs.choice(["UADA", "UADA_DDP", "UPA", "CE"]))
+    lab = labels.numpy().copy()
+    if mode != "UPA":  # UPA needs the first three action rows of every labelled sample (UPA.py:375-378)
+        for b in range(B):
+            pos = np.nonzero(lab[b] != -100)[0]
+            if rs.rand() < 0.15:
+                lab[b] = -100  # a sample without labels
+                continue
+            keep = rs.rand(len(pos)) < rs.uniform(0.2, 1.0)
+            if not keep.any():
+                keep[rs.randint(len(pos))] = True
+            lab[b, pos[~keep]] = -100
+        if mode in ("UADA", "CE") and not (lab[:, 1:] != -100).any():
+            lab[0, np.nonzero(labels.numpy()[0] != -100)[0][0]] = labels.numpy()[0][np.nonzero(labels.numpy()[0] != -100)[0][0]]
+    labels = torch.from_numpy(lab)
+    L = labels.shape[1]
+    bk = np.argwhere(lab[:, 1:] != -100)
+    R = len(bk)
+    if R == 0:
+        return fails
+    dtype = torch.bfloat16 if rs.rand() < 0.5 else torch.float32
+    z = (rs.standard_normal((R, 32064)) * rs.uniform(0.5, 4)).astype(np.float32)
+    z[:, 31744:32000] += (rs.standard_normal((R, 256)) * rs.uniform(0.5, 5)).astype(np.float32)
+    if rs.rand() < 0.5:
+        z[rs.rand(R) < 0.4, int(rs.randint(0, 31744))] = 60.0
+    zt = torch.from_numpy(z).to(dtype)
+    full = torch.zeros((B, 256 + L, 32064), dtype=torch.float32)
+    full[torch.from_numpy(bk[:, 0]), torch.from_numpy(bk[:, 1] + 256)] = zt.float()
+    w, alpha, beta, scale = float(rs.uniform(1, 8)), float(rs.uniform(0.1, 1)), float(rs.uniform(0.1, 1)), float(rs.choice([1.0, 0.25, -1.0]))
+    om = {"UADA": c_oracle.MODE_UADA, "UADA_DDP": c_oracle.MODE_UADA_DDP, "CE": c_oracle.MODE_CE, "UPA": c_oracle.MODE_UPA}[mode]
+    km = {"UADA": ops.LOSS_UADA, "UADA_DDP": ops.LOSS_UADA_DDP, "CE": ops.LOSS_CE, "UPA": ops.LOSS_UPA}[mode]
+    so, go = c_oracle.loss(full.numpy(), lab, om, w=w, alpha=alpha, beta=beta, scale=scale)
+    gor = go[bk[:, 0], bk[:, 1] + 256]
+    tag = f"seed={seed} B={B} L={L} R={R} mode={mode} dtype={dtype}"
+    gtol = (1e-2 if dtype == torch.bfloat16 else 2e-4) * max(np.abs(gor).max(), 1e-30)
+    rm = ops.LossRowMap(labels.to(DEV))
+    kinds = [ops.GRAD_FULL] + ([ops.GRAD_SLICE] if mode in ("UADA_DDP", "UPA") else [])
+    zf = zt.float().numpy()
+    for kind in kinds:
+        sc, pred, pf, g = ops.loss_rows_fwd_bwd(zt.to(DEV), rm, km, w=w, alpha=alpha, beta=beta, scale=scale, grad_kind=kind)
+        if not np.allclose(sc.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5):
+            fails.append(f"rows scalars {tag} kind={kind}: {sc.cpu().numpy()[:5]} vs {so[:5]}")
+        gg = g.float().cpu().numpy()
+        ref = gor[:, 31744:32000] if kind == ops.GRAD_SLICE else gor
+        if not (np.abs(gg - ref).max() <= gtol):
+            fails.append(f"rows grad    {tag} kind={kind}: {np.abs(gg - ref).max() / max(np.abs(gor).max(), 1e-30):.3e}")
+    pfn, psn = pf.cpu().numpy(), pred.cpu().numpy()
+    for i, (b, k) in enumerate(bk):
+        if pfn[b, k] != int(zf[i].argmax()):
+            fails.append(f"rows argmax  {tag} row {i}")
+            break
+        if lab[b, k + 1] > 2 and psn[b, k] != 31744 + int(zf[i, 31744:32000].argmax()):
+            fails.append(f"rows slice argmax {tag} row {i}")
+            break
+    if int((pfn >= 0).sum()) != R:
+        fails.append(f"rows pred count {tag}")
+    if dtype == torch.float32:
+        sc3, p3, g3, pf3 = ops.loss_fwd_bwd(full.to(DEV), labels.to(DEV), km, w=w, alpha=alpha, beta=beta, scale=scale, want_pred_full=True)
+        if not np.allclose(sc3.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5):
+            fails.append(f"full scalars {tag}")
+        if not (np.abs(g3.cpu().numpy() - go).max() <= gtol):
+            fails.append(f"full grad    {tag}: {np.abs(g3.cpu().numpy() - go).max() / max(np.abs(gor).max(), 1e-30):.3e}")
+        if not (torch.equal(pf3.cpu(), pf.cpu()) and torch.equal(p3.cpu(), pred.cpu())):
+            fails.append(f"full preds   {tag}")
+    return fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    ops.device_check()
+    t0, n, bad = time.time(), 0, []
+    while time.time() - t0 < a.seconds:
+        bad += one_case(a.seed * 1000003 + n)
+        n += 1
+    for b in bad:
+        print("FAIL", b)
+    print(f"soak_loss: {n} cases in {time.time() - t0:.0f} s, {len(bad)} failures")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
