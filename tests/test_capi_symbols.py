@@ -9,21 +9,22 @@ from conftest import ROOT
 from roboticattack_amd import _lib
 
 
-def _declared():
-    hdr = open(os.path.join(ROOT, "include", "vaa.h")).read()
+def _declared(header="vaa.h"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(vaa_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_header_and_binding_agree():
     assert _declared() == sorted(_lib.EXPORTS)
+    assert _declared("vaa_model_ops.h") == sorted(_lib.MODEL_OP_EXPORTS)  # the optional model-side operators
 
 
 def test_library_exports_every_declared_symbol():
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
     L = ctypes.CDLL(_lib.LIB_PATH)
-    for name in _declared():
+    for name in _declared() + _declared("vaa_model_ops.h"):
         assert hasattr(L, name), f"libvaa_hip.so does not export {name}"
     assert _lib.lib().vaa_version() >= 100
 
