@@ -29,7 +29,7 @@ def get_exp_id():
 
 def main(args):
     rank, world, local = vdist.env_rank_world()
-    device = torch.device(f"cuda:{local}") if torch.cuda.is_available() else torch.device("cpu")
+    device = vdist.local_device()
     if device.type == "cuda":
         torch.cuda.set_device(device)
     vdist.init_process_group(device=device if device.type == "cuda" else None)

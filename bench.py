@@ -187,7 +187,7 @@ def main():
     from roboticattack_amd.transform import RandomPatchTransform
 
     ops.device_check()
-    dev = torch.device(f"cuda:{local}")
+    dev = vdist.local_device()
     torch.cuda.set_device(dev)
     if world > 1:
         vdist.init_process_group(device=dev)  # "nccl" (= RCCL) on GPUs; VAA_DIST_BACKEND=gloo lets several ranks share one GPU (tests)

@@ -59,7 +59,7 @@ class OpenVLAAttacker(AttackBase):
         "UPA" = UPA.py's reverse-direction loss + L1 grad clip, "TMA" = TMA.py's target-token CE, same data-parallel loop."""
         rank, world, local = vdist.env_rank_world()
         if device is None:
-            device = torch.device(f"cuda:{local}") if torch.cuda.is_available() else torch.device("cpu")
+            device = vdist.local_device()
         self._rank, self._world = rank, world
         vla = (model_factory or default_model_factory)(vla_path, device)
         super().__init__(vla, None, save_dir, "adamW", resize_patch)

@@ -19,6 +19,18 @@ def env_rank_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
+def local_device() -> torch.device:
+    """cuda:LOCAL_RANK — one process per GPU. Only under VAA_DIST_BACKEND=gloo (test mode: gloo moves the buffers through the host) may
+    more ranks than GPUs run on a node; they then wrap around the visible devices."""
+    _, _, local = env_rank_world()
+    if not torch.cuda.is_available():
+        return torch.device("cpu")
+    n = torch.cuda.device_count()
+    if os.environ.get("VAA_DIST_BACKEND") == "gloo" and n > 0:
+        local %= n
+    return torch.device(f"cuda:{local}")
+
+
 def init_process_group(backend: str | None = None, device: torch.device | None = None) -> tuple[int, int]:
     """torchrun-style rendezvous (env://). Appendix A-D7: the reference broadcasts before initialising; here the
     group is always initialised first."""

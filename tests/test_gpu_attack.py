@@ -553,6 +553,25 @@ def test_bench_contract_line_tiny(model, extra_env):
     assert d["roofline"]["kernel"] == "K1_patch_apply_fwd" and d["roofline"]["bound"] == "hbm"
 
 
+def test_ddp_wrapper_cli_under_torchrun_two_ranks(tmp_path):
+    """`torchrun --nproc-per-node 2 VLAAttacker/UADA_wrapper_ddp.py` exactly as README.md:109 launches it, both ranks on the one GPU of the
+    test box (VAA_DIST_BACKEND=gloo): rendezvous before the run-id broadcast (A-D7), one run directory, rank 0 writes the patches."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "VLAAttacker", "UADA_wrapper_ddp.py"), "--vla_path", "random:tiny", "--iter", "2", "--innerLoop", "2", "--bs", "2",
+           "--warmup", "1", "--wandb_project", "false"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), timeout=600, env=dict(os.environ, VAA_DIST_BACKEND="gloo"))
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    runs = os.listdir(tmp_path / "run" / "UADA")
+    assert len(runs) == 1, runs  # both ranks agreed on rank 0's exp_id
+    assert out.stdout.count("Attack done!") == 2
+    p = torch.load(tmp_path / "run" / "UADA" / runs[0] / "last" / "patch.pt")
+    assert p.dtype == torch.float32 and tuple(p.shape) == (3, 50, 50) and float(p.min()) >= 0 and float(p.max()) <= 1
+
+
 @pytest.mark.parametrize("wrapper,torchrun", [("UADA_wrapper", False), ("UPA_wrapper", False), ("TMA_wrapper", False), ("UADA_wrapper_ddp", True)])
 def test_wrapper_clis_run_end_to_end(tmp_path, wrapper, torchrun):
     """The four reference CLIs with their DEFAULT flags (incl. the reference's `--device 1`) on a tiny model: two outer iterations each,
