@@ -70,15 +70,15 @@ __device__ __forceinline__ int round_half_up(float x) {
     return r;
 }
 
-// Schedule: image b is owned by workgroup-row (b % gx); each workgroup-row is `split` workgroups that share the image's
-// footprint slots. Small batches use split > 1 to fill the chip.
+// Schedule: image b is owned by workgroup-row (b % gx) = blockIdx.x; blockIdx.z selects a band of patch rows (see grad_sched), blockIdx.y
+// the channel of the one-channel-per-workgroup instantiations.
 //
 // Footprint walk without any per-pixel search: the footprint rows [rmin, rmax] of an image are cut into 64-column
 // segments starting at an even column; one half-wave owns one (row, segment) slot at a time and a lane owns TWO adjacent
 // pixels of it (one 4-byte load per gradient plane, one keep byte), so a lane needs ONE LDS read (packed {jlo,len} of its
 // row) to know its pixels. Slots are dealt round-robin to the half-waves of the workgroup-row.
 template <int NCH, bool TILED, bool MULTI, bool HASK, int THREADS, int K>
-__global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a, int gx, int split) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void patch_grad_scatter_kernel(GradArgs a, int gx) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned long long* tile = reinterpret_cast<unsigned long long*>(smem_raw);  // [band_rows*pw][NCH] (channels interleaved)
     __shared__ float bgrid[VAA_IMG];
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
     const int tid = threadIdx.x;
     const int c_base = (NCH == 1) ? blockIdx.y : 0;
     const int v_lo = blockIdx.z * a.band_rows;  // first patch row of this workgroup's band
-    const int wg_row = blockIdx.x / split, chunk = blockIdx.x - wg_row * split;
-    const int hw = chunk * HWS + (tid >> 5), nhw = split * HWS, hl = tid & 31;
+    const int wg_row = blockIdx.x;
+    const int hw = tid >> 5, nhw = HWS, hl = tid & 31;
     const int tile_elems = NCH * a.band_rows * a.pw;
     for (int e = tid; e < tile_elems; e += THREADS) tile[e] = 0ull;
     if (tid < VAA_IMG) bgrid[tid] = base_coord(tid);
@@ -181,16 +181,18 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
                     // frame edge also receives every clamped out-of-frame sample (padding_mode='border').
                     const float xlo = (px == 0) ? -1e30f : (float)(px - 1);
                     const float xhi = (px + pw == VAA_IMG) ? 1e30f : (float)(px + pw);
-                    const float ylo = (py == 0) ? -1e30f : (float)(py - 1);
-                    const float yhi = (py + ph == VAA_IMG) ? 1e30f : (float)(py + ph);
+                    // ... restricted to this workgroup's band of patch rows [v_lo, vb_hi): source y in [py + v_lo - 1, py + vb_hi)
+                    const int vb_hi = min(ph, v_lo + a.band_rows);
+                    const float ylo = (py == 0 && v_lo == 0) ? -1e30f : (float)(py + v_lo - 1);
+                    const float yhi = (py + ph == VAA_IMG && vb_hi == ph) ? 1e30f : (float)(py + vb_hi);
                     float jl = -1e30f, jh = 1e30f;
                     solve_interval(pa.a00, pa.a01 * (float)i + pa.c0, xlo, xhi, jl, jh);
                     solve_interval(pa.a10, pa.a11 * (float)i + pa.c1, ylo, yhi, jl, jh);
-                    if (jl <= jh) {
+                    if (jl <= jh && v_lo < ph) {
                         jlo = (int)fmaxf(0.0f, floorf(jl) - 1.0f);
                         jhi = (int)fminf((float)(VAA_IMG - 1), ceilf(jh) + 1.0f);
                     }
-                } else if (i >= py && i < py + ph) {
+                } else if (i >= py + v_lo && i < py + min(ph, v_lo + a.band_rows)) {
                     jlo = px;
                     jhi = px + pw - 1;
                 }
@@ -268,10 +270,10 @@ __global__ __launch_bounds__(THREADS) void patch_grad_scatter_kernel(GradArgs a,
                             if (a.geometry) sample_pos_frac(bgrid[j], bgrid[i], th, x0, y0, wf, nf);
                             fw[k][p] = wf; fn[k][p] = nf;
                             const int u0 = x0 - px, v0 = y0 - py;
-                            const bool inside = lane_in && (off + p < len) && !(u0 < -1 || u0 >= pw || v0 < -1 || v0 >= ph);
-                            // corners off the patch, off this workgroup's row band or off the frame get weight 0
-                            const bool uin0 = u0 >= 0, uin1 = (u0 + 1 < pw) && (x0 + 1 < VAA_IMG);
+                            // corners off the patch, off this workgroup's row band or off the frame get weight 0; a pixel without a live corner is skipped
+                            const bool uin0 = (unsigned)u0 < (unsigned)pw, uin1 = ((unsigned)(u0 + 1) < (unsigned)pw) && (x0 + 1 < VAA_IMG);
                             const bool vin0 = v0 >= v_lo && v0 < v_hi, vin1 = (v0 + 1 >= v_lo) && (v0 + 1 < v_hi) && (y0 + 1 < VAA_IMG);
+                            const bool inside = lane_in && (off + p < len) && (uin0 || uin1) && (vin0 || vin1);
                             uint32_t fp = (inside ? 1u : 0u) | (uin0 ? 2u : 0u) | (uin1 ? 4u : 0u) | (vin0 ? 8u : 0u) | (vin1 ? 16u : 0u);
                             t0v[k][p] = ((min(max(v0 - v_lo, -255), 255) + 256) << 16) | (min(max(u0, -255), 255) + 256);
                             if (!HASK && inside) {  // no stored mask: recompute it from the patch (test / stand-alone use)
@@ -464,24 +466,39 @@ int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts
 }
 
 struct GradSched {
-    int gx, split;
+    int gx, bands;
 };
 
+// Schedule of the 3-channel path (patches whose int64 tile fits 64 KB). Workgroup x = blockIdx.x owns images x, x + gx, ...; a small batch is
+// spread over the chip by cutting the PATCH into row bands (grid.z): a band's workgroup walks only the part of each footprint that maps onto
+// its rows, keeps an int64 tile of just those rows and drains just those rows of the partial tile, so the partial buffer stays one tile per
+// workgroup-row whatever the band count (slot-interleaved workgroups that each held a full tile were the previous split: 2 x the drain
+// and reduce traffic). Measured scatter + reduce, 3x50x50, bands 2 / 4 / 8: B=8 13.9 / 12.1 / 12.0, B=32 16.7 / 14.2 / 13.1,
+// B=64 18.3 / 15.1 / 16.9, B=128 23.0 / 21.2 / 29.3 us; from ~130 images on the batch alone fills the chip.
 static GradSched grad_sched(int B) {
     GradSched g;
     g.gx = B < 512 ? B : 512;
-    // two workgroups per image while the batch alone cannot fill the chip (measured at B=64: split 1 / 2 / 3 / 4 -> 24.4 / 20.8 / 22.8 /
-    // 24.7 us for scatter + reduce; at B=4096 any split > 1 only adds partial tiles)
-    g.split = (B <= 256) ? 2 : 1;
+    g.bands = B <= 32 ? 8 : (B <= 128 ? 4 : 1);
     return g;
 }
 
 constexpr size_t kLdsBudget = 144 * 1024;  // 160 KiB per CU minus the static row tables (~9 KB)
 
-static int band_rows_for(int ph, int pw) {  // patch rows whose int64 plane fits the LDS
+#ifndef VAA_K2_TARGET_WGS  // experiment knob
+#define VAA_K2_TARGET_WGS 128
+#endif
+
+// Patch rows per row band of the one-channel-per-workgroup paths: at most what the LDS holds as an int64 plane, and no more than it
+// takes for `wgs_per_band` workgroups x bands to reach ~128 workgroups (a band only walks ITS part of the footprint and drains ITS rows,
+// so small batches of large patches are spread over the chip without any extra partial tile). Never below 8 rows.
+static int band_rows_for(int ph, int pw, int wgs_per_band) {
     const size_t row_bytes = (size_t)pw * sizeof(long long);
     int rows = (int)(kLdsBudget / row_bytes);
-    return rows >= ph ? ph : rows;
+    rows = rows >= ph ? ph : rows;
+    const int want = (VAA_K2_TARGET_WGS + wgs_per_band - 1) / wgs_per_band;  // bands wanted
+    int r2 = (ph + want - 1) / want;
+    r2 = r2 < 8 ? 8 : r2;
+    return r2 < rows ? r2 : rows;
 }
 
 template <bool TILED>
@@ -489,17 +506,19 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
     GradArgs a = a0;
     const int B = a.B, ph = a.ph, pw = a.pw, n = 3 * ph * pw;
     const GradSched gs = grad_sched(B);
-    const int G = gs.gx * gs.split;  // workgroups (x) == partial tiles
+    const int G = gs.gx;  // workgroups (x) == partial tiles
     const size_t plane = (size_t)ph * pw;
     hipError_t e = hipSuccess;
     if (3 * plane * sizeof(long long) <= 64 * 1024) {  // e.g. 50x50: 60,000 B
-        a.band_rows = ph;
-        if (a.keep)
-            hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, true, 1024, 3>), dim3(G), dim3(1024), 3 * plane * sizeof(long long), st, a, gs.gx, gs.split);
-        else
-            hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, false, 1024, 3>), dim3(G), dim3(1024), 3 * plane * sizeof(long long), st, a, gs.gx, gs.split);
+        // 512 threads: two workgroups per CU (<= 128 VGPRs each, 2 x 68 KB of LDS at one band), so one scatters while the other waits on its
+        // loads or its barrier (B = 256 / 1024 / 4096: 41.8 / 76.7 / 183 us with one 1024-thread workgroup per CU -> 33.4 / 64.8 / 173 us)
+        a.band_rows = (ph + gs.bands - 1) / gs.bands;
+        const int nb = (ph + a.band_rows - 1) / a.band_rows;
+        const size_t lds = 3 * (size_t)a.band_rows * pw * sizeof(long long);
+        if (a.keep) hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, true, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
+        else hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, false, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
     } else {  // one channel per workgroup (grid.y), row bands (grid.z) when even one plane exceeds the LDS (> 135x135)
-        a.band_rows = band_rows_for(ph, pw);
+        a.band_rows = band_rows_for(ph, pw, 3 * G);
         const int nbands = (ph + a.band_rows - 1) / a.band_rows;
         const size_t bytes = (size_t)a.band_rows * pw * sizeof(long long);
         const void* fn = a.keep ? (const void*)patch_grad_scatter_kernel<1, TILED, false, true, 1024, 3>
@@ -507,9 +526,9 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
         if (bytes > 64 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e == hipSuccess) {
             if (a.keep)
-                hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, true, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx, gs.split);
+                hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, true, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx);
             else
-                hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, false, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx, gs.split);
+                hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, false, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx);
         }
     }
     if (e != hipSuccess) {
@@ -530,7 +549,7 @@ extern "C" int vaa_k2_set_debug(long long* p) { return (int)hipMemcpyToSymbol(HI
 extern "C" size_t vaa_patch_grad_ws_bytes(int B, int ph, int pw) {
     if (B <= 0 || ph <= 0 || pw <= 0) return 0;
     const vaa::GradSched g = vaa::grad_sched(B);
-    return (size_t)g.gx * g.split * 3 * (size_t)ph * pw * sizeof(float);
+    return (size_t)g.gx * 3 * (size_t)ph * pw * sizeof(float);
 }
 
 extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* patch, const int32_t* xy, const float* theta,
@@ -599,7 +618,7 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
     a.geff = nullptr; a.tile_slot = nullptr;
-    a.band_rows = band_rows_for(max_h, max_w);
+    a.band_rows = band_rows_for(max_h, max_w, 3 * B);
     const int nbands = (max_h + a.band_rows - 1) / a.band_rows;
     const size_t bytes = (size_t)a.band_rows * max_w * sizeof(long long);
     const void* fn = keep_bits ? (const void*)patch_grad_scatter_kernel<1, false, true, true, 1024, 3>
@@ -609,9 +628,9 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
         return VAA_E_LAUNCH;
     }
     if (keep_bits)
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, true, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B, 1);
+        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, true, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B);
     else
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, false, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B, 1);
+        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, false, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B);
     return check_launch("vaa_patch_grad_gather_multi");
 }
 
@@ -773,6 +792,10 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     const int b = (slot_id / nch) * 8 + xcd, ch = slot_id % nch;
     if (b >= a.B) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+#ifdef VAA_K2_TIMING
+    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    long long tlast = wall_clock64();
+#endif
 
     bool flag = false;
     if (tid < 256) flag = tile_has_kept_pixel(a.keep + (size_t)b * 3 * (VAA_NPIX / 8), tid >> 4, tid & 15);
@@ -786,6 +809,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     if (ch == 0 && tid < 256) a.tile_slot[b * 256 + tid] = flag ? (int16_t)slot : (int16_t)-1;
     __syncthreads();
 
+    K2_STAMP(0)
     int n[2];
     bool nv[2];
     float s0[2], s1[2];
@@ -830,6 +854,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                 }
             }
             __syncthreads();
+            K2_STAMP(1 + 2 * tower)
             // ---- barrier-free k-loop ----
             const uint16_t* wt = tower ? a.wt1 : a.wt0;
             const uint16_t* wp0 = wt + (size_t)n[0] * D + g * 8;
@@ -882,6 +907,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                         const float v = maybe_bf16(acc[j][q][r], a.round_bf16) * (tower ? s1[j] : s0[j]);
                         res[j][q][r] = tower ? res[j][q][r] + v : v;
                     }
+            K2_STAMP(2 + 2 * tower)
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -894,7 +920,12 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                     if (sl < M) a.geff[((size_t)b * 256 + sl) * kTileElems + n[j]] = res[j][q][r];
                 }
         }
+        K2_STAMP(5)
     }
+#ifdef VAA_K2_TIMING  // tools/scratch/k2etiming.py: flags / stage 0 / k-loop 0 / stage 1 / k-loop 1 / store, per wave
+    if (lane == 0 && vaa_k2_dbg)
+        for (int z = 0; z < 6; ++z) vaa_k2_dbg[((size_t)blockIdx.x * 16 + wv) * 6 + z] = tacc[z];
+#endif
 }
 
 }  // namespace vaa

@@ -252,7 +252,7 @@ def test_k2_bitwise_repeatable_every_size(ops, ph, pw, B):
 
 def test_k2_gradient_scale_range_and_nonfinite(ops):
     """The fixed-point format follows the data: images whose gradients differ by 2^40 in one batch (forces the lazy re-scale),
-    tiny (1e-27 after the 1e-3 of the generator; the format bottoms out at 2^-100) and huge (1e27) gradients keep fp32-level relative accuracy; an inf/nan upstream gradient poisons the output."""
+    tiny (1e-27 after the 1e-3 of the generator; the format bottoms out at 2^-100) and huge (1e27) gradients keep fp32-level relative accuracy; an inf/nan upstream gradient poisons (NaN) at least the texels autograd would."""
     B, rs = 12, np.random.RandomState(5)
     imgs = _t(synthetic.synth_images(4, B, "smooth"))
     patch_n = rs.rand(3, 50, 50).astype(np.float32)
@@ -269,7 +269,11 @@ def test_k2_gradient_scale_range_and_nonfinite(ops):
     gbad = g.clone()
     ys, xs = np.nonzero(_keep_unpack(keep)[3, 0].reshape(224, 224))
     gbad[3, 0, ys[0], xs[0]] = float("inf")
-    assert torch.isnan(ops.patch_grad_gather(gbad.to(torch.bfloat16).to(DEV), patch, xy, th, keep, True, 0)).all()
+    gb16 = gbad.to(torch.bfloat16)
+    got = ops.patch_grad_gather(gb16.to(DEV), patch, xy, th, keep, True, 0).cpu().numpy()
+    bad_ref = ~np.isfinite(c_oracle.patch_grad(_bits(gb16), patch_n, xy_n, th_n, 1, 0))  # the texels autograd would make inf / nan
+    assert bad_ref.any() and np.isnan(got[bad_ref]).all()  # a superset is poisoned (the whole row band of the workgroup that met the value)
+    assert np.isnan(got).all() or np.isfinite(got[~np.isnan(got)]).all()
 
 
 def test_k2_int64_tile_flush_huge_batch(ops):
