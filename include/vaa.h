@@ -109,7 +109,7 @@ int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* patch, const i
  * vaa_patch_resize_fwd: packed[offset_b ...] = antialiased bilinear resize of patch [3,ph,pw] to (h_b, w_b) — torchvision Resize on a
  *             tensor == torch F.interpolate(mode='bilinear', antialias=True, align_corners=False); bit-exact against torch's CPU kernel.
  * vaa_patch_resize_bwd: gpatch [3,ph,pw] = sum_b adjoint(resize_b)(gpacked_b), overwritten; ws >= vaa_patch_resize_ws_bytes(B,ph,pw)
- *             (0 for batches of up to four images: ws may then be NULL; one partial per group of four images beyond).
+ *             (one partial per image group — one image per group until the batch alone fills the chip; 0 for a single group).
  * vaa_patch_apply_fwd_multi / vaa_patch_grad_gather_multi: K1 / K2 with per-image patches. K2's output gpacked has the layout of
  *             packed and holds d L / d (every image's own resized patch); elements between the patches are not written.
  * Launch counts do not depend on B: forward = resize + K1, backward = K2 + resize adjoint + fixed-order sum over the images.
