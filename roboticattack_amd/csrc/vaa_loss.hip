@@ -597,6 +597,12 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a) {
     const RowMap me = reinterpret_cast<const RowMap*>(a.rowmap + 4)[r];
     const int nact = a.rowmap[1];
 
+    // the label's logit (one thread): requested here, behind the row loads, not after the reductions
+    float zlab_early = -INFINITY;
+    if (tid == 0) {
+        const int lv = me.lab / N;
+        if (me.lab >= 0 && lv >= v_lo && lv < v_hi) zlab_early = Vec<T>::get(z + me.lab);
+    }
     // ---- max + argmax (lowest index on ties, torch.argmax) ----
     float m = -INFINITY;
     int mi = 0x7fffffff;
@@ -641,8 +647,7 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a) {
         ps.m = M;
         ps.s = tot;
         ps.amax = bidx;
-        const int lv = me.lab / N;
-        ps.zlab = (me.lab >= 0 && lv >= v_lo && lv < v_hi) ? Vec<T>::get(z + me.lab) : -INFINITY;
+        ps.zlab = zlab_early;
         a.part[(size_t)r * a.split + h] = ps;
     }
     if (!(has_slice && wv == 0)) return;

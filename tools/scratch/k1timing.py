@@ -28,3 +28,11 @@ for role, name, labels in ((1, "footprint", ["params+rowtable", "loads issued+wa
     start = (sel[:, 7] - t0) / 100.0
     print(name, "waves", len(sel), {l: round(float(sel[:, i].mean()) / 100.0, 2) for i, l in enumerate(labels)}, "total mean", round(float(tot.mean()), 2), "max", round(float(tot.max()), 2),
           "start mean/max us", round(float(start.mean()), 2), round(float(start.max()), 2), "end max us", round(float((start + tot).max()), 2))
+# concurrency profile: waves active over time
+allm = d[:, :, 7] > 0
+st = (d[:, :, 7][allm] - t0) / 100.0
+en = st + d[:, :, :6].sum(2)[allm] / 100.0
+for t in (0.2, 0.5, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+    print("t=%.1f us active waves %d started %d finished %d" % (t, int(((st <= t) & (en > t)).sum()), int((st <= t).sum()), int((en <= t).sum())))
+bgm = (d[:, :, 6] == 0) & allm
+print("bg start percentiles", np.percentile((d[:, :, 7][bgm] - t0) / 100.0, [1, 10, 25, 50, 75, 90, 99]))
