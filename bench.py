@@ -200,8 +200,8 @@ def main():
     model, model_desc = build_model(args.model, dev)
     use_rows = hasattr(model, "forward_rows")
     tr = RandomPatchTransform(dev, False)
-    if use_rows and hasattr(model, "patch_embed_params") and os.environ.get("VAA_FUSED_EMBED_GRAD"):
-        tr.embed_with = model  # opt-in K2' path: the pixel gradient is never materialised; same step time at bs=64
+    if use_rows and hasattr(model, "patch_embed_params") and os.environ.get("VAA_FUSED_EMBED_GRAD", "1") != "0":
+        tr.embed_with = model  # K2' (SURVEY.md 8f-3), like the attack loops: the dense pixel gradient is never materialised; =0 for plain K2
     mean = [torch.tensor([0.484375, 0.455078125, 0.40625]), torch.tensor([0.5, 0.5, 0.5])]
     std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
 
@@ -290,9 +290,11 @@ def main():
         per.setdefault(name, []).append(s.elapsed_time(e) * 1e-3)
     kern = {}
     esz = 2 if use_rows and args.model == "openvla-7b" else 4
+    cfg = getattr(model, "cfg", None)
+    embed_width = (cfg.dino.dim + cfg.siglip.dim) if cfg is not None and hasattr(cfg, "dino") else 1024 + 1152  # K2': dY row width of both towers
     for name, ts in per.items():
         key = "K2e" if name.startswith("K2_patch_embed") else ("K3_slice" if name.startswith("K3_loss_rows") else name[:2])
-        nb = algo_bytes(key, B, patch_shape[1], patch_shape[2], rows=R, esize=esz)
+        nb = algo_bytes(key, B, patch_shape[1], patch_shape[2], rows=R, esize=esz, embed_width=embed_width)
         mean = float(np.mean(ts))
         kern[name] = {"launches": len(ts), "mean_us": mean * 1e6, "algo_bytes": nb, "achieved_GBs": nb / mean / 1e9,
                       "frac": nb / mean / 1e9 / HBM_PEAK_GBS}

@@ -178,13 +178,17 @@ int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int
  * patch-embed backward (modeling_prismatic.py:120-123 -> timm PatchEmbed, Conv2d(3, D, 14, stride 14) == a GEMM over 588-pixel
  * tiles) is evaluated by MFMA only for the 14x14 tiles that carry kept patch pixels and consumed in place by the gather.
  *   dy0, dy1  dev bf16 [B,256,D0], [B,256,D1]: dL/d(patch-embed output) of the DINOv2 and SigLIP towers, tokens in tile order
- *   wt0, wt1  dev bf16 [588,D0], [588,D1]: conv weights [D,3,14,14] flattened to [D,588] and transposed (frozen, keep resident)
+ *   wp0, wp1  dev bf16 [vaa_patch_embed_packed_elems(D)]: the conv weights [D,3,14,14] of a tower, flattened to [D,588], transposed to
+ *             wt [588,D] and re-ordered ONCE into MFMA fragment order by vaa_patch_embed_pack_weights (frozen weights: pack at model load,
+ *             keep resident; 592 x D elements — 588 columns + 4 of zero padding)
  *   keep_bits dev: K1's keep mask (required); round_bf16 != 0 rounds each tower's pixel gradient to bf16 before the 1/std scaling
- *             (what the unfused path does: the model hands back a bf16 pixel gradient); D0, D1 multiples of 32
+ *             (what the unfused path does: the model hands back a bf16 pixel gradient); D0, D1 multiples of 64
  *   other arguments as vaa_patch_grad_gather; ws >= vaa_patch_embed_grad_ws_bytes(B, ph, pw)
  */
+size_t vaa_patch_embed_packed_elems(int D);
+int vaa_patch_embed_pack_weights(const uint16_t* wt, int D, uint16_t* packed, void* stream);
 size_t vaa_patch_embed_grad_ws_bytes(int B, int ph, int pw);
-int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
+int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
                                 const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph, int pw,
                                 int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes,
                                 void* stream);

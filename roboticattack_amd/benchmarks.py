@@ -19,7 +19,7 @@ from .labels import mask_labels
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
 
 
-def algo_bytes(kernel: str, B: int, ph: int = 50, pw: int = 50, rows: int = 0, V: int = 32064, esize: int = 2) -> float:
+def algo_bytes(kernel: str, B: int, ph: int = 50, pw: int = 50, rows: int = 0, V: int = 32064, esize: int = 2, embed_width: int = 1024 + 1152) -> float:
     n = 3 * ph * pw
     if kernel == "K1":
         return B * (150528 + 602112) + 4 * n
@@ -28,7 +28,7 @@ def algo_bytes(kernel: str, B: int, ph: int = 50, pw: int = 50, rows: int = 0, V
     if kernel == "K2_fullframe":
         return B * 602112 + 4 * n
     if kernel == "K2e":  # ~36 kept tiles per image: their dY rows of both towers (bf16) + the two transposed weights once + gpatch
-        return B * 36 * (1024 + 1152) * 2 + 588 * (1024 + 1152) * 2 + 4 * n
+        return B * 36 * embed_width * 2 + 588 * embed_width * 2 + 4 * n
     if kernel == "K3":
         return 2.0 * rows * V * esize
     if kernel == "K3_slice":
@@ -129,8 +129,8 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
         fullframe_bytes=algo_bytes("K2_fullframe", B, ph, pw))
     dy0 = (torch.randn(B, 256, 1024, device=dev) * 0.1).to(torch.bfloat16)
     dy1 = (torch.randn(B, 256, 1152, device=dev) * 0.1).to(torch.bfloat16)
-    wt0 = (torch.randn(588, 1024, device=dev) * 0.05).to(torch.bfloat16)
-    wt1 = (torch.randn(588, 1152, device=dev) * 0.05).to(torch.bfloat16)
+    wt0 = ops.pack_embed_weights((torch.randn(588, 1024, device=dev) * 0.05).to(torch.bfloat16))
+    wt1 = ops.pack_embed_weights((torch.randn(588, 1152, device=dev) * 0.05).to(torch.bfloat16))
     rec("K2e_patch_embed_grad_gather", "K2e", lambda: ops.patch_embed_grad_gather(dy0, dy1, wt0, wt1, patch, xy, th, keep, True),
         algo_bytes("K2e", B, ph, pw), B=B, note="SURVEY 8f-3: patch-embed backward on the kept tiles (MFMA) + gather; replaces 2 dgrad GEMMs + fold + K2")
     rowmap = ops.LossRowMap(labels)

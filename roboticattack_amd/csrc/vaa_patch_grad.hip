@@ -647,7 +647,7 @@ typedef float v4f_e __attribute__((ext_vector_type(4)));
 
 struct EmbedArgs {
     const uint16_t *dy0, *dy1;  // [B,256,D0], [B,256,D1] bf16: dL/d(patch-embed output) of the two towers, tokens in tile order
-    const uint16_t *wt0, *wt1;  // [588,D0], [588,D1] bf16: conv weights [D,3,14,14] flattened and TRANSPOSED (K-contiguous)
+    const uint16_t *wt0, *wt1;  // conv weights of the two towers in the PACKED fragment order of embed_pack_weights_kernel
     const uint8_t* keep;        // [B,3,224*224/8] keep bits from K1
     float* geff;                // [B,256,588]
     int16_t* tile_slot;         // [B,256]
@@ -665,6 +665,29 @@ __device__ __forceinline__ v8s_e frag_or_zero(const uint16_t* p, bool valid) {
 
 __device__ __forceinline__ float maybe_bf16(float v, int on) { return on ? bf16_bits_to_f32(f32_to_bf16_bits(v)) : v; }
 
+// Packed weight layout (built once per model by vaa_patch_embed_pack_weights; the weights are frozen during an attack):
+//   packed[(((nb * nchunk + kc) * 2 + h) * 64 + lane) * 8 + e] = W^T[n = nb*16 + (lane & 15)][k = kc*64 + (lane >> 4)*16 + h*8 + e]   (0 for n >= 588)
+// nb = 16-column block (37 of them), kc = 64-wide k-chunk, h = k-half: exactly the B operand of one mfma_f32_16x16x32_bf16, so a wave's
+// fragment load is ONE contiguous KB (8 full lines). Reading the fragments straight from the [588,D] matrix made every load instruction
+// touch 16 lines at a 2 KB stride: the k-loops ran at ~20 B/clk per CU (12 + 14 us for the two towers against 4 + 4 us of MFMA/LDS time).
+__device__ __forceinline__ size_t packed_frag_offset(int nb, int nchunk, int kc, int h, int lane) {
+    return ((((size_t)nb * nchunk + kc) * 2 + h) * 64 + lane) * 8;
+}
+
+__global__ __launch_bounds__(256) void embed_pack_weights_kernel(const uint16_t* __restrict__ wt, int D, uint16_t* __restrict__ packed) {
+    const int nchunk = D >> 6;
+    const long nfrag = (long)kNBlocks * nchunk * 2 * 64;
+    for (long f = (long)blockIdx.x * 256 + threadIdx.x; f < nfrag; f += (long)gridDim.x * 256) {
+        const int lane = (int)(f & 63), h = (int)((f >> 6) & 1);
+        const long t = f >> 7;
+        const int kc = (int)(t % nchunk), nb = (int)(t / nchunk);
+        const int n = nb * 16 + (lane & 15), k = kc * 64 + (lane >> 4) * 16 + h * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n < kTileElems) v = *reinterpret_cast<const uint4*>(wt + (size_t)n * D + k);
+        *reinterpret_cast<uint4*>(packed + f * 8) = v;
+    }
+}
+
 // Does tile (ty, tx) hold a kept pixel in any channel? 3 planes x 14 rows x 14 bits, read as 126 INDEPENDENT byte loads that are all in
 // flight together (an early-exit loop makes them 42 dependent round trips: it was 35 of the kernel's 57 us).
 __device__ __forceinline__ bool tile_has_kept_pixel(const uint8_t* kb, int ty, int tx) {
@@ -674,10 +697,11 @@ __device__ __forceinline__ bool tile_has_kept_pixel(const uint8_t* kb, int ty, i
         const uint8_t* p = kb + (size_t)ch3 * (VAA_NPIX / 8);
 #pragma unroll
         for (int y = 0; y < kTilePx; ++y) {
-            const int bit0 = (ty * kTilePx + y) * VAA_IMG + tx * kTilePx;  // 14 consecutive bits
-            const int by = bit0 >> 3, by2 = min(by + 2, VAA_NPIX / 8 - 1);  // the third byte only matters when it exists
-            const uint32_t w = (uint32_t)p[by] | ((uint32_t)p[by + 1] << 8) | ((uint32_t)p[by2] << 16);
-            any |= (w >> (bit0 & 7)) & 0x3fffu;
+            const int bit0 = (ty * kTilePx + y) * VAA_IMG + tx * kTilePx;  // 14 consecutive bits: within one (unaligned) 32-bit word
+            const int by = min(bit0 >> 3, VAA_NPIX / 8 - 4);              // the last word of a plane is read 1..3 bytes early
+            uint32_t w;
+            __builtin_memcpy(&w, p + by, 4);
+            any |= (w >> (bit0 - 8 * by)) & 0x3fffu;
         }
     }
     return any != 0u;
@@ -715,9 +739,7 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedA
     const bool nv = n < kTileElems;
     const int c3 = nv ? n / (kTilePx * kTilePx) : 0;
     const float s0 = a.istd6[c3], s1 = a.istd6[c3 + 3];
-    const uint16_t* w0 = a.wt0 + (size_t)n * a.D0 + g * 8;
-    const uint16_t* w1 = a.wt1 + (size_t)n * a.D1 + g * 8;
-    // Up to four 16-tile row blocks share every weight fragment: per trip 2 B-fragments + 8 A-fragments are in flight, 8 MFMAs follow.
+    // Up to four 16-tile row blocks share every weight fragment: per 64-wide k-chunk 2 B-fragments + 8 A-fragments are in flight, 8 MFMAs follow.
     for (int mg = 0; mg * 64 < M; ++mg) {
         v4f_e acc0[4], acc1[4];
         const uint16_t *y0[4], *y1[4];
@@ -729,23 +751,22 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedA
             const int mr = mg * 64 + q * 16 + c;  // A-operand row of this lane in row block q
             mv[q] = mr < M;
             const int tile = mv[q] ? tiles[mr] : 0;
-            y0[q] = a.dy0 + ((size_t)b * 256 + tile) * a.D0 + g * 8;
-            y1[q] = a.dy1 + ((size_t)b * 256 + tile) * a.D1 + g * 8;
+            y0[q] = a.dy0 + ((size_t)b * 256 + tile) * a.D0 + g * 16;  // lane group g owns k = 16g .. 16g+15 of a chunk (see the packed layout)
+            y1[q] = a.dy1 + ((size_t)b * 256 + tile) * a.D1 + g * 16;
         }
         const int nq = min(4, (M - mg * 64 + 15) / 16);  // live row blocks (wave-uniform)
 #pragma unroll
         for (int tower = 0; tower < 2; ++tower) {
-            const int D = tower ? a.D1 : a.D0;
-            const uint16_t* wp = tower ? w1 : w0;
-            for (int ks = 0; ks * 32 < D; ks += 2) {
-                const bool more = (ks + 1) * 32 < D;
-                const v8s_e b0 = frag_or_zero(wp + ks * 32, nv), b1 = frag_or_zero(wp + (ks + 1) * 32, nv && more);
+            const int D = tower ? a.D1 : a.D0, nchunk = D >> 6;
+            const uint16_t* wp = (tower ? a.wt1 : a.wt0) + packed_frag_offset(nb, nchunk, 0, 0, lane);
+            for (int kc = 0; kc < nchunk; ++kc) {
+                const v8s_e b0 = *reinterpret_cast<const v8s_e*>(wp + (size_t)kc * 1024), b1 = *reinterpret_cast<const v8s_e*>(wp + (size_t)kc * 1024 + 512);
                 v8s_e a0[4], a1[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint16_t* yp = tower ? y1[q] : y0[q];
-                    a0[q] = frag_or_zero(yp + ks * 32, mv[q]);
-                    a1[q] = frag_or_zero(yp + (ks + 1) * 32, mv[q] && more);
+                    a0[q] = frag_or_zero(yp + kc * 64, mv[q]);
+                    a1[q] = frag_or_zero(yp + kc * 64 + 8, mv[q]);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -774,6 +795,80 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedA
     }
 }
 
+
+#ifndef VAA_EMBED_GROUP
+#define VAA_EMBED_GROUP 2
+#endif
+constexpr int kEmbedGroup = VAA_EMBED_GROUP;  // 64-wide k-chunks whose weight fragments a wave requests together (16 VGPRs each)
+
+// The barrier-free k-loop of the fast variant for NQ live 16-row blocks. K is walked in chunks of 64: lane group g owns k = 16g .. 16g+15
+// of a chunk, the first eight for one MFMA, the next eight for a second (any assignment of k to lanes is valid as long as A and B agree);
+// wp0 / wp1 point at this lane's slot of chunk 0 in the packed weights of the wave's two column blocks.
+//   * the weight fragments of kEmbedGroup chunks are requested together, UNCONDITIONALLY (the last groups re-request the final chunk), into two register sets in ping-pong, and consumed in order under counting waits. With
+//     predicated loads, or a ring refilled chunk by chunk, the compiler falls back to s_waitcnt vmcnt(0) in front of every chunk: one
+//     full L2 round trip per chunk, 13 us per tower.
+//   * the A fragments of chunk u+1 are read from LDS before the MFMAs of chunk u (one ds_read per row block and k-half, all issued
+//     together), so the LDS latency is covered by twelve MFMAs instead of being paid in front of every pair.
+//   * MFMA order: all row blocks against the first k-half, then the second: consecutive MFMAs never share an accumulator.
+template <int NQ>
+__device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const uint16_t* wp0, const uint16_t* wp1, int nchunk, v4f_e (&acc)[2][4]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
+    auto load_group = [&](v8s_e (&bf)[kEmbedGroup][2][2], int k0) {
+#pragma unroll
+        for (int u = 0; u < kEmbedGroup; ++u) {
+            const int kc = min(k0 + u, nchunk - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf[u][0][h] = *reinterpret_cast<const v8s_e*>(wp0 + (size_t)kc * 1024 + h * 512);
+                bf[u][1][h] = *reinterpret_cast<const v8s_e*>(wp1 + (size_t)kc * 1024 + h * 512);
+            }
+        }
+    };
+    auto compute_group = [&](const v8s_e (&bf)[kEmbedGroup][2][2], int k0) {
+        if (k0 >= nchunk) return;  // wave-uniform
+        v8s_e af[2][NQ][2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) af[0][q][h] = *reinterpret_cast<const v8s_e*>(ap + q * 16 * SA + k0 * 64 + h * 8);
+#pragma unroll
+        for (int u = 0; u < kEmbedGroup; ++u) {
+            const int kc = k0 + u;
+            if (kc < nchunk) {  // wave-uniform
+                if (u + 1 < kEmbedGroup) {
+                    const int kn = min(kc + 1, nchunk - 1);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) af[(u + 1) & 1][q][h] = *reinterpret_cast<const v8s_e*>(ap + q * 16 * SA + kn * 64 + h * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // the next chunk's LDS reads are issued before this chunk's MFMAs
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][q][h], bf[u][0][h], acc[0][q], 0, 0, 0);
+                        acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][q][h], bf[u][1][h], acc[1][q], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // two register sets in ping-pong: the requests of the next group are in flight while this group's MFMAs run
+    v8s_e bfa[kEmbedGroup][2][2], bfb[kEmbedGroup][2][2];
+    load_group(bfa, 0);
+    for (int k0 = 0; k0 < nchunk; k0 += 2 * kEmbedGroup) {
+        load_group(bfb, k0 + kEmbedGroup);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_group(bfa, k0);
+        load_group(bfa, k0 + 2 * kEmbedGroup);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_group(bfb, k0 + kEmbedGroup);
+    }
+}
 
 // Fast variant for tower widths that fit the LDS (64 x (D+8) bf16 <= 150 KB, i.e. D <= 1160): the gathered dY rows of one tower are
 // staged ONCE per workgroup (all loads in flight together, one barrier), then every wave runs a barrier-free k-loop — A fragments from
@@ -837,7 +932,10 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                 uint4 st[kEmbedStageMax / 2];
 #pragma unroll
                 for (int it = 0; it < kEmbedStageMax / 2; ++it) {
-                    const int idx = tid + (hf * (kEmbedStageMax / 2) + it) * kEmbedFastThreads;
+                    int idx = tid + (hf * (kEmbedStageMax / 2) + it) * kEmbedFastThreads;
+                    // opaque to the optimiser: otherwise the row / column split of all 2 x 18 staging slots is hoisted out of the row-group
+                    // loop, stays live across both k-loops and spills (every staging load then sat between two scratch accesses)
+                    asm volatile("" : "+v"(idx));
                     st[it] = make_uint4(0, 0, 0, 0);
                     if (idx < nchunks) {
                         const int row = idx / cpr, cc = idx - row * cpr, r = mg * 64 + row;
@@ -846,7 +944,8 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                 }
 #pragma unroll
                 for (int it = 0; it < kEmbedStageMax / 2; ++it) {
-                    const int idx = tid + (hf * (kEmbedStageMax / 2) + it) * kEmbedFastThreads;
+                    int idx = tid + (hf * (kEmbedStageMax / 2) + it) * kEmbedFastThreads;
+                    asm volatile("" : "+v"(idx));
                     if (idx < nchunks) {
                         const int row = idx / cpr, cc = idx - row * cpr;
                         *reinterpret_cast<uint4*>(&sA[row * SA + cc * 8]) = st[it];
@@ -857,46 +956,16 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
             K2_STAMP(1 + 2 * tower)
             // ---- barrier-free k-loop ----
             const uint16_t* wt = tower ? a.wt1 : a.wt0;
-            const uint16_t* wp0 = wt + (size_t)n[0] * D + g * 8;
-            const uint16_t* wp1 = wt + (size_t)n[1] * D + g * 8;
+            // column blocks beyond the 37th (the last workgroup's spare waves) read block 36: loads stay unconditional, results are never stored
+            const uint16_t* wp0 = wt + packed_frag_offset(min(ch * kEmbedFastCols + wv * 2, kNBlocks - 1), D >> 6, 0, 0, lane);
+            const uint16_t* wp1 = wt + packed_frag_offset(min(ch * kEmbedFastCols + wv * 2 + 1, kNBlocks - 1), D >> 6, 0, 0, lane);
             v4f_e acc[2][4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[j][q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
-            const int ksteps = D >> 5;
-            // software pipeline: the weight fragments of trip t+1 (two k-steps, both column blocks) are requested before trip t's
-            // LDS reads and MFMAs, so the global/L2 latency of the B operand is off the critical path
-            v8s_e bn[2][2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                bn[0][u] = frag_or_zero(wp0 + u * 32, nv[0] && u < ksteps);
-                bn[1][u] = frag_or_zero(wp1 + u * 32, nv[1] && u < ksteps);
-            }
-            for (int ks = 0; ks < ksteps; ks += 2) {
-                v8s_e bc[2][2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    bc[0][u] = bn[0][u];
-                    bc[1][u] = bn[1][u];
-                    const bool kv = ks + 2 + u < ksteps;
-                    bn[0][u] = frag_or_zero(wp0 + (ks + 2 + u) * 32, nv[0] && kv);
-                    bn[1][u] = frag_or_zero(wp1 + (ks + 2 + u) * 32, nv[1] && kv);
-                }
-                const bool k1 = ks + 1 < ksteps;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q >= nq) continue;
-                    const uint16_t* ap = &sA[(q * 16 + c) * SA + ks * 32 + g * 8];
-                    const v8s_e a0 = *reinterpret_cast<const v8s_e*>(ap);
-                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bc[0][0], acc[0][q], 0, 0, 0);
-                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bc[1][0], acc[1][q], 0, 0, 0);
-                    if (k1) {
-                        const v8s_e a1 = *reinterpret_cast<const v8s_e*>(ap + 32);
-                        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bc[0][1], acc[0][q], 0, 0, 0);
-                        acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bc[1][1], acc[1][q], 0, 0, 0);
-                    }
-                }
+            const uint16_t* ap = &sA[c * SA + g * 16];
+            switch (nq) {
+                case 1: embed_kloop<1>(ap, SA, wp0, wp1, D >> 6, acc); break;
+                case 2: embed_kloop<2>(ap, SA, wp0, wp1, D >> 6, acc); break;
+                case 3: embed_kloop<3>(ap, SA, wp0, wp1, D >> 6, acc); break;
+                default: embed_kloop<4>(ap, SA, wp0, wp1, D >> 6, acc); break;
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -930,6 +999,26 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
 
 }  // namespace vaa
 
+extern "C" size_t vaa_patch_embed_packed_elems(int D) {
+    if (D <= 0 || (D % 64) != 0) return 0;
+    return (size_t)vaa::kNBlocks * 16 * (size_t)D;  // 592 columns (588 + 4 of zero padding) x D
+}
+
+extern "C" int vaa_patch_embed_pack_weights(const uint16_t* wt, int D, uint16_t* packed, void* stream) {
+    using namespace vaa;
+    if (!wt || !packed) {
+        set_error("vaa_patch_embed_pack_weights: null pointer argument");
+        return VAA_E_INVALID;
+    }
+    if (D <= 0 || (D % 64) != 0) {
+        set_error("vaa_patch_embed_pack_weights: tower width %d is not a positive multiple of 64", D);
+        return VAA_E_INVALID;
+    }
+    const long nfrag = (long)kNBlocks * (D >> 6) * 2 * 64;
+    hipLaunchKernelGGL(embed_pack_weights_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt, D, packed);
+    return check_launch("vaa_patch_embed_pack_weights");
+}
+
 extern "C" size_t vaa_patch_embed_grad_ws_bytes(int B, int ph, int pw) {
     if (B <= 0 || ph <= 0 || pw <= 0) return 0;
     return vaa_patch_grad_ws_bytes(B, ph, pw) + (size_t)B * 256 * vaa::kTileElems * sizeof(float) + (size_t)B * 256 * sizeof(int16_t) + 256;
@@ -949,9 +1038,9 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
         set_error("vaa_patch_embed_grad_gather: null pointer argument (the keep bits of K1 are required)");
         return VAA_E_INVALID;
     }
-    if (B < 0 || ph <= 0 || pw <= 0 || D0 <= 0 || D1 <= 0 || (D0 % 32) != 0 || (D1 % 32) != 0 ||
+    if (B < 0 || ph <= 0 || pw <= 0 || D0 <= 0 || D1 <= 0 || (D0 % 64) != 0 || (D1 % 64) != 0 ||
         (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100)) {
-        set_error("vaa_patch_embed_grad_gather: bad sizes/mode (B=%d ph=%d pw=%d D0=%d D1=%d; D %% 32 == 0)", B, ph, pw, D0, D1);
+        set_error("vaa_patch_embed_grad_gather: bad sizes/mode (B=%d ph=%d pw=%d D0=%d D1=%d; D %% 64 == 0)", B, ph, pw, D0, D1);
         return VAA_E_INVALID;
     }
     if (ph > VAA_IMG || pw > VAA_IMG) {

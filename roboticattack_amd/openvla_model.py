@@ -65,8 +65,8 @@ def openvla_7b_cfg() -> OpenVLACfg:
 def tiny_cfg() -> OpenVLACfg:
     """Same topology, toy widths: CPU-runnable plumbing tests."""
     return OpenVLACfg(
-        dino=VitCfg(32, 3, 2, 64, 5, False, True),
-        siglip=VitCfg(48, 3, 2, 80, 0, False, False),
+        dino=VitCfg(64, 3, 2, 128, 5, False, True),
+        siglip=VitCfg(128, 3, 2, 256, 0, False, False),  # tower widths are multiples of 64 so that the fused patch-embed backward applies on a GPU
         llm_dim=64, llm_layers=2, llm_heads=4, llm_mlp=128,
     )
 
@@ -124,12 +124,16 @@ class Vit(nn.Module):
         self.blocks = nn.ModuleList([VitBlock(c) for _ in range(c.depth - 1)])  # the last block is never evaluated
 
     def embed_params(self):
-        """(W [D,588], bias [D], W^T [588,D] contiguous, cached) of the patch-embed GEMM — what ops.PatchApplyEmbed needs."""
+        """(W [D,588], bias [D], packed W^T, cached) of the patch-embed GEMM — what ops.PatchApplyEmbed needs. The packed weights are
+        ops.pack_embed_weights(W^T [588,D]): K2''s MFMA fragment order, rebuilt only when the parameter changes."""
+        from . import ops
         w = self.patch_embed.weight
-        hit = getattr(self, "_embed_wt", None)
+        if not (w.is_cuda and w.dtype == torch.bfloat16 and self.c.dim % 64 == 0):  # no fused backward for this tower: nothing to pack
+            return w.detach().reshape(self.c.dim, 588), self.patch_embed.bias.detach(), None
+        hit = getattr(self, "_embed_wp", None)
         if hit is None or hit[0] != w._version or hit[1] is not w:
-            hit = (w._version, w, w.detach().reshape(self.c.dim, 588).t().contiguous())
-            self._embed_wt = hit
+            hit = (w._version, w, ops.pack_embed_weights(w.detach().reshape(self.c.dim, 588).t().contiguous()))
+            self._embed_wp = hit
         return w.detach().reshape(self.c.dim, 588), self.patch_embed.bias.detach(), hit[2]
 
     def forward(self, img, embedded=None):
@@ -346,10 +350,10 @@ class OpenVLAShaped(nn.Module):
         return self
 
     def patch_embed_params(self):
-        """(w0, b0, wt0, w1, b1, wt1) for ops.PatchApplyEmbed, or None when the fused patch-embed backward does not apply
-        (tower widths must be multiples of 32, bf16 on a ROCm device)."""
+        """(w0, b0, wp0, w1, b1, wp1) for ops.PatchApplyEmbed, or None when the fused patch-embed backward does not apply
+        (tower widths must be multiples of 64, bf16 on a ROCm device)."""
         w = self.featurizer.patch_embed.weight
-        if not w.is_cuda or w.dtype != torch.bfloat16 or self.cfg.dino.dim % 32 or self.cfg.siglip.dim % 32:
+        if not w.is_cuda or w.dtype != torch.bfloat16 or self.cfg.dino.dim % 64 or self.cfg.siglip.dim % 64:
             return None
         return (*self.featurizer.embed_params(), *self.fused_featurizer.embed_params())
 

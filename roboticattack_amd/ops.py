@@ -133,17 +133,31 @@ def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, ma
     return gpatch
 
 
-def patch_embed_grad_gather(dy0, dy1, wt0, wt1, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None,
+def pack_embed_weights(wt):
+    """Conv weights of one tower, flattened and transposed to wt [588,D] bf16, re-ordered into the MFMA fragment order K2' reads
+    (vaa_patch_embed_pack_weights; once per model — the weights are frozen during an attack). Returns bf16 [592*D]."""
+    D = int(wt.shape[1])
+    _need(wt, torch.bfloat16, "wt", (588, D))
+    L = _lib.lib()
+    n = L.vaa_patch_embed_packed_elems(D)
+    if n == 0:
+        raise ValueError(f"pack_embed_weights: tower width {D} is not a multiple of 64")
+    packed = torch.empty(n, dtype=torch.bfloat16, device=wt.device)
+    _lib.check(L.vaa_patch_embed_pack_weights(wt.data_ptr(), D, packed.data_ptr(), _stream()), "vaa_patch_embed_pack_weights")
+    return packed
+
+
+def patch_embed_grad_gather(dy0, dy1, wp0, wp1, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None,
                             round_bf16: bool = True):
     """K2' (SURVEY.md 8f-3): dL/d patch from the gradients of the two ViT patch-embed OUTPUTS. dy0 [B,256,D0], dy1 [B,256,D1] bf16
-    (tokens in tile order), wt0 [588,D0], wt1 [588,D1] bf16 (conv weights flattened and transposed). Only tiles with kept pixels are
+    (tokens in tile order), wp0 / wp1 = pack_embed_weights(W^T [588,D]) of the two towers. Only tiles with kept pixels are
     evaluated (MFMA); the pixel gradient is never materialised."""
     B = dy0.shape[0]
     D0, D1 = int(dy0.shape[2]), int(dy1.shape[2])
     _need(dy0, torch.bfloat16, "dy0", (B, 256, D0))
     _need(dy1, torch.bfloat16, "dy1", (B, 256, D1))
-    _need(wt0, torch.bfloat16, "wt0", (588, D0))
-    _need(wt1, torch.bfloat16, "wt1", (588, D1))
+    _need(wp0, torch.bfloat16, "wp0", (592 * D0,))
+    _need(wp1, torch.bfloat16, "wp1", (592 * D1,))
     _need(patch, torch.float32, "patch")
     _need(xy, torch.int32, "xy", (B, 2))
     if geometry:
@@ -155,7 +169,7 @@ def patch_embed_grad_gather(dy0, dy1, wt0, wt1, patch, xy, theta, keep_bits, geo
     gpatch = torch.empty_like(patch)
     std_c = _STD if std6 is None else _lib.f32x(std6)
     with _timed("K2_patch_embed_grad_gather", B=B, ph=ph, pw=pw):
-        rc = L.vaa_patch_embed_grad_gather(dy0.data_ptr(), D0, dy1.data_ptr(), D1, wt0.data_ptr(), wt1.data_ptr(), patch.data_ptr(), xy.data_ptr(),
+        rc = L.vaa_patch_embed_grad_gather(dy0.data_ptr(), D0, dy1.data_ptr(), D1, wp0.data_ptr(), wp1.data_ptr(), patch.data_ptr(), xy.data_ptr(),
                                            theta.data_ptr() if geometry else None, keep_bits.data_ptr(), B, ph, pw, int(bool(geometry)),
                                            int(mask_mode), std_c, int(bool(round_bf16)), gpatch.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "vaa_patch_embed_grad_gather")
@@ -309,22 +323,22 @@ def unfold_tiles(x3: torch.Tensor) -> torch.Tensor:
 
 class PatchApplyEmbed(torch.autograd.Function):
     """K1 + both patch-embed GEMMs forward; backward = K2' (SURVEY.md 8f-3): the gradients of the patch-embed OUTPUTS go straight to
-    `patch_embed_grad_gather`, which evaluates the patch-embed backward only for the tiles under the patch. w: [D,588], wt: [588,D]."""
+    `patch_embed_grad_gather`, which evaluates the patch-embed backward only for the tiles under the patch. w: [D,588], wp: pack_embed_weights(w^T)."""
 
     @staticmethod
-    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode, mean6, std6, w0, b0, wt0, w1, b1, wt1):
+    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode, mean6, std6, w0, b0, wp0, w1, b1, wp1):
         p = patch.detach().contiguous()
         out, keep = patch_apply_fwd(img_u8, p, xy, theta, geometry, mask_mode, want_keep=True, mean6=mean6, std6=std6)
         e0 = torch.nn.functional.linear(unfold_tiles(out[:, :3]), w0, b0)
         e1 = torch.nn.functional.linear(unfold_tiles(out[:, 3:]), w1, b1)
-        ctx.save_for_backward(p, xy, theta if geometry else xy, keep, wt0, wt1)
+        ctx.save_for_backward(p, xy, theta if geometry else xy, keep, wp0, wp1)
         ctx.geometry, ctx.mask_mode, ctx.std6 = bool(geometry), int(mask_mode), std6
         return e0, e1
 
     @staticmethod
     def backward(ctx, d0, d1):
-        patch, xy, theta, keep, wt0, wt1 = ctx.saved_tensors
-        g = patch_embed_grad_gather(d0.to(torch.bfloat16).contiguous(), d1.to(torch.bfloat16).contiguous(), wt0, wt1, patch, xy,
+        patch, xy, theta, keep, wp0, wp1 = ctx.saved_tensors
+        g = patch_embed_grad_gather(d0.to(torch.bfloat16).contiguous(), d1.to(torch.bfloat16).contiguous(), wp0, wp1, patch, xy,
                                     theta if ctx.geometry else None, keep, ctx.geometry, ctx.mask_mode, std6=ctx.std6)
         return (g,) + (None,) * 13
 

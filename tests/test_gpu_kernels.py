@@ -883,7 +883,8 @@ def test_baseline_config_shapes_one_step_vs_oracle(ops, name, B, ph, pw, geo, ma
     assert np.abs(p.cpu().numpy().ravel() - pc).max() <= 1e-4  # north-star tolerance on the updated pixels
 
 
-@pytest.mark.parametrize("B,ph,pw,geo,D0,D1", [(6, 50, 50, 1, 64, 96), (3, 22, 31, 0, 32, 64), (4, 100, 100, 1, 128, 64), (64, 50, 50, 1, 1024, 1152)])
+@pytest.mark.parametrize("B,ph,pw,geo,D0,D1", [(6, 50, 50, 1, 64, 192), (3, 22, 31, 0, 64, 64), (4, 100, 100, 1, 128, 64), (64, 50, 50, 1, 1024, 1152),
+                                                (2, 50, 50, 1, 1216, 64)])  # the last one: a tower too wide for the LDS-resident variant
 def test_patch_embed_grad_gather_vs_unfused(ops, B, ph, pw, geo, D0, D1):
     """K2' (8f-3): patch-embed backward restricted to the kept tiles + gather == K2 on the dense pixel gradient dY @ W (folded back to
     pixel layout and rounded to bf16 like the model's own backward hands it over)."""
@@ -906,10 +907,10 @@ def test_patch_embed_grad_gather_vs_unfused(ops, B, ph, pw, geo, D0, D1):
 
     gout = torch.cat([fold(dy0, w0), fold(dy1, w1)], dim=1).contiguous()
     ref = ops.patch_grad_gather(gout, patch, xy, th if geo else None, keep, bool(geo))
-    got = ops.patch_embed_grad_gather(dy0, dy1, w0.t().contiguous(), w1.t().contiguous(), patch, xy, th if geo else None, keep, bool(geo))
+    got = ops.patch_embed_grad_gather(dy0, dy1, ops.pack_embed_weights(w0.t().contiguous()), ops.pack_embed_weights(w1.t().contiguous()), patch, xy, th if geo else None, keep, bool(geo))
     # same bf16 rounding point; the only difference is the fp32 summation order inside the two GEMMs (rare 1-ulp bf16 flips)
     assert (got - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-7
-    exact = ops.patch_embed_grad_gather(dy0, dy1, w0.t().contiguous(), w1.t().contiguous(), patch, xy, th if geo else None, keep, bool(geo),
+    exact = ops.patch_embed_grad_gather(dy0, dy1, ops.pack_embed_weights(w0.t().contiguous()), ops.pack_embed_weights(w1.t().contiguous()), patch, xy, th if geo else None, keep, bool(geo),
                                         round_bf16=False)
     assert (exact - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-7
     # ORACLE leg (no HIP code on this side): the patch-embed backward as an fp32 matmul on the host, folded to pixel layout, rounded to

@@ -207,9 +207,9 @@ def test_hf_checkpoint_name_mapping_roundtrip(tmp_path):
     assert torch.equal(src(ids, attn, pix, labels).logits, dst(ids, attn, pix, labels).logits)
     # the shapes a real openvla-7b checkpoint holds for the DINOv2-reg4 tower (timm no_embed_class): pos_embed over the 256 patch tokens
     # only, a 1-token cls_token and a 4-token reg_token; SigLIP: pos_embed 256, no prefix tokens
-    assert tuple(hf["vision_backbone.featurizer.pos_embed"].shape) == (1, 256, 32)
-    assert tuple(hf["vision_backbone.featurizer.cls_token"].shape) == (1, 1, 32) and tuple(hf["vision_backbone.featurizer.reg_token"].shape) == (1, 4, 32)
-    assert tuple(hf["vision_backbone.fused_featurizer.pos_embed"].shape) == (1, 256, 48)
+    assert tuple(hf["vision_backbone.featurizer.pos_embed"].shape) == (1, 256, 64)
+    assert tuple(hf["vision_backbone.featurizer.cls_token"].shape) == (1, 1, 64) and tuple(hf["vision_backbone.featurizer.reg_token"].shape) == (1, 4, 64)
+    assert tuple(hf["vision_backbone.fused_featurizer.pos_embed"].shape) == (1, 256, 128)
     from roboticattack_amd.openvla_model import openvla_7b_cfg
 
     c7 = openvla_7b_cfg()
@@ -282,4 +282,4 @@ def test_vit_accepts_precomputed_patch_embeds():
     w1, b1, _ = m.fused_featurizer.embed_params()
     e = (torch.nn.functional.linear(ops.unfold_tiles(pix[:, :3]), w0, b0), torch.nn.functional.linear(ops.unfold_tiles(pix[:, 3:]), w1, b1))
     assert torch.allclose(m.forward_rows(ids, pix, labels), m.forward_rows(ids, None, labels, patch_embeds=e), atol=1e-5)
-    assert m.patch_embed_params() is None  # CPU / fp32 / widths not multiples of 32: the fused backward does not apply
+    assert m.patch_embed_params() is None  # CPU / fp32 / widths not multiples of 64: the fused backward does not apply

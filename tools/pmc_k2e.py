@@ -15,8 +15,8 @@ def run():
     _, keep = ops.patch_apply_fwd(img, patch, xy, th, True, want_keep=True)
     dy0 = (torch.randn(B, 256, D0, device=dev) * 0.1).to(torch.bfloat16)
     dy1 = (torch.randn(B, 256, D1, device=dev) * 0.1).to(torch.bfloat16)
-    wt0 = (torch.randn(588, D0, device=dev) * 0.05).to(torch.bfloat16)
-    wt1 = (torch.randn(588, D1, device=dev) * 0.05).to(torch.bfloat16)
+    wt0 = ops.pack_embed_weights((torch.randn(588, D0, device=dev) * 0.05).to(torch.bfloat16))
+    wt1 = ops.pack_embed_weights((torch.randn(588, D1, device=dev) * 0.05).to(torch.bfloat16))
     for _ in range(6):
         ops.patch_embed_grad_gather(dy0, dy1, wt0, wt1, patch, xy, th, keep, True)
     torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
-os.environ["VAA_LIB_PATH"] = os.path.join(os.getcwd(), "tools/scratch/libvaa_K2TIMING.so")  # tools/scratch/build_variant.sh K2TIMING -DVAA_K2_TIMING
+os.environ["VAA_LIB_PATH"] = os.path.join(os.getcwd(), "tools/scratch/libvaa_K2TIMING_A2.so")  # tools/scratch/build_variant.sh K2TIMING -DVAA_K2_TIMING
 import numpy as np, torch
 from roboticattack_amd import benchmarks, ops, synthetic, _lib
 L = _lib.lib()
@@ -14,8 +14,8 @@ xy, th = torch.from_numpy(xy_n).to(dev), torch.from_numpy(th_n).to(dev)
 _, keep = ops.patch_apply_fwd(img, patch, xy, th, True, want_keep=True)
 dy0 = (torch.randn(B, 256, D0, device=dev) * 0.1).to(torch.bfloat16)
 dy1 = (torch.randn(B, 256, D1, device=dev) * 0.1).to(torch.bfloat16)
-wt0 = ops.pack_embed_weights((torch.randn(588, D0, device=dev) * 0.05).to(torch.bfloat16))
-wt1 = ops.pack_embed_weights((torch.randn(588, D1, device=dev) * 0.05).to(torch.bfloat16))
+wt0 = (torch.randn(588, D0, device=dev) * 0.05).to(torch.bfloat16)
+wt1 = (torch.randn(588, D1, device=dev) * 0.05).to(torch.bfloat16)
 nwg = 64 * 3
 dbg = torch.zeros(nwg * 16 * 6, dtype=torch.int64, device=dev)
 assert L.vaa_k2_set_debug(dbg.data_ptr()) == 0
