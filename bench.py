@@ -6,11 +6,12 @@
 
 One step = one inner-loop iteration of UADA_wrapper_ddp (UADA_ddp.py:189-209):
     host RNG draws -> K1 paste/warp (HIP) -> OpenVLA-7B-shaped bf16 forward + activation backward (PyTorch-ROCm)
-    -> K3 loss fwd+bwd on the labelled rows (HIP) -> K2 patch-grad gather (HIP) -> [RCCL all-reduce, 30 KB] -> K4 AdamW+clamp (HIP)
+    -> K3 loss fwd+bwd on the labelled rows (HIP) -> K2' patch-embed backward on the tiles under the patch (MFMA) + patch-grad gather
+    (HIP; plain K2 on the pixel gradient with VAA_FUSED_EMBED_GRAD=0) -> [RCCL all-reduce, 30 KB] -> K4 AdamW+clamp (HIP)
 Workload: bs=64 PER RANK (reference semantics, UADA_ddp.py:158 -> weak scaling), 3x50x50 patch, geometry=True, maskidx=[0],
 synthetic BridgeData-shaped frames resident in HBM as u8, random-init weights of the OpenVLA-7B architecture.
 Prints ONE JSON line on rank 0. `roofline` is the dominant hand-written kernel of the path — K1's `patch_apply_fwd_kernel`, which
-moves 73 % of the path's algorithmic bytes and is the longest launch of the default path (K1-K4) in profiles/r02_kbench_kernel_stats.csv —
+moves 70 % of the path's algorithmic bytes (48.2 of 69 MB) —
 timed inside the timed region (HIP events on the launch stream); `roofline_kernels`/`k2_sweep` carry every op and the K2 batch sweep; `cpu_baseline` is the reference's
 PyTorch-CPU op sequence for the same replaced ops (oracle/ref_port.py) timed on this box's host cores.
 """
@@ -313,8 +314,8 @@ def main():
         roofline = {"timing": "one start/stop HIP event pair per launch on the launching stream inside the timed region", "kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": tfile + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",
                     "mean_us": kern[dom]["mean_us"], "algo_bytes": kern[dom]["algo_bytes"],
-                    "note": "dominant = the kernel of the default hot path (K1-K4) with the most algorithmic bytes, also its longest single launch in the rocprofv3 kernel stats "
-                            "(the opt-in K2' tile GEMM of SURVEY 8f-3 is listed under roofline_kernels_standalone as K2e); "
+                    "note": "dominant = the kernel of the hot path (K1-K4) with the most algorithmic bytes "
+                            "(K2' of SURVEY 8f-3 — MFMA tile GEMM + gather — is listed under roofline_kernels / roofline_kernels_standalone as K2e); "
                             "frac_of_measured_copy_bw = achieved / this box's device-to-device copy rate measured in this run"}
 
     extra = {"host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "host_cpu_ms_per_step": host_cpu / args.steps * 1e3,

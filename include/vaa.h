@@ -174,7 +174,7 @@ int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int
                           size_t ws_bytes, void* stream);
 
 /*
- * K2' (optional) — K2 fed by the gradient of the ViT patch-embed OUTPUTS instead of the pixel gradient: the
+ * K2' (for callers that own the model's patch-embed weights) — K2 fed by the gradient of the ViT patch-embed OUTPUTS instead of the pixel gradient: the
  * patch-embed backward (modeling_prismatic.py:120-123 -> timm PatchEmbed, Conv2d(3, D, 14, stride 14) == a GEMM over 588-pixel
  * tiles) is evaluated by MFMA only for the 14x14 tiles that carry kept patch pixels and consumed in place by the gather.
  *   dy0, dy1  dev bf16 [B,256,D0], [B,256,D1]: dL/d(patch-embed output) of the DINOv2 and SigLIP towers, tokens in tile order

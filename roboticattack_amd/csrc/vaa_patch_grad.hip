@@ -22,8 +22,10 @@
 //     exact to 2^-30 of the largest gradient: against the fp64-accumulated sum of the same products the output differs by its own
 //     final fp32 rounding only (7e-8), the reference's fp32 scan-order accumulation by 3e-7 (tools/scratch/k2prec.py).
 //   * workgroups are persistent over images and keep accumulating into the same tile (the tile is in patch coordinates),
-//     then write ONE fp32 partial; a second small kernel adds the partials in fixed order. No global atomics.
-//   * patches whose int64 plane exceeds the LDS are cut into row bands (grid.z), so every size up to 224x224 is covered.
+//     then write their rows of ONE fp32 partial per workgroup-row; a second small kernel adds the partials in fixed order. No global atomics.
+//   * ROW BANDS (grid.z): a workgroup owns a band of PATCH rows — it bounds and walks only the part of each footprint whose source points
+//     fall on its rows, keeps and drains only those rows. Small batches are spread over the chip this way without extra partial tiles,
+//     and patches whose int64 plane exceeds the LDS are covered up to 224x224.
 //   * border padding: out-of-frame source points clamp onto frame-edge canvas pixels; when the patch touches the frame edge
 //     the row bounds are opened to infinity on that side, everything else is unchanged.
 //   * MULTI (resize_patch=True, config 5): one patch PER IMAGE (pdesc), the output is every image's own gradient.
