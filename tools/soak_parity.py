@@ -7,6 +7,7 @@ Every case draws a patch size (1..224 per side), a batch, placements biased towa
 rotation+shear transforms or a general affine (scale 0.3..3, any rotation, translation), then checks
   K1  : whole bf16 tensor and keep bits BIT-EXACT (uniform patch and per-image patches),
   K2  : <= 3e-6 of the gradient scale with the stored mask and with the recomputed mask, bitwise repeatable,
+  K2' : <= 5e-3 (one bf16 ulp: rounding flips of the tile gradients) against the oracle fed by an fp32 host matmul, random tower widths,
   K0  : resize forward bit-exact, adjoint <= 2e-6,
   K5  : eval-time paste byte-exact.
 Prints one line per failure (with the seed that reproduces it) and a summary; exit code 1 on any failure.
@@ -101,6 +102,23 @@ def one_case(seed):
         fails.append(f"K2       {tag}: rel err {np.abs(g1.cpu().numpy() - og).max() / sc:.3e}")
     if not torch.equal(g1, g2) or not torch.equal(g1, ops.patch_grad_gather(*args, keep, bool(geo), mm)):
         fails.append(f"K2 repeat/mask {tag}")
+    # ---- K2': patch-embed backward on the tiles under the patch + gather, against the oracle fed by an fp32 host matmul ----
+    if mm == 0 and rs.rand() < 0.3:
+        D0, D1 = int(rs.choice([64, 128, 192, 320])), int(rs.choice([64, 128, 256]))
+        if rs.rand() < 0.1:
+            D0 = 1216  # too wide for the LDS-resident variant
+        gen = torch.Generator(device=DEV).manual_seed(seed % 100003)
+        dy = [(torch.randn(B, 256, D, device=DEV, generator=gen) * float(10 ** rs.uniform(-4, 1))).to(torch.bfloat16) for D in (D0, D1)]
+        w = [(torch.randn(D, 588, device=DEV, generator=gen) * 0.05).to(torch.bfloat16) for D in (D0, D1)]
+        fused = ops.patch_embed_grad_gather(dy[0], dy[1], ops.pack_embed_weights(w[0].t().contiguous()), ops.pack_embed_weights(w[1].t().contiguous()),
+                                            t(patch), t(xy, torch.int32), t(theta.reshape(-1, 6)), keep, bool(geo)).cpu().numpy()
+        fold = lambda d, ww: (d.float().cpu() @ ww.float().cpu()).to(torch.bfloat16).view(B, 16, 16, 3, 14, 14).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 224, 224)
+        gcat = torch.cat([fold(dy[0], w[0]), fold(dy[1], w[1])], dim=1).contiguous()
+        oge = c_oracle.patch_grad(bits(gcat), patch, xy, theta, geo, 0, f64=general)
+        # one bf16 ulp (2^-8) of a tile-gradient element flips where the two GEMMs' fp32 sums straddle a rounding boundary; with a single
+        # image a texel can be one pixel's contribution, so the bound is an ulp of the largest gradient, not the 2e-3 of the batched tests
+        if not (np.abs(fused - oge).max() <= 5e-3 * max(np.abs(oge).max(), 1e-30) + 1e-30):
+            fails.append(f"K2'      {tag} D={D0}+{D1}: rel err {np.abs(fused - oge).max() / max(np.abs(oge).max(), 1e-30):.3e}")
     # ---- per-image patches + resize (config 5 path), mask rule lt-20 ----
     if rs.rand() < 0.5:
         bh, bw = int(rs.randint(2, 120)), int(rs.randint(2, 120))
