@@ -876,9 +876,12 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
 // staged ONCE per workgroup (all loads in flight together, one barrier), then every wave runs a barrier-free k-loop — A fragments from
 // LDS (16 B reads, each feeding two MFMAs: a wave owns two column blocks), B fragments (weights) from global, four k-steps ahead.
 // 8 waves x 2 column blocks = 16 column blocks per workgroup, 3 workgroups per image, all on the image's XCD.
-constexpr int kEmbedFastThreads = 512;
-constexpr int kEmbedFastCols = 16;   // column blocks per workgroup
-constexpr int kEmbedStageMax = 18;   // 16-byte chunks a thread stages per tower: 64 rows x 1152/8 chunks / 512 threads
+#ifndef VAA_EMBED_WAVES
+#define VAA_EMBED_WAVES 8
+#endif
+constexpr int kEmbedFastThreads = VAA_EMBED_WAVES * 64;
+constexpr int kEmbedFastCols = VAA_EMBED_WAVES * 2;   // column blocks per workgroup (two per wave)
+constexpr int kEmbedStageMax = ((64 * 1160 / 8 + kEmbedFastThreads - 1) / kEmbedFastThreads + 1) / 2 * 2;  // 16-byte chunks a thread stages per tower (even)
 
 __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kernel(EmbedArgs a, int nch) {
     extern __shared__ __align__(16) unsigned char embed_smem[];
@@ -1068,7 +1071,7 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     const int Dmax = D0 > D1 ? D0 : D1;
     const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
     if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
-        const int nch = (kNBlocks + kEmbedFastCols - 1) / kEmbedFastCols;  // 3 workgroups per image
+        const int nch = (kNBlocks + kEmbedFastCols - 1) / kEmbedFastCols;  // workgroups per image
         if (hipFuncSetAttribute((const void*)embed_dgrad_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast) != hipSuccess) {
             set_error("vaa_patch_embed_grad_gather: hipFuncSetAttribute failed");
             return VAA_E_LAUNCH;
