@@ -45,9 +45,8 @@ struct GradArgs {
     int band_rows;           // patch rows per row band (== ph when the whole plane fits the LDS)
     float istd6[6];          // 1/std, rounded from double on the host
     // TILED source (vaa_patch_embed_grad_gather): instead of the 6-plane bf16 pixel gradient `g`, the already combined and
-    // scaled gradient of the tiles that carry kept pixels: geff[b][slot][c*196 + y*14 + x], slot = tile_slot[b][ty*16 + tx]
+    // scaled gradient of the tiles that carry kept pixels: geff[b][ty*16 + tx][c*196 + y*14 + x] (tiles without a kept pixel are not written)
     const float* geff;
-    const int16_t* tile_slot;
 };
 
 constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTilePx;  // ViT patch-embed tiling of the 224x224 frame
@@ -291,9 +290,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             f |= fp << (8 * p);
                             if (TILED && inside) {
                                 const int ty = i / kTilePx, tx = j / kTilePx;
-                                const int slot = a.tile_slot[b * (kTilesPerSide * kTilesPerSide) + ty * kTilesPerSide + tx];
-                                // slot < 0 only for pixels without any kept channel (their tile was not evaluated): read slot 0, never used
-                                const float* gtile = a.geff + ((size_t)b * (kTilesPerSide * kTilesPerSide) + (slot < 0 ? 0 : slot)) * kTileElems +
+                                // a pixel without any kept channel may lie in a tile that was not evaluated: its value is read but never used
+                                const float* gtile = a.geff + ((size_t)b * (kTilesPerSide * kTilesPerSide) + ty * kTilesPerSide + tx) * kTileElems +
                                                      (i - ty * kTilePx) * kTilePx + (j - tx * kTilePx);
 #pragma unroll
                                 for (int cc = 0; cc < NCH; ++cc) gt[k][p][cc] = gtile[(c_base + cc) * (kTilePx * kTilePx)];
@@ -588,7 +586,7 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode; a.band_rows = ph;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.tile_slot = nullptr;
+    a.geff = nullptr;
     return launch_scatter_reduce<false>(a, gpatch, st, "vaa_patch_grad_gather");
 }
 
@@ -619,7 +617,7 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.g = gout_bf16; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.tile_slot = nullptr;
+    a.geff = nullptr;
     a.band_rows = band_rows_for(max_h, max_w, 3 * B);
     const int nbands = (max_h + a.band_rows - 1) / a.band_rows;
     const size_t bytes = (size_t)a.band_rows * max_w * sizeof(long long);
@@ -651,8 +649,7 @@ struct EmbedArgs {
     const uint16_t *dy0, *dy1;  // [B,256,D0], [B,256,D1] bf16: dL/d(patch-embed output) of the two towers, tokens in tile order
     const uint16_t *wt0, *wt1;  // conv weights of the two towers in the PACKED fragment order of embed_pack_weights_kernel
     const uint8_t* keep;        // [B,3,224*224/8] keep bits from K1
-    float* geff;                // [B,256,588]
-    int16_t* tile_slot;         // [B,256]
+    float* geff;                // [B,256,588], indexed by tile (ty*16 + tx); only the flagged tiles are written
     int B, D0, D1, round_bf16;
     float istd6[6];
 };
@@ -732,7 +729,6 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedA
     for (int q = 0; q < 4; ++q) { if (q < wv) base += wave_cnt[q]; M += wave_cnt[q]; }
     const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
     if (flag) tiles[slot] = (int16_t)tid;
-    if (ch == 0) a.tile_slot[b * 256 + tid] = flag ? (int16_t)slot : (int16_t)-1;
     __syncthreads();
 
     const int nb = ch * 4 + wv;
@@ -790,7 +786,7 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedA
                 for (int r = 0; r < 4; ++r) {  // C/D layout: column = lane&15 (pixel n), row = 4*(lane>>4)+r (tile slot)
                     const int sl = mg * 64 + q * 16 + g * 4 + r;
                     if (sl < M)
-                        a.geff[((size_t)b * 256 + sl) * kTileElems + n] =
+                        a.geff[((size_t)b * 256 + tiles[sl]) * kTileElems + n] =
                             maybe_bf16(acc0[q][r], a.round_bf16) * s0 + maybe_bf16(acc1[q][r], a.round_bf16) * s1;
                 }
         }
@@ -906,7 +902,6 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     for (int q = 0; q < 4; ++q) { if (q < wv) base += wave_cnt[q]; M += wave_cnt[q]; }
     const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
     if (flag) tiles[slot] = (int16_t)tid;
-    if (ch == 0 && tid < 256) a.tile_slot[b * 256 + tid] = flag ? (int16_t)slot : (int16_t)-1;
     __syncthreads();
 
     K2_STAMP(0)
@@ -991,7 +986,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int sl = mg * 64 + q * 16 + g * 4 + r;
-                    if (sl < M) a.geff[((size_t)b * 256 + sl) * kTileElems + n[j]] = res[j][q][r];
+                    if (sl < M) a.geff[((size_t)b * 256 + tiles[sl]) * kTileElems + n[j]] = res[j][q][r];
                 }
         }
         K2_STAMP(5)
@@ -1026,7 +1021,7 @@ extern "C" int vaa_patch_embed_pack_weights(const uint16_t* wt, int D, uint16_t*
 
 extern "C" size_t vaa_patch_embed_grad_ws_bytes(int B, int ph, int pw) {
     if (B <= 0 || ph <= 0 || pw <= 0) return 0;
-    return vaa_patch_grad_ws_bytes(B, ph, pw) + (size_t)B * 256 * vaa::kTileElems * sizeof(float) + (size_t)B * 256 * sizeof(int16_t) + 256;
+    return vaa_patch_grad_ws_bytes(B, ph, pw) + (size_t)B * 256 * vaa::kTileElems * sizeof(float) + 256;
 }
 
 extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
@@ -1065,7 +1060,6 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     EmbedArgs e;
     e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wt0; e.wt1 = wt1; e.keep = keep_bits;
     e.geff = reinterpret_cast<float*>(wsb + part_bytes);
-    e.tile_slot = reinterpret_cast<int16_t*>(wsb + part_bytes + (size_t)B * 256 * kTileElems * sizeof(float));
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
     const int Dmax = D0 > D1 ? D0 : D1;
@@ -1087,6 +1081,6 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     a.g = nullptr; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff; a.tile_slot = e.tile_slot;
+    a.geff = e.geff;
     return launch_scatter_reduce<true>(a, gpatch, st, "vaa_patch_embed_grad_gather");
 }
