@@ -883,6 +883,28 @@ def test_baseline_config_shapes_one_step_vs_oracle(ops, name, B, ph, pw, geo, ma
     assert np.abs(p.cpu().numpy().ravel() - pc).max() <= 1e-4  # north-star tolerance on the updated pixels
 
 
+def test_patch_embed_pack_weights_layout_and_errors(ops):
+    """vaa_patch_embed_pack_weights writes the layout include/vaa.h / vaa_patch_grad.hip document:
+    packed[(((nb*nchunk + kc)*2 + h)*64 + lane)*8 + e] = W^T[nb*16 + (lane & 15)][kc*64 + (lane >> 4)*16 + h*8 + e], zero for columns >= 588."""
+    D = 192
+    wt = (torch.randn(588, D, device=DEV) * 0.1).to(torch.bfloat16)
+    packed = ops.pack_embed_weights(wt).view(37, D // 64, 2, 64, 8).cpu()
+    full = torch.zeros(592, D, dtype=torch.bfloat16)
+    full[:588] = wt.cpu()
+    nb, kc, h, lane, e = torch.meshgrid(torch.arange(37), torch.arange(D // 64), torch.arange(2), torch.arange(64), torch.arange(8), indexing="ij")
+    want = full[nb * 16 + (lane & 15), kc * 64 + (lane >> 4) * 16 + h * 8 + e]
+    assert torch.equal(packed.view(torch.int16), want.view(torch.int16))
+    with pytest.raises(ValueError):
+        ops.pack_embed_weights((torch.randn(588, 96, device=DEV)).to(torch.bfloat16))  # not a multiple of 64
+    from roboticattack_amd import _lib
+
+    L = _lib.lib()
+    d = torch.zeros(16, dtype=torch.bfloat16, device=DEV)
+    rc = L.vaa_patch_embed_grad_gather(d.data_ptr(), 96, d.data_ptr(), 64, d.data_ptr(), d.data_ptr(), d.data_ptr(), d.data_ptr(), d.data_ptr(), d.data_ptr(),
+                                       1, 50, 50, 1, 0, _lib.f32x([0.5] * 6), 1, d.data_ptr(), d.data_ptr(), 1 << 30, None)
+    assert rc == -1 and b"64" in L.vaa_last_error()  # VAA_E_INVALID: tower widths must be multiples of 64
+
+
 @pytest.mark.parametrize("B,ph,pw,geo,D0,D1", [(6, 50, 50, 1, 64, 192), (3, 22, 31, 0, 64, 64), (4, 100, 100, 1, 128, 64), (64, 50, 50, 1, 1024, 1152),
                                                 (2, 50, 50, 1, 1216, 64)])  # the last one: a tower too wide for the LDS-resident variant
 def test_patch_embed_grad_gather_vs_unfused(ops, B, ph, pw, geo, D0, D1):
