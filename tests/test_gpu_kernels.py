@@ -883,6 +883,37 @@ def test_baseline_config_shapes_one_step_vs_oracle(ops, name, B, ph, pw, geo, ma
     assert np.abs(p.cpu().numpy().ravel() - pc).max() <= 1e-4  # north-star tolerance on the updated pixels
 
 
+def test_patch_embed_grad_gather_vs_torch_conv_autograd(ops):
+    """K2' against plain PyTorch-CPU autograd through the REAL formulation it replaces: the reference's paste/warp/normalise forward
+    (oracle/ref_port.py, appply_random_transform.py:104-136), `.to(bfloat16)` (UADA.py:142), then timm's PatchEmbed of both towers as
+    F.conv2d(x, W[D,3,14,14], stride=14) (modeling_prismatic.py:120-123) with tokens flattened row-major, and an upstream gradient on the
+    conv OUTPUTS. Pins the (c, y, x) column order of the flattened conv weight, the token order and the tower / channel split; the
+    remaining difference is the bf16 rounding point of the pixel gradient (the CPU chain rounds it once per tower as well)."""
+    B, ph, pw, D0, D1 = 3, 50, 50, 64, 128
+    rs = np.random.RandomState(31)
+    imgs = synthetic.synth_images(8, B, "noise")
+    patch_n = rs.rand(3, ph, pw).astype(np.float32)
+    xy_n, th_n = _random_case(rs, B, ph, pw)
+    gen = torch.Generator().manual_seed(3)
+    w = [(torch.randn(D, 3, 14, 14, generator=gen) * 0.05).to(torch.bfloat16) for D in (D0, D1)]
+    dy = [(torch.randn(B, D, 16, 16, generator=gen) * 0.1).to(torch.bfloat16) for D in (D0, D1)]  # gradient w.r.t. the conv outputs [B,D,16,16]
+    # ---- reference chain on the CPU ----
+    p = torch.from_numpy(patch_n).clone().requires_grad_(True)
+    x = ref_port.apply_random_patch_batch(list(imgs), p, xy_n, th_n, True).to(torch.bfloat16)
+    e0 = torch.nn.functional.conv2d(x[:, :3], w[0], stride=14)
+    e1 = torch.nn.functional.conv2d(x[:, 3:], w[1], stride=14)
+    torch.autograd.backward([e0, e1], [dy[0], dy[1]])
+    want = p.grad.numpy()
+    # ---- K2' ----
+    patch, xy, th = _t(patch_n), _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6))
+    _, keep = ops.patch_apply_fwd(_t(imgs), patch, xy, th, True, 0)
+    wp = [ops.pack_embed_weights(ww.reshape(ww.shape[0], 588).t().contiguous().to(DEV)) for ww in w]
+    tok = [d.flatten(2).transpose(1, 2).contiguous().to(DEV) for d in dy]  # [B,256,D], token t = ty*16 + tx (timm: x.flatten(2).transpose(1, 2))
+    got = ops.patch_embed_grad_gather(tok[0], tok[1], wp[0], wp[1], patch, xy, th, keep, True).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max()  # bf16 conv backward on the CPU vs fp32-accumulated MFMA rounded to bf16
+    assert np.corrcoef(got.ravel(), want.ravel())[0, 1] > 0.99999
+
+
 def test_patch_embed_pack_weights_layout_and_errors(ops):
     """vaa_patch_embed_pack_weights writes the layout include/vaa.h / vaa_patch_grad.hip document:
     packed[(((nb*nchunk + kc)*2 + h)*64 + lane)*8 + e] = W^T[nb*16 + (lane & 15)][kc*64 + (lane >> 4)*16 + h*8 + e], zero for columns >= 588."""
