@@ -192,6 +192,13 @@ int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1
                                 const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph, int pw,
                                 int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes,
                                 void* stream);
+/* the same with one patch per image (resize_patch=True; packed / pdesc / gpacked as in vaa_patch_grad_gather_multi):
+ * ws >= vaa_patch_embed_grad_multi_ws_bytes(B); the resize adjoint then folds gpacked into the base patch's gradient */
+size_t vaa_patch_embed_grad_multi_ws_bytes(int B);
+int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
+                                      const float* packed, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                                      const uint8_t* keep_bits, int B, int max_h, int max_w, int geometry, int mask_mode, const float* std6,
+                                      int round_bf16, float* gpacked, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * K4 — replaces transformers.AdamW.step + `patch.data.clamp(0,1)` + zero_grad (UADA.py:155-157; UADA_ddp.py:208-209),

@@ -38,6 +38,8 @@ EXPORTS = (
     "vaa_patch_embed_grad_gather",
     "vaa_patch_embed_packed_elems",
     "vaa_patch_embed_pack_weights",
+    "vaa_patch_embed_grad_multi_ws_bytes",
+    "vaa_patch_embed_grad_gather_multi",
     "vaa_patch_resize_fwd",
     "vaa_patch_resize_ws_bytes",
     "vaa_patch_resize_bwd",
@@ -120,6 +122,10 @@ def lib() -> C.CDLL:
     L.vaa_patch_embed_pack_weights.argtypes = [vp, i32, vp, vp]
     L.vaa_patch_embed_grad_gather.restype = i32
     L.vaa_patch_embed_grad_gather.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
+    L.vaa_patch_embed_grad_multi_ws_bytes.restype = sz
+    L.vaa_patch_embed_grad_multi_ws_bytes.argtypes = [i32]
+    L.vaa_patch_embed_grad_gather_multi.restype = i32
+    L.vaa_patch_embed_grad_gather_multi.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
     L.vaa_patch_resize_fwd.restype = i32
     L.vaa_patch_resize_fwd.argtypes = [vp, i32, i32, vp, i32, vp, vp]
     L.vaa_patch_resize_ws_bytes.restype = sz

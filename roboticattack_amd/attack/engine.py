@@ -46,10 +46,11 @@ class AttackBase:
         self.save_dir = save_dir
         self.device = torch.device(getattr(vla, "device", "cuda"))
         self.randomPatchTransform = RandomPatchTransform(self.device, resize_patch)
-        if os.environ.get("VAA_FUSED_EMBED_GRAD", "1") != "0" and hasattr(vla, "forward_rows") and hasattr(vla, "patch_embed_params") and not resize_patch:
+        if os.environ.get("VAA_FUSED_EMBED_GRAD", "1") != "0" and hasattr(vla, "forward_rows") and hasattr(vla, "patch_embed_params"):
             # a model that exposes its patch-embed parameters is handed patch-embed OUTPUTS in training steps and K2' never
-            # builds the dense pixel gradient (the embed backward runs on the ~36 tiles under the patch only). A black-box model (no
-            # patch_embed_params) and VAA_FUSED_EMBED_GRAD=0 keep the pixel_values boundary of the reference.
+            # builds the dense pixel gradient (the embed backward runs on the ~36 tiles under the patch only; per-image patches of
+            # resize_patch=True included). A black-box model (no patch_embed_params) and VAA_FUSED_EMBED_GRAD=0 keep the pixel_values
+            # boundary of the reference.
             self.randomPatchTransform.embed_with = vla
         self.mean = [torch.tensor(MEAN0), torch.tensor(MEAN1)]
         self.std = [torch.tensor(STD0), torch.tensor(STD1)]

@@ -540,6 +540,26 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
     return launch_partial_reduce((const float*)a.partial, gpatch, n, G, st, who);
 }
 
+// one workgroup per (image, channel, row band); every image's own gradient is drained into gpacked
+template <bool TILED>
+static int launch_scatter_multi(GradArgs a, int max_h, int max_w, hipStream_t st, const char* who) {
+    const int B = a.B;
+    a.band_rows = band_rows_for(max_h, max_w, 3 * B);
+    const int nbands = (max_h + a.band_rows - 1) / a.band_rows;
+    const size_t bytes = (size_t)a.band_rows * max_w * sizeof(long long);
+    const void* fn = a.keep ? (const void*)patch_grad_scatter_kernel<1, TILED, true, true, 1024, 3>
+                            : (const void*)patch_grad_scatter_kernel<1, TILED, true, false, 1024, 3>;
+    if (bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute failed", who);
+        return VAA_E_LAUNCH;
+    }
+    if (a.keep)
+        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, true, true, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, st, a, B);
+    else
+        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, true, false, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, st, a, B);
+    return check_launch(who);
+}
+
 }  // namespace vaa
 
 #ifdef VAA_K2_TIMING
@@ -618,20 +638,7 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
     a.geff = nullptr;
-    a.band_rows = band_rows_for(max_h, max_w, 3 * B);
-    const int nbands = (max_h + a.band_rows - 1) / a.band_rows;
-    const size_t bytes = (size_t)a.band_rows * max_w * sizeof(long long);
-    const void* fn = keep_bits ? (const void*)patch_grad_scatter_kernel<1, false, true, true, 1024, 3>
-                               : (const void*)patch_grad_scatter_kernel<1, false, true, false, 1024, 3>;
-    if (bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-        set_error("vaa_patch_grad_gather_multi: hipFuncSetAttribute failed");
-        return VAA_E_LAUNCH;
-    }
-    if (keep_bits)
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, true, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B);
-    else
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, false, true, false, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, (hipStream_t)stream, a, B);
-    return check_launch("vaa_patch_grad_gather_multi");
+    return launch_scatter_multi<false>(a, max_h, max_w, (hipStream_t)stream, "vaa_patch_grad_gather_multi");
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -999,6 +1006,28 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
 
 }  // namespace vaa
 
+namespace vaa {
+
+// tile gradients of every image (both towers) into e.geff; the LDS-resident variant while a tower's 64 gathered rows fit
+static int launch_embed_tiles(const EmbedArgs& e, hipStream_t st, const char* who) {
+    const int B = e.B, Dmax = e.D0 > e.D1 ? e.D0 : e.D1;
+    const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
+    if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
+        const int nch = (kNBlocks + kEmbedFastCols - 1) / kEmbedFastCols;  // workgroups per image
+        if (hipFuncSetAttribute((const void*)embed_dgrad_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast) != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute failed", who);
+            return VAA_E_LAUNCH;
+        }
+        hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
+    } else {  // wide towers: fragments straight from global memory
+        const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
+        hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedThreads), 0, st, e, nch);
+    }
+    return VAA_OK;
+}
+
+}  // namespace vaa
+
 extern "C" size_t vaa_patch_embed_packed_elems(int D) {
     if (D <= 0 || (D % 64) != 0) return 0;
     return (size_t)vaa::kNBlocks * 16 * (size_t)D;  // 592 columns (588 + 4 of zero padding) x D
@@ -1062,19 +1091,7 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     e.geff = reinterpret_cast<float*>(wsb + part_bytes);
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
-    const int Dmax = D0 > D1 ? D0 : D1;
-    const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
-    if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
-        const int nch = (kNBlocks + kEmbedFastCols - 1) / kEmbedFastCols;  // workgroups per image
-        if (hipFuncSetAttribute((const void*)embed_dgrad_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast) != hipSuccess) {
-            set_error("vaa_patch_embed_grad_gather: hipFuncSetAttribute failed");
-            return VAA_E_LAUNCH;
-        }
-        hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
-    } else {  // wide towers: fragments straight from global memory
-        const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
-        hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedThreads), 0, st, e, nch);
-    }
+    if (launch_embed_tiles(e, st, "vaa_patch_embed_grad_gather") != VAA_OK) return VAA_E_LAUNCH;
     int rc = check_launch("vaa_patch_embed_grad_gather(tiles)");
     if (rc != VAA_OK) return rc;
     GradArgs a;
@@ -1083,4 +1100,53 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
     a.geff = e.geff;
     return launch_scatter_reduce<true>(a, gpatch, st, "vaa_patch_embed_grad_gather");
+}
+
+extern "C" size_t vaa_patch_embed_grad_multi_ws_bytes(int B) {
+    if (B <= 0) return 0;
+    return (size_t)B * 256 * vaa::kTileElems * sizeof(float) + 256;
+}
+
+// K2' with one patch per image (resize_patch=True): the tile gradients do not depend on the patches, the gather runs in MULTI mode.
+extern "C" int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
+                                                 const float* packed, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                                                 const uint8_t* keep_bits, int B, int max_h, int max_w, int geometry, int mask_mode,
+                                                 const float* std6, int round_bf16, float* gpacked, void* ws, size_t ws_bytes, void* stream) {
+    using namespace vaa;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return VAA_OK;
+    if (!dy0 || !dy1 || !wp0 || !wp1 || !pdesc || !xy || !std6 || !gpacked || !keep_bits || (geometry && !theta)) {
+        set_error("vaa_patch_embed_grad_gather_multi: null pointer argument (the keep bits of K1 are required)");
+        return VAA_E_INVALID;
+    }
+    if (B < 0 || max_h <= 0 || max_w <= 0 || D0 <= 0 || D1 <= 0 || (D0 % 64) != 0 || (D1 % 64) != 0 ||
+        (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100)) {
+        set_error("vaa_patch_embed_grad_gather_multi: bad sizes/mode (B=%d max_h=%d max_w=%d D0=%d D1=%d; D %% 64 == 0)", B, max_h, max_w, D0, D1);
+        return VAA_E_INVALID;
+    }
+    if (max_h > VAA_IMG || max_w > VAA_IMG) {
+        set_error("vaa_patch_embed_grad_gather_multi: patch bound %dx%d larger than the frame", max_h, max_w);
+        return VAA_E_UNSUPPORTED;
+    }
+    if (geometry && mask_mode == VAA_MASK_NE_M100) {
+        set_error("vaa_patch_embed_grad_gather_multi: VAA_MASK_NE_M100 is defined for geometry=0 only");
+        return VAA_E_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < vaa_patch_embed_grad_multi_ws_bytes(B)) {
+        set_error("vaa_patch_embed_grad_gather_multi: workspace %zu B < required %zu B", ws_bytes, vaa_patch_embed_grad_multi_ws_bytes(B));
+        return VAA_E_WORKSPACE;
+    }
+    EmbedArgs e;
+    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wp0; e.wt1 = wp1; e.keep = keep_bits; e.geff = reinterpret_cast<float*>(ws);
+    e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
+    for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
+    if (launch_embed_tiles(e, st, "vaa_patch_embed_grad_gather_multi") != VAA_OK) return VAA_E_LAUNCH;
+    int rc = check_launch("vaa_patch_embed_grad_gather_multi(tiles)");
+    if (rc != VAA_OK) return rc;
+    GradArgs a;
+    a.g = nullptr; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
+    a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
+    for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
+    a.geff = e.geff;
+    return launch_scatter_multi<true>(a, max_h, max_w, st, "vaa_patch_embed_grad_gather_multi");
 }

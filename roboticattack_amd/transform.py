@@ -148,6 +148,9 @@ class RandomPatchTransform:
         sizes, xy_n, theta_n = self._draw_resized(img.shape[0], int(patch.shape[1]), int(patch.shape[2]), geometry)
         self.last_sizes = sizes
         xy, theta = self._to_dev(xy_n, theta_n)
+        emb = self._embed_params(patch, out_dtype)
+        if emb is not None:
+            return ops.PatchEmbeds(ops.PatchApplyResizedEmbed.apply(patch, img, sizes, xy, theta, bool(geometry), ops.MASK_LT_M20, mean6, std6, *emb))
         out = ops.PatchApplyResized.apply(patch, img, sizes, xy, theta, bool(geometry), ops.MASK_LT_M20, mean6, std6)
         return out if out_dtype == torch.bfloat16 else out.to(out_dtype)
 

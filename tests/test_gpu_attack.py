@@ -489,9 +489,11 @@ def test_bench_py_two_ranks_one_gpu(tmp_path):
     assert d["cpu_baseline"] is None and d["roofline"]["kernel"] == "K1_patch_apply_fwd"
 
 
-def test_patch_embed_grad_path_matches_pixel_grad_path(monkeypatch):
+@pytest.mark.parametrize("resize", [False, True])
+def test_patch_embed_grad_path_matches_pixel_grad_path(resize):
     """SURVEY.md 8f-3 end to end: one UADA step with the patch-embed backward restricted to the kept tiles (K2') gives the same loss and
-    the same patch gradient as the path through the dense bf16 pixel gradient (K2)."""
+    the same patch gradient as the path through the dense bf16 pixel gradient (K2) — with one patch for the batch and with
+    resize_patch=True (per-image patches: K2' in per-image mode + the resize adjoint)."""
     from roboticattack_amd import ops, synthetic
     from roboticattack_amd.labels import mask_labels
     from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
@@ -510,7 +512,7 @@ def test_patch_embed_grad_path_matches_pixel_grad_path(monkeypatch):
     std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
     res = []
     for fused in (True, False):
-        tr = RandomPatchTransform(DEV, False)
+        tr = RandomPatchTransform(DEV, resize)
         tr.embed_with = m if fused else None
         img = tr.stage_images(torch.from_numpy(batch["pixel_values"]))
         random.seed(5); np.random.seed(5)

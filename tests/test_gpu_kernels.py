@@ -914,6 +914,35 @@ def test_patch_embed_grad_gather_vs_torch_conv_autograd(ops):
     assert np.corrcoef(got.ravel(), want.ravel())[0, 1] > 0.99999
 
 
+def test_patch_embed_grad_gather_multi_vs_oracle(ops):
+    """K2' with one patch per image (resize_patch=True): per-image gradients against the oracle fed by an fp32 host matmul, folded to
+    pixel layout and rounded to bf16 per tower (image by image through vaa_oracle_patch_grad_multi)."""
+    B, D0, D1 = 5, 128, 64
+    rs = np.random.RandomState(17)
+    imgs = synthetic.synth_images(6, B, "noise")
+    sizes = np.array([[61, 61], [139, 139], [100, 80], [30, 120], [75, 75]], np.int32)  # 139x139: more than one row band
+    pdesc_n, total = ops.make_pdesc(sizes)
+    packed_n = rs.rand(total).astype(np.float32)
+    xy_n = np.stack([[rs.randint(0, 224 - w + 1), rs.randint(0, 224 - h + 1)] for h, w in sizes]).astype(np.int32)
+    _, th_n = _random_case(rs, B, 50, 50)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    dy = [(torch.randn(B, 256, D, device=DEV, generator=gen) * 0.1).to(torch.bfloat16) for D in (D0, D1)]
+    w = [(torch.randn(D, 588, device=DEV, generator=gen) * 0.05).to(torch.bfloat16) for D in (D0, D1)]
+    packed, pdesc, xy, th = _t(packed_n), _t(pdesc_n), _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6))
+    mh = (int(sizes[:, 0].max()), int(sizes[:, 1].max()))
+    _, keep = ops.patch_apply_fwd_multi(_t(imgs), packed, pdesc, mh, xy, th, True, 0)
+    got = ops.patch_embed_grad_gather_multi(dy[0], dy[1], ops.pack_embed_weights(w[0].t().contiguous()), ops.pack_embed_weights(w[1].t().contiguous()),
+                                            packed, pdesc, mh, xy, th, keep, True).cpu().numpy()
+    fold = lambda d, ww: (d.float().cpu() @ ww.float().cpu()).to(torch.bfloat16).view(B, 16, 16, 3, 14, 14).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 224, 224)
+    gcat = torch.cat([fold(dy[0], w[0]), fold(dy[1], w[1])], dim=1).contiguous()
+    want = c_oracle.patch_grad_multi(_bits(gcat), packed_n, pdesc_n, xy_n, th_n, 1, 0)
+    for (h, ww_, off, _z) in pdesc_n:
+        a, b = got[off : off + 3 * h * ww_], want[off : off + 3 * h * ww_]
+        assert np.abs(a - b).max() <= 5e-3 * np.abs(b).max() + 1e-9  # one bf16 ulp of a tile gradient: per-image results have few terms per texel
+    unf = ops.patch_grad_gather_multi(gcat.to(DEV), packed, pdesc, mh, xy, th, keep, True).cpu().numpy()  # the unfused HIP path on the same bf16 gradient
+    assert np.abs(unf - want).max() <= 3e-6 * np.abs(want).max()
+
+
 def test_patch_embed_pack_weights_layout_and_errors(ops):
     """vaa_patch_embed_pack_weights writes the layout include/vaa.h / vaa_patch_grad.hip document:
     packed[(((nb*nchunk + kc)*2 + h)*64 + lane)*8 + e] = W^T[nb*16 + (lane & 15)][kc*64 + (lane >> 4)*16 + h*8 + e], zero for columns >= 588."""
