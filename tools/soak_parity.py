@@ -147,6 +147,20 @@ def one_case(seed):
             a, b = gp[off : off + 3 * h * w], o_gp[off : off + 3 * h * w]
             if not (np.abs(a - b).max() <= 3e-6 * max(np.abs(b).max(), 1e-30)):
                 fails.append(f"K2 multi {tag} image {h}x{w}: rel err {np.abs(a - b).max() / max(np.abs(b).max(), 1e-30):.3e}")
+        if not general and rs.rand() < 0.4:  # K2' in per-image mode against the oracle fed by an fp32 host matmul
+            D0, D1 = int(rs.choice([64, 128, 192])), int(rs.choice([64, 128]))
+            gen = torch.Generator(device=DEV).manual_seed(seed % 100019)
+            dy = [(torch.randn(B, 256, D, device=DEV, generator=gen) * 0.1).to(torch.bfloat16) for D in (D0, D1)]
+            w = [(torch.randn(D, 588, device=DEV, generator=gen) * 0.05).to(torch.bfloat16) for D in (D0, D1)]
+            fm = ops.patch_embed_grad_gather_multi(dy[0], dy[1], ops.pack_embed_weights(w[0].t().contiguous()), ops.pack_embed_weights(w[1].t().contiguous()),
+                                                   t(o_packed), t(pdesc_n), mh, t(xy2, torch.int32), t(theta.reshape(-1, 6)), k2, bool(geo)).cpu().numpy()
+            fold = lambda d, ww: (d.float().cpu() @ ww.float().cpu()).to(torch.bfloat16).view(B, 16, 16, 3, 14, 14).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 224, 224)
+            gcat = torch.cat([fold(dy[0], w[0]), fold(dy[1], w[1])], dim=1).contiguous()
+            om = c_oracle.patch_grad_multi(bits(gcat), o_packed, pdesc_n, xy2, theta, geo, 0)
+            for (h, w_, off, _z) in pdesc_n:
+                a, b = fm[off : off + 3 * h * w_], om[off : off + 3 * h * w_]
+                if not (np.abs(a - b).max() <= 5e-3 * max(np.abs(b).max(), 1e-30) + 1e-30):
+                    fails.append(f"K2' multi {tag} image {h}x{w_} D={D0}+{D1}: rel err {np.abs(a - b).max() / max(np.abs(b).max(), 1e-30):.3e}")
         gb = ops.patch_resize_bwd(t(o_gp), t(pdesc_n), bh, bw).cpu().numpy()
         o_gb = c_oracle.patch_resize_bwd(o_gp, pdesc_n, bh, bw)
         if not (np.abs(gb - o_gb).max() <= 2e-6 * max(np.abs(o_gb).max(), 1e-30)):
