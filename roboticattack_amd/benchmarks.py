@@ -228,8 +228,16 @@ def rank_shapes(iters=20, device="cuda:0"):
     g = synthetic.synth_upstream_grad(7, B).to(dev)
     gp = ops.patch_grad_gather_multi(g, packed, pdesc, max_hw, xy, th, keep, True)
     kept_px = int(sum(int(h) * int(w) for h, w in sizes))
+    dy0 = (torch.randn(B, 256, 1024, device=dev) * 0.1).to(torch.bfloat16)
+    dy1 = (torch.randn(B, 256, 1152, device=dev) * 0.1).to(torch.bfloat16)
+    wp0 = ops.pack_embed_weights((torch.randn(588, 1024, device=dev) * 0.05).to(torch.bfloat16))
+    wp1 = ops.pack_embed_weights((torch.randn(588, 1152, device=dev) * 0.05).to(torch.bfloat16))
+    ntile = int(sum(((int(h) + 13) // 14 + 1) * ((int(w) + 13) // 14 + 1) for h, w in sizes))  # ~tiles under the (warped) patches
     c5 = {}
     for name, fn, nb in (
+        ("K2e_patch_embed_grad_gather_multi",
+         lambda: ops.patch_embed_grad_gather_multi(dy0, dy1, wp0, wp1, packed, pdesc, max_hw, xy, th, keep, True),
+         ntile * (1024 + 1152) * 2 + 588 * (1024 + 1152) * 2 + 4 * total),
         ("K0_patch_resize_fwd", lambda: ops.patch_resize_fwd(patch, pdesc, total), 4 * 3 * 100 * 100 + 4 * total),
         ("K1_patch_apply_fwd_multi", lambda: ops.patch_apply_fwd_multi(img, packed, pdesc, max_hw, xy, th, True), B * (150528 + 602112) + 4 * total),
         ("K2_patch_grad_gather_multi", lambda: ops.patch_grad_gather_multi(g, packed, pdesc, max_hw, xy, th, keep, True), 12 * kept_px + 4 * total),

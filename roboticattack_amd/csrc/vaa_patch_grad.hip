@@ -745,7 +745,7 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedA
     const int c3 = nv ? n / (kTilePx * kTilePx) : 0;
     const float s0 = a.istd6[c3], s1 = a.istd6[c3 + 3];
     // Up to four 16-tile row blocks share every weight fragment: per 64-wide k-chunk 2 B-fragments + 8 A-fragments are in flight, 8 MFMAs follow.
-    for (int mg = 0; mg * 64 < M; ++mg) {
+    for (int mg = blockIdx.y; mg * 64 < M; mg += gridDim.y) {  // 64-tile row groups: spread over grid.y when the patch can cover more
         v4f_e acc0[4], acc1[4];
         const uint16_t *y0[4], *y1[4];
         bool mv[4];
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
         s0[j] = a.istd6[c3];
         s1[j] = a.istd6[c3 + 3];
     }
-    for (int mg = 0; mg * 64 < M; ++mg) {
+    for (int mg = blockIdx.y; mg * 64 < M; mg += gridDim.y) {  // 64-tile row groups: spread over grid.y when the patch can cover more
         const int rows = min(64, M - mg * 64), nq = (rows + 15) >> 4;  // workgroup-uniform
         float res[2][4][4];  // [column block][row block][r]: tower 0's scaled contribution, then + tower 1's
 #pragma unroll
@@ -1009,8 +1009,12 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
 namespace vaa {
 
 // tile gradients of every image (both towers) into e.geff; the LDS-resident variant while a tower's 64 gathered rows fit
-static int launch_embed_tiles(const EmbedArgs& e, hipStream_t st, const char* who) {
+static int launch_embed_tiles(const EmbedArgs& e, int ph, int pw, hipStream_t st, const char* who) {
     const int B = e.B, Dmax = e.D0 > e.D1 ? e.D0 : e.D1;
+    // a warped ph x pw patch touches at most ~(1.5 ph / 14 + 2) x (1.5 pw / 14 + 2) of the 256 tiles of a frame; beyond 64 tiles the row
+    // groups of an image go to separate workgroups (grid.y) instead of being walked in sequence (B=4, 100..139 px: 40 -> 21 us)
+    const int tiles_bound = ((3 * ph / 2 + 13) / 14 + 2) * ((3 * pw / 2 + 13) / 14 + 2);
+    const unsigned ny = (unsigned)(tiles_bound <= 64 ? 1 : (tiles_bound <= 128 ? 2 : 4));
     const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
     if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
         const int nch = (kNBlocks + kEmbedFastCols - 1) / kEmbedFastCols;  // workgroups per image
@@ -1018,10 +1022,10 @@ static int launch_embed_tiles(const EmbedArgs& e, hipStream_t st, const char* wh
             set_error("%s: hipFuncSetAttribute failed", who);
             return VAA_E_LAUNCH;
         }
-        hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
+        hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
     } else {  // wide towers: fragments straight from global memory
         const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
-        hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch), dim3(kEmbedThreads), 0, st, e, nch);
+        hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedThreads), 0, st, e, nch);
     }
     return VAA_OK;
 }
@@ -1091,7 +1095,7 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     e.geff = reinterpret_cast<float*>(wsb + part_bytes);
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
-    if (launch_embed_tiles(e, st, "vaa_patch_embed_grad_gather") != VAA_OK) return VAA_E_LAUNCH;
+    if (launch_embed_tiles(e, ph, pw, st, "vaa_patch_embed_grad_gather") != VAA_OK) return VAA_E_LAUNCH;
     int rc = check_launch("vaa_patch_embed_grad_gather(tiles)");
     if (rc != VAA_OK) return rc;
     GradArgs a;
@@ -1140,7 +1144,7 @@ extern "C" int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, co
     e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wp0; e.wt1 = wp1; e.keep = keep_bits; e.geff = reinterpret_cast<float*>(ws);
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
-    if (launch_embed_tiles(e, st, "vaa_patch_embed_grad_gather_multi") != VAA_OK) return VAA_E_LAUNCH;
+    if (launch_embed_tiles(e, max_h, max_w, st, "vaa_patch_embed_grad_gather_multi") != VAA_OK) return VAA_E_LAUNCH;
     int rc = check_launch("vaa_patch_embed_grad_gather_multi(tiles)");
     if (rc != VAA_OK) return rc;
     GradArgs a;
