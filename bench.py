@@ -294,6 +294,8 @@ def main():
     for name, s, e, info in timer:
         per.setdefault(name, []).append(s.elapsed_time(e) * 1e-3)
     kern = {}
+    # means, like rocprofv3's per-kernel average (medians of the same brackets come out ~2 us lower: 13.7-14.3 us for K1, below even the
+    # back-to-back figure, because part of an event pair's cost overlaps with a real kernel's dispatch but not with an empty bracket)
     empty_us = float(np.mean(per.pop("_empty_bracket"))) * 1e6 if "_empty_bracket" in per else 0.0
     esz = 2 if use_rows and args.model == "openvla-7b" else 4
     cfg = getattr(model, "cfg", None)
