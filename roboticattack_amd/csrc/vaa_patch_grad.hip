@@ -47,6 +47,7 @@ struct GradArgs {
     // TILED source (vaa_patch_embed_grad_gather): instead of the 6-plane bf16 pixel gradient `g`, the already combined and
     // scaled gradient of the tiles that carry kept pixels: geff[b][ty*16 + tx][c*196 + y*14 + x] (tiles without a kept pixel are not written)
     const float* geff;
+    const float* geff2;      // second tower's tile gradients when the tile kernel ran one tower per workgroup (else nullptr): the gather adds the two
 };
 
 constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTilePx;  // ViT patch-embed tiling of the 224x224 frame
@@ -294,7 +295,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                 const float* gtile = a.geff + ((size_t)b * (kTilesPerSide * kTilesPerSide) + ty * kTilesPerSide + tx) * kTileElems +
                                                      (i - ty * kTilePx) * kTilePx + (j - tx * kTilePx);
 #pragma unroll
-                                for (int cc = 0; cc < NCH; ++cc) gt[k][p][cc] = gtile[(c_base + cc) * (kTilePx * kTilePx)];
+                                for (int cc = 0; cc < NCH; ++cc) {
+                                    float gv = gtile[(c_base + cc) * (kTilePx * kTilePx)];
+                                    if (a.geff2) gv += (a.geff2 + (gtile - a.geff))[(c_base + cc) * (kTilePx * kTilePx)];  // tower 0 + tower 1: the tile kernel's own sum
+                                    gt[k][p][cc] = gv;
+                                }
                             }
                         }
                         flg[k] = f;
@@ -606,7 +611,7 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode; a.band_rows = ph;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr;
     return launch_scatter_reduce<false>(a, gpatch, st, "vaa_patch_grad_gather");
 }
 
@@ -637,7 +642,7 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.g = gout_bf16; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr;
     return launch_scatter_multi<false>(a, max_h, max_w, (hipStream_t)stream, "vaa_patch_grad_gather_multi");
 }
 
@@ -657,7 +662,9 @@ struct EmbedArgs {
     const uint16_t *wt0, *wt1;  // conv weights of the two towers in the PACKED fragment order of embed_pack_weights_kernel
     const uint8_t* keep;        // [B,3,224*224/8] keep bits from K1
     float* geff;                // [B,256,588], indexed by tile (ty*16 + tx); only the flagged tiles are written
+    float* geff2;               // tower_split: tower 1's tile gradients (same layout)
     int B, D0, D1, round_bf16;
+    int tower_split;            // one tower per workgroup (grid.z = 2): halves the per-workgroup chain while the launch is far from filling the chip
     float istd6[6];
 };
 
@@ -927,8 +934,8 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     for (int mg = blockIdx.y; mg * 64 < M; mg += gridDim.y) {  // 64-tile row groups: spread over grid.y when the patch can cover more
         const int rows = min(64, M - mg * 64), nq = (rows + 15) >> 4;  // workgroup-uniform
         float res[2][4][4];  // [column block][row block][r]: tower 0's scaled contribution, then + tower 1's
-#pragma unroll
-        for (int tower = 0; tower < 2; ++tower) {
+        const int t_lo = a.tower_split ? (int)blockIdx.z : 0, t_hi = a.tower_split ? t_lo + 1 : 2;
+        for (int tower = t_lo; tower < t_hi; ++tower) {
             const int D = tower ? a.D1 : a.D0, SA = D + 8, cpr = D >> 3;  // 16-byte chunks per row
             const uint16_t* dy = tower ? a.dy1 : a.dy0;
             const int nchunks = nq * 16 * cpr;
@@ -981,7 +988,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = maybe_bf16(acc[j][q][r], a.round_bf16) * (tower ? s1[j] : s0[j]);
-                        res[j][q][r] = tower ? res[j][q][r] + v : v;
+                        res[j][q][r] = (tower != t_lo) ? res[j][q][r] + v : v;
                     }
             K2_STAMP(2 + 2 * tower)
         }
@@ -993,7 +1000,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int sl = mg * 64 + q * 16 + g * 4 + r;
-                    if (sl < M) a.geff[((size_t)b * 256 + tiles[sl]) * kTileElems + n[j]] = res[j][q][r];
+                    if (sl < M) (t_lo ? a.geff2 : a.geff)[((size_t)b * 256 + tiles[sl]) * kTileElems + n[j]] = res[j][q][r];
                 }
         }
         K2_STAMP(5)
@@ -1009,20 +1016,24 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
 namespace vaa {
 
 // tile gradients of every image (both towers) into e.geff; the LDS-resident variant while a tower's 64 gathered rows fit
-static int launch_embed_tiles(const EmbedArgs& e, int ph, int pw, hipStream_t st, const char* who) {
+static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, const char* who) {
     const int B = e.B, Dmax = e.D0 > e.D1 ? e.D0 : e.D1;
     // a warped ph x pw patch touches at most ~(1.5 ph / 14 + 2) x (1.5 pw / 14 + 2) of the 256 tiles of a frame; beyond 64 tiles the row
     // groups of an image go to separate workgroups (grid.y) instead of being walked in sequence (B=4, 100..139 px: 40 -> 21 us)
     const int tiles_bound = ((3 * ph / 2 + 13) / 14 + 2) * ((3 * pw / 2 + 13) / 14 + 2);
     const unsigned ny = (unsigned)(tiles_bound <= 64 ? 1 : (tiles_bound <= 128 ? 2 : 4));
     const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
+    e.tower_split = 0;
     if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
         const int nch = (kNBlocks + kEmbedFastCols - 1) / kEmbedFastCols;  // workgroups per image
+        // while twice the workgroups still fit one residency wave of the chip, a workgroup takes ONE tower (grid.z): its chain halves
+        // (bs=8: tile kernel 21 -> 12 us); the gather adds the two towers' tile gradients — the very fp32 add the unsplit kernel does
+        e.tower_split = (ny == 1 && e.geff2 && (long)((B + 7) / 8 * 8) * nch * 2 <= 256) ? 1 : 0;
         if (hipFuncSetAttribute((const void*)embed_dgrad_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast) != hipSuccess) {
             set_error("%s: hipFuncSetAttribute failed", who);
             return VAA_E_LAUNCH;
         }
-        hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
+        hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, e.tower_split ? 2u : 1u), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
     } else {  // wide towers: fragments straight from global memory
         const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
         hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedThreads), 0, st, e, nch);
@@ -1054,7 +1065,7 @@ extern "C" int vaa_patch_embed_pack_weights(const uint16_t* wt, int D, uint16_t*
 
 extern "C" size_t vaa_patch_embed_grad_ws_bytes(int B, int ph, int pw) {
     if (B <= 0 || ph <= 0 || pw <= 0) return 0;
-    return vaa_patch_grad_ws_bytes(B, ph, pw) + (size_t)B * 256 * vaa::kTileElems * sizeof(float) + 256;
+    return vaa_patch_grad_ws_bytes(B, ph, pw) + 2 * (size_t)B * 256 * vaa::kTileElems * sizeof(float) + 256;  // partial tiles + one tile-gradient buffer per tower
 }
 
 extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
@@ -1093,6 +1104,7 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     EmbedArgs e;
     e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wt0; e.wt1 = wt1; e.keep = keep_bits;
     e.geff = reinterpret_cast<float*>(wsb + part_bytes);
+    e.geff2 = e.geff + (size_t)B * 256 * kTileElems;
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
     if (launch_embed_tiles(e, ph, pw, st, "vaa_patch_embed_grad_gather") != VAA_OK) return VAA_E_LAUNCH;
@@ -1102,13 +1114,13 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
     a.g = nullptr; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff;
+    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr;
     return launch_scatter_reduce<true>(a, gpatch, st, "vaa_patch_embed_grad_gather");
 }
 
 extern "C" size_t vaa_patch_embed_grad_multi_ws_bytes(int B) {
     if (B <= 0) return 0;
-    return (size_t)B * 256 * vaa::kTileElems * sizeof(float) + 256;
+    return 2 * (size_t)B * 256 * vaa::kTileElems * sizeof(float) + 256;
 }
 
 // K2' with one patch per image (resize_patch=True): the tile gradients do not depend on the patches, the gather runs in MULTI mode.
@@ -1142,6 +1154,7 @@ extern "C" int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, co
     }
     EmbedArgs e;
     e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wp0; e.wt1 = wp1; e.keep = keep_bits; e.geff = reinterpret_cast<float*>(ws);
+    e.geff2 = e.geff + (size_t)B * 256 * kTileElems;
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
     if (launch_embed_tiles(e, max_h, max_w, st, "vaa_patch_embed_grad_gather_multi") != VAA_OK) return VAA_E_LAUNCH;
@@ -1151,6 +1164,6 @@ extern "C" int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, co
     a.g = nullptr; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff;
+    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr;
     return launch_scatter_multi<true>(a, max_h, max_w, st, "vaa_patch_embed_grad_gather_multi");
 }

@@ -43,7 +43,8 @@ def test_sizes_and_argument_errors_without_gpu():
     # K2': packed weights = 37 column blocks x 16 columns (588 + 4 of padding) x D; towers must be multiples of 64 wide
     assert L.vaa_patch_embed_packed_elems(1024) == 592 * 1024 and L.vaa_patch_embed_packed_elems(96) == 0 and L.vaa_patch_embed_packed_elems(0) == 0
     assert L.vaa_patch_embed_pack_weights(None, 1024, None, None) == -1 and b"null pointer" in L.vaa_last_error()
-    assert L.vaa_patch_embed_grad_ws_bytes(64, 50, 50) == L.vaa_patch_grad_ws_bytes(64, 50, 50) + 64 * 256 * 588 * 4 + 256
+    assert L.vaa_patch_embed_grad_ws_bytes(64, 50, 50) == L.vaa_patch_grad_ws_bytes(64, 50, 50) + 2 * 64 * 256 * 588 * 4 + 256  # partials + a tile-gradient buffer per tower
+    assert L.vaa_patch_embed_grad_multi_ws_bytes(4) == 2 * 4 * 256 * 588 * 4 + 256
     rc = L.vaa_patch_apply_fwd(None, None, None, None, 1, 50, 50, 1, 0, _lib.f32x([0] * 6), _lib.f32x([1] * 6), None, None, None)
     assert rc == -1 and b"null pointer" in L.vaa_last_error()
     rc = L.vaa_patch_update(None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-6, 1, 0.0, 1.0, None, None)
