@@ -943,6 +943,30 @@ def test_patch_embed_grad_gather_multi_vs_oracle(ops):
     assert np.abs(unf - want).max() <= 3e-6 * np.abs(want).max()
 
 
+def test_patch_embed_tile_kernel_tower_split_matches_unsplit(ops):
+    """Small batches run the tile kernel with one tower per workgroup and let the gather add the two towers' tile gradients; larger ones
+    keep both towers in one workgroup. Same fp32 add either way: the per-image gradients of the same 8 images agree to the last bits
+    whether they are a batch of 8 (split) or the head of a batch of 48 (unsplit) — not bitwise, only because the gather cuts the patch into a
+    different number of row bands for the two batch sizes (each band rounds to its own 2^-30 fixed-point quantum)."""
+    Bs, Bl, D0, D1 = 8, 48, 128, 192
+    rs = np.random.RandomState(41)
+    imgs = synthetic.synth_images(9, Bl, "noise")
+    sizes = np.full((Bl, 2), 50, np.int32)
+    pdesc_n, total = ops.make_pdesc(sizes)
+    packed = _t(rs.rand(total).astype(np.float32))
+    xy_n, th_n = _random_case(rs, Bl, 50, 50)
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    dy = [(torch.randn(Bl, 256, D, device=DEV, generator=gen) * 0.1).to(torch.bfloat16) for D in (D0, D1)]
+    wp = [ops.pack_embed_weights((torch.randn(588, D, device=DEV, generator=gen) * 0.05).to(torch.bfloat16)) for D in (D0, D1)]
+    pdesc, xy, th = _t(pdesc_n), _t(xy_n, torch.int32), _t(th_n.reshape(-1, 6))
+    _, keep = ops.patch_apply_fwd_multi(_t(imgs), packed, pdesc, (50, 50), xy, th, True, 0)
+    big = ops.patch_embed_grad_gather_multi(dy[0], dy[1], wp[0], wp[1], packed, pdesc, (50, 50), xy, th, keep, True)
+    n8 = 8 * 3 * 50 * 50
+    small = ops.patch_embed_grad_gather_multi(dy[0][:Bs].contiguous(), dy[1][:Bs].contiguous(), wp[0], wp[1], packed[:n8].contiguous(), pdesc[:Bs].contiguous(),
+                                              (50, 50), xy[:Bs].contiguous(), th[:Bs].contiguous(), keep[:Bs].contiguous(), True)
+    assert float((small - big[:n8]).abs().max()) <= 2e-7 * float(big[:n8].abs().max()) and float(small.abs().max()) > 0
+
+
 def test_patch_embed_pack_weights_layout_and_errors(ops):
     """vaa_patch_embed_pack_weights writes the layout include/vaa.h / vaa_patch_grad.hip document:
     packed[(((nb*nchunk + kc)*2 + h)*64 + lane)*8 + e] = W^T[nb*16 + (lane & 15)][kc*64 + (lane >> 4)*16 + h*8 + e], zero for columns >= 588."""
