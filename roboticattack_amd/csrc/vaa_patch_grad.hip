@@ -893,6 +893,7 @@ constexpr int kEmbedFastThreads = VAA_EMBED_WAVES * 64;
 constexpr int kEmbedFastCols = VAA_EMBED_WAVES * 2;   // column blocks per workgroup (two per wave)
 constexpr int kEmbedStageMax = ((64 * 1160 / 8 + kEmbedFastThreads - 1) / kEmbedFastThreads + 1) / 2 * 2;  // 16-byte chunks a thread stages per tower (even)
 
+template <bool SPLIT>  // SPLIT: one tower per workgroup (blockIdx.z), its tile gradients into geff / geff2; else both towers, summed
 __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kernel(EmbedArgs a, int nch) {
     extern __shared__ __align__(16) unsigned char embed_smem[];
     uint16_t* sA = reinterpret_cast<uint16_t*>(embed_smem);
@@ -934,8 +935,10 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     for (int mg = blockIdx.y; mg * 64 < M; mg += gridDim.y) {  // 64-tile row groups: spread over grid.y when the patch can cover more
         const int rows = min(64, M - mg * 64), nq = (rows + 15) >> 4;  // workgroup-uniform
         float res[2][4][4];  // [column block][row block][r]: tower 0's scaled contribution, then + tower 1's
-        const int t_lo = a.tower_split ? (int)blockIdx.z : 0, t_hi = a.tower_split ? t_lo + 1 : 2;
-        for (int tower = t_lo; tower < t_hi; ++tower) {
+        const int t_lo = SPLIT ? (int)blockIdx.z : 0;
+#pragma unroll
+        for (int tt = 0; tt < (SPLIT ? 1 : 2); ++tt) {
+            const int tower = SPLIT ? t_lo : tt;
             const int D = tower ? a.D1 : a.D0, SA = D + 8, cpr = D >> 3;  // 16-byte chunks per row
             const uint16_t* dy = tower ? a.dy1 : a.dy0;
             const int nchunks = nq * 16 * cpr;
@@ -1029,11 +1032,13 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
         // while twice the workgroups still fit one residency wave of the chip, a workgroup takes ONE tower (grid.z): its chain halves
         // (bs=8: tile kernel 21 -> 12 us); the gather adds the two towers' tile gradients — the very fp32 add the unsplit kernel does
         e.tower_split = (ny == 1 && e.geff2 && (long)((B + 7) / 8 * 8) * nch * 2 <= 256) ? 1 : 0;
-        if (hipFuncSetAttribute((const void*)embed_dgrad_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast) != hipSuccess) {
+        const void* fn = e.tower_split ? (const void*)embed_dgrad_tiles_lds_kernel<true> : (const void*)embed_dgrad_tiles_lds_kernel<false>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast) != hipSuccess) {
             set_error("%s: hipFuncSetAttribute failed", who);
             return VAA_E_LAUNCH;
         }
-        hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, e.tower_split ? 2u : 1u), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
+        if (e.tower_split) hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel<true>, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, 2), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
+        else hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel<false>, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, 1), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
     } else {  // wide towers: fragments straight from global memory
         const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
         hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedThreads), 0, st, e, nch);
