@@ -45,6 +45,10 @@ def test_sizes_and_argument_errors_without_gpu():
     assert L.vaa_patch_embed_pack_weights(None, 1024, None, None) == -1 and b"null pointer" in L.vaa_last_error()
     assert L.vaa_patch_embed_grad_ws_bytes(64, 50, 50) == L.vaa_patch_grad_ws_bytes(64, 50, 50) + 2 * 64 * 256 * 588 * 4 + 256  # partials + a tile-gradient buffer per tower
     assert L.vaa_patch_embed_grad_multi_ws_bytes(4) == 2 * 4 * 256 * 588 * 4 + 256
+    # empty batches return before anything is validated or launched
+    assert L.vaa_patch_embed_grad_gather_multi(None, 64, None, 64, None, None, None, None, None, None, None, 0, 50, 50, 1, 0, _lib.f32x([1] * 6), 1, None, None, 0, None) == 0
+    assert L.vaa_patch_grad_gather_multi(None, None, None, None, None, None, 0, 50, 50, 1, 0, _lib.f32x([1] * 6), None, None) == 0
+    assert L.vaa_patch_embed_grad_gather_multi(None, 64, None, 64, None, None, None, None, None, None, None, 2, 50, 50, 1, 0, _lib.f32x([1] * 6), 1, None, None, 0, None) == -1
     rc = L.vaa_patch_apply_fwd(None, None, None, None, 1, 50, 50, 1, 0, _lib.f32x([0] * 6), _lib.f32x([1] * 6), None, None, None)
     assert rc == -1 and b"null pointer" in L.vaa_last_error()
     rc = L.vaa_patch_update(None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-6, 1, 0.0, 1.0, None, None)
