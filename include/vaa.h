@@ -93,6 +93,10 @@ int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, const int32_t
  *   std6     host [6]
  *   gpatch   dev  [3,ph,pw] float32, overwritten with dL/d patch (sum over the B images)
  *   ws       dev  scratch of at least vaa_patch_grad_ws_bytes(B,ph,pw) bytes (contents undefined on entry and exit)
+ * Numerics: every bilinear contribution fl(G*w) is accumulated as an integer (quantum 2^-30 of the largest |G| a workgroup meets), the
+ * partial tiles are added in a fixed order: the same arguments give the same bits, for every patch size up to 224x224 (no global or
+ * floating-point atomics); the result is the exact sum of the reference's fp32 products rounded once. A non-finite upstream value makes
+ * (at least) the patch rows it touches NaN.
  */
 size_t vaa_patch_grad_ws_bytes(int B, int ph, int pw);
 int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* patch, const int32_t* xy, const float* theta,
