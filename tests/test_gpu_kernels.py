@@ -732,6 +732,38 @@ def test_k3_rows_path_vs_oracle(ops, mode, maskidx, dtype, B):
         assert np.allclose(sc3.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5)
 
 
+@pytest.mark.parametrize("mode", ["UADA", "UADA_DDP"])
+def test_k3_rows_path_wide_vocabulary(ops, mode):
+    """A vocabulary beyond 32,768 columns takes the 512-thread instantiation of the row kernels (OpenVLA's 32,064 takes the 256-thread
+    one): same checks against the C oracle."""
+    from roboticattack_amd.labels import mask_labels
+
+    B, V = 3, 40064
+    rs = np.random.RandomState(5)
+    _, labels, _ = synthetic.synth_text_batch(91, B)
+    labels = mask_labels(labels, [0, 3])
+    L = labels.shape[1]
+    rows = _rows(labels.numpy())
+    R = len(rows)
+    rb, rp = np.array([r[0] for r in rows]), np.array([r[1] for r in rows])
+    z = (rs.standard_normal((R, V)) * 2).astype(np.float32)
+    z[:, 31744:32000] += (rs.standard_normal((R, 256)) * 3).astype(np.float32)
+    z[::2, 39000] = 35.0
+    full = torch.zeros((B, 256 + L, V), dtype=torch.float32)
+    full[torch.from_numpy(rb), torch.from_numpy(rp)] = torch.from_numpy(z)
+    omode = {"UADA": c_oracle.MODE_UADA, "UADA_DDP": c_oracle.MODE_UADA_DDP}[mode]
+    kmode = {"UADA": ops.LOSS_UADA, "UADA_DDP": ops.LOSS_UADA_DDP}[mode]
+    so, go = c_oracle.loss(full.numpy(), labels.numpy(), omode, w=5.0)
+    gor = go[rb, rp]
+    rm = ops.LossRowMap(labels.to(DEV))
+    sc, pred, pred_full, g = ops.loss_rows_fwd_bwd(torch.from_numpy(z).to(DEV), rm, kmode, w=5.0, grad_kind=ops.GRAD_FULL)
+    assert np.allclose(sc.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5)
+    assert np.abs(g.float().cpu().numpy() - gor).max() <= 2e-4 * max(np.abs(gor).max(), 1e-30)
+    pf = pred_full.cpu().numpy().reshape(B, L - 1)
+    for i, (b, p) in enumerate(rows):
+        assert pf[b, p - 256] == int(z[i].argmax())
+
+
 def test_head_loss_rows_matches_generic_head_backward(ops):
     """LM head + loss on the labelled rows with the backward contracting over the 256 action columns (UADA_DDP / UPA)
     equals the generic path (full [R,V] gradient @ W) to bf16 GEMM rounding; CE modes take the full-row route inside the same op."""

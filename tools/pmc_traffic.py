@@ -76,8 +76,8 @@ def main():
     ops = {"K1_patch_apply_fwd": ("patch_apply_fwd_kernel",),
            "K2_patch_grad_gather": ("patch_grad_scatter_kernel<3, false, false", "patch_grad_reduce_kernel|30208"),
            "K2_patch_embed_grad_gather": ("embed_dgrad_tiles", "patch_grad_scatter_kernel<3, true, false", "patch_grad_reduce_kernel|30208"),
-           "K3_loss_rows_fwd_bwd": ("rows_stats_kernel", "rows_finish_kernel<unsigned short>|512"),        # UADA_DDP: gradient slice, one finishing workgroup
-           "K3_full_rows_fwd_bwd": ("rows_stats_kernel", "rows_finish_kernel<unsigned short>|131072"),      # UADA: full-row gradient, R x split workgroups
+           "K3_loss_rows_fwd_bwd": ("rows_stats_kernel", "rows_finish_kernel<unsigned short, 256>|256"),        # UADA_DDP: gradient slice, one finishing workgroup
+           "K3_full_rows_fwd_bwd": ("rows_stats_kernel", "rows_finish_kernel<unsigned short, 256>|131072"),      # UADA: full-row gradient, R x split workgroups
            "K4_patch_update": ("patch_update_kernel",)}
     # a kernel that belongs to two ops (reduce: K2 and K2'; stats: both K3 modes) ran once per op call, so its per-launch mean is counted once in each
     out["ops"] = {}
