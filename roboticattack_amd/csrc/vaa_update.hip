@@ -23,15 +23,55 @@ struct UpdArgs {
     float lr, b1, b2, eps, step_size, one_m_b1, one_m_b2, l1_clip, grad_scale;
 };
 
+constexpr int kUpdRegs = 8;  // elements a thread keeps in registers: patches up to 8,192 elements (3x50x50 = 7,500) make ONE memory round trip
+
+__device__ __forceinline__ float update_one(const UpdArgs& a, float g, float p, float& m, float& v) {
+    if (a.mode == VAA_OPT_ADAMW_HF) {
+        m = __builtin_fmaf(g, a.one_m_b1, m * a.b1);      // exp_avg.mul_(b1).add_(g, alpha=1-b1)
+        v = v * a.b2 + (a.one_m_b2 * g) * g;              // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
+        const float denom = sqrtf(v) + a.eps;             // v.sqrt().add_(eps)
+        p = p + ((-a.step_size) * m) / denom;             // p.addcdiv_(m, denom, value=-step_size)
+    } else {
+        const float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+        p = p - a.lr * sg;
+    }
+    return fminf(1.0f, fmaxf(0.0f, p));                   // patch.data.clamp(0, 1)
+}
+
+// SMALL: n <= 1024 * kUpdRegs — gradient, patch and both moments are requested at once and stay in registers across the statistics, so the
+// op is one load latency + one block reduction + the stores (7.2 -> 5.x us); larger patches re-read the gradient after the reduction.
+template <bool SMALL>
 __global__ __launch_bounds__(1024) void patch_update_kernel(UpdArgs a) {
     __shared__ double sh_abs[16], sh_sum[16];
     __shared__ float coef_sh;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool adam = a.mode == VAA_OPT_ADAMW_HF;
+    float gq[kUpdRegs], pq[kUpdRegs], mq[kUpdRegs], vq[kUpdRegs];
     double sa = 0.0, ss = 0.0;
-    for (int i = tid; i < a.n; i += 1024) {
-        const float g = a.g[i] * a.grad_scale;
-        sa += fabs((double)g);
-        ss += (double)g;
+    if (SMALL) {
+#pragma unroll
+        for (int e = 0; e < kUpdRegs; ++e) {
+            const int i = tid + e * 1024;
+            gq[e] = 0.0f; pq[e] = 0.0f; mq[e] = 0.0f; vq[e] = 0.0f;
+            if (i < a.n) {
+                gq[e] = a.g[i]; pq[e] = a.patch[i];
+                if (adam) { mq[e] = a.m[i]; vq[e] = a.v[i]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < kUpdRegs; ++e) {  // the same increasing-index order per thread as the streaming form below
+            if (tid + e * 1024 < a.n) {
+                const float g = gq[e] * a.grad_scale;
+                sa += fabs((double)g);
+                ss += (double)g;
+            }
+        }
+    } else {
+        for (int i = tid; i < a.n; i += 1024) {
+            const float g = a.g[i] * a.grad_scale;
+            sa += fabs((double)g);
+            ss += (double)g;
+        }
     }
     sa = wave_sum(sa);
     ss = wave_sum(ss);
@@ -50,21 +90,26 @@ __global__ __launch_bounds__(1024) void patch_update_kernel(UpdArgs a) {
     }
     __syncthreads();
     const float coef = coef_sh;
-    for (int i = tid; i < a.n; i += 1024) {
-        const float g = a.g[i] * a.grad_scale * coef;
-        float p = a.patch[i];
-        if (a.mode == VAA_OPT_ADAMW_HF) {
-            const float m = __builtin_fmaf(g, a.one_m_b1, a.m[i] * a.b1);   // exp_avg.mul_(b1).add_(g, alpha=1-b1)
-            const float v = a.v[i] * a.b2 + (a.one_m_b2 * g) * g;           // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
-            a.m[i] = m;
-            a.v[i] = v;
-            const float denom = sqrtf(v) + a.eps;                          // v.sqrt().add_(eps)
-            p = p + ((-a.step_size) * m) / denom;                          // p.addcdiv_(m, denom, value=-step_size)
-        } else {
-            const float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
-            p = p - a.lr * sg;
+    if (SMALL) {
+#pragma unroll
+        for (int e = 0; e < kUpdRegs; ++e) {
+            const int i = tid + e * 1024;
+            if (i < a.n) {
+                const float g = gq[e] * a.grad_scale * coef;
+                float m = mq[e], v = vq[e];
+                const float p = update_one(a, g, pq[e], m, v);
+                if (adam) { a.m[i] = m; a.v[i] = v; }
+                a.patch[i] = p;
+            }
         }
-        a.patch[i] = fminf(1.0f, fmaxf(0.0f, p));                          // patch.data.clamp(0, 1)
+    } else {
+        for (int i = tid; i < a.n; i += 1024) {
+            const float g = a.g[i] * a.grad_scale * coef;
+            float m = adam ? a.m[i] : 0.0f, v = adam ? a.v[i] : 0.0f;
+            const float p = update_one(a, g, a.patch[i], m, v);
+            if (adam) { a.m[i] = m; a.v[i] = v; }
+            a.patch[i] = p;
+        }
     }
 }
 
@@ -89,6 +134,7 @@ extern "C" int vaa_patch_update(float* patch, const float* g, float* m, float* v
     a.one_m_b1 = (float)(1.0 - b1);
     a.one_m_b2 = (float)(1.0 - b2);
     a.step_size = (mode == VAA_OPT_ADAMW_HF) ? (float)((double)lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step))) : 0.0f;
-    hipLaunchKernelGGL(patch_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    if (n <= 1024 * kUpdRegs) hipLaunchKernelGGL(patch_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(patch_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     return check_launch("vaa_patch_update");
 }
