@@ -69,3 +69,24 @@ def test_two_rank_gloo(tmp_path):
     assert np.abs(r0["mean_grad"] - r0["full"]).max() <= 2e-6 * np.abs(r0["full"]).max()  # N ranks == 1 rank with N x batch
     assert np.allclose(r0["s"], [3.0, 4.0, 3.0, 8.0]) and np.array_equal(r0["s"], r1["s"])  # fused scalars (sums)
     assert r0["mx"] == r1["mx"] == 1.0 and r0["av"] == r1["av"] == 0.5
+
+
+def test_local_device_follows_local_rank(monkeypatch):
+    """dist.local_device(): cuda:LOCAL_RANK, wrapping around the visible GPUs only in the gloo test mode; the CPU when there is no GPU."""
+    import torch
+
+    from roboticattack_amd import dist as vdist
+
+    monkeypatch.setenv("RANK", "5")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert vdist.env_rank_world() == (5, 8, 5)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    assert vdist.local_device() == torch.device("cpu")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.delenv("VAA_DIST_BACKEND", raising=False)
+    assert vdist.local_device() == torch.device("cuda:5")  # one process per GPU: no silent wrap-around in production
+    monkeypatch.setenv("VAA_DIST_BACKEND", "gloo")
+    assert vdist.local_device() == torch.device("cuda:1")
+
