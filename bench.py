@@ -175,6 +175,11 @@ def cpu_baseline(bs, patch_shape, budget_s=25.0):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON record: libraries that print banners to the process's stdout (RCCL / gloo at init, MIOpen, ...)
+    # are sent to stderr for the duration of the run; the original stdout is restored for the record
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if args.gpus != world and world == 1 and args.gpus > 1:
         print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1 here)", file=sys.stderr)
@@ -376,7 +381,11 @@ def main():
         "peak_mem_GiB": peak_mem, "loss_finite": finite,
     }
     line.update(extra)
-    print(json.dumps(line))
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    os.close(stdout_fd)
+    print(json.dumps(line), flush=True)
+    os.dup2(2, 1)  # whatever the teardown prints goes to stderr as well
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
