@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--model", type=str, default="openvla-7b", choices=["openvla-7b", "tiny", "surrogate"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-suite", action="store_true")
+    ap.add_argument("--no-per-rank", action="store_true", help="skip the bs=8 / bs=4 per-rank step block of the N=1 record")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host CPU work for cpu_baseline")
     return ap.parse_args()
 
@@ -173,25 +174,130 @@ def cpu_baseline(bs, patch_shape, budget_s=25.0):
     }
 
 
+class StepRunner:
+    """One rank's attack-loop state for a per-rank batch of B images: the inner step of attack/uada_ddp.py on synthetic frames resident in HBM."""
+
+    def __init__(self, model, dev, B, patch_shape, rank, world):
+        from roboticattack_amd import dist as vdist
+        from roboticattack_amd import ops, synthetic
+        from roboticattack_amd.labels import mask_labels
+        from roboticattack_amd.optim import PatchOptimizer
+        from roboticattack_amd.transform import RandomPatchTransform
+
+        self.ops, self.model, self.dev, self.B, self.world = ops, model, dev, B, world
+        self.use_rows = hasattr(model, "forward_rows")
+        self.tr = RandomPatchTransform(dev, False)
+        if self.use_rows and hasattr(model, "patch_embed_params") and os.environ.get("VAA_FUSED_EMBED_GRAD", "1") != "0":
+            self.tr.embed_with = model  # K2' (SURVEY.md 8f-3), like the attack loops: the dense pixel gradient is never materialised; =0 for plain K2
+        self.mean = [torch.tensor([0.484375, 0.455078125, 0.40625]), torch.tensor([0.5, 0.5, 0.5])]
+        self.std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
+        self.batch = synthetic.synth_batch(1234 + rank, B, "noise", as_pil=False)
+        self.img = self.tr.stage_images(torch.from_numpy(self.batch["pixel_values"]))
+        self.input_ids = self.batch["input_ids"].to(dev)
+        self.attn = self.batch["attention_mask"].to(dev)
+        self.labels = mask_labels(self.batch["labels"].clone(), [0]).to(dev)
+        torch.manual_seed(42)  # UADA_wrapper_ddp.py:53: every rank seeds 42
+        patch = torch.rand(patch_shape).to(dev) if rank == 0 else torch.empty(patch_shape).to(dev)
+        vdist.broadcast_patch(patch)
+        self.patch = patch.requires_grad_(True)
+        self.opt = PatchOptimizer(self.patch, 1e-3, "adamW")
+        self.sync = vdist.PatchGradSync(self.patch.numel(), 4, dev)
+        self.inv_world = 1.0 / world
+        self.scal = torch.zeros(8, device=dev)
+        self.row_index = model.label_row_index(self.labels) if self.use_rows else None  # once per outer iteration, as the attack loops do
+        self.row_map = ops.LossRowMap(self.labels) if self.use_rows else None               # K3's device row map, same lifetime
+        self.pack = model.make_pack(self.attn) if hasattr(model, "make_pack") else None
+        self.pick = torch.tensor([1, 2, 7], dtype=torch.int64, device=dev)
+        self.R = int((self.labels[:, 1:] != -100).sum())
+
+    def step(self):  # attack/uada_ddp.py inner step
+        ops, model = self.ops, self.model
+        self.opt.zero_grad()
+        pix = self.tr.apply_random_patch_batch(self.img, self.patch, self.mean, self.std, geometry=True)  # host RNG draws + K1
+        if self.use_rows:
+            pe = pix if isinstance(pix, ops.PatchEmbeds) else None
+            h = model.hidden_rows(self.input_ids, None if pe is not None else pix, self.row_index, patch_embeds=pe, pack=self.pack)
+            total, scalars, _, _ = ops.HeadLossRows.apply(h, model.lm_head.weight, self.row_map, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0)  # LM head + K3
+        else:
+            out = model(input_ids=self.input_ids, attention_mask=self.attn, pixel_values=pix, labels=None)
+            total, scalars, _, _ = ops.DiscrepancyLoss.apply(out.logits.contiguous(), self.labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
+        total.backward()  # ... -> K2 (or K2' fed by the patch-embed output gradients)
+        g_sum, _ = self.sync.allreduce_step(self.patch.grad, scalars, self.pick)  # [grad | CE, MSE, UAD, sum(grad)]: one all-reduce per step
+        self.opt.step(grad=g_sum.view_as(self.patch), grad_scale=self.inv_world)  # K4
+        self.scal.copy_(scalars)
+
+
+def timed_steps(runner, steps, warmup, world, dev, profile=False):
+    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; returns the max over ranks (s) and host costs."""
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        runner.step()
+    barrier()
+    if profile:
+        runner.ops.prof_start(64 * steps)  # per-dispatch start/stop events on every hand-written kernel of the timed region
+    t0 = time.perf_counter()
+    host_enqueue, cpu0 = 0.0, time.thread_time()
+    for _ in range(steps):
+        th0 = time.perf_counter()
+        runner.step()
+        host_enqueue += time.perf_counter() - th0  # wall time the host spends inside step() (no explicit sync inside a step)
+    host_cpu = time.thread_time() - cpu0  # CPU time of the launching thread: the real host cost (enqueue wall time also contains back-pressure waits)
+    barrier()
+    dt = time.perf_counter() - t0
+    recs = runner.ops.prof_collect() if profile else []
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), host_enqueue / steps, host_cpu / steps, recs
+
+
+# kernel name (substring of the launch site's name) -> operator of the hot path
+KERNEL_OPS = (("patch_apply_fwd_kernel", "K1"), ("embed_dgrad_tiles", "K2e"), ("patch_grad_scatter_kernel", "K2"), ("patch_grad_reduce_kernel", "K2"),
+              ("rows_stats_kernel", "K3"), ("rows_finish_kernel", "K3"), ("loss_stats_kernel", "K3"), ("loss_grad_kernel", "K3"), ("step_epilogue_kernel", "EPI"), ("patch_update_kernel", "K4"),
+              ("patch_resize", "K0"))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the driver's N > 1 form passes
+    the rendezvous itself and never gets here). With fewer visible GPUs than ranks the run falls back to gloo with ranks sharing GPUs —
+    a functional run (tests), flagged in the record, not a scaling measurement."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    if torch.cuda.device_count() < args.gpus and not env.get("VAA_DIST_BACKEND"):
+        print(f"bench.py: {torch.cuda.device_count()} GPU(s) visible for --gpus {args.gpus}: ranks share GPUs over gloo (functional run only)", file=sys.stderr)
+        env["VAA_DIST_BACKEND"] = "gloo"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
     # stdout carries ONE line, the JSON record: libraries that print banners to the process's stdout (RCCL / gloo at init, MIOpen, ...)
     # are sent to stderr for the duration of the run; the original stdout is restored for the record
     sys.stdout.flush()
     stdout_fd = os.dup(1)
     os.dup2(2, 1)
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1 here)", file=sys.stderr)
-        sys.exit(2)
     import torch.distributed as dist
 
     from roboticattack_amd import dist as vdist
-    from roboticattack_amd import ops, synthetic
+    from roboticattack_amd import ops
     from roboticattack_amd.benchmarks import HBM_PEAK_GBS, algo_bytes, k2_sweep, kernel_suite
-    from roboticattack_amd.labels import mask_labels
-    from roboticattack_amd.optim import PatchOptimizer
-    from roboticattack_amd.transform import RandomPatchTransform
 
     ops.device_check()
     dev = vdist.local_device()
@@ -205,59 +311,12 @@ def main():
     patch_shape = [int(v) for v in args.patch.split(",")]
     B = args.bs
     model, model_desc = build_model(args.model, dev)
-    use_rows = hasattr(model, "forward_rows")
-    tr = RandomPatchTransform(dev, False)
-    if use_rows and hasattr(model, "patch_embed_params") and os.environ.get("VAA_FUSED_EMBED_GRAD", "1") != "0":
-        tr.embed_with = model  # K2' (SURVEY.md 8f-3), like the attack loops: the dense pixel gradient is never materialised; =0 for plain K2
-    mean = [torch.tensor([0.484375, 0.455078125, 0.40625]), torch.tensor([0.5, 0.5, 0.5])]
-    std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
-
-    batch = synthetic.synth_batch(1234 + rank, B, "noise", as_pil=False)
-    img = tr.stage_images(torch.from_numpy(batch["pixel_values"]))
-    input_ids = batch["input_ids"].to(dev)
-    attn = batch["attention_mask"].to(dev)
-    labels = mask_labels(batch["labels"].clone(), [0]).to(dev)
-    if rank == 0:
-        patch = torch.rand(patch_shape).to(dev)
-    else:
-        patch = torch.empty(patch_shape).to(dev)
-    vdist.broadcast_patch(patch)
-    patch.requires_grad_(True)
-    opt = PatchOptimizer(patch, 1e-3, "adamW")
-    sync = vdist.PatchGradSync(patch.numel(), 4, dev)
-    inv_world = 1.0 / world
-    scal = torch.zeros(8, device=dev)
-    row_index = model.label_row_index(labels) if use_rows else None  # once per outer iteration, as the attack loops do
-    row_map = ops.LossRowMap(labels) if use_rows else None               # K3's device row map, same lifetime
-    pack = model.make_pack(attn) if hasattr(model, "make_pack") else None  # padding rows of the right-padded prompts are never computed
-    pick = torch.tensor([1, 2, 7], dtype=torch.int64, device=dev)
-
-    def step():  # attack/uada_ddp.py inner step
-        opt.zero_grad()
-        pix = tr.apply_random_patch_batch(img, patch, mean, std, geometry=True)  # host RNG draws + K1
-        if ops.TIMER is not None:  # an EMPTY start/stop bracket on the same stream: what the event pair itself adds to every timed op
-            with ops._timed("_empty_bracket"):
-                pass
-        if use_rows:
-            pe = pix if isinstance(pix, ops.PatchEmbeds) else None
-            h = model.hidden_rows(input_ids, None if pe is not None else pix, row_index, patch_embeds=pe, pack=pack)
-            total, scalars, _, _ = ops.HeadLossRows.apply(h, model.lm_head.weight, row_map, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0)  # LM head + K3
-        else:
-            out = model(input_ids=input_ids, attention_mask=attn, pixel_values=pix, labels=None)
-            total, scalars, _, _ = ops.DiscrepancyLoss.apply(out.logits.contiguous(), labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
-        total.backward()  # ... -> K2 (or K2' fed by the patch-embed output gradients)
-        g_sum, _ = sync.allreduce_step(patch.grad, scalars, pick)  # [grad | CE, MSE, UAD, sum(grad)]: one all-reduce per step
-        opt.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4
-        scal.copy_(scalars)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    runner = StepRunner(model, dev, B, patch_shape, rank, world)
+    use_rows, tr, R = runner.use_rows, runner.tr, runner.R
 
     # PCIe leg, outside the timed region: staging the batch's frames (host list of uint8 HWC arrays -> HBM), done once per
     # OUTER iteration by the attack loops; the reference re-does ToTensor + H2D for every image on every inner step.
-    host_frames = [np.ascontiguousarray(f) for f in batch["pixel_values"]]
+    host_frames = [np.ascontiguousarray(f) for f in runner.batch["pixel_values"]]
     tr.stage_images(host_frames)
     torch.cuda.synchronize()
     t_stage = time.perf_counter()
@@ -266,26 +325,39 @@ def main():
     torch.cuda.synchronize()
     stage_ms = (time.perf_counter() - t_stage) * 1e3
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ops.TIMER = []
-    t0 = time.perf_counter()
-    host_enqueue, cpu0 = 0.0, time.thread_time()
-    for _ in range(args.steps):
-        th0 = time.perf_counter()
-        step()
-        host_enqueue += time.perf_counter() - th0  # wall time the host spends inside step() (no explicit sync inside a step)
-    host_cpu = time.thread_time() - cpu0  # CPU time of the launching thread: the real host cost (enqueue wall time also contains back-pressure waits)
-    barrier()
-    dt = time.perf_counter() - t0
-    timer, ops.TIMER = ops.TIMER, None
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    # ---- the timed region: weak scaling, bs = args.bs PER RANK (reference semantics, UADA_ddp.py:158) ----
+    dt, host_enqueue, host_cpu, recs = timed_steps(runner, args.steps, args.warmup, world, dev, profile=True)
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
-    finite = bool(torch.isfinite(scal).all())
+    finite = bool(torch.isfinite(runner.scal).all())
+
+    # ---- strong scaling (BASELINE config 3: "bs=64 over N GPUs"): the same global batch split over the ranks ----
+    strong = None
+    if world > 1:
+        bs_s = max(1, B // world)
+        r_s = StepRunner(model, dev, bs_s, patch_shape, rank, world)
+        dt_s, enq_s, cpu_s, _ = timed_steps(r_s, args.steps, args.warmup, world, dev)
+        strong = {"per_rank_bs": bs_s, "global_batch": bs_s * world, "ms_per_step": dt_s / args.steps * 1e3, "steps_per_s": args.steps / dt_s,
+                  "images_per_s": bs_s * world * args.steps / dt_s, "host_cpu_ms_per_step": cpu_s * 1e3,
+                  "note": "global batch fixed at the N=1 workload's bs, split evenly over the ranks (BASELINE config 3); timed like the weak region: "
+                          "W warm-up steps, K steps between barrier + synchronize, max over ranks"}
+        del r_s
+
+    # ---- the per-rank step of the strong-scaling configs on ONE GPU (N=1 only): what each of 8 ranks runs in configs 3/4 (bs=8) and 5 (bs=4) ----
+    per_rank = None
+    if world == 1 and not args.no_per_rank and args.model == "openvla-7b":
+        per_rank = {}
+        ips64 = B * args.steps / dt
+        for b in (8, 4):
+            rb = StepRunner(model, dev, b, patch_shape, rank, world)
+            dt_b, enq_b, cpu_b, _ = timed_steps(rb, max(args.steps, 10), max(args.warmup, 3), world, dev)
+            n_b = max(args.steps, 10)
+            per_rank[f"bs{b}"] = {"ms_per_step": dt_b / n_b * 1e3, "images_per_s": b * n_b / dt_b, "images_per_s_vs_bs%d" % B: (b * n_b / dt_b) / ips64,
+                                  "projected_speedup_%d_ranks_before_comm" % (B // b): (B // b) * (b * n_b / dt_b) / ips64,
+                                  "host_cpu_ms_per_step": cpu_b * 1e3, "host_enqueue_ms_per_step": enq_b * 1e3, "labelled_rows": rb.R}
+            del rb
+        per_rank["note"] = ("full-model step (same code path as the timed region) at the per-rank batches of BASELINE configs 3/4 (64 or 32 images over 8 or 4 "
+                            "ranks -> bs=8) and 5 (32 over 8 -> bs=4), on this one GPU; projected speedup = ranks x images/s at that batch / images/s at "
+                            "bs=%d, i.e. the strong-scaling ceiling before the 30 KB all-reduce" % B)
 
     if rank != 0:
         if world > 1:
@@ -293,52 +365,53 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- per-kernel durations inside the timed region (events on the launch stream) ----
-    R = int((labels[:, 1:] != -100).sum())
+    # ---- per-kernel durations inside the timed region: every dispatch's own begin/end timestamps (vaa_prof_*) ----
     per = {}
-    for name, s, e, info in timer:
-        per.setdefault(name, []).append(s.elapsed_time(e) * 1e-3)
-    kern = {}
-    # means, like rocprofv3's per-kernel average (medians of the same brackets come out ~2 us lower: 13.7-14.3 us for K1, below even the
-    # back-to-back figure, because part of an event pair's cost overlaps with a real kernel's dispatch but not with an empty bracket)
-    empty_us = float(np.mean(per.pop("_empty_bracket"))) * 1e6 if "_empty_bracket" in per else 0.0
+    for name, us in recs:
+        per.setdefault(name, []).append(us)
     esz = 2 if use_rows and args.model == "openvla-7b" else 4
     cfg = getattr(model, "cfg", None)
     embed_width = (cfg.dino.dim + cfg.siglip.dim) if cfg is not None and hasattr(cfg, "dino") else 1024 + 1152  # K2': dY row width of both towers
+    kern, op_us = {}, {}
     for name, ts in per.items():
-        key = "K2e" if name.startswith("K2_patch_embed") else ("K3_slice" if name.startswith("K3_loss_rows") else name[:2])
-        nb = algo_bytes(key, B, patch_shape[1], patch_shape[2], rows=R, esize=esz, embed_width=embed_width)
-        bracket = float(np.mean(ts))
-        mean = max(bracket - empty_us * 1e-6, 1e-9)  # in-step duration of the op: its event bracket minus the empty bracket of the same run
-        kern[name] = {"launches": len(ts), "mean_us": mean * 1e6, "event_bracket_us": bracket * 1e6, "algo_bytes": nb, "achieved_GBs": nb / mean / 1e9,
-                      "frac": nb / mean / 1e9 / HBM_PEAK_GBS}
-    # dominant kernel: most algorithmic bytes (K1, one launch per op -> the event bracket is the kernel); every op is in `roofline_kernels`
-    dom = max(kern, key=lambda k: kern[k]["algo_bytes"]) if kern else None
-    traffic = None
-    tfile = "profiles/traffic_r02.json"  # rocprofv3 --pmc passes of tools/pmc_traffic.py (same kernels, same shapes); NOT measured in this run
-    tpath = os.path.join(ROOT, tfile)
-    tr_ops = json.load(open(tpath)).get("ops", {}) if os.path.exists(tpath) else {}
-    if dom:
-        traffic = tr_ops.get(dom, {}).get("hbm_bytes_per_launch")
-    for name in kern:
-        kern[name]["traffic"] = tr_ops.get(name, {}).get("hbm_bytes_per_launch")
+        op = next((o for sub, o in KERNEL_OPS if sub in name), "other")
+        t = np.asarray(ts)
+        kern[name] = {"op": op, "launches": len(ts), "launches_per_step": len(ts) / args.steps, "mean_us": float(t.mean()), "median_us": float(np.median(t)),
+                      "min_us": float(t.min()), "max_us": float(t.max())}
+        op_us[op] = op_us.get(op, 0.0) + float(t.sum()) / args.steps
+    fused = tr.embed_with is not None
+    if fused and "K2" in op_us:  # the TILED scatter + reduce belong to K2'
+        op_us["K2e"] = op_us.get("K2e", 0.0) + op_us.pop("K2")
+    op_bytes = {"K1": algo_bytes("K1", B, patch_shape[1], patch_shape[2]), "K2": algo_bytes("K2", B, patch_shape[1], patch_shape[2]),
+                "K2e": algo_bytes("K2e", B, patch_shape[1], patch_shape[2], embed_width=embed_width),
+                "K3": algo_bytes("K3_slice" if use_rows else "K3", B, rows=R, esize=esz), "K4": algo_bytes("K4", B, patch_shape[1], patch_shape[2])}
+    hot_ops = {o: {"us_per_step": u, "algo_bytes": op_bytes.get(o), "achieved_GBs": (op_bytes[o] / u / 1e3 if o in op_bytes else None),
+                   "frac": (op_bytes[o] / u / 1e3 / HBM_PEAK_GBS if o in op_bytes else None)} for o, u in op_us.items()}
+    k1name = next((n for n in kern if "patch_apply_fwd_kernel" in n), None)
+    tfile = next((f for f in ("profiles/traffic_r03.json", "profiles/traffic_r02.json") if os.path.exists(os.path.join(ROOT, f))), None)
+    tr_ops = json.load(open(os.path.join(ROOT, tfile))).get("ops", {}) if tfile else {}
     roofline = None
-    if dom:
-        roofline = {"timing": "IN-STEP: one start/stop HIP event pair around the launch on the launching stream inside the timed region, minus the mean of an EMPTY "
-                              "start/stop pair recorded on the same stream in every step (empty_bracket_us: the marker packets and gaps the pair itself adds); "
-                              "agrees with the in-step rocprofv3 average of profiles/r02_bench_kernel_stats.csv", "empty_bracket_us": empty_us, "kernel": dom, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": tfile + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",
-                    "mean_us": kern[dom]["mean_us"], "algo_bytes": kern[dom]["algo_bytes"],
-                    "note": "dominant = the kernel of the hot path (K1-K4) with the most algorithmic bytes "
-                            "(K2' of SURVEY 8f-3 — MFMA tile GEMM + gather — is listed under roofline_kernels / roofline_kernels_standalone as K2e); "
-                            "frac_of_measured_copy_bw = achieved / this box's device-to-device copy rate measured in this run"}
+    if k1name:
+        k1 = kern[k1name]
+        nb = op_bytes["K1"]
+        roofline = {"kernel": "patch_apply_fwd_kernel (K1)", "bound": "hbm", "achieved": nb / k1["mean_us"] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": nb / k1["mean_us"] / 1e3 / HBM_PEAK_GBS, "mean_us": k1["mean_us"], "min_us": k1["min_us"], "samples": k1["launches"],
+                    "algo_bytes": nb, "traffic": tr_ops.get("K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch"),
+                    "traffic_source": (tfile or "none") + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",
+                    "timing": "IN-STEP, per dispatch: every K1 launch of the timed region goes through hipExtLaunchKernel with its own start/stop event pair, "
+                              "which the runtime binds to that dispatch's begin/end timestamps — the quantity rocprofv3 --kernel-trace reports "
+                              "(profiles/r03_bench_kernel_stats.csv is the rocprofv3 summary of the same command); mean over all launches of the timed steps, "
+                              "no marker brackets, no subtraction",
+                    "note": "dominant = the kernel of the hot path with the most algorithmic bytes (48.2 of ~69 MB per step); every hand-written kernel of the "
+                            "timed region is listed in roofline_kernels, per-operator sums in hot_path_ops"}
 
-    extra = {"host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "host_cpu_ms_per_step": host_cpu / args.steps * 1e3,
+    extra = {"host_enqueue_ms_per_step": host_enqueue * 1e3, "host_cpu_ms_per_step": host_cpu * 1e3,
              "host_overhead_note": "host_cpu = CPU time of the launching thread per step (python + HIP launches): what N ranks on one host need N times in parallel; "
                                    "host_enqueue = wall time inside step() without an explicit sync (it also contains waits on a full launch queue / staged H2D copies, "
-                                   "so it scales with the GPU work); the step is GPU-bound while ms_per_step exceeds host_cpu"}
+                                   "so it scales with the GPU work); the step is GPU-bound while ms_per_step exceeds host_cpu",
+             "hot_path_us_per_step": sum(op_us.values()), "hot_path_launches_per_step": sum(k["launches_per_step"] for k in kern.values())}
     if not args.no_kernel_suite:
-        del model
+        del runner, model, tr  # the transform holds the model (embed_with)
         torch.cuda.empty_cache()
         from roboticattack_amd.benchmarks import device_copy_bandwidth, k1_sweep, rank_shapes
 
@@ -350,18 +423,16 @@ def main():
         extra["k2_sweep"] = k2_sweep(device=str(dev))
         extra["k1_sweep"] = k1_sweep(device=str(dev))
         extra["rank_shapes"] = rank_shapes(device=str(dev))
-        if roofline:
-            roofline["measured_device_copy_GBs"] = copy_bw
         ks = extra["roofline_kernels_standalone"]
-        used_k2 = "K2e_patch_embed_grad_gather" if tr.embed_with is not None else "K2_patch_grad_gather"
-        gpu_ops_s = sum(v["mean_us"] for k, v in ks.items() if not k.startswith("K2") or k == used_k2) * 1e-6
+        used_k2 = "K2e_patch_embed_grad_gather" if fused else "K2_patch_grad_gather"
+        gpu_ops_s = sum(v["mean_us"] for k, v in ks.items() if (not k.startswith("K2") or k == used_k2) and k != "K3_full_rows_fwd_bwd") * 1e-6
         extra["gpu_patch_path_steps_per_s"] = 1.0 / gpu_ops_s
-        if roofline and roofline["kernel"] in ks:
-            # headline figures stay the IN-STEP ones; the same kernel launched back to back (hipGraph replays of 10 launches between two
-            # events, same process — what profiles/r02_kbench_kernel_stats.csv shows) is reported next to them
-            k = ks[roofline["kernel"]]
-            roofline.update({"standalone_mean_us": k["mean_us"], "standalone_achieved": k["achieved_GBs"], "standalone_frac": k["achieved_GBs"] / HBM_PEAK_GBS,
-                             "frac_of_measured_copy_bw": roofline["achieved"] / copy_bw, "standalone_frac_of_measured_copy_bw": k["achieved_GBs"] / copy_bw})
+        if roofline:
+            # the same kernel launched back to back (hipGraph replays of 10 launches between two events, same process) next to the in-step figure
+            k = ks["K1_patch_apply_fwd"]
+            roofline.update({"measured_device_copy_GBs": copy_bw, "standalone_mean_us": k["mean_us"], "standalone_achieved": k["achieved_GBs"],
+                             "standalone_frac": k["achieved_GBs"] / HBM_PEAK_GBS, "frac_of_measured_copy_bw": roofline["achieved"] / copy_bw,
+                             "standalone_frac_of_measured_copy_bw": k["achieved_GBs"] / copy_bw})
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # host-CPU leg only at N=1 (rank 0), as the bench contract asks
         cpu = cpu_baseline(B, patch_shape, args.cpu_budget)
@@ -374,10 +445,11 @@ def main():
         "config": {"workload": f"UADA_wrapper_ddp inner step: bs={B} per rank (global {B * world}), patch {args.patch}, geometry=True, maskidx=[0], "
                                f"{model_desc}; frames resident in HBM as u8",
                    "global_batch": B * world, "images_per_s": B * world * args.steps / dt, "parallelism": f"dp{world}",
+                   "backend": (os.environ.get("VAA_DIST_BACKEND") or "nccl (RCCL)") if world > 1 else None,
                    "labelled_rows_per_rank": R, "tunableop_entries_loaded": _tunable_entries(), "lm_head": "labelled rows only" if use_rows else "full logits",
                    "h2d_stage_ms_per_outer_iteration": stage_ms,
                    "pcie_inclusive_value_if_restaged_every_step": world * args.steps / (dt + args.steps * stage_ms * 1e-3)},
-        "roofline": roofline, "roofline_kernels": kern, "cpu_baseline": cpu,
+        "roofline": roofline, "strong_scaling": strong, "per_rank_step": per_rank, "hot_path_ops": hot_ops, "roofline_kernels": kern, "cpu_baseline": cpu,
         "peak_mem_GiB": peak_mem, "loss_finite": finite,
     }
     line.update(extra)

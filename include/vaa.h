@@ -68,6 +68,20 @@ int vaa_version(void);
 int vaa_device_check(void);
 
 /*
+ * Per-dispatch timing of the library's own kernels (measurement aid; no reference counterpart). While armed, every kernel the library
+ * launches is dispatched with its own start/stop event pair bound to THAT dispatch (hipExtLaunchKernel): its elapsed time is the
+ * dispatch's begin-to-end GPU time, the quantity `rocprofv3 --kernel-trace` reports, read inside a running step without marker packets.
+ *   vaa_prof_start(capacity): allocate (once) `capacity` event pairs, drop earlier records, arm; capacity 0 disarms. Dispatches beyond
+ *             the capacity run unprofiled. Do not arm during stream capture.
+ *   vaa_prof_stop(): disarm; returns the number of records.
+ *   vaa_prof_get(i, &name, &usec): waits for record i's dispatch and returns the kernel's name (static string) and duration in us.
+ * Process-wide state behind a mutex; the launching thread arms / disarms between steps.
+ */
+int vaa_prof_start(int capacity);
+int vaa_prof_stop(void);
+int vaa_prof_get(int i, const char** name, float* usec);
+
+/*
  * K1 — replaces RandomPatchTransform.apply_random_patch_batch (appply_random_transform.py:104-136) followed by the
  * caller's `.to(torch.bfloat16)` (UADA.py:142), and paste_patch_fix (:160-188) with mask_mode=VAA_MASK_NE_M100,
  * geometry=0. The random draws (:120-128) stay on the host so the RNG streams match; their results come in as xy/theta.

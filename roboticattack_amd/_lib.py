@@ -49,6 +49,9 @@ EXPORTS = (
     "vaa_loss_rowmap_build",
     "vaa_loss_rows_ws_bytes",
     "vaa_loss_rows_fwd_bwd",
+    "vaa_prof_start",
+    "vaa_prof_stop",
+    "vaa_prof_get",
 )
 
 
@@ -59,8 +62,19 @@ class VaaError(RuntimeError):
 _lib = None
 
 
-def build(verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+def _up_to_date() -> bool:
+    """libvaa_hip.so exists and is newer than every source it is built from."""
+    if not os.path.exists(LIB_PATH):
+        return False
+    t = os.path.getmtime(LIB_PATH)
+    src = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(src, f) for f in os.listdir(src)] + [os.path.join(_HERE, "..", "include", f) for f in ("vaa.h", "vaa_model_ops.h")]
+    return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
+
+
+def build(verbose: bool = False, force: bool = True) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU). force=False skips the compile when the
+    library is newer than its sources (what N ranks racing for a missing library need: one compiles, the others find it done)."""
     import fcntl
     import subprocess
 
@@ -69,6 +83,8 @@ def build(verbose: bool = False) -> str:
     with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
+            if not force and _up_to_date():  # another rank built it while this one waited for the lock
+                return LIB_PATH
             out = subprocess.run(["bash", script], capture_output=True, text=True)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
@@ -84,13 +100,9 @@ def lib() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH) and not os.environ.get("VAA_LIB_PATH") and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
-        import fcntl
-
-        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:  # wait for a build another rank may be running
-            fcntl.flock(lock, fcntl.LOCK_EX)
-            fcntl.flock(lock, fcntl.LOCK_UN)
-        if not os.path.exists(LIB_PATH):
-            build()  # compiling the HIP extension is not a fallback: the product still runs only through libvaa_hip.so
+        # compiling the HIP extension is not a fallback: the product still runs only through libvaa_hip.so. Under torchrun every rank gets
+        # here at once: build() takes the lock and re-checks, so ONE rank compiles and the others return as soon as the library is there
+        build(force=False)
     if not os.path.exists(LIB_PATH):
         raise VaaError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
@@ -154,6 +166,12 @@ def lib() -> C.CDLL:
     L.vaa_patch_update.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp, vp]
     L.vaa_patch_apply_eval.restype = i32
     L.vaa_patch_apply_eval.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.vaa_prof_start.restype = i32
+    L.vaa_prof_start.argtypes = [i32]
+    L.vaa_prof_stop.restype = i32
+    L.vaa_prof_stop.argtypes = []
+    L.vaa_prof_get.restype = i32
+    L.vaa_prof_get.argtypes = [i32, C.POINTER(C.c_char_p), C.POINTER(f32)]
     # optional model-side operators (include/vaa_model_ops.h)
     lng = C.c_long
     L.vaa_model_rope.restype = i32

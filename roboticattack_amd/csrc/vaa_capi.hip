@@ -3,6 +3,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "vaa_common.h"
 
 namespace vaa {
@@ -25,9 +28,72 @@ int check_launch(const char* what) {
     return VAA_OK;
 }
 
+// ---- per-dispatch profiler (vaa_prof_*) ----
+struct ProfRec {
+    hipEvent_t start, stop;
+    const char* name;
+};
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;   // pool of event pairs; the first g_prof_used are recorded
+static int g_prof_used = 0;
+static bool g_prof_armed = false;
+
+bool prof_next(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+    if (!g_prof_armed) return false;  // unlocked fast path: arming/disarming happens between steps, on the launching thread
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_armed || g_prof_used >= (int)g_prof.size()) return false;  // pool exhausted: later dispatches run unprofiled
+    ProfRec& r = g_prof[g_prof_used++];
+    r.name = name;
+    *start = r.start;
+    *stop = r.stop;
+    return true;
+}
+
 }  // namespace vaa
 
 extern "C" {
+
+int vaa_prof_start(int capacity) {
+    using namespace vaa;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (capacity < 0) { set_error("vaa_prof_start: negative capacity"); return VAA_E_INVALID; }
+    while ((int)g_prof.size() < capacity) {
+        ProfRec r;
+        r.name = "";
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
+            set_error("vaa_prof_start: hipEventCreate failed");
+            (void)hipGetLastError();
+            return VAA_E_LAUNCH;
+        }
+        g_prof.push_back(r);
+    }
+    g_prof_used = 0;
+    g_prof_armed = capacity > 0;
+    return VAA_OK;
+}
+
+int vaa_prof_stop(void) {
+    std::lock_guard<std::mutex> lk(vaa::g_prof_mu);
+    vaa::g_prof_armed = false;
+    return vaa::g_prof_used;
+}
+
+int vaa_prof_get(int i, const char** name, float* usec) {
+    using namespace vaa;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (i < 0 || i >= g_prof_used || !usec) { set_error("vaa_prof_get: record %d out of range (%d recorded)", i, g_prof_used); return VAA_E_INVALID; }
+    float ms = 0.0f;
+    hipError_t e = hipEventSynchronize(g_prof[i].stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof[i].start, g_prof[i].stop);
+    if (e != hipSuccess) {
+        set_error("vaa_prof_get: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return VAA_E_LAUNCH;
+    }
+    if (name) *name = g_prof[i].name;
+    *usec = ms * 1000.0f;
+    return VAA_OK;
+}
 
 const char* vaa_last_error(void) { return vaa::g_err; }
 

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/vaa.h"
@@ -20,6 +21,19 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 // vaa_patch_grad.hip: gpatch[e] = sum_p partial[p][e] (p < nparts, e < n) in a fixed order with fp64 accumulation
 int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts, hipStream_t st, const char* who);
+
+// Per-dispatch timing (include/vaa.h: vaa_prof_*): while the profiler is armed every kernel of the library is dispatched through
+// hipExtLaunchKernel with its own start/stop event pair, which the runtime binds to THAT dispatch's begin/end timestamps (the figures
+// rocprofv3 --kernel-trace reports), so a kernel's duration inside a real step is read without bracketing markers.
+bool prof_next(const char* name, hipEvent_t* start, hipEvent_t* stop);
+
+template <typename F, typename... Args>
+inline void launch_k(const char* name, F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    hipEvent_t s, e;
+    if (prof_next(name, &s, &e)) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, s, e, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
+#define VAA_LAUNCH(kernel, grid, block, lds, stream, ...) ::vaa::launch_k(#kernel, kernel, grid, block, lds, stream, __VA_ARGS__)
 
 struct Norm6 {
     float mean[6];

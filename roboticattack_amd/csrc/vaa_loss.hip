@@ -597,14 +597,16 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a) {
     constexpr int nthr = kNA / N;
     float x[N];
     if (has_slice && wv == 0 && lane < nthr) Vec<T>::load(z + kA0 + lane * N, x);
-    const RowMap me = reinterpret_cast<const RowMap*>(a.rowmap + 4)[r];
+    // a caller row count beyond the map's own count (vaa.h: scalars[0] = NaN then) must not index unbuilt map entries
+    RowMap me = {0, 0, -1, 0};
+    if (r < a.rowmap[0]) me = reinterpret_cast<const RowMap*>(a.rowmap + 4)[r];
     const int nact = a.rowmap[1];
 
     // the label's logit (one thread): requested here, behind the row loads, not after the reductions
     float zlab_early = -INFINITY;
     if (tid == 0) {
         const int lv = me.lab / N;
-        if (me.lab >= 0 && lv >= v_lo && lv < v_hi) zlab_early = Vec<T>::get(z + me.lab);
+        if (me.lab >= 0 && me.lab < a.V && lv >= v_lo && lv < v_hi) zlab_early = Vec<T>::get(z + me.lab);
     }
     // ---- max + argmax (lowest index on ties, torch.argmax) ----
     float m = -INFINITY;
@@ -713,6 +715,7 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
     __shared__ double sh[kRowsT / 64][7];
     const RowMap* rm = reinterpret_cast<const RowMap*>(a.rowmap + 4);
     const int Rdev = a.rowmap[0];
+    const int Rn = min(a.R, Rdev);  // rows both the caller and the map know: a mismatch publishes NaN and never leaves the map
     // this workgroup's part of its row: issue the loads before the fold (addresses do not depend on it)
     const bool full_grad = a.grad && !a.grad_slice && (a.mode == VAA_LOSS_UADA || a.mode == VAA_LOSS_CE);
     const bool zero_fill = a.grad && !a.grad_slice && !full_grad;  // FULL storage asked for a slice-only mode: zeros outside the slice
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
             u.set(q, t);
         }
     };
-    for (int rr = tid; rr < a.R; rr += kRowsT) {
+    for (int rr = tid; rr < Rn; rr += kRowsT) {
         const RowMap m = rm[rr];
         float zl;
         int am;
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
             const double ag = bin_center(m.lab), ap = bin_center(ss.pred);  // cal_UAD, UADA.py:408-418
             acc[2] += fabs(ap - ag) / (ag > 0 ? fabs(ag + 1.0) : fabs(ag - 1.0));
         }
-        if (a.mode == VAA_LOSS_UPA && m.ord == 0 && rr + 2 < a.R) {  // first three labelled rows of a sample are consecutive ranks
+        if (a.mode == VAA_LOSS_UPA && m.ord == 0 && rr + 2 < Rn) {  // first three labelled rows of a sample are consecutive ranks
             Upa3 u;
             upa_of(rr, u);
             double c1, nd;
@@ -804,9 +807,10 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
             a.scalars[1] = (float)CE; a.scalars[2] = (float)MSE; a.scalars[3] = (float)aux0;
             a.scalars[4] = (float)aux1; a.scalars[5] = (float)nrow; a.scalars[6] = (float)nact; a.scalars[7] = (float)UAD;
         }
-        for (int rr = tid; rr < a.R; rr += kRowsT) {
+        for (int rr = tid; rr < Rn; rr += kRowsT) {
             const RowMap m = rm[rr];
             const int pos = m.b * (a.L - 1) + m.k;
+            if ((unsigned)pos >= (unsigned)(a.B * (a.L - 1))) continue;  // a map built for other sizes than the caller states
             if (a.pred_tokens && m.lab > 2) a.pred_tokens[pos] = a.slice[rr].pred;
             if (a.pred_full) {
                 int am = first_am;
@@ -818,7 +822,7 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
             }
         }
     }
-    if (!a.grad || r >= a.R) return;
+    if (!a.grad || r >= Rn) return;
     const RowMap me = rm[r];
     if (a.mode == VAA_LOSS_UADA_DDP && !zero_fill) return;  // slice already written by the statistics kernel
     // ---- gradient of this row (part h) ----
@@ -826,7 +830,7 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
     float kce = nrow > 0 ? (float)(dce / nrow) : 0.0f, kE = 0.0f;
     if (a.mode == VAA_LOSS_UPA) {
         kce = 0.0f;
-        if (me.ord < 3 && r - me.ord + 2 < a.R) {
+        if (me.ord < 3 && r - me.ord >= 0 && r - me.ord + 2 < Rn) {
             Upa3 u;
             upa_of(r - me.ord, u);
             kE = (float)(u.dE(me.ord, (double)a.alpha, (double)a.beta, aux1, a.B) / 255.0);
@@ -940,12 +944,12 @@ extern "C" int vaa_loss_fwd_bwd_ex(const void* logits, int dtype, int layout, co
     a.w = params[0]; a.alpha = params[1]; a.beta = params[2]; a.scale = params[3];
     const int J = (L - 1) < 8 ? (L - 1) : 8;  // workgroups per sample; the attacks label at most 8 positions per sample
     const unsigned G = (unsigned)B * (unsigned)J;
-    if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(loss_stats_kernel<float>, dim3(G), dim3(kRowThreads), 0, st, a, J);
-    else hipLaunchKernelGGL(loss_stats_kernel<uint16_t>, dim3(G), dim3(kRowThreads), 0, st, a, J);
+    if (dtype == VAA_DTYPE_F32) VAA_LAUNCH(loss_stats_kernel<float>, dim3(G), dim3(kRowThreads), 0, st, a, J);
+    else VAA_LAUNCH(loss_stats_kernel<uint16_t>, dim3(G), dim3(kRowThreads), 0, st, a, J);
     int rc = check_launch("vaa_loss_fwd_bwd(stats)");
     if (rc != VAA_OK) return rc;
-    if (dtype == VAA_DTYPE_F32) hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(G), dim3(kGradT), 0, st, a, J);
-    else hipLaunchKernelGGL(loss_grad_kernel<uint16_t>, dim3(G), dim3(kGradT), 0, st, a, J);
+    if (dtype == VAA_DTYPE_F32) VAA_LAUNCH(loss_grad_kernel<float>, dim3(G), dim3(kGradT), 0, st, a, J);
+    else VAA_LAUNCH(loss_grad_kernel<uint16_t>, dim3(G), dim3(kGradT), 0, st, a, J);
     rc = check_launch("vaa_loss_fwd_bwd(grad)");
     return rc;
 }
@@ -971,7 +975,7 @@ extern "C" int vaa_loss_rowmap_build(const int64_t* labels, int B, int L, void* 
         set_error("vaa_loss_rowmap_build: buffer %zu B < required %zu B", rowmap_bytes, vaa_loss_rowmap_bytes(B, L));
         return VAA_E_WORKSPACE;
     }
-    hipLaunchKernelGGL(loss_rowmap_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, B, L, (int*)rowmap);
+    VAA_LAUNCH(loss_rowmap_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, B, L, (int*)rowmap);
     return check_launch("vaa_loss_rowmap_build");
 }
 
@@ -1005,6 +1009,10 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
         set_error("vaa_loss_rows_fwd_bwd: mode %d has a cross-entropy term, its gradient is not confined to the action slice", mode);
         return VAA_E_INVALID;
     }
+    if ((long)R > (long)B * (L - 1)) {
+        set_error("vaa_loss_rows_fwd_bwd: R=%d exceeds the B*(L-1)=%ld label positions of the row map", R, (long)B * (L - 1));
+        return VAA_E_INVALID;
+    }
     if (V > 4 * kRowsTMax * 32) {
         set_error("vaa_loss_rows_fwd_bwd: vocabulary %d exceeds the %d columns the row kernels keep in registers", V, 4 * kRowsTMax * 32);
         return VAA_E_UNSUPPORTED;
@@ -1022,11 +1030,11 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
     const int nt = rows_threads(V);
     const dim3 gs((unsigned)(R * a.split));
     if (dtype == VAA_DTYPE_F32) {
-        if (nt == 256) hipLaunchKernelGGL((rows_stats_kernel<float, 256>), gs, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((rows_stats_kernel<float, 512>), gs, dim3(512), 0, st, a);
+        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256>), gs, dim3(256), 0, st, a);
+        else VAA_LAUNCH((rows_stats_kernel<float, 512>), gs, dim3(512), 0, st, a);
     } else {
-        if (nt == 256) hipLaunchKernelGGL((rows_stats_kernel<uint16_t, 256>), gs, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((rows_stats_kernel<uint16_t, 512>), gs, dim3(512), 0, st, a);
+        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256>), gs, dim3(256), 0, st, a);
+        else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512>), gs, dim3(512), 0, st, a);
     }
     int rc = check_launch("vaa_loss_rows_fwd_bwd(stats)");
     if (rc != VAA_OK) return rc;
@@ -1036,11 +1044,11 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
     const int gsplit = full_rows ? a.split : 1;
     const unsigned G = full_rows ? (unsigned)(R * gsplit) : ((grad && mode == VAA_LOSS_UPA) ? (unsigned)R : 1u);
     if (dtype == VAA_DTYPE_F32) {
-        if (nt == 256) hipLaunchKernelGGL((rows_finish_kernel<float, 256>), dim3(G), dim3(256), 0, st, a, gsplit);
-        else hipLaunchKernelGGL((rows_finish_kernel<float, 512>), dim3(G), dim3(512), 0, st, a, gsplit);
+        if (nt == 256) VAA_LAUNCH((rows_finish_kernel<float, 256>), dim3(G), dim3(256), 0, st, a, gsplit);
+        else VAA_LAUNCH((rows_finish_kernel<float, 512>), dim3(G), dim3(512), 0, st, a, gsplit);
     } else {
-        if (nt == 256) hipLaunchKernelGGL((rows_finish_kernel<uint16_t, 256>), dim3(G), dim3(256), 0, st, a, gsplit);
-        else hipLaunchKernelGGL((rows_finish_kernel<uint16_t, 512>), dim3(G), dim3(512), 0, st, a, gsplit);
+        if (nt == 256) VAA_LAUNCH((rows_finish_kernel<uint16_t, 256>), dim3(G), dim3(256), 0, st, a, gsplit);
+        else VAA_LAUNCH((rows_finish_kernel<uint16_t, 512>), dim3(G), dim3(512), 0, st, a, gsplit);
     }
     return check_launch("vaa_loss_rows_fwd_bwd(finish)");
 }

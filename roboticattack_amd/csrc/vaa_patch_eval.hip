@@ -124,6 +124,6 @@ extern "C" int vaa_patch_apply_eval(const uint8_t* img_u8, const float* patch, c
     EvalArgs a;
     a.img = img_u8; a.patch = patch; a.xy = xy; a.theta = theta; a.geometry = geometry; a.out = out_u8; a.B = B; a.ph = ph; a.pw = pw;
     const long total = (long)B * kEvItemsPerImg;
-    hipLaunchKernelGGL(patch_apply_eval_kernel, dim3((unsigned)((total + kEvThreads - 1) / kEvThreads)), dim3(kEvThreads), 0, (hipStream_t)stream, a);
+    VAA_LAUNCH(patch_apply_eval_kernel, dim3((unsigned)((total + kEvThreads - 1) / kEvThreads)), dim3(kEvThreads), 0, (hipStream_t)stream, a);
     return check_launch("vaa_patch_apply_eval");
 }

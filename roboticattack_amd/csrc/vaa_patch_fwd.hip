@@ -352,7 +352,7 @@ static int launch_patch_apply(const char* who, const uint8_t* img_u8, const floa
     int fsplit = 16;  // footprint workgroups per image: ~6,400 pixel-lanes per 50x50 footprint -> 2 slot rounds each
     while (fsplit > 1 && (long)B * fsplit > 1024) fsplit >>= 1;  // ~1024 footprint workgroups in total is the measured optimum
     const long n_fp = (long)B * fsplit;
-    hipLaunchKernelGGL(patch_apply_fwd_kernel, dim3((unsigned)(n_fp + n_bg)), dim3(kFwdThreads), 0, (hipStream_t)stream, a,
+    VAA_LAUNCH(patch_apply_fwd_kernel, dim3((unsigned)(n_fp + n_bg)), dim3(kFwdThreads), 0, (hipStream_t)stream, a,
                        (int)n_fp, fsplit);
     return check_launch(who);
 }

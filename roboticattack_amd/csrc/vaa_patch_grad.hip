@@ -151,7 +151,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
             }
         }
         if (rezero) {
-            __syncthreads();
+            __syncthreads();  // every thread has read `poison`
+            if (MULTI && tid == 0) nonfinite = 0;  // per-image output: the next image starts clean (ordered before its phase 1 by the caller's barrier)
             for (int el = tid; el < tp * NCH; el += THREADS) tile[el] = 0ull;
         }
     };
@@ -416,7 +417,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 if (v_lo < ph) drain(a.partial + a.pdesc[4 * b + 2], ph, pw, false, true);
                 __syncthreads();
                 E = kExpUnset;
-                if (tid == 0) nonfinite = 0;
             }
         }
     }
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void patch_grad_reduce_kernel(const float* __r
 }
 
 int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts, hipStream_t st, const char* who) {
-    hipLaunchKernelGGL(patch_grad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, partial, gpatch, n, nparts);
+    VAA_LAUNCH(patch_grad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, partial, gpatch, n, nparts);
     return check_launch(who);
 }
 
@@ -520,8 +520,8 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
         a.band_rows = (ph + gs.bands - 1) / gs.bands;
         const int nb = (ph + a.band_rows - 1) / a.band_rows;
         const size_t lds = 3 * (size_t)a.band_rows * pw * sizeof(long long);
-        if (a.keep) hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, true, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
-        else hipLaunchKernelGGL((patch_grad_scatter_kernel<3, TILED, false, false, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
+        if (a.keep) VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, true, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
+        else VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, false, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
     } else {  // one channel per workgroup (grid.y), row bands (grid.z) when even one plane exceeds the LDS (> 135x135)
         a.band_rows = band_rows_for(ph, pw, 3 * G);
         const int nbands = (ph + a.band_rows - 1) / a.band_rows;
@@ -531,9 +531,9 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
         if (bytes > 64 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e == hipSuccess) {
             if (a.keep)
-                hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, true, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx);
+                VAA_LAUNCH((patch_grad_scatter_kernel<1, TILED, false, true, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx);
             else
-                hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, false, false, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx);
+                VAA_LAUNCH((patch_grad_scatter_kernel<1, TILED, false, false, 1024, 3>), dim3(G, 3, nbands), dim3(1024), bytes, st, a, gs.gx);
         }
     }
     if (e != hipSuccess) {
@@ -559,9 +559,9 @@ static int launch_scatter_multi(GradArgs a, int max_h, int max_w, hipStream_t st
         return VAA_E_LAUNCH;
     }
     if (a.keep)
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, true, true, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, st, a, B);
+        VAA_LAUNCH((patch_grad_scatter_kernel<1, TILED, true, true, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, st, a, B);
     else
-        hipLaunchKernelGGL((patch_grad_scatter_kernel<1, TILED, true, false, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, st, a, B);
+        VAA_LAUNCH((patch_grad_scatter_kernel<1, TILED, true, false, 1024, 3>), dim3(B, 3, nbands), dim3(1024), bytes, st, a, B);
     return check_launch(who);
 }
 
@@ -1037,11 +1037,11 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
             set_error("%s: hipFuncSetAttribute failed", who);
             return VAA_E_LAUNCH;
         }
-        if (e.tower_split) hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel<true>, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, 2), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
-        else hipLaunchKernelGGL(embed_dgrad_tiles_lds_kernel<false>, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, 1), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
+        if (e.tower_split) VAA_LAUNCH(embed_dgrad_tiles_lds_kernel<true>, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, 2), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
+        else VAA_LAUNCH(embed_dgrad_tiles_lds_kernel<false>, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, 1), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
     } else {  // wide towers: fragments straight from global memory
         const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
-        hipLaunchKernelGGL(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedThreads), 0, st, e, nch);
+        VAA_LAUNCH(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedThreads), 0, st, e, nch);
     }
     return VAA_OK;
 }
@@ -1064,7 +1064,7 @@ extern "C" int vaa_patch_embed_pack_weights(const uint16_t* wt, int D, uint16_t*
         return VAA_E_INVALID;
     }
     const long nfrag = (long)kNBlocks * (D >> 6) * 2 * 64;
-    hipLaunchKernelGGL(embed_pack_weights_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt, D, packed);
+    VAA_LAUNCH(embed_pack_weights_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt, D, packed);
     return check_launch("vaa_patch_embed_pack_weights");
 }
 

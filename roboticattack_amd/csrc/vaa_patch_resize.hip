@@ -275,7 +275,7 @@ extern "C" int vaa_patch_resize_fwd(const float* patch, int ph, int pw, const in
     ResizeArgs a;
     a.patch = patch; a.gpacked = nullptr; a.pdesc = pdesc; a.out = packed; a.B = B; a.ph = ph; a.pw = pw;
     const int slices = B * 3 >= 256 ? 4 : 32;  // few images: more workgroups per plane so the launch still spreads over the chip
-    hipLaunchKernelGGL(patch_resize_fwd_kernel, dim3(B, 3, slices), dim3(256), 0, (hipStream_t)stream, a);
+    VAA_LAUNCH(patch_resize_fwd_kernel, dim3(B, 3, slices), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("vaa_patch_resize_fwd");
 }
 
@@ -303,7 +303,7 @@ extern "C" int vaa_patch_resize_bwd(const float* gpacked, int ph, int pw, const 
     const int group = resize_group(B, ph, pw), groups = (B + group - 1) / group;
     ResizeArgs a;
     a.patch = nullptr; a.gpacked = gpacked; a.pdesc = pdesc; a.out = groups > 1 ? (float*)ws : gpatch; a.B = B; a.ph = ph; a.pw = pw;
-    hipLaunchKernelGGL(patch_resize_bwd_kernel, dim3(groups, 3, (ph * pw + 255) / 256), dim3(256), 0, st, a, group);
+    VAA_LAUNCH(patch_resize_bwd_kernel, dim3(groups, 3, (ph * pw + 255) / 256), dim3(256), 0, st, a, group);
     rc = check_launch("vaa_patch_resize_bwd");
     if (rc != VAA_OK || groups == 1) return rc;
     return launch_partial_reduce((const float*)ws, gpatch, 3 * ph * pw, groups, st, "vaa_patch_resize_bwd(reduce)");

@@ -134,7 +134,7 @@ extern "C" int vaa_patch_update(float* patch, const float* g, float* m, float* v
     a.one_m_b1 = (float)(1.0 - b1);
     a.one_m_b2 = (float)(1.0 - b2);
     a.step_size = (mode == VAA_OPT_ADAMW_HF) ? (float)((double)lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step))) : 0.0f;
-    if (n <= 1024 * kUpdRegs) hipLaunchKernelGGL(patch_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(patch_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    if (n <= 1024 * kUpdRegs) VAA_LAUNCH(patch_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    else VAA_LAUNCH(patch_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     return check_launch("vaa_patch_update");
 }

@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .constants import IGNORE_INDEX, MODEL_VOCAB, N_IMG_TOKENS
+from .constants import IGNORE_INDEX, MODEL_VOCAB, N_IMG_TOKENS, PAD_ID
 
 
 @dataclass
@@ -51,6 +51,11 @@ class OpenVLACfg:
     vocab: int = MODEL_VOCAB
     rms_eps: float = 1e-6
     rope_theta: float = 10000.0
+    # prompt-length bucket of the rows-only path: L is padded up to max(seq_floor, multiple of seq_multiple) so that the GEMM shapes of a
+    # step do not depend on the longest prompt of the batch (the TunableOp selections then apply on every rank and every outer iteration;
+    # 0 = off). 44 = the longest prompt of the BridgeData-shaped loaders: at bs=64 nearly every batch has that length anyway.
+    seq_floor: int = 0
+    seq_multiple: int = 1
 
 
 def openvla_7b_cfg() -> OpenVLACfg:
@@ -59,6 +64,7 @@ def openvla_7b_cfg() -> OpenVLACfg:
         # cls + 4 register tokens are concatenated afterwards (the checkpoint holds pos_embed 256, cls_token 1, reg_token 4)
         dino=VitCfg(1024, 24, 16, 4096, 5, False, True),
         siglip=VitCfg(1152, 27, 16, 4304, 0, False, False),
+        seq_floor=44, seq_multiple=4,
     )
 
 
@@ -357,17 +363,58 @@ class OpenVLAShaped(nn.Module):
             return None
         return (*self.featurizer.embed_params(), *self.fused_featurizer.embed_params())
 
+    def _towers(self, in0, in1, embedded: bool):
+        """The two vision towers are independent until the projector. At the small per-rank batches of the strong-scaling configs
+        (bs = 8 / 4: ViT GEMMs of ~2,000 rows, 36-130 output tiles for 256 CUs) one tower leaves most of the chip idle, so the SigLIP
+        tower runs on a second HIP stream next to DINOv2 — forward, and backward too (autograd replays each node on its forward
+        stream). VAA_TOWER_STREAMS=0 / 1 forces it off / on; default: on while the batch is at most 16 images."""
+        import os
+
+        f = (lambda m, x: m(None, embedded=x)) if embedded else (lambda m, x: m(x))
+        mode = os.environ.get("VAA_TOWER_STREAMS", "auto")
+        if not in0.is_cuda or mode == "0" or (mode != "1" and in0.shape[0] > 16):
+            return f(self.featurizer, in0), f(self.fused_featurizer, in1)
+        cur = torch.cuda.current_stream(in0.device)
+        side = getattr(self, "_side_stream", None)
+        if side is None or side.device != in0.device:
+            side = self._side_stream = torch.cuda.Stream(device=in0.device)
+        side.wait_stream(cur)
+        in1.record_stream(side)  # allocated on the main stream, read on the side stream
+        with torch.cuda.stream(side):
+            f1 = f(self.fused_featurizer, in1)
+        f0 = f(self.featurizer, in0)
+        cur.wait_stream(side)
+        f1.record_stream(cur)
+        return f0, f1
+
+    def seq_bucket(self, L: int) -> int:
+        """Padded prompt length of the rows-only path (cfg.seq_floor / seq_multiple; VAA_SEQ_FLOOR overrides the floor, 0 = off)."""
+        import os
+
+        floor = int(os.environ.get("VAA_SEQ_FLOOR", self.cfg.seq_floor))
+        if floor <= 0 or os.environ.get("VAA_SEQ_PACK"):
+            return L
+        m = max(1, self.cfg.seq_multiple)
+        return max(floor, (L + m - 1) // m * m)
+
     def hidden_states(self, input_ids, pixel_values, rows=None, patch_embeds=None, pack=None):
         """[B, 1+256+(L-1), D] final-norm hidden states of the multimodal sequence (modeling_prismatic.py:366-415); with
         `rows` (flat position indices into the PADDED [B*T] layout) only those positions of the LAST layer are evaluated and
         [R,D] is returned. `pack` (SeqPack): the Llama stack runs on the packed token axis ([1, sum T_b, D] is returned unless
         `rows` is given)."""
         if patch_embeds is not None:
-            feats = torch.cat([self.featurizer(None, embedded=patch_embeds[0]), self.fused_featurizer(None, embedded=patch_embeds[1])], dim=2)
+            in0, in1, kw = patch_embeds[0], patch_embeds[1], True
         else:
-            img, img_fused = torch.split(pixel_values, [3, 3], dim=1)
-            feats = torch.cat([self.featurizer(img), self.fused_featurizer(img_fused)], dim=2)
+            (in0, in1), kw = torch.split(pixel_values, [3, 3], dim=1), False
+        f0, f1 = self._towers(in0, in1, kw)
+        feats = torch.cat([f0, f1], dim=2)
         proj = self.fc3(F.gelu(self.fc2(F.gelu(self.fc1(feats)))))
+        if rows is not None and pack is None:
+            # rows-only path: right-pad the prompts to the bucket length (causal attention: the labelled rows do not see the extra pad
+            # positions); `rows` from label_row_index already addresses the bucketed layout
+            Lb = self.seq_bucket(input_ids.shape[1])
+            if Lb != input_ids.shape[1]:
+                input_ids = F.pad(input_ids, (0, Lb - input_ids.shape[1]), value=PAD_ID)
         emb = self.embed_tokens(input_ids)
         x = torch.cat([emb[:, :1], proj.to(emb.dtype), emb[:, 1:]], dim=1)
         T = x.shape[1]
@@ -405,12 +452,11 @@ class OpenVLAShaped(nn.Module):
         p = SeqPack(attention_mask)
         return p if p.total < attention_mask.shape[0] * p.T_pad else None
 
-    @staticmethod
-    def label_row_index(labels):
-        """Flat indices (into the [B*S] hidden rows, S = 256 + L) of the labelled rows in (b,k) row-major order of
+    def label_row_index(self, labels):
+        """Flat indices (into the [B*S] hidden rows, S = 256 + seq_bucket(L)) of the labelled rows in (b,k) row-major order of
         labels[b,k+1] != -100. Costs one host sync (nonzero); the attack loops compute it once per outer iteration."""
         B, L = labels.shape
-        S = N_IMG_TOKENS + L
+        S = N_IMG_TOKENS + self.seq_bucket(L)
         bk = (labels[:, 1:] != IGNORE_INDEX).nonzero(as_tuple=False)  # [R,2] sorted row-major
         return bk[:, 0] * S + N_IMG_TOKENS + bk[:, 1]
 
@@ -450,7 +496,7 @@ def enable_tuned_gemms() -> bool:
 
         tunable.enable(True)
         tunable.tuning_enable(False)
-        tunable.set_filename(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop", "openvla7b_bs64_mi355x.csv"), insert_device_ordinal=True)
+        tunable.set_filename(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop", "openvla7b_mi355x.csv"), insert_device_ordinal=True)
         return True
     except Exception:
         return False

@@ -79,6 +79,25 @@ def _workspace(device, nbytes: int, kind: str = "k2") -> torch.Tensor:
     return ws
 
 
+def prof_start(capacity: int = 4096) -> None:
+    """Arm the library's per-dispatch timer (vaa_prof_start): every kernel it launches from now on carries its own start/stop events."""
+    _lib.check(_lib.lib().vaa_prof_start(int(capacity)), "vaa_prof_start")
+
+
+def prof_collect() -> list:
+    """Disarm and return [(kernel name, microseconds)] in launch order (waits for the recorded dispatches)."""
+    import ctypes as C
+
+    L = _lib.lib()
+    n = L.vaa_prof_stop()
+    out = []
+    name, us = C.c_char_p(), C.c_float()
+    for i in range(n):
+        _lib.check(L.vaa_prof_get(i, C.byref(name), C.byref(us)), "vaa_prof_get")
+        out.append((name.value.decode(), float(us.value)))
+    return out
+
+
 def device_check() -> None:
     _lib.check(_lib.lib().vaa_device_check(), "vaa_device_check")
 

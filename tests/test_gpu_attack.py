@@ -486,7 +486,30 @@ def test_bench_py_two_ranks_one_gpu(tmp_path):
     d = json.loads(lines0[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["loss_finite"]
     assert abs(d["value"] - 2 * d["sync_steps_per_s"]) < 1e-9 and d["config"]["global_batch"] == 8
-    assert d["cpu_baseline"] is None and d["roofline"]["kernel"] == "K1_patch_apply_fwd"
+    assert d["cpu_baseline"] is None and d["roofline"]["kernel"].startswith("patch_apply_fwd_kernel")
+    ss = d["strong_scaling"]  # BASELINE config 3's shape: the N=1 batch split over the ranks
+    assert ss["per_rank_bs"] == 2 and ss["global_batch"] == 4 and ss["images_per_s"] > 0 and abs(ss["images_per_s"] * ss["ms_per_step"] * 1e-3 - 4) < 1e-6
+
+
+def test_bench_py_self_launches_its_ranks():
+    """`python3 bench.py --gpus 2` WITHOUT a launcher (the form the driver's N=1 command has) re-executes itself under torch.distributed.run,
+    one rank per GPU; on this 1-GPU box the two ranks share the GPU over gloo (flagged in the record). ONE JSON line, n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VAA_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "tiny", "--bs", "4",
+                          "--no-cpu-baseline", "--no-kernel-suite"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["loss_finite"] and d["config"]["global_batch"] == 8 and d["strong_scaling"]["per_rank_bs"] == 2
+    if torch.cuda.device_count() < 2:
+        assert d["config"]["backend"] == "gloo"
 
 
 @pytest.mark.parametrize("resize", [False, True])
@@ -552,7 +575,14 @@ def test_bench_contract_line_tiny(model, extra_env):
     assert "workload" in d["config"] and "model" not in d["config"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in d["roofline"], key
-    assert d["roofline"]["kernel"] == "K1_patch_apply_fwd" and d["roofline"]["bound"] == "hbm"
+    assert d["roofline"]["kernel"].startswith("patch_apply_fwd_kernel") and d["roofline"]["bound"] == "hbm"
+    # the in-step figures come from per-dispatch events of the library's own launches: one K1 and one K4 launch per timed step, each a few us
+    k = d["roofline_kernels"]
+    k1 = next(v for n, v in k.items() if "patch_apply_fwd_kernel" in n)
+    k4 = next(v for n, v in k.items() if "patch_update_kernel" in n)
+    assert k1["launches"] == 2 and k4["launches"] == 2 and 1.0 < k1["mean_us"] < 200.0 and d["roofline"]["samples"] == 2
+    assert abs(d["roofline"]["achieved"] - d["roofline"]["algo_bytes"] / k1["mean_us"] / 1e3) < 1e-6 * d["roofline"]["achieved"]
+    assert d["strong_scaling"] is None and d["per_rank_step"] is None and set(d["hot_path_ops"]) >= {"K1", "K3", "K4"}
 
 
 def test_ddp_wrapper_cli_under_torchrun_two_ranks(tmp_path):

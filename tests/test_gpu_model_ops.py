@@ -113,6 +113,34 @@ def test_model_with_and_without_fused_ops(monkeypatch):
     assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.99
 
 
+def test_model_vision_towers_on_two_streams_bitwise(monkeypatch):
+    """The SigLIP tower on a second HIP stream next to DINOv2 (default for per-rank batches <= 16): same kernels, same operands ->
+    logits and pixel gradient are bitwise those of the single-stream run, repeatedly (no allocator reuse hazard across the streams)."""
+    from roboticattack_amd import synthetic
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+
+    cfg = OpenVLACfg(dino=VitCfg(128, 4, 2, 256, 5, False, True), siglip=VitCfg(192, 5, 2, 384, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=4)
+    ids, labels, _ = synthetic.synth_text_batch(5, 4, 18, 22)
+    labels = mask_labels(labels, [0]).to(DEV)
+    pix0 = torch.randn(4, 6, 224, 224, device=DEV).to(torch.bfloat16)
+    outs = []
+    for mode in ("0", "1", "1", "0", "1"):
+        monkeypatch.setenv("VAA_TOWER_STREAMS", mode)
+        pix = pix0.clone().requires_grad_(True)
+        rows = m.forward_rows(ids.to(DEV), pix, labels)
+        rows.float().square().mean().backward()
+        junk = torch.randn(1 << 22, device=DEV)  # churn the caching allocator between runs
+        del junk
+        outs.append((rows.detach().clone(), pix.grad.detach().clone()))
+    torch.cuda.synchronize()
+    for r, g in outs[1:]:
+        assert torch.equal(r, outs[0][0]) and torch.equal(g, outs[0][1])
+    assert float(outs[0][1].float().abs().max()) > 0
+
+
 def test_model_tn_dgrad_matches_autograd(monkeypatch):
     """Resident W^T + TN-layout dgrad (FrozenLinearsFn) vs autograd's `dy @ W`: same logits, same pixel gradient up to GEMM summation order."""
     from roboticattack_amd import synthetic

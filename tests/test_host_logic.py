@@ -150,6 +150,29 @@ def test_tiny_model_rows_equal_full_logits():
     assert all(not p.requires_grad for p in m.parameters())
 
 
+def test_prompt_length_bucket_keeps_the_labelled_rows():
+    """cfg.seq_floor / seq_multiple pad the prompts of the rows-only path to a canonical length (stable GEMM shapes -> the shipped
+    hipBLASLt selections apply to every batch); causal attention: the labelled rows must not change."""
+    import dataclasses
+
+    from roboticattack_amd.openvla_model import OpenVLAShaped, openvla_7b_cfg, tiny_cfg
+
+    assert openvla_7b_cfg().seq_floor == 44 and openvla_7b_cfg().seq_multiple == 4
+    plain = OpenVLAShaped(tiny_cfg()).init_random(0).eval()
+    buck = OpenVLAShaped(dataclasses.replace(tiny_cfg(), seq_floor=32, seq_multiple=4)).eval()
+    buck.load_state_dict(plain.state_dict())
+    ids, labels, attn = synthetic.synth_text_batch(1, 3, 18, 24)
+    labels = mask_labels(labels, [0, 2])
+    L = labels.shape[1]
+    assert plain.seq_bucket(L) == L and buck.seq_bucket(L) == 32 and buck.seq_bucket(33) == 36 and buck.seq_bucket(44) == 44
+    pix = torch.randn(3, 6, 224, 224)
+    a = plain.forward_rows(ids, pix, labels)
+    b = buck.forward_rows(ids, pix, labels)
+    assert a.shape == b.shape and torch.allclose(a, b, atol=1e-5)
+    ri = buck.label_row_index(labels)
+    assert int(ri.max()) < 3 * (256 + 32) and torch.equal(ri % (256 + 32), plain.label_row_index(labels) % (256 + L))
+
+
 def test_upa_change_target_matches_reference():
     """UPA.py:358-364 (guide mode): the reference's sequential in-place assignment and its single torch.randint draw."""
     import types
