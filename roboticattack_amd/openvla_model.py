@@ -367,12 +367,13 @@ class OpenVLAShaped(nn.Module):
         """The two vision towers are independent until the projector. At the small per-rank batches of the strong-scaling configs
         (bs = 8 / 4: ViT GEMMs of ~2,000 rows, 36-130 output tiles for 256 CUs) one tower leaves most of the chip idle, so the SigLIP
         tower runs on a second HIP stream next to DINOv2 — forward, and backward too (autograd replays each node on its forward
-        stream). VAA_TOWER_STREAMS=0 / 1 forces it off / on; default: on while the batch is at most 16 images."""
+        stream). Measured on one MI355X: bs=8 78.2 -> 74.7 ms/step, bs=64 473 -> 468 (the towers' tails overlap). VAA_TOWER_STREAMS=0
+        turns it off."""
         import os
 
         f = (lambda m, x: m(None, embedded=x)) if embedded else (lambda m, x: m(x))
         mode = os.environ.get("VAA_TOWER_STREAMS", "auto")
-        if not in0.is_cuda or mode == "0" or (mode != "1" and in0.shape[0] > 16):
+        if not in0.is_cuda or mode == "0":
             return f(self.featurizer, in0), f(self.fused_featurizer, in1)
         cur = torch.cuda.current_stream(in0.device)
         side = getattr(self, "_side_stream", None)
@@ -483,9 +484,10 @@ class OpenVLAShaped(nn.Module):
 
 
 def enable_tuned_gemms() -> bool:
-    """Point PyTorch-ROCm's TunableOp at the GEMM selections recorded on an MI355X for the bs=64 OpenVLA-7B step
-    (roboticattack_amd/tunableop/*.csv, one identical copy per device ordinal; made with PYTORCH_TUNABLEOP_TUNING=1, 30 ms per
-    candidate). Tuning itself stays off: unknown shapes fall back to the default hipBLASLt heuristic, a validator mismatch
+    """Point PyTorch-ROCm's TunableOp at the GEMM selections recorded on an MI355X for the OpenVLA-7B step at the per-rank batches of the
+    BASELINE configs — bs = 64 (weak scaling), 8 (configs 3 / 4: 64 or 32 images over 8 or 4 ranks) and 4 (config 5) with prompts
+    bucketed to 44 tokens (cfg.seq_floor) — (roboticattack_amd/tunableop/*.csv, one identical copy per device ordinal; made by
+    tools/tune_gemms.sh). Tuning itself stays off: unknown shapes fall back to the default hipBLASLt heuristic, a validator mismatch
     (different ROCm / hipBLASLt build) ignores the file. Worth ~3 % of the step; honours a user's own PYTORCH_TUNABLEOP_* env."""
     import os
 

@@ -285,7 +285,7 @@ def test_ddp_attacker_single_rank(tmp_path, attack, monkeypatch):
     assert os.path.exists(os.path.join(str(tmp_path), "0", "patch.pt"))
 
 
-def _two_rank_worker(rank, world, port, out_dir, attack, num_iter, inner, bs):
+def _two_rank_worker(rank, world, port, out_dir, attack, num_iter, inner, bs, resize=False, psize=50):
     """One rank of the PRODUCT data-parallel attacker; both ranks share cuda:0, gloo carries the all-reduce through the host."""
     import sys
 
@@ -308,8 +308,8 @@ def _two_rank_worker(rank, world, port, out_dir, attack, num_iter, inner, bs):
 
     optim.PatchOptimizer.step = rec
     OpenVLAAttacker.val_batches = 1
-    params = dict(vla_path="surrogate:3", dataset_name="synthetic", save_dir=os.path.join(out_dir, f"rank{rank}"), resize_patch=False,
-                  patch_size=[3, 50, 50], lr=0.03, bs=bs, warmup=1, num_iter=num_iter, maskidx=[0] if attack == "UADA" else [0, 1, 2],
+    params = dict(vla_path="surrogate:3", dataset_name="synthetic", save_dir=os.path.join(out_dir, f"rank{rank}"), resize_patch=resize,
+                  patch_size=[3, psize, psize], lr=0.03, bs=bs, warmup=1, num_iter=num_iter, maskidx=[0] if attack == "UADA" else [0, 1, 2],
                   innerLoop=inner, geometry=True, use_wandb=False, MSE_weights=5, device=torch.device("cuda:0"))
     if attack != "UADA":
         params.update(attack_type=attack, target_action=0.25)
@@ -319,7 +319,7 @@ def _two_rank_worker(rank, world, port, out_dir, attack, num_iter, inner, bs):
              log=np.array([att.last_train_log[k] for k in sorted(att.last_train_log)], np.float64))
 
 
-def _single_process_two_shard_reference(attack, num_iter, inner, bs, world=2):
+def _single_process_two_shard_reference(attack, num_iter, inner, bs, world=2, resize=False, psize=50):
     """What N ranks must equal: ONE process computes every rank's shard gradient with that rank's data
     and the rank-identical RNG stream (every rank seeds 42), sums them in rank order, and applies the mean through K4."""
     import random
@@ -332,9 +332,9 @@ def _single_process_two_shard_reference(attack, num_iter, inner, bs, world=2):
     from roboticattack_amd.surrogate import SurrogateVLA
 
     _seed()
-    base = AttackBase(SurrogateVLA(seed=3).to(DEV), None, "", "adamW", False)
+    base = AttackBase(SurrogateVLA(seed=3).to(DEV), None, "", "adamW", resize)
     t = base.randomPatchTransform
-    patch = torch.rand([3, 50, 50]).to(DEV).requires_grad_(True)
+    patch = torch.rand([3, psize, psize]).to(DEV).requires_grad_(True)
     opt = PatchOptimizer(patch, 0.03, "adamW", l1_clip=1e-3 if attack == "UPA" else 0.0)
     sched = CosineWarmupSchedule(opt, 1, num_iter, 0.5)
     mode = {"UADA": ops.LOSS_UADA_DDP, "UPA": ops.LOSS_UPA, "TMA": ops.LOSS_CE}[attack]
@@ -364,11 +364,11 @@ def _single_process_two_shard_reference(attack, num_iter, inner, bs, world=2):
             snaps.append(patch.detach().cpu().numpy().copy())
         sched.step()
         if i % 200 == 0:  # the validation pass of UADA_ddp.py:233 draws placements too (val_batches = 1 in this test)
-            t._draw(bs, 50, 50, True)
+            t._draw_resized(bs, psize, psize, True) if resize else t._draw(bs, psize, psize, True)
     return np.stack(snaps)
 
 
-@pytest.mark.parametrize("attack", ["UADA", "UPA", "TMA"])
+@pytest.mark.parametrize("attack", ["UADA", "UPA", "TMA", "UPA_resize"])
 def test_ddp_attacker_two_ranks_vs_single_process(tmp_path, attack):
     """The product data-parallel loop (UADA_ddp.py:138-221 mirror) with WORLD_SIZE = 2: two processes share the one GPU of the test box
     (VAA_DIST_BACKEND=gloo). After EVERY inner step both ranks hold bit-identical patches, and the trajectory equals the single-process
@@ -382,12 +382,12 @@ def test_ddp_attacker_two_ranks_vs_single_process(tmp_path, attack):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), attack, num_iter, inner, bs), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), attack, num_iter, inner, bs, resize, psize), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "ddp_r0.npz"), np.load(tmp_path / "ddp_r1.npz")
-    assert r0["snaps"].shape == (num_iter * inner, 3, 50, 50)
+    assert r0["snaps"].shape == (num_iter * inner, 3, psize, psize)
     assert np.array_equal(r0["snaps"], r1["snaps"]), "ranks must stay bit-identical after every inner step"
     assert np.array_equal(r0["final"], r1["final"]) and np.array_equal(r0["log"], r1["log"])
-    ref = _single_process_two_shard_reference(attack, num_iter, inner, bs)
+    ref = _single_process_two_shard_reference(attack, num_iter, inner, bs, resize=resize, psize=psize)
     err = np.abs(r0["snaps"] - ref).reshape(len(ref), -1).max(1)
     assert err.max() <= 1e-4, err
     assert np.abs(ref[-1] - ref[inner - 1]).max() > 1e-3  # the patch really moved (lr = 0 only during outer iteration 0)
