@@ -175,22 +175,21 @@ def cpu_baseline(bs, patch_shape, budget_s=25.0):
 
 
 class StepRunner:
-    """One rank's attack-loop state for a per-rank batch of B images: the inner step of attack/uada_ddp.py on synthetic frames resident in HBM."""
+    """One rank's attack-loop state for a per-rank batch of B images: the inner step of attack/uada_ddp.py — the SAME code
+    (AttackBase.fused_ddp_step / model_loss) — on synthetic frames resident in HBM."""
 
     def __init__(self, model, dev, B, patch_shape, rank, world):
         from roboticattack_amd import dist as vdist
         from roboticattack_amd import ops, synthetic
+        from roboticattack_amd.attack.engine import AttackBase
         from roboticattack_amd.labels import mask_labels
         from roboticattack_amd.optim import PatchOptimizer
-        from roboticattack_amd.transform import RandomPatchTransform
 
         self.ops, self.model, self.dev, self.B, self.world = ops, model, dev, B, world
-        self.use_rows = hasattr(model, "forward_rows")
-        self.tr = RandomPatchTransform(dev, False)
-        if self.use_rows and hasattr(model, "patch_embed_params") and os.environ.get("VAA_FUSED_EMBED_GRAD", "1") != "0":
-            self.tr.embed_with = model  # K2' (SURVEY.md 8f-3), like the attack loops: the dense pixel gradient is never materialised; =0 for plain K2
-        self.mean = [torch.tensor([0.484375, 0.455078125, 0.40625]), torch.tensor([0.5, 0.5, 0.5])]
-        self.std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
+        self.att = AttackBase(model, None, "", "adamW", False)  # K2' (SURVEY.md 8f-3) when the model exposes its patch-embed weights; VAA_FUSED_EMBED_GRAD=0: plain K2
+        self.use_rows = self.att.use_rows
+        self.tr = self.att.randomPatchTransform
+        self.fused = self.att.fused_ddp_available()  # K2's final sum + K3's fold + the DDP message in one launch (VAA_FUSED_EPILOGUE=0: separate launches)
         self.batch = synthetic.synth_batch(1234 + rank, B, "noise", as_pil=False)
         self.img = self.tr.stage_images(torch.from_numpy(self.batch["pixel_values"]))
         self.input_ids = self.batch["input_ids"].to(dev)
@@ -204,27 +203,23 @@ class StepRunner:
         self.sync = vdist.PatchGradSync(self.patch.numel(), 4, dev)
         self.inv_world = 1.0 / world
         self.scal = torch.zeros(8, device=dev)
-        self.row_index = model.label_row_index(self.labels) if self.use_rows else None  # once per outer iteration, as the attack loops do
-        self.row_map = ops.LossRowMap(self.labels) if self.use_rows else None               # K3's device row map, same lifetime
-        self.pack = model.make_pack(self.attn) if hasattr(model, "make_pack") else None
-        self.pick = torch.tensor([1, 2, 7], dtype=torch.int64, device=dev)
+        self.pick = torch.tensor([1, 2, 7, 0], dtype=torch.int64, device=dev)
         self.R = int((self.labels[:, 1:] != -100).sum())
 
     def step(self):  # attack/uada_ddp.py inner step
-        ops, model = self.ops, self.model
+        a, ops = self.att, self.ops
         self.opt.zero_grad()
-        pix = self.tr.apply_random_patch_batch(self.img, self.patch, self.mean, self.std, geometry=True)  # host RNG draws + K1
-        if self.use_rows:
-            pe = pix if isinstance(pix, ops.PatchEmbeds) else None
-            h = model.hidden_rows(self.input_ids, None if pe is not None else pix, self.row_index, patch_embeds=pe, pack=self.pack)
-            total, scalars, _, _ = ops.HeadLossRows.apply(h, model.lm_head.weight, self.row_map, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0)  # LM head + K3
+        if self.fused:
+            # host draws -> K1 (tile-major) -> model -> K3 statistics -> backward -> K2' tiles + scatter -> epilogue: the message is in sync.buf
+            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, True, 5.0, self.sync.buf, self.scal)
+            g_sum, _ = self.sync.allreduce_packed()  # [grad | CE, MSE, UAD, total]: one all-reduce per step
         else:
-            out = model(input_ids=self.input_ids, attention_mask=self.attn, pixel_values=pix, labels=None)
-            total, scalars, _, _ = ops.DiscrepancyLoss.apply(out.logits.contiguous(), self.labels, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, ops.LAYOUT_FULL)
-        total.backward()  # ... -> K2 (or K2' fed by the patch-embed output gradients)
-        g_sum, _ = self.sync.allreduce_step(self.patch.grad, scalars, self.pick)  # [grad | CE, MSE, UAD, sum(grad)]: one all-reduce per step
+            pix = self.tr.apply_random_patch_batch(self.img, self.patch, mean=a.mean, std=a.std, geometry=True)  # host RNG draws + K1
+            total, scalars, _ = a.model_loss(self.input_ids, self.attn, pix, self.labels, ops.LOSS_UADA_DDP, w=5.0)  # model + LM head + K3
+            total.backward()  # ... -> K2 (or K2' fed by the patch-embed output gradients)
+            g_sum, _ = self.sync.allreduce_step(self.patch.grad, scalars, self.pick)
+            self.scal.copy_(scalars)
         self.opt.step(grad=g_sum.view_as(self.patch), grad_scale=self.inv_world)  # K4
-        self.scal.copy_(scalars)
 
 
 def timed_steps(runner, steps, warmup, world, dev, profile=False):
@@ -258,7 +253,7 @@ def timed_steps(runner, steps, warmup, world, dev, profile=False):
 
 
 # kernel name (substring of the launch site's name) -> operator of the hot path
-KERNEL_OPS = (("patch_apply_fwd_kernel", "K1"), ("embed_dgrad_tiles", "K2e"), ("patch_grad_scatter_kernel", "K2"), ("patch_grad_reduce_kernel", "K2"),
+KERNEL_OPS = (("patch_apply_fwd_kernel", "K1"), ("patch_apply_tiles_kernel", "K1"), ("embed_dgrad_tiles", "K2e"), ("patch_grad_scatter_kernel", "K2"), ("patch_grad_reduce_kernel", "K2"),
               ("rows_stats_kernel", "K3"), ("rows_finish_kernel", "K3"), ("loss_stats_kernel", "K3"), ("loss_grad_kernel", "K3"), ("step_epilogue_kernel", "EPI"), ("patch_update_kernel", "K4"),
               ("patch_resize", "K0"))
 
@@ -387,14 +382,14 @@ def main():
                 "K3": algo_bytes("K3_slice" if use_rows else "K3", B, rows=R, esize=esz), "K4": algo_bytes("K4", B, patch_shape[1], patch_shape[2])}
     hot_ops = {o: {"us_per_step": u, "algo_bytes": op_bytes.get(o), "achieved_GBs": (op_bytes[o] / u / 1e3 if o in op_bytes else None),
                    "frac": (op_bytes[o] / u / 1e3 / HBM_PEAK_GBS if o in op_bytes else None)} for o, u in op_us.items()}
-    k1name = next((n for n in kern if "patch_apply_fwd_kernel" in n), None)
+    k1name = next((n for n in kern if "patch_apply_tiles_kernel" in n or "patch_apply_fwd_kernel" in n), None)
     tfile = next((f for f in ("profiles/traffic_r03.json", "profiles/traffic_r02.json") if os.path.exists(os.path.join(ROOT, f))), None)
     tr_ops = json.load(open(os.path.join(ROOT, tfile))).get("ops", {}) if tfile else {}
     roofline = None
     if k1name:
         k1 = kern[k1name]
         nb = op_bytes["K1"]
-        roofline = {"kernel": "patch_apply_fwd_kernel (K1)", "bound": "hbm", "achieved": nb / k1["mean_us"] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"kernel": k1name + " (K1)", "bound": "hbm", "achieved": nb / k1["mean_us"] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": nb / k1["mean_us"] / 1e3 / HBM_PEAK_GBS, "mean_us": k1["mean_us"], "min_us": k1["min_us"], "samples": k1["launches"],
                     "algo_bytes": nb, "traffic": tr_ops.get("K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch"),
                     "traffic_source": (tfile or "none") + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",

@@ -99,6 +99,20 @@ int vaa_patch_apply_fwd(const uint8_t* img_u8, const float* patch, const int32_t
                         uint8_t* keep_bits, void* stream);
 
 /*
+ * K1 in TILE-MAJOR form — the same values as vaa_patch_apply_fwd, laid out as the operands of the two ViT patch-embed GEMMs
+ * (modeling_prismatic.py:120-123 -> timm PatchEmbed, Conv2d(3, D, 14, stride 14) == a GEMM over 588-pixel tiles), for callers that own the
+ * patch-embed weights (K2' below): the [B,6,224,224] tensor and its two 19 MB im2col copies per step are never made.
+ *   pdesc     dev [B,4] or NULL: per-image patches as in vaa_patch_apply_fwd_multi (ph/pw are then upper bounds)
+ *   out0,out1 dev bf16 [B,256,588]: tile t = ty*16 + tx, element c*196 + y*14 + x; out0 = first normalisation (channels 0-2 of
+ *             pixel_values), out1 = second (channels 3-5). e_k = out_k @ W_k^T + b_k with W_k = conv weight [D,3,14,14] flattened to [D,588]
+ *   keep_tiles dev u16 [B,3,256,14] or NULL: bit x of word (c, t, y) = channel c of pixel (14 ty + y, 14 tx + x) shows the patch
+ *   tile_flags dev u32 [B,256] or NULL: != 0 when tile t holds a kept pixel in any channel (the tile list K2' evaluates)
+ */
+int vaa_patch_apply_fwd_tiles(const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta, int B,
+                              int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6, uint16_t* out0,
+                              uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* stream);
+
+/*
  * K2 — replaces the autograd backward of K1 to the patch (implicit in `.backward()`, UADA.py:148): bf16->f32 cast,
  * /std of both normalisations summed, where-mask, grid_sample-backward scatter, slice, sum over the batch.
  *   gout_bf16 dev [B,6,224,224] bfloat16 bits: dL/d pixel_values from the model
@@ -192,6 +206,25 @@ int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int
                           size_t ws_bytes, void* stream);
 
 /*
+ * Split form of vaa_loss_rows_fwd_bwd for the data-parallel step (UADA_ddp.py:199-209), whose backward does not wait for the loss scalars:
+ *   vaa_loss_rows_stats : the statistics pass alone; in VAA_LOSS_UADA_DDP mode it also writes the gradient (grad may be NULL; other modes
+ *             need the folded scalars for their gradient and must use vaa_loss_rows_fwd_bwd). ws as in vaa_loss_rows_fwd_bwd.
+ *   vaa_step_epilogue   : ONE launch between the backward and the gradient exchange — replaces K2's final reduce launch, K3's finishing
+ *             launch and the packing of the DDP message (dist.PatchGradSync):
+ *               msg[0..n)    = sum of K2's `nparts` partial tiles [nparts][n] (n = 3*ph*pw), the fixed order of vaa_patch_grad_gather:
+ *                              bitwise the gradient that call would have written
+ *               rowmap != NULL: the statistics in loss_ws (left by vaa_loss_rows_stats with the same R, B, L, V, mode, params) are folded:
+ *                              scalars[8], pred_tokens, pred_full_tokens as vaa_loss_rows_fwd_bwd writes them
+ *               rowmap == NULL: scalars is an INPUT (already final)
+ *               msg[n..n+4)  = {CE, w^2*MSE, UAD, total}: the logging scalars that travel with the gradient (C3 + C4 in one all-reduce)
+ */
+int vaa_loss_rows_stats(const void* logits, int dtype, const void* rowmap, int R, int B, int L, int V, int mode, const float* params, void* grad,
+                        int grad_kind, void* ws, size_t ws_bytes, void* stream);
+int vaa_step_epilogue(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode, const float* params,
+                      const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, float* msg,
+                      void* stream);
+
+/*
  * K2' (for callers that own the model's patch-embed weights) — K2 fed by the gradient of the ViT patch-embed OUTPUTS instead of the pixel gradient: the
  * patch-embed backward (modeling_prismatic.py:120-123 -> timm PatchEmbed, Conv2d(3, D, 14, stride 14) == a GEMM over 588-pixel
  * tiles) is evaluated by MFMA only for the 14x14 tiles that carry kept patch pixels and consumed in place by the gather.
@@ -210,6 +243,13 @@ int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1
                                 const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph, int pw,
                                 int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes,
                                 void* stream);
+/* the same fed by the tile-major mask of vaa_patch_apply_fwd_tiles (keep_tiles, tile_flags: both required). gpatch == NULL leaves the final
+ * fixed-order sum to the caller: the vaa_patch_grad_partials(B) partial tiles [parts][3*ph*pw] f32 then sit at the start of ws. */
+int vaa_patch_grad_partials(int B);
+int vaa_patch_embed_grad_gather_tiles(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
+                                      const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
+                                      const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
+                                      int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream);
 /* the same with one patch per image (resize_patch=True; packed / pdesc / gpacked as in vaa_patch_grad_gather_multi):
  * ws >= vaa_patch_embed_grad_multi_ws_bytes(B); the resize adjoint then folds gpacked into the base patch's gradient */
 size_t vaa_patch_embed_grad_multi_ws_bytes(int B);

@@ -49,6 +49,11 @@ EXPORTS = (
     "vaa_loss_rowmap_build",
     "vaa_loss_rows_ws_bytes",
     "vaa_loss_rows_fwd_bwd",
+    "vaa_patch_apply_fwd_tiles",
+    "vaa_patch_grad_partials",
+    "vaa_patch_embed_grad_gather_tiles",
+    "vaa_loss_rows_stats",
+    "vaa_step_epilogue",
     "vaa_prof_start",
     "vaa_prof_stop",
     "vaa_prof_get",
@@ -166,6 +171,16 @@ def lib() -> C.CDLL:
     L.vaa_patch_update.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp, vp]
     L.vaa_patch_apply_eval.restype = i32
     L.vaa_patch_apply_eval.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.vaa_patch_apply_fwd_tiles.restype = i32
+    L.vaa_patch_apply_fwd_tiles.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, vp, vp, vp]
+    L.vaa_patch_grad_partials.restype = i32
+    L.vaa_patch_grad_partials.argtypes = [i32]
+    L.vaa_patch_embed_grad_gather_tiles.restype = i32
+    L.vaa_patch_embed_grad_gather_tiles.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
+    L.vaa_loss_rows_stats.restype = i32
+    L.vaa_loss_rows_stats.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, i32, vp, sz, vp]
+    L.vaa_step_epilogue.restype = i32
+    L.vaa_step_epilogue.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp]
     L.vaa_prof_start.restype = i32
     L.vaa_prof_start.argtypes = [i32]
     L.vaa_prof_stop.restype = i32

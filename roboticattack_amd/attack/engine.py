@@ -66,16 +66,7 @@ class AttackBase:
         `action_logits.argmax(dim=2)` (UADA.py:165-167, TMA.py:148-149) that its relative-distance / L1 / ASR metrics and the
         best-patch selection read; the action-slice argmax of UADA.py:395 only feeds UAD, which K3 reports in scalars[7]."""
         if self.use_rows:
-            # labels are fixed during an outer iteration: the row index (one host sync) and the device row map of K3 are cached per
-            # tensor OBJECT; the cache holds a reference, so identity cannot be recycled by the allocator, and in-place edits bump _version
-            if getattr(self, "_row_ref", None) is not labels or self._row_ver != labels._version:
-                self._row_ref, self._row_ver, self._row_index = labels, labels._version, self.vla.label_row_index(labels)
-                self._row_map = ops.LossRowMap(labels)
-            pack = None
-            if hasattr(self.vla, "make_pack") and attention_mask is not None:  # drop the padding rows (cached like the row index)
-                if getattr(self, "_pack_ref", None) is not attention_mask or self._pack_ver != attention_mask._version:
-                    self._pack_ref, self._pack_ver, self._pack = attention_mask, attention_mask._version, self.vla.make_pack(attention_mask)
-                pack = self._pack
+            pack = self._rows_cache(labels, attention_mask)
             pe = pix if isinstance(pix, ops.PatchEmbeds) else None  # patched batch handed over as patch-embed outputs (pixel gradient never built)
             if need_grad and hasattr(self.vla, "hidden_rows"):
                 # LM head + loss on the labelled rows (SURVEY.md section 8f-2): the head's backward contracts over the 256 action
@@ -97,6 +88,50 @@ class AttackBase:
         scalars, _, _, pred_full = ops.loss_fwd_bwd(logits.detach().contiguous(), labels, mode, w, alpha, beta, scale, ops.LAYOUT_FULL,
                                                     want_grad=False, want_pred_full=True)
         return None, scalars, pred_full
+
+    def _rows_cache(self, labels, attention_mask):
+        """labels are fixed during an outer iteration: the row index (one host sync) and the device row map of K3 are cached per
+        tensor OBJECT; the cache holds a reference, so identity cannot be recycled by the allocator, and in-place edits bump _version.
+        Returns the sequence pack (or None)."""
+        if getattr(self, "_row_ref", None) is not labels or self._row_ver != labels._version:
+            self._row_ref, self._row_ver, self._row_index = labels, labels._version, self.vla.label_row_index(labels)
+            self._row_map = ops.LossRowMap(labels)
+            self._row_count = int(self._row_index.numel())
+        pack = None
+        if hasattr(self.vla, "make_pack") and attention_mask is not None:  # drop the padding rows (cached like the row index)
+            if getattr(self, "_pack_ref", None) is not attention_mask or self._pack_ver != attention_mask._version:
+                self._pack_ref, self._pack_ver, self._pack = attention_mask, attention_mask._version, self.vla.make_pack(attention_mask)
+            pack = self._pack
+        return pack
+
+    # ---- the data-parallel UADA step with the fused epilogue ----
+    def fused_ddp_available(self) -> bool:
+        """K1 (tile-major) -> model -> K3 statistics (+ gradient slice) -> K2' tiles + scatter -> ONE epilogue launch (K2's final sum, K3's
+        fold, the DDP message) needs a model that exposes its patch-embed weights and its hidden rows, and one patch per batch."""
+        t = self.randomPatchTransform
+        return (os.environ.get("VAA_FUSED_EPILOGUE", "1") != "0" and self.use_rows and hasattr(self.vla, "hidden_rows")
+                and t.embed_with is not None and not t.resize_patch)
+
+    def fused_ddp_step(self, pixel_values, patch, input_ids, attention_mask, labels, geometry, w, msg, scalars):
+        """The UADA_ddp inner step (UADA_ddp.py:189-206) up to the gradient exchange, six hand-written launches around the model:
+        K1 -> [ViTs, Llama, LM head on the labelled rows] -> K3 statistics + gradient slice -> [head / model backward] -> K2' tile GEMM ->
+        scatter -> epilogue. On return `msg` (f32 [3*ph*pw + 4]) holds [patch gradient | CE, w^2*MSE, UAD, total] of THIS rank, ready for
+        one all-reduce, and `scalars` (f32[8]) the loss scalars; returns the full-vocabulary predictions [B,L-1] (i32, device).
+        Nothing is synchronised; patch.grad is not touched."""
+        pack = self._rows_cache(labels, attention_mask)
+        if self._row_count == 0:
+            raise ValueError("fused_ddp_step: no labelled position in the batch")
+        sink = {}
+        pe = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std, geometry=geometry, grad_sink=sink)
+        h = self.vla.hidden_rows(input_ids, None, self._row_index, patch_embeds=pe, pack=pack)
+        W = self.vla.lm_head.weight
+        logits = torch.nn.functional.linear(h.detach(), W)  # [R,V]: the LM head on the labelled rows (SURVEY.md 8f-2)
+        gsl = torch.empty((logits.shape[0], ops.N_ACTION), dtype=logits.dtype, device=logits.device)
+        ws = ops.loss_rows_stats(logits, self._row_map, ops.LOSS_UADA_DDP, w, grad=gsl)      # K3: statistics + d loss / d action logits
+        h.backward(gsl @ W[ops.ACTION_LO : ops.ACTION_LO + ops.N_ACTION])                     # head backward over 256 columns, model backward, K2'
+        _, pred_full = ops.step_epilogue(sink["partials"], msg, scalars, rowmap=self._row_map, R=int(logits.shape[0]), V=int(W.shape[0]),
+                                         mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws)
+        return pred_full
 
     # ---- metrics (host, once per outer iteration) ----
     def decode_pred_gt(self, pred: torch.Tensor, labels: torch.Tensor):

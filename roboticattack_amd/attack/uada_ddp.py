@@ -107,9 +107,11 @@ class OpenVLAAttacker(AttackBase):
 
             self._tma_target = tma_target_tokens(float(self.target_action) * torch.ones(7).numpy(), self.maskidx, self.action_tokenizer).to(dev)
         sync = vdist.PatchGradSync(patch.numel(), 4, dev)
-        pick = torch.tensor([1, 2, 7], dtype=torch.int64, device=dev)  # CE, w^2*MSE (or the attack loss), UAD of K3's scalars
+        pick = torch.tensor([1, 2, 7, 0], dtype=torch.int64, device=dev)  # CE, w^2*MSE, UAD, total of K3's scalars
         inv_world = 1.0 / world_size
-        inv_n = 1.0 / patch.numel()
+        # UADA on a model that exposes its patch-embed weights: K2's final sum, K3's fold and the message packing are ONE launch
+        fused = self.attack_type == "UADA" and self.fused_ddp_available()
+        scalars = torch.zeros(8, dtype=torch.float32, device=dev)
 
         for i, data in enumerate(self.train_loader):
             if i == self.num_iter:
@@ -118,18 +120,23 @@ class OpenVLAAttacker(AttackBase):
             labels = self._prepare_labels(labels)
             for inner_loop in range(self.innerLoop):
                 optimizer.zero_grad()
-                pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
-                                                                          geometry=self.geometry)
-                total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, self._loss_mode(), w=float(self.MSE_weights),
-                                                       alpha=self.alpha, beta=self.belta)
-                total.backward()  # K2 inside
-                local_grad_sum = patch.grad.sum() if inner_loop == self.innerLoop - 1 else None  # logged once per outer iteration
-                # C3 + C4 in one message: [grad | CE, MSE, UAD, sum(grad)]
-                g_sum, s_sum = sync.allreduce_step(patch.grad, scalars, pick)
+                if fused:
+                    self.fused_ddp_step(pixel_values, patch, input_ids, attention_mask, labels, self.geometry, float(self.MSE_weights),
+                                        sync.buf, scalars)
+                    g_sum, s_sum = sync.allreduce_packed()  # C3 + C4 in one message: [grad | CE, MSE, UAD, total]
+                else:
+                    pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
+                                                                              geometry=self.geometry)
+                    total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, self._loss_mode(), w=float(self.MSE_weights),
+                                                           alpha=self.alpha, beta=self.belta)
+                    total.backward()  # K2 inside
+                    g_sum, s_sum = sync.allreduce_step(patch.grad, scalars, pick)
                 optimizer.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4, DDP mean folded in
             scheduler.step()
             s = (s_sum * inv_world).cpu().numpy()
-            log_patch_grad = vdist.allreduce_scalar(float(local_grad_sum.item()) * inv_n, "MAX", dev)  # UADA_ddp.py:216-217
+            # UADA_ddp.py:207,216-217: `patch.grad.mean()` AFTER DistributedDataParallel averaged the gradient, i.e. the mean of the averaged
+            # gradient (identical on every rank, so the reference's MAX all-reduce of it is the value itself): K4 reports it
+            log_patch_grad = float(optimizer.last_stats[1].item())
             train_logdata = {"TRAIN_attack_loss(CE)": float(s[0]), "TRAIN_patch_gradient": log_patch_grad,
                              "TRAIN_LR": optimizer.param_groups[0]["lr"], "TRAIN_attack_loss (MSE_Distance)": float(s[1]),
                              "TRAIN_UAD": float(s[2])}

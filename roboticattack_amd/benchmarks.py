@@ -133,6 +133,14 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
     wt1 = ops.pack_embed_weights((torch.randn(588, 1152, device=dev) * 0.05).to(torch.bfloat16))
     rec("K2e_patch_embed_grad_gather", "K2e", lambda: ops.patch_embed_grad_gather(dy0, dy1, wt0, wt1, patch, xy, th, keep, True),
         algo_bytes("K2e", B, ph, pw), B=B, note="SURVEY 8f-3: patch-embed backward on the kept tiles (MFMA) + gather; replaces 2 dgrad GEMMs + fold + K2")
+    # the tile-major forms the attack step runs with a model that exposes its patch-embed weights
+    rec("K1t_patch_apply_fwd_tiles", "K1", lambda: ops.patch_apply_fwd_tiles(img, patch, xy, th, True), algo_bytes("K1", B, ph, pw), B=B,
+        note="K1 writing the two patch-embed GEMM operands [B,256,588] + tile-major keep words + tile flags (no im2col copies)")
+    _, _, keep_t, tflags = ops.patch_apply_fwd_tiles(img, patch, xy, th, True)
+    rec("K2et_patch_embed_grad_gather_tiles", "K2e", lambda: ops.patch_embed_grad_gather_tiles(dy0, dy1, wt0, wt1, patch, xy, th, keep_t, tflags, True),
+        algo_bytes("K2e", B, ph, pw), B=B, note="K2' fed by K1's tile flags / keep words")
+    rec("K2et_deferred_reduce", "K2e", lambda: ops.patch_embed_grad_gather_tiles(dy0, dy1, wt0, wt1, patch, xy, th, keep_t, tflags, True, defer_reduce=True),
+        algo_bytes("K2e", B, ph, pw), B=B, note="tile GEMM + scatter only: the final sum is the step epilogue's")
     rowmap = ops.LossRowMap(labels)
     gslice = torch.empty((R, 256), dtype=logits_dtype, device=dev)
     rec("K3_loss_rows_fwd_bwd", "K3_slice",
@@ -142,6 +150,13 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
     rec("K3_full_rows_fwd_bwd", "K3",
         lambda: ops.loss_rows_fwd_bwd(logits, rowmap, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=glog),
         algo_bytes("K3", B, rows=R, esize=logits.element_size()), rows=R, note="UADA (1/CE term): full-row gradient, SURVEY 8d's 2*R'*V*e")
+    parts = ops.patch_embed_grad_gather_tiles(dy0, dy1, wt0, wt1, patch, xy, th, keep_t, tflags, True, defer_reduce=True)
+    msg, scal8 = torch.zeros(3 * ph * pw + 4, device=dev), torch.zeros(8, device=dev)
+    ws3 = ops.loss_rows_stats(logits, rowmap, ops.LOSS_UADA_DDP, w=5.0, grad=gslice)
+    rec("K3s_loss_rows_stats", "K3_slice", lambda: ops.loss_rows_stats(logits, rowmap, ops.LOSS_UADA_DDP, w=5.0, grad=gslice),
+        algo_bytes("K3_slice", B, rows=R, esize=logits.element_size()), rows=R, note="K3 statistics + gradient slice (the fold is the epilogue's)")
+    rec("EPI_step_epilogue", "K2", lambda: ops.step_epilogue(parts, msg, scal8, rowmap=rowmap, R=R, V=32064, mode=ops.LOSS_UADA_DDP, w=5.0, loss_ws=ws3),
+        parts.numel() * 4 + 4 * 3 * ph * pw, note="K2's final fixed-order sum + K3's fold + the DDP message in one launch")
     rec("K4_patch_update", "K4", lambda: ops.patch_update(patch, gp, m, v, ops.OPT_ADAMW_HF, 1e-3, 1), algo_bytes("K4", B, ph, pw))
     return res
 

@@ -162,6 +162,40 @@ __device__ __forceinline__ void solve_interval(float a, float base, float lo, fl
     }
 }
 
+// out[e] = sum_p partial[p][e] (p < nparts, e < n) for the 64 elements of block `blk`, in a fixed two-level order (16 interleaved slices,
+// then slice 0..15), fp64: the body of patch_grad_reduce_kernel, shared with the step epilogue (256 threads; sl = 16 KB of LDS).
+// A thread owns four consecutive elements (16 B loads); block = 16 element-quads x 16 slices.
+__device__ __forceinline__ void partial_reduce_block(const float* __restrict__ partial, float* __restrict__ out, int n, int nparts, int blk,
+                                                     double (*sl)[16][4]) {
+    const int el = threadIdx.x & 15, s = threadIdx.x >> 4;
+    const int e = (blk * 16 + el) * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (e + 3 < n && (n & 3) == 0) {
+#pragma unroll 8
+        for (int p = s; p < nparts; p += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)p * n + e);
+            acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
+        }
+    } else {
+        for (int p = s; p < nparts; p += 16)
+#pragma unroll
+            for (int z = 0; z < 4; ++z)
+                if (e + z < n) acc[z] += (double)partial[(size_t)p * n + e + z];
+    }
+#pragma unroll
+    for (int z = 0; z < 4; ++z) sl[s][el][z] = acc[z];
+    __syncthreads();
+    if (s < 4) {  // thread (s, el) of the second level sums element z = s of quad el
+        const int z = s;
+        if (e + z < n) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += sl[q][el][z];
+            out[e + z] = (float)t;
+        }
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

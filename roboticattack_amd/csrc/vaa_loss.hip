@@ -706,6 +706,112 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a) {
     }
 }
 
+struct FoldOut {
+    double nrow, nact, CE, MSE, UAD, total, aux0, aux1, dce;
+    int Rn;
+};
+
+// Folds the R compact row statistics into the loss scalars in a fixed order (thread t takes rows t, t + kRowsT, ...; block_sums), and — for
+// the publishing workgroup — writes scalars[8] and the two prediction maps. Shared by rows_finish_kernel and the step epilogue.
+template <int kRowsT>
+__device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, double (*sh)[7]) {
+    const int tid = threadIdx.x;
+    const RowMap* rm = reinterpret_cast<const RowMap*>(a.rowmap + 4);
+    const int Rdev = a.rowmap[0];
+    const int Rn = min(a.R, Rdev);  // rows both the caller and the map know: a mismatch publishes NaN and never leaves the map
+    auto row_lse = [&](int rr, float& zlab, int& amax) {  // combine the parts of row rr
+        float M = -INFINITY;
+        for (int q = 0; q < a.split; ++q) M = fmaxf(M, a.part[(size_t)rr * a.split + q].m);
+        float tot = 0.0f, best = -INFINITY;
+        zlab = -INFINITY;
+        amax = 0x7fffffff;
+        for (int q = 0; q < a.split; ++q) {
+            const PartStat p = a.part[(size_t)rr * a.split + q];
+            tot += p.s * expf(p.m - M);
+            zlab = fmaxf(zlab, p.zlab);
+            if (p.m > best || (p.m == best && p.amax < amax)) { best = p.m; amax = p.amax; }
+        }
+        return M + logf(tot);
+    };
+    if (publish) {  // the publishing workgroup clears the prediction maps NOW, under the statistics' load latency; the barriers of the
+                    // block reduction below order these stores before the per-row stores that follow it
+        const int P0 = a.B * (a.L - 1);
+        if (a.pred_tokens) for (int q = tid; q < P0; q += kRowsT) a.pred_tokens[q] = -1;
+        if (a.pred_full) for (int q = tid; q < P0; q += kRowsT) a.pred_full[q] = -1;
+    }
+    int first_am = 0;  // full-vocabulary argmax of this thread's first row (rr = tid), kept for the publication
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // ce, mse, uad, nrow, nact, upa sum(cos+1), upa sum ||e'-l'||
+    for (int rr = tid; rr < Rn; rr += kRowsT) {
+        const RowMap m = rm[rr];
+        float zl;
+        int am;
+        const float lse = row_lse(rr, zl, am);
+        if (rr == tid) first_am = am;
+        acc[3] += 1.0;
+        acc[0] += (double)lse - (double)zl;
+        if (m.lab > 2) {
+            const SliceStat ss = a.slice[rr];
+            acc[4] += 1.0;
+            const double q = (double)ss.E / 256.0, t = (m.lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10: 1/256 -> 0)
+            acc[1] += (q - t) * (q - t);
+            const double ag = bin_center(m.lab), ap = bin_center(ss.pred);  // cal_UAD, UADA.py:408-418
+            acc[2] += fabs(ap - ag) / (ag > 0 ? fabs(ag + 1.0) : fabs(ag - 1.0));
+        }
+        if (a.mode == VAA_LOSS_UPA && m.ord == 0 && rr + 2 < Rn) {  // first three labelled rows of a sample are consecutive ranks
+            Upa3 u;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                RowStat t;
+                t.E = a.slice[rr + q].E;
+                t.lab = rm[rr + q].lab;
+                u.set(q, t);
+            }
+            double c1, nd;
+            u.terms(c1, nd);
+            acc[5] += c1;
+            acc[6] += nd;
+        }
+    }
+    block_sums<7, kRowsT>(acc, sh);
+    FoldOut f;
+    f.Rn = Rn;
+    f.nrow = acc[3]; f.nact = acc[4];
+    f.CE = f.nrow > 0 ? acc[0] / f.nrow : 0.0;
+    f.MSE = f.nact > 0 ? (double)a.w * a.w * acc[1] / f.nact : 0.0;
+    f.UAD = f.nact > 0 ? acc[2] / f.nact : 0.0;
+    f.total = 0.0; f.aux0 = 0.0; f.aux1 = 0.0; f.dce = 0.0;
+    if (a.mode == VAA_LOSS_UPA) {
+        f.aux0 = acc[5] / a.B;
+        f.aux1 = 1.0 / (acc[6] / a.B + 1e-3);  // UPA.py:384
+        f.total = (double)a.alpha * f.aux0 + (double)a.beta * f.aux1;
+    } else if (a.mode == VAA_LOSS_UADA) { f.total = f.MSE + 1.0 / f.CE; f.dce = -1.0 / (f.CE * f.CE); }  // UADA.py:147
+    else if (a.mode == VAA_LOSS_UADA_DDP) { f.total = f.MSE; }                                           // UADA_ddp.py:203-206
+    else { f.total = (double)a.scale * f.CE; f.dce = (double)a.scale; }                                 // TMA.py:148
+    if (publish) {
+        if (tid == 0) {
+            const bool ok = Rdev == a.R;  // the caller's row count must be the row map's
+            a.scalars[0] = ok ? (float)f.total : __uint_as_float(0x7fc00000u);
+            a.scalars[1] = (float)f.CE; a.scalars[2] = (float)f.MSE; a.scalars[3] = (float)f.aux0;
+            a.scalars[4] = (float)f.aux1; a.scalars[5] = (float)f.nrow; a.scalars[6] = (float)f.nact; a.scalars[7] = (float)f.UAD;
+        }
+        for (int rr = tid; rr < Rn; rr += kRowsT) {
+            const RowMap m = rm[rr];
+            const int pos = m.b * (a.L - 1) + m.k;
+            if ((unsigned)pos >= (unsigned)(a.B * (a.L - 1))) continue;  // a map built for other sizes than the caller states
+            if (a.pred_tokens && m.lab > 2) a.pred_tokens[pos] = a.slice[rr].pred;
+            if (a.pred_full) {
+                int am = first_am;
+                if (rr != tid) {  // more rows than threads: combine the parts again
+                    float zl;
+                    row_lse(rr, zl, am);
+                }
+                a.pred_full[pos] = am;
+            }
+        }
+    }
+    return f;
+}
+
 // grid = R x split (full-row gradients) or R (slice / no gradient); every workgroup folds the statistics in the same fixed order.
 template <typename T, int kRowsT>
 __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsplit) {
@@ -714,8 +820,6 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
     const int tid = threadIdx.x;
     __shared__ double sh[kRowsT / 64][7];
     const RowMap* rm = reinterpret_cast<const RowMap*>(a.rowmap + 4);
-    const int Rdev = a.rowmap[0];
-    const int Rn = min(a.R, Rdev);  // rows both the caller and the map know: a mismatch publishes NaN and never leaves the map
     // this workgroup's part of its row: issue the loads before the fold (addresses do not depend on it)
     const bool full_grad = a.grad && !a.grad_slice && (a.mode == VAA_LOSS_UADA || a.mode == VAA_LOSS_CE);
     const bool zero_fill = a.grad && !a.grad_slice && !full_grad;  // FULL storage asked for a slice-only mode: zeros outside the slice
@@ -745,14 +849,6 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
         }
         return M + logf(tot);
     };
-    if (blockIdx.x == 0) {  // the publishing workgroup clears the prediction maps NOW, under the statistics' load latency; the barriers of the
-                             // block reduction below order these stores before the per-row stores that follow it
-        const int P0 = a.B * (a.L - 1);
-        if (a.pred_tokens) for (int q = tid; q < P0; q += kRowsT) a.pred_tokens[q] = -1;
-        if (a.pred_full) for (int q = tid; q < P0; q += kRowsT) a.pred_full[q] = -1;
-    }
-    int first_am = 0;  // full-vocabulary argmax of this thread's first row (rr = tid), kept for the publication
-    double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // ce, mse, uad, nrow, nact, upa sum(cos+1), upa sum ||e'-l'||
     auto upa_of = [&](int r0, Upa3& u) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -762,66 +858,9 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
             u.set(q, t);
         }
     };
-    for (int rr = tid; rr < Rn; rr += kRowsT) {
-        const RowMap m = rm[rr];
-        float zl;
-        int am;
-        const float lse = row_lse(rr, zl, am);
-        if (rr == tid) first_am = am;
-        acc[3] += 1.0;
-        acc[0] += (double)lse - (double)zl;
-        if (m.lab > 2) {
-            const SliceStat ss = a.slice[rr];
-            acc[4] += 1.0;
-            const double q = (double)ss.E / 256.0, t = (m.lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10: 1/256 -> 0)
-            acc[1] += (q - t) * (q - t);
-            const double ag = bin_center(m.lab), ap = bin_center(ss.pred);  // cal_UAD, UADA.py:408-418
-            acc[2] += fabs(ap - ag) / (ag > 0 ? fabs(ag + 1.0) : fabs(ag - 1.0));
-        }
-        if (a.mode == VAA_LOSS_UPA && m.ord == 0 && rr + 2 < Rn) {  // first three labelled rows of a sample are consecutive ranks
-            Upa3 u;
-            upa_of(rr, u);
-            double c1, nd;
-            u.terms(c1, nd);
-            acc[5] += c1;
-            acc[6] += nd;
-        }
-    }
-    block_sums<7, kRowsT>(acc, sh);
-    const double nrow = acc[3], nact = acc[4];
-    const double CE = nrow > 0 ? acc[0] / nrow : 0.0;
-    const double MSE = nact > 0 ? (double)a.w * a.w * acc[1] / nact : 0.0;
-    const double UAD = nact > 0 ? acc[2] / nact : 0.0;
-    double total = 0.0, aux0 = 0.0, aux1 = 0.0, dce = 0.0;
-    if (a.mode == VAA_LOSS_UPA) {
-        aux0 = acc[5] / a.B;
-        aux1 = 1.0 / (acc[6] / a.B + 1e-3);  // UPA.py:384
-        total = (double)a.alpha * aux0 + (double)a.beta * aux1;
-    } else if (a.mode == VAA_LOSS_UADA) { total = MSE + 1.0 / CE; dce = -1.0 / (CE * CE); }  // UADA.py:147
-    else if (a.mode == VAA_LOSS_UADA_DDP) { total = MSE; }                                     // UADA_ddp.py:203-206
-    else { total = (double)a.scale * CE; dce = (double)a.scale; }                             // TMA.py:148
-    if (blockIdx.x == 0) {  // publication
-        if (tid == 0) {
-            const bool ok = Rdev == a.R;  // the caller's row count must be the row map's
-            a.scalars[0] = ok ? (float)total : __uint_as_float(0x7fc00000u);
-            a.scalars[1] = (float)CE; a.scalars[2] = (float)MSE; a.scalars[3] = (float)aux0;
-            a.scalars[4] = (float)aux1; a.scalars[5] = (float)nrow; a.scalars[6] = (float)nact; a.scalars[7] = (float)UAD;
-        }
-        for (int rr = tid; rr < Rn; rr += kRowsT) {
-            const RowMap m = rm[rr];
-            const int pos = m.b * (a.L - 1) + m.k;
-            if ((unsigned)pos >= (unsigned)(a.B * (a.L - 1))) continue;  // a map built for other sizes than the caller states
-            if (a.pred_tokens && m.lab > 2) a.pred_tokens[pos] = a.slice[rr].pred;
-            if (a.pred_full) {
-                int am = first_am;
-                if (rr != tid) {  // more rows than threads: combine the parts again
-                    float zl;
-                    row_lse(rr, zl, am);
-                }
-                a.pred_full[pos] = am;
-            }
-        }
-    }
+    const FoldOut f = rows_fold<kRowsT>(a, blockIdx.x == 0, sh);
+    const int Rn = f.Rn;
+    const double nrow = f.nrow, nact = f.nact, dce = f.dce, aux1 = f.aux1;
     if (!a.grad || r >= Rn) return;
     const RowMap me = rm[r];
     if (a.mode == VAA_LOSS_UADA_DDP && !zero_fill) return;  // slice already written by the statistics kernel
@@ -877,6 +916,37 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
             o[e] = gv;
         }
         Vec<T>::store(g + (size_t)v0, o);
+    }
+}
+
+// Step epilogue (vaa_step_epilogue): ONE launch between the backward and the gradient exchange.
+//   workgroups 0 .. nred-1 : msg[e] = sum over K2's partial tiles, the fixed order of patch_grad_reduce_kernel (bitwise the same result)
+//   workgroup  nred        : K3's statistics folded into scalars[8] + the prediction maps (what rows_finish_kernel does in the slice modes
+//                            whose gradient does not wait for it), then the tail of the sync message msg[n..n+4) = {CE, w^2*MSE, UAD, total}
+struct EpiArgs {
+    const float* partials;
+    float* msg;
+    const float* scalars_in;  // fold == 0: final scalars of an earlier vaa_loss_rows_fwd_bwd, only copied into the message
+    int n, nparts, nred, fold;
+};
+
+__global__ __launch_bounds__(256) void step_epilogue_kernel(EpiArgs e, RowsArgs a) {
+    __shared__ double sl[16][16][4];
+    if ((int)blockIdx.x < e.nred) {
+        partial_reduce_block(e.partials, e.msg, e.n, e.nparts, blockIdx.x, sl);
+        return;
+    }
+    float* tail = e.msg + e.n;
+    if (e.fold) {
+        double (*sh)[7] = reinterpret_cast<double (*)[7]>(&sl[0][0][0]);
+        const FoldOut f = rows_fold<256>(a, true, sh);
+        if (threadIdx.x == 0) {
+            const bool ok = a.rowmap[0] == a.R;
+            tail[0] = (float)f.CE; tail[1] = (float)f.MSE; tail[2] = (float)f.UAD;
+            tail[3] = ok ? (float)f.total : __uint_as_float(0x7fc00000u);
+        }
+    } else if (threadIdx.x == 0) {
+        tail[0] = e.scalars_in[1]; tail[1] = e.scalars_in[2]; tail[2] = e.scalars_in[7]; tail[3] = e.scalars_in[0];
     }
 }
 
@@ -984,51 +1054,46 @@ extern "C" size_t vaa_loss_rows_ws_bytes(int R) {
     return (size_t)R * (4 * sizeof(vaa::PartStat) + sizeof(vaa::SliceStat));
 }
 
-extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int R, int B, int L, int V, int mode,
-                                     const float* params, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, void* grad,
-                                     int grad_kind, void* ws, size_t ws_bytes, void* stream) {
-    using namespace vaa;
-    if (!logits || !rowmap || !params || !scalars) {
-        set_error("vaa_loss_rows_fwd_bwd: null pointer argument");
+namespace vaa {
+
+// argument checks + RowsArgs shared by vaa_loss_rows_fwd_bwd / vaa_loss_rows_stats / vaa_step_epilogue
+static int rows_args(const char* who, const void* logits, int dtype, const void* rowmap, int R, int B, int L, int V, int mode, const float* params,
+                     float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, void* grad, int grad_kind, void* ws, size_t ws_bytes, RowsArgs& a) {
+    if (!rowmap || !params) {
+        set_error("%s: null pointer argument", who);
         return VAA_E_INVALID;
-    }
-    if (R == 0 && B > 0 && L > 1) {  // nothing is labelled: every scalar is 0 (the reference's means over empty sets are not defined), no prediction
-        hipStream_t st0 = (hipStream_t)stream;
-        hipError_t e = hipMemsetAsync(scalars, 0, 8 * sizeof(float), st0);
-        if (e == hipSuccess && pred_tokens) e = hipMemsetAsync(pred_tokens, 0xff, (size_t)B * (L - 1) * sizeof(int32_t), st0);
-        if (e == hipSuccess && pred_full_tokens) e = hipMemsetAsync(pred_full_tokens, 0xff, (size_t)B * (L - 1) * sizeof(int32_t), st0);
-        if (e != hipSuccess) { set_error("vaa_loss_rows_fwd_bwd: %s", hipGetErrorString(e)); return VAA_E_LAUNCH; }
-        return VAA_OK;
     }
     if (R <= 0 || B <= 0 || L <= 1 || V < kA0 + kNA || (V % 8) != 0 || mode < 0 || mode > VAA_LOSS_CE ||
         (dtype != VAA_DTYPE_F32 && dtype != VAA_DTYPE_BF16) || (grad_kind != VAA_GRAD_FULL && grad_kind != VAA_GRAD_SLICE)) {
-        set_error("vaa_loss_rows_fwd_bwd: bad sizes/mode (R=%d B=%d L=%d V=%d mode=%d dtype=%d grad_kind=%d)", R, B, L, V, mode, dtype, grad_kind);
+        set_error("%s: bad sizes/mode (R=%d B=%d L=%d V=%d mode=%d dtype=%d grad_kind=%d)", who, R, B, L, V, mode, dtype, grad_kind);
         return VAA_E_INVALID;
     }
     if (grad && grad_kind == VAA_GRAD_SLICE && (mode == VAA_LOSS_UADA || mode == VAA_LOSS_CE)) {
-        set_error("vaa_loss_rows_fwd_bwd: mode %d has a cross-entropy term, its gradient is not confined to the action slice", mode);
+        set_error("%s: mode %d has a cross-entropy term, its gradient is not confined to the action slice", who, mode);
         return VAA_E_INVALID;
     }
     if ((long)R > (long)B * (L - 1)) {
-        set_error("vaa_loss_rows_fwd_bwd: R=%d exceeds the B*(L-1)=%ld label positions of the row map", R, (long)B * (L - 1));
+        set_error("%s: R=%d exceeds the B*(L-1)=%ld label positions of the row map", who, R, (long)B * (L - 1));
         return VAA_E_INVALID;
     }
     if (V > 4 * kRowsTMax * 32) {
-        set_error("vaa_loss_rows_fwd_bwd: vocabulary %d exceeds the %d columns the row kernels keep in registers", V, 4 * kRowsTMax * 32);
+        set_error("%s: vocabulary %d exceeds the %d columns the row kernels keep in registers", who, V, 4 * kRowsTMax * 32);
         return VAA_E_UNSUPPORTED;
     }
     if (!ws || ws_bytes < vaa_loss_rows_ws_bytes(R)) {
-        set_error("vaa_loss_rows_fwd_bwd: workspace %zu B < required %zu B", ws_bytes, vaa_loss_rows_ws_bytes(R));
+        set_error("%s: workspace %zu B < required %zu B", who, ws_bytes, vaa_loss_rows_ws_bytes(R));
         return VAA_E_WORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream;
-    RowsArgs a;
     a.logits = logits; a.rowmap = (const int*)rowmap; a.part = (PartStat*)ws; a.slice = (SliceStat*)((char*)ws + (size_t)R * 4 * sizeof(PartStat));
     a.grad = grad; a.scalars = scalars; a.pred_tokens = pred_tokens; a.pred_full = pred_full_tokens;
     a.R = R; a.B = B; a.L = L; a.V = V; a.mode = mode; a.split = rows_split(R, V); a.grad_slice = (grad_kind == VAA_GRAD_SLICE) ? 1 : 0;
     a.w = params[0]; a.alpha = params[1]; a.beta = params[2]; a.scale = params[3];
-    const int nt = rows_threads(V);
-    const dim3 gs((unsigned)(R * a.split));
+    return VAA_OK;
+}
+
+static int launch_rows_stats(const RowsArgs& a, int dtype, hipStream_t st, const char* who) {
+    const int nt = rows_threads(a.V);
+    const dim3 gs((unsigned)(a.R * a.split));
     if (dtype == VAA_DTYPE_F32) {
         if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256>), gs, dim3(256), 0, st, a);
         else VAA_LAUNCH((rows_stats_kernel<float, 512>), gs, dim3(512), 0, st, a);
@@ -1036,10 +1101,37 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
         if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256>), gs, dim3(256), 0, st, a);
         else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512>), gs, dim3(512), 0, st, a);
     }
-    int rc = check_launch("vaa_loss_rows_fwd_bwd(stats)");
+    return check_launch(who);
+}
+
+}  // namespace vaa
+
+extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int R, int B, int L, int V, int mode,
+                                     const float* params, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, void* grad,
+                                     int grad_kind, void* ws, size_t ws_bytes, void* stream) {
+    using namespace vaa;
+    const char* who = "vaa_loss_rows_fwd_bwd";
+    if (!logits || !scalars) {
+        set_error("%s: null pointer argument", who);
+        return VAA_E_INVALID;
+    }
+    if (R == 0 && B > 0 && L > 1) {  // nothing is labelled: every scalar is 0 (the reference's means over empty sets are not defined), no prediction
+        hipStream_t st0 = (hipStream_t)stream;
+        hipError_t e = hipMemsetAsync(scalars, 0, 8 * sizeof(float), st0);
+        if (e == hipSuccess && pred_tokens) e = hipMemsetAsync(pred_tokens, 0xff, (size_t)B * (L - 1) * sizeof(int32_t), st0);
+        if (e == hipSuccess && pred_full_tokens) e = hipMemsetAsync(pred_full_tokens, 0xff, (size_t)B * (L - 1) * sizeof(int32_t), st0);
+        if (e != hipSuccess) { set_error("%s: %s", who, hipGetErrorString(e)); return VAA_E_LAUNCH; }
+        return VAA_OK;
+    }
+    RowsArgs a;
+    int rc = rows_args(who, logits, dtype, rowmap, R, B, L, V, mode, params, scalars, pred_tokens, pred_full_tokens, grad, grad_kind, ws, ws_bytes, a);
+    if (rc != VAA_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    rc = launch_rows_stats(a, dtype, st, "vaa_loss_rows_fwd_bwd(stats)");
     if (rc != VAA_OK) return rc;
     // the finishing pass: per (row, part) when a full-row gradient (or a zero fill) has to be written, else one workgroup per row
     // (UPA slice) or a single workgroup (UADA_DDP slice: only the scalars are left to do)
+    const int nt = rows_threads(V);
     const bool full_rows = grad && grad_kind == VAA_GRAD_FULL;
     const int gsplit = full_rows ? a.split : 1;
     const unsigned G = full_rows ? (unsigned)(R * gsplit) : ((grad && mode == VAA_LOSS_UPA) ? (unsigned)R : 1u);
@@ -1051,4 +1143,45 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
         else VAA_LAUNCH((rows_finish_kernel<uint16_t, 512>), dim3(G), dim3(512), 0, st, a, gsplit);
     }
     return check_launch("vaa_loss_rows_fwd_bwd(finish)");
+}
+
+// The statistics pass of vaa_loss_rows_fwd_bwd alone (UADA_DDP mode: it also writes the gradient slice, which needs nothing from other
+// rows). The scalars and the prediction maps are then produced by vaa_step_epilogue from the same workspace.
+extern "C" int vaa_loss_rows_stats(const void* logits, int dtype, const void* rowmap, int R, int B, int L, int V, int mode, const float* params,
+                                   void* grad, int grad_kind, void* ws, size_t ws_bytes, void* stream) {
+    using namespace vaa;
+    const char* who = "vaa_loss_rows_stats";
+    if (!logits) {
+        set_error("%s: null pointer argument", who);
+        return VAA_E_INVALID;
+    }
+    if (grad && mode != VAA_LOSS_UADA_DDP) {
+        set_error("%s: only VAA_LOSS_UADA_DDP has a gradient that does not depend on the folded scalars (mode %d: use vaa_loss_rows_fwd_bwd)", who, mode);
+        return VAA_E_INVALID;
+    }
+    RowsArgs a;
+    int rc = rows_args(who, logits, dtype, rowmap, R, B, L, V, mode, params, nullptr, nullptr, nullptr, grad, grad_kind, ws, ws_bytes, a);
+    if (rc != VAA_OK) return rc;
+    return launch_rows_stats(a, dtype, (hipStream_t)stream, who);
+}
+
+extern "C" int vaa_step_epilogue(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
+                                 const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
+                                 int32_t* pred_full_tokens, float* msg, void* stream) {
+    using namespace vaa;
+    const char* who = "vaa_step_epilogue";
+    if (!partials || !msg || !scalars || nparts <= 0 || n <= 0) {
+        set_error("%s: bad arguments (nparts=%d n=%d)", who, nparts, n);
+        return VAA_E_INVALID;
+    }
+    EpiArgs e;
+    e.partials = partials; e.msg = msg; e.scalars_in = scalars; e.n = n; e.nparts = nparts; e.nred = (n + 63) / 64; e.fold = rowmap ? 1 : 0;
+    RowsArgs a = {};
+    if (rowmap) {
+        int rc = rows_args(who, nullptr, VAA_DTYPE_BF16, rowmap, R, B, L, V, mode, params, scalars, pred_tokens, pred_full_tokens, nullptr, VAA_GRAD_SLICE,
+                           const_cast<void*>(loss_ws), loss_ws_bytes, a);
+        if (rc != VAA_OK) return rc;
+    }
+    VAA_LAUNCH(step_epilogue_kernel, dim3((unsigned)(e.nred + 1)), dim3(256), 0, (hipStream_t)stream, e, a);
+    return check_launch(who);
 }

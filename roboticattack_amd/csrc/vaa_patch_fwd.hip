@@ -60,15 +60,14 @@ __host__ __device__ inline uint32_t norm_pack(float v, const Norm6& n, int c) {
     return bf16_rne(o0) | (bf16_rne(o1) << 16);
 }
 
-// Conservative ITEM bounds of output row i of image b: items [it_lo, it_hi] (16-pixel groups) may contain a pixel whose
-// source point touches the patch; it_hi < it_lo when the row is clear. Both kernel roles call this same function, which
-// is what makes their ownership of items disjoint and complete.
-__device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it_lo, int& it_hi) {
+// Conservative COLUMN span of output row i of image b: pixels [jlo, jhi] may have a source point that touches the patch; jhi < jlo
+// (normalised to [0, -1]) when the row is clear. Every role of both K1 kernels derives its ownership from this one function.
+__device__ __forceinline__ void row_span(const FwdArgs a, int b, int i, int& jlo, int& jhi) {
     const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
     int ph, pw;
     const float* unused;
     patch_of(a, b, ph, pw, unused);
-    int jlo = 0, jhi = -1;
+    jlo = 0; jhi = -1;
     if (a.geometry) {
         float th[6];
 #pragma unroll
@@ -90,9 +89,17 @@ __device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it
         jhi = px + pw - 1;
     }
     // an interval that lies wholly beyond the frame (possible when a side is open to +-infinity: patch on the frame edge) clamps to
-    // jhi < jlo with jlo > 0; normalise every empty row to [0, -1] so that BOTH roles see "no items" (the background role packs the
-    // count into 8 bits and would otherwise skip items nobody writes)
+    // jhi < jlo with jlo > 0; normalise every empty row to [0, -1] so that ALL roles see "nothing" (the background role of the planar
+    // kernel packs the count into 8 bits and would otherwise skip items nobody writes)
     if (jhi < jlo) { jlo = 0; jhi = -1; }
+}
+
+// Conservative ITEM bounds of output row i of image b: items [it_lo, it_hi] (16-pixel groups) may contain a pixel whose
+// source point touches the patch; it_hi < it_lo when the row is clear. Both roles of the planar kernel call this same function, which
+// is what makes their ownership of items disjoint and complete.
+__device__ __forceinline__ void row_items(const FwdArgs a, int b, int i, int& it_lo, int& it_hi) {
+    int jlo, jhi;
+    row_span(a, b, i, jlo, jhi);
     it_lo = jlo >> 4;
     it_hi = (jhi < jlo) ? -1 : (jhi >> 4);
 }
@@ -317,6 +324,199 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_fwd_kernel(const FwdA
     K1_FLUSH(1)
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K1 in TILE-MAJOR form (vaa_patch_apply_fwd_tiles): the same values, written as the two ViT patch-embed GEMM operands
+//   out0 / out1 [B,256,588] bf16 : tile t = ty*16 + tx of the 14x14 tiling, element c*196 + y*14 + x (timm PatchEmbed's im2col order,
+//                                  modeling_prismatic.py:120-123) — what `unfold(pixel_values)` would produce, without the two 19 MB
+//                                  permute copies per step;
+//   keep_t [B,3,256,14] u16      : bit x of word (c, t, y) = channel c of pixel (14 ty + y, 14 tx + x) shows the patch;
+//   flags  [B,256] u32           : != 0 when tile t holds a kept pixel (any channel): the tile list of K2' without its 42-load flag pass.
+// Ownership is per TILE: a tile is a footprint tile when the conservative column span (row_span) of any of its 14 rows meets it.
+//   BACKGROUND workgroup = one tile row (b, ty): 9,408 contiguous input bytes staged through LDS, every thread converts pixel PAIRS
+//       (6 input bytes -> one dword per channel and tower) so that consecutive lanes write consecutive dwords of a tile; footprint
+//       tiles are skipped; keep words / flags of its background tiles are cleared.
+//   FOOTPRINT workgroup (dispatched first) = a share of the footprint tiles of one image, one tile per WAVE, one lane per pixel in four
+//       passes of 56 lanes whose loads are all in flight together: exact warp sample, mask, normalise; keep words by ballot, the tile flag
+//       by the wave.
+struct TileOut {
+    uint16_t* out0;
+    uint16_t* out1;
+    uint16_t* keep_t;
+    uint32_t* flags;  // byte w of word t: wave w of the footprint workgroup saw a kept pixel in its rows of tile t
+};
+
+constexpr int kTS = 14, kTPS = 16, kTElems = 3 * kTS * kTS;  // tile side, tiles per side, elements per tile and tower (588)
+constexpr int kRowBytes = VAA_IMG * 3;                         // 672
+constexpr int kTileRowBytes = kTS * kRowBytes;                 // 9,408 = 588 x 16 B
+constexpr int kPairSlots = kTPS * kTS * (kTS / 2);             // 1,568 pixel pairs per tile row
+
+__device__ __forceinline__ bool tile_meets(const int* lo, const int* hi, int tx) {  // lo/hi: the 14 row spans of the tile row
+    bool f = false;
+#pragma unroll
+    for (int y = 0; y < kTS; ++y) f = f || (hi[y] >= lo[y] && lo[y] <= kTS * tx + kTS - 1 && hi[y] >= kTS * tx);
+    return f;
+}
+
+__global__ __launch_bounds__(kFwdThreads) void patch_apply_tiles_kernel(const FwdArgs a, const TileOut o, int n_fp, int fsplit) {
+    __shared__ uint32_t lut[3 * 256];
+    __shared__ __align__(16) uint8_t inbuf[kTileRowBytes];  // background: the tile row's input bytes; footprint: bgrid + tables (aliased below)
+    __shared__ int sp_lo[VAA_IMG], sp_hi[VAA_IMG];
+    __shared__ int16_t tiles[256];
+    __shared__ int wave_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool bg = (int)blockIdx.x >= n_fp;
+    uint4 pre[3];
+    int b, ty = 0;
+    if (bg) {
+        const int id = (int)blockIdx.x - n_fp;
+        b = id >> 4; ty = id & 15;
+        const uint4* src = reinterpret_cast<const uint4*>(a.img + ((size_t)b * VAA_IMG + kTS * ty) * kRowBytes);  // 16-byte aligned: 672 = 42 x 16
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + k * kFwdThreads;
+            pre[k] = idx < kTileRowBytes / 16 ? src[idx] : make_uint4(0, 0, 0, 0);
+        }
+    } else {
+        b = (int)blockIdx.x / fsplit;
+    }
+#pragma unroll
+    for (int e = tid; e < 768; e += kFwdThreads) lut[e] = norm_pack((float)(e & 255) / 255.0f, a.nrm, e >> 8);
+
+    if (bg) {
+        // ------------------------------------------------------------------ background role: tile row (b, ty)
+        if (tid < kTS) row_span(a, b, kTS * ty + tid, sp_lo[tid], sp_hi[tid]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + k * kFwdThreads;
+            if (idx < kTileRowBytes / 16) reinterpret_cast<uint4*>(inbuf)[idx] = pre[k];
+        }
+        __syncthreads();
+        __shared__ uint8_t fp_tile[kTPS];
+        if (tid < kTPS) fp_tile[tid] = tile_meets(sp_lo, sp_hi, tid) ? 1 : 0;
+        __syncthreads();
+        const size_t tbase = ((size_t)b * 256 + ty * kTPS) * kTElems;
+        for (int s = tid; s < kPairSlots; s += kFwdThreads) {
+            const int t = s / 98, r = s - t * 98;
+            if (fp_tile[t]) continue;  // owned by the footprint role
+            const int y = r / 7, xp = r - y * 7;
+            const uint8_t* ip = inbuf + (y * VAA_IMG + kTS * t + 2 * xp) * 3;  // 6 bytes, 2-byte aligned
+            const uint32_t h0 = *reinterpret_cast<const uint16_t*>(ip), h1 = *reinterpret_cast<const uint16_t*>(ip + 2),
+                           h2 = *reinterpret_cast<const uint16_t*>(ip + 4);
+            const uint32_t A0 = lut[h0 & 255u], A1 = lut[256 + (h0 >> 8)], A2 = lut[512 + (h1 & 255u)];       // pixel 0: channels 0..2
+            const uint32_t B0 = lut[h1 >> 8], B1 = lut[256 + (h2 & 255u)], B2 = lut[512 + (h2 >> 8)];         // pixel 1
+            const size_t e = tbase + (size_t)t * kTElems + y * kTS + 2 * xp;                                    // even: dword aligned
+            *reinterpret_cast<uint32_t*>(o.out0 + e) = __builtin_amdgcn_perm(B0, A0, 0x05040100u);
+            *reinterpret_cast<uint32_t*>(o.out1 + e) = __builtin_amdgcn_perm(B0, A0, 0x07060302u);
+            *reinterpret_cast<uint32_t*>(o.out0 + e + 196) = __builtin_amdgcn_perm(B1, A1, 0x05040100u);
+            *reinterpret_cast<uint32_t*>(o.out1 + e + 196) = __builtin_amdgcn_perm(B1, A1, 0x07060302u);
+            *reinterpret_cast<uint32_t*>(o.out0 + e + 392) = __builtin_amdgcn_perm(B2, A2, 0x05040100u);
+            *reinterpret_cast<uint32_t*>(o.out1 + e + 392) = __builtin_amdgcn_perm(B2, A2, 0x07060302u);
+        }
+        if (o.keep_t) {  // keep words of the background tiles: 3 channels x 16 tiles x 14 rows
+            for (int w = tid; w < 3 * kTPS * kTS; w += kFwdThreads) {
+                const int c = w / (kTPS * kTS), rem = w - c * (kTPS * kTS), t = rem / kTS;
+                if (!fp_tile[t]) o.keep_t[(((size_t)b * 3 + c) * 256 + ty * kTPS) * kTS + rem] = (uint16_t)0;
+            }
+        }
+        if (o.flags && tid < kTPS && !fp_tile[tid]) o.flags[(size_t)b * 256 + ty * kTPS + tid] = 0u;
+        return;
+    }
+
+    // ---------------------------------------------------------------------- footprint role: footprint tiles of image b
+    float* bgrid = reinterpret_cast<float*>(inbuf);  // 224 floats
+    const int chunk = (int)blockIdx.x - b * fsplit;
+    if (tid < VAA_IMG) { bgrid[tid] = base_coord(tid); row_span(a, b, tid, sp_lo[tid], sp_hi[tid]); }
+    __syncthreads();
+    const bool flag = tile_meets(sp_lo + kTS * (tid >> 4), sp_hi + kTS * (tid >> 4), tid & 15);  // thread t = tile t
+    const unsigned long long mk = __ballot(flag);
+    if (lane == 0) wave_cnt[wv] = __popcll(mk);
+    __syncthreads();
+    int base = 0, M = 0;
+    for (int q = 0; q < 4; ++q) { if (q < wv) base += wave_cnt[q]; M += wave_cnt[q]; }
+    if (flag) tiles[base + __popcll(mk & ((1ull << lane) - 1ull))] = (int16_t)tid;
+    __syncthreads();
+    const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
+    int ph, pw;
+    const float* patch;
+    patch_of(a, b, ph, pw, patch);
+    const int plane = ph * pw;
+    float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    if (a.geometry) {
+#pragma unroll
+        for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
+    }
+    // One tile per iteration, one lane per pixel: wave w takes rows 4w..4w+3 (14 lanes = one row = one keep word). Every load of a pixel
+    // (3 camera bytes, 12 patch texels at addresses clamped into the patch) is issued before anything is consumed; the canvas rule (-100
+    // outside the paste, 0 beyond the frame) is applied to the loaded values. No barrier in the loop: byte w of a tile's flag word is wave w's.
+    const int yr = lane / kTS, x = lane - yr * kTS, y = 4 * wv + yr;
+    const bool active = lane < 4 * kTS && y < kTS;
+    for (int ti = chunk; ti < M; ti += fsplit) {
+        const int t = tiles[ti], tty = t >> 4, ttx = t & 15;
+        const int i = kTS * tty + (active ? y : 0), j = kTS * ttx + (active ? x : 0);
+        uint32_t L[3] = {0u, 0u, 0u};
+        bool kept[3] = {false, false, false};
+        if (active) {
+            const uint8_t* sp = a.img + ((size_t)(b * VAA_IMG + i) * VAA_IMG + j) * 3;
+            const uint32_t by0 = sp[0], by1 = sp[1], by2 = sp[2];
+            float cv[3];
+            bool inside;
+            if (a.geometry) {
+                const Samp s = sample_pos(bgrid[j], bgrid[i], th);
+                const int u0 = s.x0 - px, v0 = s.y0 - py;
+                inside = !(u0 < -1 || u0 >= pw || v0 < -1 || v0 >= ph);
+                const int uc0 = min(max(u0, 0), pw - 1), uc1 = min(max(u0 + 1, 0), pw - 1);
+                const int vc0 = min(max(v0, 0), ph - 1), vc1 = min(max(v0 + 1, 0), ph - 1);
+                float tx4[3][4];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* pc = patch + c * plane;
+                    tx4[c][0] = pc[vc0 * pw + uc0]; tx4[c][1] = pc[vc0 * pw + uc1];
+                    tx4[c][2] = pc[vc1 * pw + uc0]; tx4[c][3] = pc[vc1 * pw + uc1];
+                }
+                const bool ux0 = (unsigned)u0 < (unsigned)pw, ux1 = (unsigned)(u0 + 1) < (unsigned)pw;
+                const bool vy0 = (unsigned)v0 < (unsigned)ph, vy1 = (unsigned)(v0 + 1) < (unsigned)ph;
+                const bool fx1 = s.x0 + 1 < VAA_IMG, fy1 = s.y0 + 1 < VAA_IMG;  // (x0, y0) itself is always inside the frame
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float vnw = (ux0 && vy0) ? tx4[c][0] : -100.0f;
+                    const float vne = !fx1 ? 0.0f : ((ux1 && vy0) ? tx4[c][1] : -100.0f);
+                    const float vsw = !fy1 ? 0.0f : ((ux0 && vy1) ? tx4[c][2] : -100.0f);
+                    const float vse = !(fx1 && fy1) ? 0.0f : ((ux1 && vy1) ? tx4[c][3] : -100.0f);
+                    cv[c] = __builtin_fmaf(vse, s.se, __builtin_fmaf(vsw, s.sw, __builtin_fmaf(vne, s.ne, vnw * s.nw)));
+                }
+            } else {
+                const int u = j - px, v = i - py;
+                inside = (unsigned)u < (unsigned)pw && (unsigned)v < (unsigned)ph;
+                const int uc = min(max(u, 0), pw - 1), vc = min(max(v, 0), ph - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cv[c] = patch[c * plane + vc * pw + uc];
+            }
+            L[0] = lut[by0]; L[1] = lut[256 + by1]; L[2] = lut[512 + by2];
+            if (inside) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (keep_rule(cv[c], a.mask_mode)) { L[c] = norm_pack(cv[c], a.nrm, c); kept[c] = true; }
+            }
+            const size_t e = ((size_t)b * 256 + t) * kTElems + y * kTS + x;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o.out0[e + c * 196] = (uint16_t)(L[c] & 0xffffu);
+                o.out1[e + c * 196] = (uint16_t)(L[c] >> 16);
+            }
+        }
+        unsigned long long many = 0ull;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {  // 14 consecutive lanes = one row of the tile = one keep word
+            const unsigned long long m = __ballot(kept[c]);
+            many |= m;
+            if (o.keep_t && active && x == 0)
+                o.keep_t[(((size_t)b * 3 + c) * 256 + t) * kTS + y] = (uint16_t)((m >> lane) & 0x3fffull);
+        }
+        if (o.flags && lane == 0) reinterpret_cast<uint8_t*>(o.flags + (size_t)b * 256 + t)[wv] = (uint8_t)(many != 0ull ? 1 : 0);
+    }
+}
+
 }  // namespace vaa
 
 namespace vaa {
@@ -380,4 +580,43 @@ extern "C" int vaa_patch_apply_fwd_multi(const uint8_t* img_u8, const float* pac
     }
     return vaa::launch_patch_apply("vaa_patch_apply_fwd_multi", img_u8, packed, pdesc, xy, theta, B, max_h, max_w, geometry, mask_mode, mean6,
                                    std6, out_bf16, keep_bits, stream);
+}
+
+// K1 in tile-major form (see patch_apply_tiles_kernel): the operands of the two ViT patch-embed GEMMs + tile-major keep words + tile flags.
+extern "C" int vaa_patch_apply_fwd_tiles(const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                                         int B, int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
+                                         uint16_t* out0, uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* stream) {
+    using namespace vaa;
+    const char* who = "vaa_patch_apply_fwd_tiles";
+    if (B == 0) return VAA_OK;
+    if (!img_u8 || !patch || !xy || !out0 || !out1 || !mean6 || !std6 || (geometry && !theta)) {
+        set_error("%s: null pointer argument", who);
+        return VAA_E_INVALID;
+    }
+    if (B < 0 || ph <= 0 || pw <= 0 || (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100)) {
+        set_error("%s: bad sizes/mode (B=%d ph=%d pw=%d mask_mode=%d)", who, B, ph, pw, mask_mode);
+        return VAA_E_INVALID;
+    }
+    if (ph > VAA_IMG || pw > VAA_IMG) {
+        set_error("%s: patch %dx%d larger than the %dx%d frame", who, ph, pw, VAA_IMG, VAA_IMG);
+        return VAA_E_UNSUPPORTED;
+    }
+    if (geometry && mask_mode == VAA_MASK_NE_M100) {
+        set_error("%s: VAA_MASK_NE_M100 is defined for geometry=0 only (appply_random_transform.py:153,179)", who);
+        return VAA_E_UNSUPPORTED;
+    }
+    FwdArgs a;
+    a.img = img_u8; a.patch = patch; a.xy = xy; a.theta = theta; a.out = nullptr; a.keep = nullptr; a.pdesc = pdesc;
+    a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
+    for (int q = 0; q < 6; ++q) { a.nrm.mean[q] = mean6[q]; a.nrm.stdv[q] = std6[q]; }
+    TileOut o;
+    o.out0 = out0; o.out1 = out1; o.keep_t = keep_tiles; o.flags = tile_flags;
+    // footprint workgroups per image: each pays a ~2 us prologue (LUT, 224 row spans, tile list) before its first tile, so FEWER, longer-lived
+    // workgroups win here — measured at bs=64 with 1024 / 512 / 256 / 128 in total: 18.7 / 16.2 / 18.6 / 25.8 us (a 50x50 footprint meets ~45
+    // tiles: ~6 per workgroup at 8 per image); small batches keep 16 per image
+    int fsplit = 16;
+    while (fsplit > 1 && (long)B * fsplit > 512) fsplit >>= 1;
+    const long n_fp = (long)B * fsplit, n_bg = (long)B * 16;
+    VAA_LAUNCH(patch_apply_tiles_kernel, dim3((unsigned)(n_fp + n_bg)), dim3(kFwdThreads), 0, (hipStream_t)stream, a, o, (int)n_fp, fsplit);
+    return check_launch(who);
 }

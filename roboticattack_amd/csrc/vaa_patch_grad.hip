@@ -29,6 +29,8 @@
 //   * border padding: out-of-frame source points clamp onto frame-edge canvas pixels; when the patch touches the frame edge
 //     the row bounds are opened to infinity on that side, everything else is unchanged.
 //   * MULTI (resize_patch=True, config 5): one patch PER IMAGE (pdesc), the output is every image's own gradient.
+#include <type_traits>
+
 #include "vaa_common.h"
 
 namespace vaa {
@@ -47,7 +49,8 @@ struct GradArgs {
     // TILED source (vaa_patch_embed_grad_gather): instead of the 6-plane bf16 pixel gradient `g`, the already combined and
     // scaled gradient of the tiles that carry kept pixels: geff[b][ty*16 + tx][c*196 + y*14 + x] (tiles without a kept pixel are not written)
     const float* geff;
-    const float* geff2;      // second tower's tile gradients when the tile kernel ran one tower per workgroup (else nullptr): the gather adds the two
+    const float* geff2;      // non-null: the tile kernel ran one tower per workgroup and `geff` holds {tower 0, tower 1} PAIRS per element: the gather adds the two
+    const uint16_t* keep_t;  // TILED only: K1's tile-major keep words [B,3,256,14] (vaa_patch_apply_fwd_tiles) instead of `keep`
 };
 
 constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTilePx;  // ViT patch-embed tiling of the 224x224 frame
@@ -232,7 +235,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 }
                 const float* pimg = MULTI ? a.patch + a.pdesc[4 * b + 2] : a.patch;
                 const uint16_t* gimg = a.g + (size_t)b * 6 * VAA_NPIX;
-                const uint8_t* kimg = HASK ? a.keep + (size_t)b * 3 * (VAA_NPIX / 8) : nullptr;  // HASK: K1's keep bits are given
+                const bool ktiled = TILED && HASK && a.keep_t != nullptr;  // workgroup-uniform
+                const uint8_t* kimg = (HASK && !ktiled) ? a.keep + (size_t)b * 3 * (VAA_NPIX / 8) : nullptr;  // HASK: K1's keep bits are given
+                const uint16_t* ktimg = ktiled ? a.keep_t + (size_t)b * 3 * 256 * kTilePx : nullptr;
                 if (!MULTI && absorbed + (long)nslots * 64 > kFlushPixels) {  // int64 headroom (pathological zoom-outs / huge batches only)
                     __syncthreads();
                     drain(a.partial + (size_t)blockIdx.x * 3 * plane, ph, pw, flushed, true);
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                         const bool lane_in = sidx < nslots && off < len;
                         const int j0 = min((int)(w >> 16) + off, VAA_IMG - 2);  // even
                         const int pix0 = i * VAA_IMG + j0;
-                        uint32_t f = (uint32_t)(pix0 & 7) << 16;
+                        uint32_t f = ktiled ? 0u : (uint32_t)(pix0 & 7) << 16;  // tile-major keep words are shifted to bit 0 when they are loaded
 #pragma unroll
                         for (int p = 0; p < 2; ++p) {
                             const int j = j0 + p;
@@ -290,16 +295,25 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                 }
                             }
                             f |= fp << (8 * p);
-                            if (TILED && inside) {
-                                const int ty = i / kTilePx, tx = j / kTilePx;
-                                // a pixel without any kept channel may lie in a tile that was not evaluated: its value is read but never used
-                                const float* gtile = a.geff + ((size_t)b * (kTilesPerSide * kTilesPerSide) + ty * kTilesPerSide + tx) * kTileElems +
-                                                     (i - ty * kTilePx) * kTilePx + (j - tx * kTilePx);
+                        }
+                        if (TILED && ((f & 0x0101u) != 0u)) {
+                            // the lane's two pixels are adjacent elements of one tile row (14 is even): ONE load per channel fetches both
+                            // (8 bytes, or 16 when the tile kernel ran one tower per workgroup and left {tower 0, tower 1} pairs).
+                            // A pixel without any kept channel may lie in a tile that was not evaluated: its value is read but never used
+                            const int ty = i / kTilePx, tx = j0 / kTilePx;
+                            const size_t gel = ((size_t)b * (kTilesPerSide * kTilesPerSide) + ty * kTilesPerSide + tx) * kTileElems +
+                                               (i - ty * kTilePx) * kTilePx + (j0 - tx * kTilePx);
 #pragma unroll
-                                for (int cc = 0; cc < NCH; ++cc) {
-                                    float gv = gtile[(c_base + cc) * (kTilePx * kTilePx)];
-                                    if (a.geff2) gv += (a.geff2 + (gtile - a.geff))[(c_base + cc) * (kTilePx * kTilePx)];  // tower 0 + tower 1: the tile kernel's own sum
-                                    gt[k][p][cc] = gv;
+                            for (int cc = 0; cc < NCH; ++cc) {
+                                const size_t ge = gel + (c_base + cc) * (kTilePx * kTilePx);  // even
+                                if (a.geff2) {  // {tower 0, tower 1} pairs, added here — the tile kernel's own fp32 sum
+                                    const float4 v4 = *reinterpret_cast<const float4*>(a.geff + 2 * ge);
+                                    gt[k][0][cc] = v4.x + v4.y;
+                                    gt[k][1][cc] = v4.z + v4.w;
+                                } else {
+                                    const float2 v2 = *reinterpret_cast<const float2*>(a.geff + ge);
+                                    gt[k][0][cc] = v2.x;
+                                    gt[k][1][cc] = v2.y;
                                 }
                             }
                         }
@@ -309,7 +323,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             for (int cc = 0; cc < NCH; ++cc) {
                                 const int c = c_base + cc;
 #ifndef VAA_K2_ABLATE_NO_LOADS
-                                if (HASK) kb[k][cc] = kimg[(size_t)c * (VAA_NPIX / 8) + (pix0 >> 3)];
+                                if (HASK) {
+                                    if (ktiled) {  // word (c, tile, y), bit x: a lane's pixel pair never straddles a tile (14 is even)
+                                        const int ty = i / kTilePx, tx = j0 / kTilePx;
+                                        kb[k][cc] = (uint32_t)ktimg[((size_t)c * 256 + ty * kTilesPerSide + tx) * kTilePx + (i - ty * kTilePx)] >> (j0 - tx * kTilePx);
+                                    } else {
+                                        kb[k][cc] = kimg[(size_t)c * (VAA_NPIX / 8) + (pix0 >> 3)];
+                                    }
+                                }
                                 if (!TILED) {
                                     g0[k][cc] = *reinterpret_cast<const uint32_t*>(gimg + (size_t)c * VAA_NPIX + pix0);
                                     g1[k][cc] = *reinterpret_cast<const uint32_t*>(gimg + (size_t)(c + 3) * VAA_NPIX + pix0);
@@ -436,33 +457,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ __launch_bounds__(256) void patch_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gpatch,
                                                                  int n, int nparts) {
     __shared__ double sl[16][16][4];
-    const int el = threadIdx.x & 15, s = threadIdx.x >> 4;
-    const int e = (blockIdx.x * 16 + el) * 4;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if (e + 3 < n && (n & 3) == 0) {
-#pragma unroll 8
-        for (int p = s; p < nparts; p += 16) {
-            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)p * n + e);
-            acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
-        }
-    } else {
-        for (int p = s; p < nparts; p += 16)
-#pragma unroll
-            for (int z = 0; z < 4; ++z)
-                if (e + z < n) acc[z] += (double)partial[(size_t)p * n + e + z];
-    }
-#pragma unroll
-    for (int z = 0; z < 4; ++z) sl[s][el][z] = acc[z];
-    __syncthreads();
-    if (s < 4) {  // thread (s, el) of the second level sums element z = s of quad el
-        const int z = s;
-        if (e + z < n) {
-            double t = 0.0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t += sl[q][el][z];
-            gpatch[e + z] = (float)t;
-        }
-    }
+    partial_reduce_block(partial, gpatch, n, nparts, blockIdx.x, sl);
 }
 
 int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts, hipStream_t st, const char* who) {
@@ -541,7 +536,7 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
         return VAA_E_LAUNCH;
     }
     int rc = check_launch(who);
-    if (rc != VAA_OK) return rc;
+    if (rc != VAA_OK || !gpatch) return rc;  // gpatch == nullptr: the caller's step epilogue adds the partial tiles
     return launch_partial_reduce((const float*)a.partial, gpatch, n, G, st, who);
 }
 
@@ -611,7 +606,7 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode; a.band_rows = ph;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
     return launch_scatter_reduce<false>(a, gpatch, st, "vaa_patch_grad_gather");
 }
 
@@ -642,7 +637,7 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.g = gout_bf16; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
     return launch_scatter_multi<false>(a, max_h, max_w, (hipStream_t)stream, "vaa_patch_grad_gather_multi");
 }
 
@@ -661,8 +656,9 @@ struct EmbedArgs {
     const uint16_t *dy0, *dy1;  // [B,256,D0], [B,256,D1] bf16: dL/d(patch-embed output) of the two towers, tokens in tile order
     const uint16_t *wt0, *wt1;  // conv weights of the two towers in the PACKED fragment order of embed_pack_weights_kernel
     const uint8_t* keep;        // [B,3,224*224/8] keep bits from K1
+    const uint32_t* flags;      // [B,256] tile flag words from K1's tile-major form (else nullptr: derived from `keep`)
     float* geff;                // [B,256,588], indexed by tile (ty*16 + tx); only the flagged tiles are written
-    float* geff2;               // tower_split: tower 1's tile gradients (same layout)
+    float* geff2;               // non-null: room for the pair layout of tower_split ({tower 0, tower 1} per element, in geff)
     int B, D0, D1, round_bf16;
     int tower_split;            // one tower per workgroup (grid.z = 2): halves the per-workgroup chain while the launch is far from filling the chip
     float istd6[6];
@@ -735,7 +731,7 @@ __global__ __launch_bounds__(kEmbedThreads) void embed_dgrad_tiles_kernel(EmbedA
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
 
     // ---- which tiles carry a kept pixel (any channel): thread t = tile t ----
-    const bool flag = tile_has_kept_pixel(a.keep + (size_t)b * 3 * (VAA_NPIX / 8), tid >> 4, tid & 15);
+    const bool flag = a.flags ? a.flags[(size_t)b * 256 + tid] != 0 : tile_has_kept_pixel(a.keep + (size_t)b * 3 * (VAA_NPIX / 8), tid >> 4, tid & 15);
     const unsigned long long m = __ballot(flag);
     if (lane == 0) wave_cnt[wv] = __popcll(m);
     __syncthreads();
@@ -822,24 +818,23 @@ constexpr int kEmbedGroup = VAA_EMBED_GROUP;  // 64-wide k-chunks whose weight f
 //   * the A fragments of chunk u+1 are read from LDS before the MFMAs of chunk u (one ds_read per row block and k-half, all issued
 //     together), so the LDS latency is covered by twelve MFMAs instead of being paid in front of every pair.
 //   * MFMA order: all row blocks against the first k-half, then the second: consecutive MFMAs never share an accumulator.
-template <int NQ>
-__device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const uint16_t* wp0, const uint16_t* wp1, int nchunk, v4f_e (&acc)[2][4]) {
+template <int NQ, int NB>
+__device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const uint16_t* const (&wp)[NB], int nchunk, v4f_e (&acc)[NB][4]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[j][q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
-    auto load_group = [&](v8s_e (&bf)[kEmbedGroup][2][2], int k0) {
+    auto load_group = [&](v8s_e (&bf)[kEmbedGroup][NB][2], int k0) {
 #pragma unroll
         for (int u = 0; u < kEmbedGroup; ++u) {
             const int kc = min(k0 + u, nchunk - 1);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bf[u][0][h] = *reinterpret_cast<const v8s_e*>(wp0 + (size_t)kc * 1024 + h * 512);
-                bf[u][1][h] = *reinterpret_cast<const v8s_e*>(wp1 + (size_t)kc * 1024 + h * 512);
-            }
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) bf[u][j][h] = *reinterpret_cast<const v8s_e*>(wp[j] + (size_t)kc * 1024 + h * 512);
         }
     };
-    auto compute_group = [&](const v8s_e (&bf)[kEmbedGroup][2][2], int k0) {
+    auto compute_group = [&](const v8s_e (&bf)[kEmbedGroup][NB][2], int k0) {
         if (k0 >= nchunk) return;  // wave-uniform
         v8s_e af[2][NQ][2];
 #pragma unroll
@@ -861,16 +856,16 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][q][h], bf[u][0][h], acc[0][q], 0, 0, 0);
-                        acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][q][h], bf[u][1][h], acc[1][q], 0, 0, 0);
-                    }
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][q][h], bf[u][j][h], acc[j][q], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
     // two register sets in ping-pong: the requests of the next group are in flight while this group's MFMAs run
-    v8s_e bfa[kEmbedGroup][2][2], bfb[kEmbedGroup][2][2];
+    v8s_e bfa[kEmbedGroup][NB][2], bfb[kEmbedGroup][NB][2];
     load_group(bfa, 0);
     for (int k0 = 0; k0 < nchunk; k0 += 2 * kEmbedGroup) {
         load_group(bfb, k0 + kEmbedGroup);
@@ -884,16 +879,18 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
 
 // Fast variant for tower widths that fit the LDS (64 x (D+8) bf16 <= 150 KB, i.e. D <= 1160): the gathered dY rows of one tower are
 // staged ONCE per workgroup (all loads in flight together, one barrier), then every wave runs a barrier-free k-loop — A fragments from
-// LDS (16 B reads, each feeding two MFMAs: a wave owns two column blocks), B fragments (weights) from global, four k-steps ahead.
-// 8 waves x 2 column blocks = 16 column blocks per workgroup, 3 workgroups per image, all on the image's XCD.
+// LDS (16 B reads, each feeding NB MFMAs: a wave owns NB column blocks), B fragments (weights) from global, four k-steps ahead.
+// The 37 column blocks of a tile are cut into `nch` contiguous ranges (one workgroup each, all on the image's XCD) and a range is dealt
+// to the 8 waves as evenly as possible (1..3 blocks per wave, the waves with one more block on different SIMDs).
 #ifndef VAA_EMBED_WAVES
 #define VAA_EMBED_WAVES 8
 #endif
 constexpr int kEmbedFastThreads = VAA_EMBED_WAVES * 64;
-constexpr int kEmbedFastCols = VAA_EMBED_WAVES * 2;   // column blocks per workgroup (two per wave)
 constexpr int kEmbedStageMax = ((64 * 1160 / 8 + kEmbedFastThreads - 1) / kEmbedFastThreads + 1) / 2 * 2;  // 16-byte chunks a thread stages per tower (even)
 
-template <bool SPLIT>  // SPLIT: one tower per workgroup (blockIdx.z), its tile gradients into geff / geff2; else both towers, summed
+// SPLIT: one tower per workgroup (blockIdx.z), its tile gradients into geff / geff2 (the gather adds the two); else both towers, summed.
+// NB: most column blocks a wave owns (ceil(ceil(37 / nch) / 8)).
+template <bool SPLIT, int NB>
 __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kernel(EmbedArgs a, int nch) {
     extern __shared__ __align__(16) unsigned char embed_smem[];
     uint16_t* sA = reinterpret_cast<uint16_t*>(embed_smem);
@@ -909,7 +906,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
 #endif
 
     bool flag = false;
-    if (tid < 256) flag = tile_has_kept_pixel(a.keep + (size_t)b * 3 * (VAA_NPIX / 8), tid >> 4, tid & 15);
+    if (tid < 256) flag = a.flags ? a.flags[(size_t)b * 256 + tid] != 0 : tile_has_kept_pixel(a.keep + (size_t)b * 3 * (VAA_NPIX / 8), tid >> 4, tid & 15);
     const unsigned long long m = __ballot(flag);
     if (lane == 0 && wv < 4) wave_cnt[wv] = __popcll(m);
     __syncthreads();
@@ -920,21 +917,25 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     __syncthreads();
 
     K2_STAMP(0)
-    int n[2];
-    bool nv[2];
-    float s0[2], s1[2];
+    // this wave's column blocks: [nb0, nb0 + nbw) of the workgroup's range [ch * per, min(37, (ch + 1) * per))
+    const int per = (kNBlocks + nch - 1) / nch;
+    const int wg_lo = ch * per, wg_n = max(0, min(kNBlocks, wg_lo + per) - wg_lo);
+    const int wbase = wg_n / VAA_EMBED_WAVES, wrem = wg_n - wbase * VAA_EMBED_WAVES;
+    const int nbw = wbase + (wv < wrem ? 1 : 0), nb0 = wg_lo + wv * wbase + min(wv, wrem);  // nbw <= NB by the host's choice of NB
+    int n[NB];
+    bool nv[NB];
+    float s0[NB], s1[NB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int nb = ch * kEmbedFastCols + wv * 2 + j;
-        n[j] = nb * 16 + c;
-        nv[j] = nb < kNBlocks && n[j] < kTileElems;
+    for (int j = 0; j < NB; ++j) {
+        n[j] = (nb0 + j) * 16 + c;
+        nv[j] = j < nbw && n[j] < kTileElems;
         const int c3 = nv[j] ? n[j] / (kTilePx * kTilePx) : 0;
         s0[j] = a.istd6[c3];
         s1[j] = a.istd6[c3 + 3];
     }
     for (int mg = blockIdx.y; mg * 64 < M; mg += gridDim.y) {  // 64-tile row groups: spread over grid.y when the patch can cover more
         const int rows = min(64, M - mg * 64), nq = (rows + 15) >> 4;  // workgroup-uniform
-        float res[2][4][4];  // [column block][row block][r]: tower 0's scaled contribution, then + tower 1's
+        float res[NB][4][4];  // [column block][row block][r]: tower 0's scaled contribution, then + tower 1's
         const int t_lo = SPLIT ? (int)blockIdx.z : 0;
 #pragma unroll
         for (int tt = 0; tt < (SPLIT ? 1 : 2); ++tt) {
@@ -973,19 +974,40 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
             K2_STAMP(1 + 2 * tower)
             // ---- barrier-free k-loop ----
             const uint16_t* wt = tower ? a.wt1 : a.wt0;
-            // column blocks beyond the 37th (the last workgroup's spare waves) read block 36: loads stay unconditional, results are never stored
-            const uint16_t* wp0 = wt + packed_frag_offset(min(ch * kEmbedFastCols + wv * 2, kNBlocks - 1), D >> 6, 0, 0, lane);
-            const uint16_t* wp1 = wt + packed_frag_offset(min(ch * kEmbedFastCols + wv * 2 + 1, kNBlocks - 1), D >> 6, 0, 0, lane);
-            v4f_e acc[2][4];
-            const uint16_t* ap = &sA[c * SA + g * 16];
-            switch (nq) {
-                case 1: embed_kloop<1>(ap, SA, wp0, wp1, D >> 6, acc); break;
-                case 2: embed_kloop<2>(ap, SA, wp0, wp1, D >> 6, acc); break;
-                case 3: embed_kloop<3>(ap, SA, wp0, wp1, D >> 6, acc); break;
-                default: embed_kloop<4>(ap, SA, wp0, wp1, D >> 6, acc); break;
-            }
+            // blocks beyond this wave's count (or beyond the 37th) re-read its last block: loads stay unconditional, results are never stored
+            const uint16_t* wp[NB];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NB; ++j)
+                wp[j] = wt + packed_frag_offset(min(nb0 + min(j, max(nbw - 1, 0)), kNBlocks - 1), D >> 6, 0, 0, lane);
+            v4f_e acc[NB][4];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
+            const uint16_t* ap = &sA[c * SA + g * 16];
+            // a wave with fewer blocks than NB runs the narrower loop (wave-uniform): no dummy MFMAs on the SIMD it shares with a fuller wave
+            auto run = [&](auto nbtag) {
+                constexpr int NBW = decltype(nbtag)::value;
+                const uint16_t* wq[NBW];
+                v4f_e ac[NBW][4];
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) wq[j] = wp[j];
+                switch (nq) {
+                    case 1: embed_kloop<1, NBW>(ap, SA, wq, D >> 6, ac); break;
+                    case 2: embed_kloop<2, NBW>(ap, SA, wq, D >> 6, ac); break;
+                    case 3: embed_kloop<3, NBW>(ap, SA, wq, D >> 6, ac); break;
+                    default: embed_kloop<4, NBW>(ap, SA, wq, D >> 6, ac); break;
+                }
+#pragma unroll
+                for (int j = 0; j < NBW; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[j][q] = ac[j][q];
+            };
+            if (nbw >= NB) run(std::integral_constant<int, NB>{});
+            else if (NB >= 3 && nbw == 2) run(std::integral_constant<int, (NB >= 3 ? 2 : 1)>{});
+            else if (NB >= 2 && nbw == 1) run(std::integral_constant<int, 1>{});
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -996,14 +1018,18 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
             K2_STAMP(2 + 2 * tower)
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NB; ++j) {
             if (!nv[j]) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int sl = mg * 64 + q * 16 + g * 4 + r;
-                    if (sl < M) (t_lo ? a.geff2 : a.geff)[((size_t)b * 256 + tiles[sl]) * kTileElems + n[j]] = res[j][q][r];
+                    if (sl < M) {
+                        const size_t el = ((size_t)b * 256 + tiles[sl]) * kTileElems + n[j];
+                        if (SPLIT) a.geff[el * 2 + t_lo] = res[j][q][r];  // {tower 0, tower 1} interleaved: ONE 8-byte load per element in the gather
+                        else a.geff[el] = res[j][q][r];
+                    }
                 }
         }
         K2_STAMP(5)
@@ -1028,17 +1054,30 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
     const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
     e.tower_split = 0;
     if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
-        const int nch = (kNBlocks + kEmbedFastCols - 1) / kEmbedFastCols;  // workgroups per image
-        // while twice the workgroups still fit one residency wave of the chip, a workgroup takes ONE tower (grid.z): its chain halves
-        // (bs=8: tile kernel 21 -> 12 us); the gather adds the two towers' tile gradients — the very fp32 add the unsplit kernel does
-        e.tower_split = (ny == 1 && e.geff2 && (long)((B + 7) / 8 * 8) * nch * 2 <= 256) ? 1 : 0;
-        const void* fn = e.tower_split ? (const void*)embed_dgrad_tiles_lds_kernel<true> : (const void*)embed_dgrad_tiles_lds_kernel<false>;
+        // Workgroups per image. A workgroup's time is a chain — tile list, staging of a tower's rows, k-loop, (second tower), store —, so while
+        // the launch fits ONE residency wave of the 256 CUs a workgroup takes ONE tower (grid.z = 2: its chain halves; the gather adds the two
+        // towers' tile gradients — the very fp32 add the unsplit kernel does) and as few column blocks as that leaves room for:
+        //   B <= 24: 5 x 2 workgroups per image, 1 block per wave;  B <= 40: 3 x 2, <= 2 blocks;  B <= 64: 2 x 2, <= 3 blocks (256 workgroups at 64)
+        // beyond that the batch fills the chip several times over and the unsplit form (3 per image, both towers, no second buffer) is kept.
+        const long Bpad = (B + 7) / 8 * 8;
+        int nch = 3;
+        if (ny == 1 && e.geff2 && Bpad <= 64) {
+            e.tower_split = 1;
+            nch = Bpad <= 24 ? 5 : (Bpad <= 40 ? 3 : 2);
+        }
+        const int nbmax = ((kNBlocks + nch - 1) / nch + VAA_EMBED_WAVES - 1) / VAA_EMBED_WAVES;  // 1, 2 or 3
+        const void* fn = nullptr;
+        if (e.tower_split) fn = nbmax == 1 ? (const void*)embed_dgrad_tiles_lds_kernel<true, 1> : (nbmax == 2 ? (const void*)embed_dgrad_tiles_lds_kernel<true, 2> : (const void*)embed_dgrad_tiles_lds_kernel<true, 3>);
+        else fn = (const void*)embed_dgrad_tiles_lds_kernel<false, 2>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast) != hipSuccess) {
             set_error("%s: hipFuncSetAttribute failed", who);
             return VAA_E_LAUNCH;
         }
-        if (e.tower_split) VAA_LAUNCH(embed_dgrad_tiles_lds_kernel<true>, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, 2), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
-        else VAA_LAUNCH(embed_dgrad_tiles_lds_kernel<false>, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny, 1), dim3(kEmbedFastThreads), lds_fast, st, e, nch);
+        const dim3 grid((unsigned)Bpad * nch, ny, e.tower_split ? 2 : 1), blk(kEmbedFastThreads);
+        if (!e.tower_split) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<false, 2>), grid, blk, lds_fast, st, e, nch);
+        else if (nbmax == 1) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 1>), grid, blk, lds_fast, st, e, nch);
+        else if (nbmax == 2) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 2>), grid, blk, lds_fast, st, e, nch);
+        else VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 3>), grid, blk, lds_fast, st, e, nch);
     } else {  // wide towers: fragments straight from global memory
         const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
         VAA_LAUNCH(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedThreads), 0, st, e, nch);
@@ -1073,54 +1112,80 @@ extern "C" size_t vaa_patch_embed_grad_ws_bytes(int B, int ph, int pw) {
     return vaa_patch_grad_ws_bytes(B, ph, pw) + 2 * (size_t)B * 256 * vaa::kTileElems * sizeof(float) + 256;  // partial tiles + one tile-gradient buffer per tower
 }
 
-extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
-                                           const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph,
-                                           int pw, int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws,
-                                           size_t ws_bytes, void* stream) {
-    using namespace vaa;
+namespace vaa {
+
+// K2' for one patch per batch. keep_tiles / tile_flags (K1's tile-major outputs) replace keep_bits when given; gpatch == nullptr leaves the
+// fixed-order sum of the partial tiles (ws[0 .. parts*3*ph*pw), parts = vaa_patch_grad_partials(B)) to the caller's vaa_step_epilogue.
+static int embed_grad_gather_impl(const char* who, const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
+                                  const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, const uint16_t* keep_tiles,
+                                  const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6, int round_bf16,
+                                  float* gpatch, bool defer_reduce, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 && gpatch && ph > 0 && pw > 0) {
-        if (hipMemsetAsync(gpatch, 0, (size_t)3 * ph * pw * sizeof(float), st) != hipSuccess) return check_launch("vaa_patch_embed_grad_gather(memset)");
+        if (hipMemsetAsync(gpatch, 0, (size_t)3 * ph * pw * sizeof(float), st) != hipSuccess) return check_launch(who);
         return VAA_OK;
     }
-    if (!dy0 || !dy1 || !wt0 || !wt1 || !xy || !std6 || !gpatch || !keep_bits || (geometry && !theta)) {
-        set_error("vaa_patch_embed_grad_gather: null pointer argument (the keep bits of K1 are required)");
+    const bool tiled_keep = keep_tiles != nullptr;
+    if (!dy0 || !dy1 || !wt0 || !wt1 || !xy || !std6 || (!gpatch && !defer_reduce) || (!keep_bits && !tiled_keep) || (tiled_keep && !tile_flags) ||
+        (geometry && !theta)) {
+        set_error("%s: null pointer argument (the keep mask of K1 is required)", who);
         return VAA_E_INVALID;
     }
-    if (B < 0 || ph <= 0 || pw <= 0 || D0 <= 0 || D1 <= 0 || (D0 % 64) != 0 || (D1 % 64) != 0 ||
+    if (B <= 0 || ph <= 0 || pw <= 0 || D0 <= 0 || D1 <= 0 || (D0 % 64) != 0 || (D1 % 64) != 0 ||
         (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100)) {
-        set_error("vaa_patch_embed_grad_gather: bad sizes/mode (B=%d ph=%d pw=%d D0=%d D1=%d; D %% 64 == 0)", B, ph, pw, D0, D1);
+        set_error("%s: bad sizes/mode (B=%d ph=%d pw=%d D0=%d D1=%d; D %% 64 == 0)", who, B, ph, pw, D0, D1);
         return VAA_E_INVALID;
     }
     if (ph > VAA_IMG || pw > VAA_IMG) {
-        set_error("vaa_patch_embed_grad_gather: patch %dx%d larger than the frame", ph, pw);
+        set_error("%s: patch %dx%d larger than the frame", who, ph, pw);
         return VAA_E_UNSUPPORTED;
     }
     if (geometry && mask_mode == VAA_MASK_NE_M100) {
-        set_error("vaa_patch_embed_grad_gather: VAA_MASK_NE_M100 is defined for geometry=0 only");
+        set_error("%s: VAA_MASK_NE_M100 is defined for geometry=0 only", who);
         return VAA_E_UNSUPPORTED;
     }
     if (!ws || ws_bytes < vaa_patch_embed_grad_ws_bytes(B, ph, pw)) {
-        set_error("vaa_patch_embed_grad_gather: workspace %zu B < required %zu B", ws_bytes, vaa_patch_embed_grad_ws_bytes(B, ph, pw));
+        set_error("%s: workspace %zu B < required %zu B", who, ws_bytes, vaa_patch_embed_grad_ws_bytes(B, ph, pw));
         return VAA_E_WORKSPACE;
     }
     char* wsb = reinterpret_cast<char*>(ws);
     const size_t part_bytes = (vaa_patch_grad_ws_bytes(B, ph, pw) + 255) / 256 * 256;
     EmbedArgs e;
-    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wt0; e.wt1 = wt1; e.keep = keep_bits;
+    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wt0; e.wt1 = wt1; e.keep = keep_bits; e.flags = tile_flags;
     e.geff = reinterpret_cast<float*>(wsb + part_bytes);
     e.geff2 = e.geff + (size_t)B * 256 * kTileElems;
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
-    if (launch_embed_tiles(e, ph, pw, st, "vaa_patch_embed_grad_gather") != VAA_OK) return VAA_E_LAUNCH;
-    int rc = check_launch("vaa_patch_embed_grad_gather(tiles)");
+    if (launch_embed_tiles(e, ph, pw, st, who) != VAA_OK) return VAA_E_LAUNCH;
+    int rc = check_launch(who);
     if (rc != VAA_OK) return rc;
     GradArgs a;
-    a.g = nullptr; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws;
+    a.g = nullptr; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr;
-    return launch_scatter_reduce<true>(a, gpatch, st, "vaa_patch_embed_grad_gather");
+    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles;
+    if (keep_tiles) a.keep = reinterpret_cast<const uint8_t*>(keep_tiles);  // non-null selects the stored-mask instantiation
+    return launch_scatter_reduce<true>(a, defer_reduce ? nullptr : gpatch, st, who);
+}
+
+}  // namespace vaa
+
+extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
+                                           const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph,
+                                           int pw, int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, keep_bits, nullptr, nullptr, B, ph, pw,
+                                       geometry, mask_mode, std6, round_bf16, gpatch, false, ws, ws_bytes, stream);
+}
+
+extern "C" int vaa_patch_grad_partials(int B) { return B > 0 ? vaa::grad_sched(B).gx : 0; }
+
+extern "C" int vaa_patch_embed_grad_gather_tiles(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
+                                                 const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
+                                                 const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
+                                                 int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream) {
+    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather_tiles", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, nullptr, keep_tiles, tile_flags, B,
+                                       ph, pw, geometry, mask_mode, std6, round_bf16, gpatch, gpatch == nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" size_t vaa_patch_embed_grad_multi_ws_bytes(int B) {
@@ -1158,7 +1223,7 @@ extern "C" int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, co
         return VAA_E_WORKSPACE;
     }
     EmbedArgs e;
-    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wp0; e.wt1 = wp1; e.keep = keep_bits; e.geff = reinterpret_cast<float*>(ws);
+    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wp0; e.wt1 = wp1; e.keep = keep_bits; e.flags = nullptr; e.geff = reinterpret_cast<float*>(ws);
     e.geff2 = e.geff + (size_t)B * 256 * kTileElems;
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
@@ -1169,6 +1234,6 @@ extern "C" int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, co
     a.g = nullptr; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr;
+    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = nullptr;
     return launch_scatter_multi<true>(a, max_h, max_w, st, "vaa_patch_embed_grad_gather_multi");
 }

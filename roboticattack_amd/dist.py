@@ -75,13 +75,16 @@ class PatchGradSync:
         return self.buf[: self.n_grad], self.buf[self.n_grad :]
 
     def allreduce_step(self, grad: torch.Tensor, loss_scalars: torch.Tensor, pick: torch.Tensor):
-        """One inner step's message [grad | loss_scalars[pick] | sum(grad)] packed with three small launches (copy, gather, sum)
-        instead of the copy/copy/stack/mean chain, then ONE all-reduce(sum). `pick` is an int64 device index of n_scalars-1 entries;
-        the last slot carries sum(grad) (the caller divides by numel for the logged mean gradient)."""
+        """One inner step's message [grad | loss_scalars[pick]] packed with two small launches (copy, gather), then ONE all-reduce(sum).
+        `pick` is an int64 device index of n_scalars entries. (The fused step writes the same message with vaa_step_epilogue and calls
+        allreduce_packed.)"""
         g = grad.reshape(-1)
         self.buf[: self.n_grad].copy_(g)
         torch.index_select(loss_scalars, 0, pick, out=self.buf[self.n_grad : self.n_grad + pick.numel()])
-        torch.sum(g.view(1, -1), dim=1, out=self.buf[self.n_grad + pick.numel() : self.n_grad + pick.numel() + 1])
+        return self.allreduce_packed()
+
+    def allreduce_packed(self):
+        """The message is already in `buf` ([grad | scalars], e.g. written by vaa_step_epilogue): ONE all-reduce(sum), views returned."""
         if self.world > 1:
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
         return self.buf[: self.n_grad], self.buf[self.n_grad :]

@@ -127,6 +127,35 @@ def patch_apply_fwd(img_u8, patch, xy, theta, geometry: bool, mask_mode: int = M
     return out, keep
 
 
+def patch_apply_fwd_tiles(img_u8, patch, xy, theta, geometry: bool, mask_mode: int = MASK_LT_M20, mean6=None, std6=None, pdesc=None, max_hw=None):
+    """K1 in tile-major form (vaa_patch_apply_fwd_tiles): -> (out0, out1 bf16 [B,256,588], keep_tiles u16 [B,3,256,14], tile_flags u32 [B,256]).
+    out_k are the operands of the two ViT patch-embed GEMMs (tile t = ty*16 + tx, element c*196 + y*14 + x). pdesc/max_hw: per-image patches."""
+    B = img_u8.shape[0]
+    _need(img_u8, torch.uint8, "img_u8", (B, IMG, IMG, 3))
+    _need(patch, torch.float32, "patch")
+    _need(xy, torch.int32, "xy", (B, 2))
+    if geometry:
+        _need(theta, torch.float32, "theta", (B, 6))
+    if pdesc is not None:
+        _need(pdesc, torch.int32, "pdesc", (B, 4))
+        ph, pw = int(max_hw[0]), int(max_hw[1])
+    else:
+        ph, pw = int(patch.shape[1]), int(patch.shape[2])
+    dev = img_u8.device
+    out0 = torch.empty((B, 256, 588), dtype=torch.bfloat16, device=dev)
+    out1 = torch.empty((B, 256, 588), dtype=torch.bfloat16, device=dev)
+    keep_t = torch.empty((B, 3, 256, 14), dtype=torch.int16, device=dev)
+    flags = torch.empty((B, 256), dtype=torch.int32, device=dev)
+    mean_c = _MEAN if mean6 is None else _lib.f32x(mean6)
+    std_c = _STD if std6 is None else _lib.f32x(std6)
+    with _timed("K1_patch_apply_fwd_tiles", B=B, ph=ph, pw=pw):
+        rc = _lib.lib().vaa_patch_apply_fwd_tiles(
+            img_u8.data_ptr(), patch.data_ptr(), pdesc.data_ptr() if pdesc is not None else None, xy.data_ptr(), theta.data_ptr() if geometry else None,
+            B, ph, pw, int(bool(geometry)), int(mask_mode), mean_c, std_c, out0.data_ptr(), out1.data_ptr(), keep_t.data_ptr(), flags.data_ptr(), _stream())
+    _lib.check(rc, "vaa_patch_apply_fwd_tiles")
+    return out0, out1, keep_t, flags
+
+
 def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None):
     """K2. gout_bf16 [B,6,224,224] bf16 -> dL/d patch [3,ph,pw] f32 (sum over the batch)."""
     B = gout_bf16.shape[0]
@@ -192,6 +221,39 @@ def patch_embed_grad_gather(dy0, dy1, wp0, wp1, patch, xy, theta, keep_bits, geo
                                            theta.data_ptr() if geometry else None, keep_bits.data_ptr(), B, ph, pw, int(bool(geometry)),
                                            int(mask_mode), std_c, int(bool(round_bf16)), gpatch.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "vaa_patch_embed_grad_gather")
+    return gpatch
+
+
+def patch_embed_grad_gather_tiles(dy0, dy1, wp0, wp1, patch, xy, theta, keep_tiles, tile_flags, geometry: bool, mask_mode: int = MASK_LT_M20,
+                                  std6=None, round_bf16: bool = True, defer_reduce: bool = False):
+    """K2' fed by the tile-major mask of patch_apply_fwd_tiles. defer_reduce=True returns (partials view [parts, 3*ph*pw] of the workspace):
+    the fixed-order sum is then left to ops.step_epilogue."""
+    B = dy0.shape[0]
+    D0, D1 = int(dy0.shape[2]), int(dy1.shape[2])
+    _need(dy0, torch.bfloat16, "dy0", (B, 256, D0))
+    _need(dy1, torch.bfloat16, "dy1", (B, 256, D1))
+    _need(wp0, torch.bfloat16, "wp0", (592 * D0,))
+    _need(wp1, torch.bfloat16, "wp1", (592 * D1,))
+    _need(patch, torch.float32, "patch")
+    _need(xy, torch.int32, "xy", (B, 2))
+    if geometry:
+        _need(theta, torch.float32, "theta", (B, 6))
+    _need(keep_tiles, torch.int16, "keep_tiles", (B, 3, 256, 14))
+    _need(tile_flags, torch.int32, "tile_flags", (B, 256))
+    ph, pw = int(patch.shape[1]), int(patch.shape[2])
+    L = _lib.lib()
+    ws = _workspace(patch.device, L.vaa_patch_embed_grad_ws_bytes(B, ph, pw), "k2e")
+    gpatch = None if defer_reduce else torch.empty_like(patch)
+    std_c = _STD if std6 is None else _lib.f32x(std6)
+    with _timed("K2_patch_embed_grad_gather_tiles", B=B, ph=ph, pw=pw):
+        rc = L.vaa_patch_embed_grad_gather_tiles(dy0.data_ptr(), D0, dy1.data_ptr(), D1, wp0.data_ptr(), wp1.data_ptr(), patch.data_ptr(), xy.data_ptr(),
+                                                 theta.data_ptr() if geometry else None, keep_tiles.data_ptr(), tile_flags.data_ptr(), B, ph, pw,
+                                                 int(bool(geometry)), int(mask_mode), std_c, int(bool(round_bf16)),
+                                                 gpatch.data_ptr() if gpatch is not None else None, ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "vaa_patch_embed_grad_gather_tiles")
+    if defer_reduce:
+        parts, n = L.vaa_patch_grad_partials(B), 3 * ph * pw
+        return ws[: parts * n * 4].view(torch.float32).view(parts, n)
     return gpatch
 
 
@@ -373,21 +435,29 @@ class PatchApplyEmbed(torch.autograd.Function):
     `patch_embed_grad_gather`, which evaluates the patch-embed backward only for the tiles under the patch. w: [D,588], wp: pack_embed_weights(w^T)."""
 
     @staticmethod
-    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode, mean6, std6, w0, b0, wp0, w1, b1, wp1):
+    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode, mean6, std6, w0, b0, wp0, w1, b1, wp1, sink=None):
+        """sink (a dict, optional): the backward then leaves K2''s partial tiles in sink["partials"] and returns NO gradient for `patch`
+        — the caller's step epilogue (ops.step_epilogue) adds them straight into the DDP message."""
+        ctx.sink = sink
         p = patch.detach().contiguous()
-        out, keep = patch_apply_fwd(img_u8, p, xy, theta, geometry, mask_mode, want_keep=True, mean6=mean6, std6=std6)
-        e0 = torch.nn.functional.linear(unfold_tiles(out[:, :3]), w0, b0)
-        e1 = torch.nn.functional.linear(unfold_tiles(out[:, 3:]), w1, b1)
-        ctx.save_for_backward(p, xy, theta if geometry else xy, keep, wp0, wp1)
+        # K1 writes the two GEMM operands directly (tile-major): no [B,6,224,224] tensor, no im2col copies
+        t0, t1, keep_t, flags = patch_apply_fwd_tiles(img_u8, p, xy, theta, geometry, mask_mode, mean6=mean6, std6=std6)
+        e0 = torch.nn.functional.linear(t0, w0, b0)
+        e1 = torch.nn.functional.linear(t1, w1, b1)
+        ctx.save_for_backward(p, xy, theta if geometry else xy, keep_t, flags, wp0, wp1)
         ctx.geometry, ctx.mask_mode, ctx.std6 = bool(geometry), int(mask_mode), std6
         return e0, e1
 
     @staticmethod
     def backward(ctx, d0, d1):
-        patch, xy, theta, keep, wp0, wp1 = ctx.saved_tensors
-        g = patch_embed_grad_gather(d0.to(torch.bfloat16).contiguous(), d1.to(torch.bfloat16).contiguous(), wp0, wp1, patch, xy,
-                                    theta if ctx.geometry else None, keep, ctx.geometry, ctx.mask_mode, std6=ctx.std6)
-        return (g,) + (None,) * 13
+        patch, xy, theta, keep_t, flags, wp0, wp1 = ctx.saved_tensors
+        g = patch_embed_grad_gather_tiles(d0.to(torch.bfloat16).contiguous(), d1.to(torch.bfloat16).contiguous(), wp0, wp1, patch, xy,
+                                          theta if ctx.geometry else None, keep_t, flags, ctx.geometry, ctx.mask_mode, std6=ctx.std6,
+                                          defer_reduce=ctx.sink is not None)
+        if ctx.sink is not None:
+            ctx.sink["partials"] = g
+            g = None
+        return (g,) + (None,) * 14
 
 
 class PatchApplyResizedEmbed(torch.autograd.Function):
@@ -527,6 +597,50 @@ def loss_rows_fwd_bwd(logits, rowmap: LossRowMap, mode: int, w: float = 5.0, alp
                                      grad.data_ptr() if want_grad else None, int(grad_kind), ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "vaa_loss_rows_fwd_bwd")
     return scalars, pred, pred_full, (grad if want_grad else None)
+
+
+def loss_rows_stats(logits, rowmap: LossRowMap, mode: int, w: float = 5.0, alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0, grad=None):
+    """The statistics pass of K3 alone (vaa_loss_rows_stats). In LOSS_UADA_DDP mode `grad` [R,256] receives the gradient slice in the same pass.
+    Returns the workspace tensor that step_epilogue folds into the scalars."""
+    dt = _lib.DTYPE_F32 if logits.dtype == torch.float32 else _lib.DTYPE_BF16
+    _need(logits, logits.dtype, "logits")
+    if logits.dim() != 2 or logits.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.VaaError(f"logits: expected f32|bf16 [R,V], got {logits.dtype} {tuple(logits.shape)}")
+    R, V = int(logits.shape[0]), int(logits.shape[1])
+    L = _lib.lib()
+    ws = _workspace(logits.device, L.vaa_loss_rows_ws_bytes(R), "k3")
+    if grad is not None:
+        _need(grad, logits.dtype, "grad", (R, N_ACTION))
+    with _timed("K3_loss_rows_stats", B=rowmap.B, L=rowmap.L, V=V, rows=R):
+        rc = L.vaa_loss_rows_stats(logits.data_ptr(), dt, rowmap.buf.data_ptr(), R, rowmap.B, rowmap.L, V, int(mode), _lib.f32x([w, alpha, beta, scale]),
+                                   grad.data_ptr() if grad is not None else None, GRAD_SLICE, ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "vaa_loss_rows_stats")
+    return ws
+
+
+def step_epilogue(partials, msg, scalars, rowmap: LossRowMap = None, R: int = 0, V: int = 32064, mode: int = LOSS_UADA_DDP, w: float = 5.0,
+                  alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0, loss_ws=None, want_pred: bool = True):
+    """vaa_step_epilogue: msg[0..n) = fixed-order sum of K2's partial tiles [parts, n]; with `rowmap` (+ the workspace loss_rows_stats left)
+    K3's statistics are folded into `scalars` (f32[8], output) and the prediction maps; msg[n..n+4) = {CE, w^2*MSE, UAD, total}.
+    Returns (pred_slice, pred_full) or (None, None)."""
+    _need(partials, torch.float32, "partials")
+    parts, n = int(partials.shape[0]), int(partials.shape[1])
+    _need(msg, torch.float32, "msg")
+    _need(scalars, torch.float32, "scalars", (8,))
+    if msg.numel() < n + 4:
+        raise _lib.VaaError(f"msg: needs {n + 4} floats, has {msg.numel()}")
+    pred = pred_full = None
+    if rowmap is not None and want_pred:
+        pred = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=msg.device)
+        pred_full = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=msg.device)
+    with _timed("EPI_step_epilogue", n=n, parts=parts):
+        rc = _lib.lib().vaa_step_epilogue(
+            partials.data_ptr(), parts, n, rowmap.buf.data_ptr() if rowmap is not None else None, int(R), rowmap.B if rowmap is not None else 0,
+            rowmap.L if rowmap is not None else 0, int(V), int(mode), _lib.f32x([w, alpha, beta, scale]),
+            loss_ws.data_ptr() if loss_ws is not None else None, loss_ws.numel() if loss_ws is not None else 0, scalars.data_ptr(),
+            pred.data_ptr() if pred is not None else None, pred_full.data_ptr() if pred_full is not None else None, msg.data_ptr(), _stream())
+    _lib.check(rc, "vaa_step_epilogue")
+    return pred, pred_full
 
 
 class DiscrepancyLossRows(torch.autograd.Function):

@@ -378,6 +378,8 @@ def test_ddp_attacker_two_ranks_vs_single_process(tmp_path, attack):
     import torch.multiprocessing as mp
 
     num_iter, inner, bs = 3, 3, 2
+    resize, psize = attack.endswith("_resize"), (100 if attack.endswith("_resize") else 50)
+    attack = attack.split("_")[0]
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -390,7 +392,8 @@ def test_ddp_attacker_two_ranks_vs_single_process(tmp_path, attack):
     ref = _single_process_two_shard_reference(attack, num_iter, inner, bs, resize=resize, psize=psize)
     err = np.abs(r0["snaps"] - ref).reshape(len(ref), -1).max(1)
     assert err.max() <= 1e-4, err
-    assert np.abs(ref[-1] - ref[inner - 1]).max() > 1e-3  # the patch really moved (lr = 0 only during outer iteration 0)
+    assert np.abs(ref[-1] - ref[inner - 1]).max() > 3e-4  # the patch really moved (lr = 0 only during outer iteration 0; UPA's L1 clip
+    # spreads 1e-3 of gradient norm over 30,000 texels of the 100x100 patch, so that case moves least)
     assert os.path.exists(tmp_path / "rank0" / "last" / "patch.pt") and not os.path.exists(tmp_path / "rank1" / "last")  # rank 0 writes
 
 
@@ -486,7 +489,7 @@ def test_bench_py_two_ranks_one_gpu(tmp_path):
     d = json.loads(lines0[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["loss_finite"]
     assert abs(d["value"] - 2 * d["sync_steps_per_s"]) < 1e-9 and d["config"]["global_batch"] == 8
-    assert d["cpu_baseline"] is None and d["roofline"]["kernel"].startswith("patch_apply_fwd_kernel")
+    assert d["cpu_baseline"] is None and d["roofline"]["kernel"].startswith("patch_apply_")
     ss = d["strong_scaling"]  # BASELINE config 3's shape: the N=1 batch split over the ranks
     assert ss["per_rank_bs"] == 2 and ss["global_batch"] == 4 and ss["images_per_s"] > 0 and abs(ss["images_per_s"] * ss["ms_per_step"] * 1e-3 - 4) < 1e-6
 
@@ -575,10 +578,10 @@ def test_bench_contract_line_tiny(model, extra_env):
     assert "workload" in d["config"] and "model" not in d["config"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in d["roofline"], key
-    assert d["roofline"]["kernel"].startswith("patch_apply_fwd_kernel") and d["roofline"]["bound"] == "hbm"
+    assert d["roofline"]["kernel"].startswith("patch_apply_") and d["roofline"]["bound"] == "hbm"
     # the in-step figures come from per-dispatch events of the library's own launches: one K1 and one K4 launch per timed step, each a few us
     k = d["roofline_kernels"]
-    k1 = next(v for n, v in k.items() if "patch_apply_fwd_kernel" in n)
+    k1 = next(v for n, v in k.items() if "patch_apply_" in n)
     k4 = next(v for n, v in k.items() if "patch_update_kernel" in n)
     assert k1["launches"] == 2 and k4["launches"] == 2 and 1.0 < k1["mean_us"] < 200.0 and d["roofline"]["samples"] == 2
     assert abs(d["roofline"]["achieved"] - d["roofline"]["algo_bytes"] / k1["mean_us"] / 1e3) < 1e-6 * d["roofline"]["achieved"]
@@ -622,3 +625,56 @@ def test_wrapper_clis_run_end_to_end(tmp_path, wrapper, torchrun):
     assert patches, out.stdout[-2000:]
     p = torch.load(patches[0])
     assert p.dtype == torch.float32 and tuple(p.shape) == (3, 50, 50) and float(p.min()) >= 0 and float(p.max()) <= 1
+
+
+def test_fused_epilogue_step_equals_separate_launches(monkeypatch):
+    """The data-parallel UADA step with the fused epilogue (AttackBase.fused_ddp_step: K1 tile-major -> model -> K3 statistics -> backward
+    -> K2' -> ONE epilogue launch -> K4) against the same step through HeadLossRows + patch.grad + the packed message: the patch after every
+    step, the loss scalars and the message are BITWISE equal (same kernels, same orders; only the launch count differs)."""
+    import random
+
+    from roboticattack_amd import dist as vdist
+    from roboticattack_amd import ops, synthetic
+    from roboticattack_amd.attack.engine import AttackBase
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+    from roboticattack_amd.optim import PatchOptimizer
+
+    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, False, True), siglip=VitCfg(192, 3, 2, 384, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=9)
+    B = 6
+    batch = synthetic.synth_batch(3, B, "noise", as_pil=False)
+    ids, attn = batch["input_ids"].to(DEV), batch["attention_mask"].to(DEV)
+    labels = mask_labels(batch["labels"].clone(), [0]).to(DEV)
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setenv("VAA_FUSED_EPILOGUE", "1" if fused else "0")
+        att = AttackBase(m, None, "", "adamW", False)
+        assert att.fused_ddp_available() == fused and att.randomPatchTransform.embed_with is m
+        img = att.randomPatchTransform.stage_images(torch.from_numpy(batch["pixel_values"]))
+        random.seed(5); np.random.seed(5)
+        patch = torch.rand(3, 50, 50, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
+        opt = PatchOptimizer(patch, 2e-3, "adamW")
+        sync = vdist.PatchGradSync(patch.numel(), 4, torch.device(DEV))
+        pick = torch.tensor([1, 2, 7, 0], dtype=torch.int64, device=DEV)
+        scal = torch.zeros(8, device=DEV)
+        snaps = []
+        for _ in range(3):
+            opt.zero_grad()
+            if fused:
+                att.fused_ddp_step(img, patch, ids, attn, labels, True, 5.0, sync.buf, scal)
+                g_sum, s_sum = sync.allreduce_packed()
+                assert patch.grad is None
+            else:
+                pix = att.randomPatchTransform.apply_random_patch_batch(img, patch, mean=att.mean, std=att.std, geometry=True)
+                total, scalars, _ = att.model_loss(ids, attn, pix, labels, ops.LOSS_UADA_DDP, w=5.0)
+                total.backward()
+                g_sum, s_sum = sync.allreduce_step(patch.grad, scalars, pick)
+                scal.copy_(scalars)
+            opt.step(grad=g_sum.view_as(patch), grad_scale=1.0)
+            snaps.append((patch.detach().clone(), scal.clone(), sync.buf.clone(), opt.last_stats.clone()))
+        runs.append(snaps)
+    for (p1, s1, b1, st1), (p2, s2, b2, st2) in zip(*runs):
+        assert torch.equal(p1, p2) and torch.equal(s1, s2) and torch.equal(b1, b2) and torch.equal(st1, st2)
+    assert float((runs[0][-1][0] - runs[0][0][0]).abs().max()) > 0 and bool(torch.isfinite(runs[0][-1][1]).all())

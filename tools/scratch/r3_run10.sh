@@ -1,0 +1,13 @@
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r3
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "embed or epilogue or tiles" > gpurun_out/r3/t_k2e.log 2>&1; tail -3 gpurun_out/r3/t_k2e.log
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank > gpurun_out/r3/bench_e.json 2> gpurun_out/r3/bench_e.err; tail -2 gpurun_out/r3/bench_e.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r3/bench_e.json').read().strip().splitlines()[-1])
+print('value',d['value'],'ms',d['ms_per_step'])
+print('roofline',{k:d['roofline'][k] for k in ('frac','mean_us','min_us','samples')})
+print(d['hot_path_us_per_step'], d['hot_path_launches_per_step'])
+for k,v in d['roofline_kernels'].items(): print(k[:60], v['launches_per_step'], round(v['mean_us'],2), round(v['min_us'],2))
+PY
