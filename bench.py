@@ -209,8 +209,12 @@ class StepRunner:
     def step(self):  # attack/uada_ddp.py inner step
         a, ops = self.att, self.ops
         self.opt.zero_grad()
+        if self.fused and self.world == 1:
+            # host draws -> K1 (tile-major) -> model -> K3 statistics -> backward -> K2' tiles + scatter -> epilogue incl. K4 (nothing to exchange)
+            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, True, 5.0, self.sync.buf, self.scal, optimizer=self.opt)
+            return
         if self.fused:
-            # host draws -> K1 (tile-major) -> model -> K3 statistics -> backward -> K2' tiles + scatter -> epilogue: the message is in sync.buf
+            # ... -> epilogue: the message is in sync.buf -> all-reduce -> K4
             a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, True, 5.0, self.sync.buf, self.scal)
             g_sum, _ = self.sync.allreduce_packed()  # [grad | CE, MSE, UAD, total]: one all-reduce per step
         else:

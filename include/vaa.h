@@ -223,6 +223,14 @@ int vaa_loss_rows_stats(const void* logits, int dtype, const void* rowmap, int R
 int vaa_step_epilogue(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode, const float* params,
                       const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, float* msg,
                       void* stream);
+/* Single-GPU form (UADA.py:148-157: nothing sits between the gradient and optimizer.step()): the epilogue also applies K4 — vaa_patch_update
+ * with grad_scale = 1 and no L1 clip — to every gradient element as it is produced (same per-element arithmetic: patch / m / v get the
+ * bits the separate launch would write). stat_part dev f64 [ceil(n/64)][2] or NULL: per-block {sum |g|, sum g}; their sums give K4's
+ * logged {sum|g|, mean g = sum g / n}. */
+int vaa_step_epilogue_update(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
+                             const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
+                             int32_t* pred_full_tokens, float* msg, float* patch, float* m, float* v, int opt_mode, float lr, float beta1,
+                             float beta2, float eps, int step, double* stat_part, void* stream);
 
 /*
  * K2' (for callers that own the model's patch-embed weights) — K2 fed by the gradient of the ViT patch-embed OUTPUTS instead of the pixel gradient: the

@@ -54,6 +54,7 @@ EXPORTS = (
     "vaa_patch_embed_grad_gather_tiles",
     "vaa_loss_rows_stats",
     "vaa_step_epilogue",
+    "vaa_step_epilogue_update",
     "vaa_prof_start",
     "vaa_prof_stop",
     "vaa_prof_get",
@@ -181,6 +182,9 @@ def lib() -> C.CDLL:
     L.vaa_loss_rows_stats.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, i32, vp, sz, vp]
     L.vaa_step_epilogue.restype = i32
     L.vaa_step_epilogue.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp]
+    L.vaa_step_epilogue_update.restype = i32
+    L.vaa_step_epilogue_update.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32,
+                                           i32, vp, vp]
     L.vaa_prof_start.restype = i32
     L.vaa_prof_start.argtypes = [i32]
     L.vaa_prof_stop.restype = i32

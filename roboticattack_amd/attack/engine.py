@@ -112,12 +112,13 @@ class AttackBase:
         return (os.environ.get("VAA_FUSED_EPILOGUE", "1") != "0" and self.use_rows and hasattr(self.vla, "hidden_rows")
                 and t.embed_with is not None and not t.resize_patch)
 
-    def fused_ddp_step(self, pixel_values, patch, input_ids, attention_mask, labels, geometry, w, msg, scalars):
+    def fused_ddp_step(self, pixel_values, patch, input_ids, attention_mask, labels, geometry, w, msg, scalars, optimizer=None):
         """The UADA_ddp inner step (UADA_ddp.py:189-206) up to the gradient exchange, six hand-written launches around the model:
         K1 -> [ViTs, Llama, LM head on the labelled rows] -> K3 statistics + gradient slice -> [head / model backward] -> K2' tile GEMM ->
         scatter -> epilogue. On return `msg` (f32 [3*ph*pw + 4]) holds [patch gradient | CE, w^2*MSE, UAD, total] of THIS rank, ready for
         one all-reduce, and `scalars` (f32[8]) the loss scalars; returns the full-vocabulary predictions [B,L-1] (i32, device).
-        Nothing is synchronised; patch.grad is not touched."""
+        Nothing is synchronised; patch.grad is not touched. `optimizer` (single-GPU run, no L1 clip): K4 is applied by the epilogue launch
+        itself — five launches per step, the caller then calls neither the all-reduce nor optimizer.step()."""
         pack = self._rows_cache(labels, attention_mask)
         if self._row_count == 0:
             raise ValueError("fused_ddp_step: no labelled position in the batch")
@@ -130,7 +131,8 @@ class AttackBase:
         ws = ops.loss_rows_stats(logits, self._row_map, ops.LOSS_UADA_DDP, w, grad=gsl)      # K3: statistics + d loss / d action logits
         h.backward(gsl @ W[ops.ACTION_LO : ops.ACTION_LO + ops.N_ACTION])                     # head backward over 256 columns, model backward, K2'
         _, pred_full = ops.step_epilogue(sink["partials"], msg, scalars, rowmap=self._row_map, R=int(logits.shape[0]), V=int(W.shape[0]),
-                                         mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws)
+                                         mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws,
+                                         update=optimizer.fused_update_args() if optimizer is not None else None)
         return pred_full
 
     # ---- metrics (host, once per outer iteration) ----

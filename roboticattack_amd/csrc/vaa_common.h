@@ -162,11 +162,36 @@ __device__ __forceinline__ void solve_interval(float a, float base, float lo, fl
     }
 }
 
+// K4's per-element arithmetic (vaa_update.hip; also applied by the step epilogue when the update is fused into it: one source, same bits)
+struct UpdArgs {
+    float* patch;
+    const float* g;
+    float* m;
+    float* v;
+    float* stats;
+    int n, mode;
+    float lr, b1, b2, eps, step_size, one_m_b1, one_m_b2, l1_clip, grad_scale;
+};
+
+__device__ __forceinline__ float update_one(const UpdArgs& a, float g, float p, float& m, float& v) {
+    if (a.mode == VAA_OPT_ADAMW_HF) {
+        m = __builtin_fmaf(g, a.one_m_b1, m * a.b1);      // exp_avg.mul_(b1).add_(g, alpha=1-b1)
+        v = v * a.b2 + (a.one_m_b2 * g) * g;              // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
+        const float denom = sqrtf(v) + a.eps;             // v.sqrt().add_(eps)
+        p = p + ((-a.step_size) * m) / denom;             // p.addcdiv_(m, denom, value=-step_size)
+    } else {
+        const float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+        p = p - a.lr * sg;
+    }
+    return fminf(1.0f, fmaxf(0.0f, p));                   // patch.data.clamp(0, 1)
+}
+
 // out[e] = sum_p partial[p][e] (p < nparts, e < n) for the 64 elements of block `blk`, in a fixed two-level order (16 interleaved slices,
 // then slice 0..15), fp64: the body of patch_grad_reduce_kernel, shared with the step epilogue (256 threads; sl = 16 KB of LDS).
 // A thread owns four consecutive elements (16 B loads); block = 16 element-quads x 16 slices.
-__device__ __forceinline__ void partial_reduce_block(const float* __restrict__ partial, float* __restrict__ out, int n, int nparts, int blk,
-                                                     double (*sl)[16][4]) {
+// Returns true in the threads that own a result element (index `oe`, value `ov`) after storing it.
+__device__ __forceinline__ bool partial_reduce_block(const float* __restrict__ partial, float* __restrict__ out, int n, int nparts, int blk,
+                                                     double (*sl)[16][4], int& oe, float& ov) {
     const int el = threadIdx.x & 15, s = threadIdx.x >> 4;
     const int e = (blk * 16 + el) * 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -192,8 +217,12 @@ __device__ __forceinline__ void partial_reduce_block(const float* __restrict__ p
 #pragma unroll
             for (int q = 0; q < 16; ++q) t += sl[q][el][z];
             out[e + z] = (float)t;
+            oe = e + z;
+            ov = (float)t;
+            return true;
         }
     }
+    return false;
 }
 
 template <typename T>

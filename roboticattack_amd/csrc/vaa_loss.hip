@@ -10,6 +10,11 @@
 //           registers, block-reduce max / sum-exp; the 256 action logits sit in one wave's registers -> soft-argmax by shuffles.
 //   grad  : same grid; every labelled row folds the per-row statistics into the global scalars it needs (1/CE, UPA means;
 //           fixed order -> deterministic), then writes g = kCE*(softmax - onehot) + kE*p_a*((a+1) - E).
+#include <math.h>
+#include <stdlib.h>
+
+#include <mutex>
+
 #include "vaa_common.h"
 
 namespace vaa {
@@ -568,8 +573,45 @@ __device__ __forceinline__ void store_slice_or_row(const RowsArgs& a, int r, int
     else Vec<T>::store(g + (size_t)r * a.V + col0, o);
 }
 
+struct FoldOut {
+    double nrow, nact, CE, MSE, UAD, total, aux0, aux1, dce;
+    int Rn;
+};
+template <int kRowsT, bool COH = false>
+__device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, double (*sh)[7]);
+
+struct SliceStat;
 template <typename T, int kRowsT>
-__global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a) {
+__device__ __forceinline__ void rows_full_gradient(const RowsArgs& a, const FoldOut& f, int r, int v_lo, int v_hi, const float (&v)[32 / Vec<T>::N][Vec<T>::N],
+                                                   float lse, float alse, float E);
+
+// statistics words another workgroup of the SAME launch wrote: agent-scope atomics go past the per-XCD L2 (COH); plain accesses otherwise
+template <bool COH, typename S>
+__device__ __forceinline__ S stat_load(const S* p) {
+    static_assert(sizeof(S) == 16, "four words");
+    if (!COH) return *p;
+    unsigned w[4];
+#pragma unroll
+    for (int z = 0; z < 4; ++z) w[z] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p) + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    S v;
+    __builtin_memcpy(&v, w, 16);
+    return v;
+}
+template <bool COH, typename S>
+__device__ __forceinline__ void stat_store(S* p, const S& v) {
+    static_assert(sizeof(S) == 16, "four words");
+    if (!COH) { *p = v; return; }
+    unsigned w[4];
+    __builtin_memcpy(w, &v, 16);
+#pragma unroll
+    for (int z = 0; z < 4; ++z) __hip_atomic_store(reinterpret_cast<unsigned*>(p) + z, w[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ONEPASS (full-row gradients of UADA / CE, whose scale needs the folded scalars): the statistics pass keeps its 32 logits per thread in
+// registers across a grid-wide barrier, folds the statistics and writes the gradient from them — the logits are read ONCE (the two-launch
+// form reads every row again in its finishing launch). bar: two zeroed words owned by this launch's stream, left zero.
+template <typename T, int kRowsT, bool ONEPASS>
+__global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a, unsigned* bar) {
     constexpr int N = Vec<T>::N;
     constexpr int MAXV = 32 / N;  // 32 logits per thread in registers: covers V/split <= 16384
     const int r = blockIdx.x / a.split, h = blockIdx.x - r * a.split;
@@ -653,9 +695,10 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a) {
         ps.s = tot;
         ps.amax = bidx;
         ps.zlab = zlab_early;
-        a.part[(size_t)r * a.split + h] = ps;
+        stat_store<ONEPASS>(&a.part[(size_t)r * a.split + h], ps);
     }
-    if (!(has_slice && wv == 0)) return;
+    if (!ONEPASS && !(has_slice && wv == 0)) return;
+    if (has_slice && wv == 0) {
     // ---- action slice: soft-argmax statistics by one wave (UADA.py:384-389, UPA.py:370-374) ----
     const bool own = lane < nthr;
     if (!own) {
@@ -690,7 +733,7 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a) {
         ss.E = E;
         ss.pred = kA0 + besti;
         ss.pad = 0;
-        a.slice[r] = ss;
+        stat_store<ONEPASS>(&a.slice[r], ss);
     }
     if (a.mode == VAA_LOSS_UADA_DDP && a.grad && own) {  // gradient of w^2*mean((E/256 - t)^2): needs this row and the row COUNT only
         float o[N];
@@ -704,16 +747,111 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a) {
         for (int e = 0; e < N; ++e) o[e] = kE * expf(x[e] - alse) * ((float)(lane * N + e + 1) - E);
         store_slice_or_row<T>(a, r, kA0 + lane * N, o);
     }
+    }
+    if (!ONEPASS) return;
+    // ---- grid-wide hand-over without cache-wide fences: every cross-workgroup word travels through agent-scope atomics (they bypass the
+    // per-XCD L2), the LAST workgroup to arrive folds the statistics once and raises a flag, everybody else waits for the flag only.
+    // (A release/acquire fence pair per workgroup — L2 write-back + invalidate, after which 512 workgroups each re-fetched all statistics
+    // through the fabric — made this form 2x SLOWER than two launches: 42 vs 20 us at R' = 128.) ----
+    __shared__ int bar_ok, am_last;
+    __shared__ float row_sh[8];
+    __shared__ double shf[kRowsT / 64][7];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's statistics stores (agent-scope atomic stores below) have completed
+    __syncthreads();
+    unsigned* res = bar + 4;  // 16 words: the folded quantities the gradient needs
+    if (tid == 0) {
+        const unsigned nwg = gridDim.x;
+        const unsigned old = atomicAdd(&bar[0], 1u);
+        am_last = old == nwg - 1;
+        bar_ok = 1;
+    }
+    __syncthreads();
+    FoldOut f;
+    if (am_last) {
+        f = rows_fold<kRowsT, true>(a, true, shf);  // coherent loads; publishes scalars[8] + the prediction maps like rows_finish_kernel's block 0
+        if (tid == 0) {
+            const double pub[4] = {f.nrow, f.nact, f.dce, 0.0};
+            const unsigned* pw = reinterpret_cast<const unsigned*>(pub);
+#pragma unroll
+            for (int z = 0; z < 6; ++z) __hip_atomic_store(&res[z], pw[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&res[6], (unsigned)f.Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // everybody has arrived: re-arm the ticket
+            __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the flag
+        }
+    } else {
+        if (tid == 0) {
+            int it = 0;
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && it < (1 << 22)) { __builtin_amdgcn_s_sleep(2); ++it; }
+            bar_ok = it < (1 << 22);  // a launch that never became fully resident gives up instead of hanging: NaN gradient
+        }
+        __syncthreads();
+        unsigned w6[7];
+#pragma unroll
+        for (int z = 0; z < 7; ++z) w6[z] = __hip_atomic_load(&res[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double pub[3];
+        __builtin_memcpy(pub, w6, 24);
+        f.nrow = pub[0]; f.nact = pub[1]; f.dce = pub[2]; f.Rn = (int)w6[6];
+    }
+    if (!bar_ok) f.dce = __longlong_as_double(0x7ff8000000000000ll);
+    if (tid == 0 && r < f.Rn) {  // this row's own statistics (its other parts belong to sibling workgroups): one thread fetches, LDS broadcasts
+        const SliceStat ms = stat_load<true>(&a.slice[r]);
+        float M = -INFINITY, tot = 0.0f;
+        for (int q = 0; q < a.split; ++q) M = fmaxf(M, stat_load<true>(&a.part[(size_t)r * a.split + q]).m);
+        for (int q = 0; q < a.split; ++q) {
+            const PartStat p = stat_load<true>(&a.part[(size_t)r * a.split + q]);
+            tot += p.s * expf(p.m - M);
+        }
+        row_sh[0] = M + logf(tot); row_sh[1] = ms.alse; row_sh[2] = ms.E;
+    }
+    __syncthreads();
+    if (a.grad && r < f.Rn) rows_full_gradient<T, kRowsT>(a, f, r, v_lo, v_hi, v, row_sh[0], row_sh[1], row_sh[2]);
+    // the last workgroup to LEAVE lowers the flag: the words are zero again when the launch ends
+    __syncthreads();
+    if (tid == 0 && atomicAdd(&bar[2], 1u) == gridDim.x - 1) {
+        __hip_atomic_store(&bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-struct FoldOut {
-    double nrow, nact, CE, MSE, UAD, total, aux0, aux1, dce;
-    int Rn;
-};
+// d total / d logits of row r, part [v_lo, v_hi), from the logits a thread holds (v[c] = vector v_lo + tid + c * kRowsT): full-row modes
+// (UADA: 1/CE^2 term + the action-slice term, CE).
+template <typename T, int kRowsT>
+__device__ __forceinline__ void rows_full_gradient(const RowsArgs& a, const FoldOut& f, int r, int v_lo, int v_hi, const float (&v)[32 / Vec<T>::N][Vec<T>::N],
+                                                   float lse, float alse, float E) {
+    constexpr int N = Vec<T>::N;
+    constexpr int MAXV = 32 / N;
+    const int tid = threadIdx.x;
+    const RowMap me = reinterpret_cast<const RowMap*>(a.rowmap + 4)[r];
+    struct { float alse, E; } ms = {alse, E};
+    const float kce = f.nrow > 0 ? (float)(f.dce / f.nrow) : 0.0f;
+    float kE = 0.0f;
+    if (a.mode != VAA_LOSS_CE && me.lab > 2) {
+        const double q = (double)ms.E / 256.0, t = (me.lab > 31872) ? 0.0 : 1.0;
+        kE = (float)((double)a.w * a.w * 2.0 * (q - t) / f.nact / 256.0);
+    }
+    T* g = reinterpret_cast<T*>(a.grad) + (size_t)r * a.V;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int q = v_lo + tid + c * kRowsT;
+        if (q >= v_hi) continue;
+        const int v0 = q * N;
+        const bool in_slice = (v0 >= kA0 && v0 < kA0 + kNA);
+        float o[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            float gv = 0.0f;
+            if (kce != 0.0f) gv = kce * (expf(v[c][e] - lse) - ((v0 + e) == me.lab ? 1.0f : 0.0f));
+            if (in_slice && kE != 0.0f) gv += kE * expf(v[c][e] - ms.alse) * ((float)(v0 + e - kA0 + 1) - ms.E);
+            o[e] = gv;
+        }
+        Vec<T>::store(g + (size_t)v0, o);
+    }
+}
 
 // Folds the R compact row statistics into the loss scalars in a fixed order (thread t takes rows t, t + kRowsT, ...; block_sums), and — for
 // the publishing workgroup — writes scalars[8] and the two prediction maps. Shared by rows_finish_kernel and the step epilogue.
-template <int kRowsT>
+template <int kRowsT, bool COH>
 __device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, double (*sh)[7]) {
     const int tid = threadIdx.x;
     const RowMap* rm = reinterpret_cast<const RowMap*>(a.rowmap + 4);
@@ -721,12 +859,12 @@ __device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, do
     const int Rn = min(a.R, Rdev);  // rows both the caller and the map know: a mismatch publishes NaN and never leaves the map
     auto row_lse = [&](int rr, float& zlab, int& amax) {  // combine the parts of row rr
         float M = -INFINITY;
-        for (int q = 0; q < a.split; ++q) M = fmaxf(M, a.part[(size_t)rr * a.split + q].m);
+        for (int q = 0; q < a.split; ++q) M = fmaxf(M, stat_load<COH>(&a.part[(size_t)rr * a.split + q]).m);
         float tot = 0.0f, best = -INFINITY;
         zlab = -INFINITY;
         amax = 0x7fffffff;
         for (int q = 0; q < a.split; ++q) {
-            const PartStat p = a.part[(size_t)rr * a.split + q];
+            const PartStat p = stat_load<COH>(&a.part[(size_t)rr * a.split + q]);
             tot += p.s * expf(p.m - M);
             zlab = fmaxf(zlab, p.zlab);
             if (p.m > best || (p.m == best && p.amax < amax)) { best = p.m; amax = p.amax; }
@@ -750,7 +888,7 @@ __device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, do
         acc[3] += 1.0;
         acc[0] += (double)lse - (double)zl;
         if (m.lab > 2) {
-            const SliceStat ss = a.slice[rr];
+            const SliceStat ss = stat_load<COH>(&a.slice[rr]);
             acc[4] += 1.0;
             const double q = (double)ss.E / 256.0, t = (m.lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10: 1/256 -> 0)
             acc[1] += (q - t) * (q - t);
@@ -762,7 +900,7 @@ __device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, do
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 RowStat t;
-                t.E = a.slice[rr + q].E;
+                t.E = stat_load<COH>(&a.slice[rr + q]).E;
                 t.lab = rm[rr + q].lab;
                 u.set(q, t);
             }
@@ -798,7 +936,7 @@ __device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, do
             const RowMap m = rm[rr];
             const int pos = m.b * (a.L - 1) + m.k;
             if ((unsigned)pos >= (unsigned)(a.B * (a.L - 1))) continue;  // a map built for other sizes than the caller states
-            if (a.pred_tokens && m.lab > 2) a.pred_tokens[pos] = a.slice[rr].pred;
+            if (a.pred_tokens && m.lab > 2) a.pred_tokens[pos] = stat_load<COH>(&a.slice[rr]).pred;
             if (a.pred_full) {
                 int am = first_am;
                 if (rr != tid) {  // more rows than threads: combine the parts again
@@ -928,12 +1066,33 @@ struct EpiArgs {
     float* msg;
     const float* scalars_in;  // fold == 0: final scalars of an earlier vaa_loss_rows_fwd_bwd, only copied into the message
     int n, nparts, nred, fold;
+    int fuse_update;          // single-GPU step: K4's per-element update applied right where the gradient element is produced
+    UpdArgs upd;
+    double* stat_part;        // fuse_update: [nred][2] = {sum |g|, sum g} over the block's 64 elements (the caller adds them for the log)
 };
 
 __global__ __launch_bounds__(256) void step_epilogue_kernel(EpiArgs e, RowsArgs a) {
     __shared__ double sl[16][16][4];
     if ((int)blockIdx.x < e.nred) {
-        partial_reduce_block(e.partials, e.msg, e.n, e.nparts, blockIdx.x, sl);
+        int oe = 0;
+        float g = 0.0f;
+        const bool own = partial_reduce_block(e.partials, e.msg, e.n, e.nparts, blockIdx.x, sl, oe, g);
+        if (!e.fuse_update) return;
+        // K4 on the element this thread just produced (grad_scale = 1, no L1 clip: vaa_step_epilogue_update checks): same arithmetic, same bits
+        if (own) {
+            float m = e.upd.mode == VAA_OPT_ADAMW_HF ? e.upd.m[oe] : 0.0f, v = e.upd.mode == VAA_OPT_ADAMW_HF ? e.upd.v[oe] : 0.0f;
+            const float p = update_one(e.upd, g, e.upd.patch[oe], m, v);
+            if (e.upd.mode == VAA_OPT_ADAMW_HF) { e.upd.m[oe] = m; e.upd.v[oe] = v; }
+            e.upd.patch[oe] = p;
+        }
+        if (e.stat_part) {  // the owners are threads 0..63 (slices 0..3 x 16 quads) = wave 0
+            double sa = own ? fabs((double)g) : 0.0, ss = own ? (double)g : 0.0;
+            if (threadIdx.x < 64) {
+                sa = wave_sum(sa);
+                ss = wave_sum(ss);
+                if (threadIdx.x == 0) { e.stat_part[2 * blockIdx.x] = sa; e.stat_part[2 * blockIdx.x + 1] = ss; }
+            }
+        }
         return;
     }
     float* tail = e.msg + e.n;
@@ -1091,15 +1250,47 @@ static int rows_args(const char* who, const void* logits, int dtype, const void*
     return VAA_OK;
 }
 
-static int launch_rows_stats(const RowsArgs& a, int dtype, hipStream_t st, const char* who) {
+// Barrier words of the one-pass form: two zero-initialised words per stream that uses it (the launch leaves them zero), in the library's
+// own device image — nothing is allocated, the caller's workspace keeps its "contents undefined" contract.
+constexpr int kBarSlots = 64;
+__device__ unsigned g_rows_bar[kBarSlots][32];  // {ticket, flag, leave count, -, 16 words of folded results}
+
+static unsigned* rows_bar_for(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t owner[kBarSlots];
+    static int used = 0;
+    static unsigned* base = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!base && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_rows_bar)) != hipSuccess) {
+        (void)hipGetLastError();
+        base = nullptr;
+        return nullptr;
+    }
+    for (int i = 0; i < used; ++i)
+        if (owner[i] == st) return base + 32 * i;
+    if (used == kBarSlots) return nullptr;  // more streams than slots: the caller falls back to the two-launch form
+    owner[used] = st;
+    return base + 32 * used++;
+}
+
+static int launch_rows_stats(const RowsArgs& a, int dtype, hipStream_t st, const char* who, unsigned* bar = nullptr) {
     const int nt = rows_threads(a.V);
     const dim3 gs((unsigned)(a.R * a.split));
-    if (dtype == VAA_DTYPE_F32) {
-        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256>), gs, dim3(256), 0, st, a);
-        else VAA_LAUNCH((rows_stats_kernel<float, 512>), gs, dim3(512), 0, st, a);
+    unsigned* nobar = nullptr;
+    if (bar) {  // one pass: statistics, grid barrier, fold, full-row gradient from the registers
+        if (dtype == VAA_DTYPE_F32) {
+            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, true>), gs, dim3(256), 0, st, a, bar);
+            else VAA_LAUNCH((rows_stats_kernel<float, 512, true>), gs, dim3(512), 0, st, a, bar);
+        } else {
+            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, true>), gs, dim3(256), 0, st, a, bar);
+            else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, true>), gs, dim3(512), 0, st, a, bar);
+        }
+    } else if (dtype == VAA_DTYPE_F32) {
+        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, false>), gs, dim3(256), 0, st, a, nobar);
+        else VAA_LAUNCH((rows_stats_kernel<float, 512, false>), gs, dim3(512), 0, st, a, nobar);
     } else {
-        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256>), gs, dim3(256), 0, st, a);
-        else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512>), gs, dim3(512), 0, st, a);
+        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, false>), gs, dim3(256), 0, st, a, nobar);
+        else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, false>), gs, dim3(512), 0, st, a, nobar);
     }
     return check_launch(who);
 }
@@ -1127,6 +1318,19 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
     int rc = rows_args(who, logits, dtype, rowmap, R, B, L, V, mode, params, scalars, pred_tokens, pred_full_tokens, grad, grad_kind, ws, ws_bytes, a);
     if (rc != VAA_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    // EXPERIMENT, off by default (VAA_K3_ONE_PASS=1): full-row gradients (UADA's 1/CE^2, CE) in ONE launch — the statistics pass keeps its
+    // logits in registers across a grid-wide hand-over and writes the gradient from them, so every row is read once (16.4 MB instead of
+    // 25.4 MB at R' = 128). Measured on MI355X (tools/k3_onepass_check.py, profiles/r03_k3_onepass.txt): bitwise the same outputs, but 33 us
+    // against 20 us for the two launches (42 us with release/acquire fences instead of agent-scope atomics): a device-scope round trip
+    // across the XCDs costs more than the kernel boundary it replaces. The two-launch form stays the product path.
+    if (getenv("VAA_K3_ONE_PASS") && grad && grad_kind == VAA_GRAD_FULL && (mode == VAA_LOSS_UADA || mode == VAA_LOSS_CE) && (long)R * a.split <= 1024) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const hipError_t ce = hipStreamIsCapturing(st, &cs);
+        if (ce != hipSuccess) (void)hipGetLastError();
+        const bool capturing = ce != hipSuccess || cs != hipStreamCaptureStatusNone;
+        unsigned* bar = capturing ? nullptr : rows_bar_for(st);
+        if (bar) return launch_rows_stats(a, dtype, st, "vaa_loss_rows_fwd_bwd(one pass)", bar);
+    }
     rc = launch_rows_stats(a, dtype, st, "vaa_loss_rows_fwd_bwd(stats)");
     if (rc != VAA_OK) return rc;
     // the finishing pass: per (row, part) when a full-row gradient (or a zero fill) has to be written, else one workgroup per row
@@ -1165,17 +1369,20 @@ extern "C" int vaa_loss_rows_stats(const void* logits, int dtype, const void* ro
     return launch_rows_stats(a, dtype, (hipStream_t)stream, who);
 }
 
-extern "C" int vaa_step_epilogue(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
-                                 const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
-                                 int32_t* pred_full_tokens, float* msg, void* stream) {
-    using namespace vaa;
-    const char* who = "vaa_step_epilogue";
+namespace vaa {
+
+static int step_epilogue_impl(const char* who, const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
+                              const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
+                              int32_t* pred_full_tokens, float* msg, const UpdArgs* upd, double* stat_part, void* stream) {
     if (!partials || !msg || !scalars || nparts <= 0 || n <= 0) {
         set_error("%s: bad arguments (nparts=%d n=%d)", who, nparts, n);
         return VAA_E_INVALID;
     }
-    EpiArgs e;
+    EpiArgs e = {};
     e.partials = partials; e.msg = msg; e.scalars_in = scalars; e.n = n; e.nparts = nparts; e.nred = (n + 63) / 64; e.fold = rowmap ? 1 : 0;
+    e.fuse_update = upd ? 1 : 0;
+    if (upd) e.upd = *upd;
+    e.stat_part = stat_part;
     RowsArgs a = {};
     if (rowmap) {
         int rc = rows_args(who, nullptr, VAA_DTYPE_BF16, rowmap, R, B, L, V, mode, params, scalars, pred_tokens, pred_full_tokens, nullptr, VAA_GRAD_SLICE,
@@ -1184,4 +1391,41 @@ extern "C" int vaa_step_epilogue(const float* partials, int nparts, int n, const
     }
     VAA_LAUNCH(step_epilogue_kernel, dim3((unsigned)(e.nred + 1)), dim3(256), 0, (hipStream_t)stream, e, a);
     return check_launch(who);
+}
+
+}  // namespace vaa
+
+extern "C" int vaa_step_epilogue(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
+                                 const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
+                                 int32_t* pred_full_tokens, float* msg, void* stream) {
+    return vaa::step_epilogue_impl("vaa_step_epilogue", partials, nparts, n, rowmap, R, B, L, V, mode, params, loss_ws, loss_ws_bytes, scalars, pred_tokens,
+                                   pred_full_tokens, msg, nullptr, nullptr, stream);
+}
+
+// The single-GPU step has no exchange between the gradient and the update: K4 (vaa_patch_update without L1 clip, grad_scale = 1) is applied by
+// the epilogue on every gradient element as it is produced — same per-element arithmetic, same bits in patch / m / v. The logged statistics come
+// back as per-block partial sums stat_part [ceil(n/64)][2] = {sum |g|, sum g} (fp64) for the caller to add.
+extern "C" int vaa_step_epilogue_update(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
+                                        const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
+                                        int32_t* pred_full_tokens, float* msg, float* patch, float* m, float* v, int opt_mode, float lr, float beta1,
+                                        float beta2, float eps, int step, double* stat_part, void* stream) {
+    using namespace vaa;
+    const char* who = "vaa_step_epilogue_update";
+    if (!patch || (opt_mode == VAA_OPT_ADAMW_HF && (!m || !v))) {
+        set_error("%s: null pointer argument", who);
+        return VAA_E_INVALID;
+    }
+    if ((opt_mode != VAA_OPT_ADAMW_HF && opt_mode != VAA_OPT_PGD_SIGN) || (opt_mode == VAA_OPT_ADAMW_HF && step < 1)) {
+        set_error("%s: bad optimiser mode/step (mode=%d step=%d)", who, opt_mode, step);
+        return VAA_E_INVALID;
+    }
+    UpdArgs u = {};
+    u.patch = patch; u.g = nullptr; u.m = m; u.v = v; u.stats = nullptr; u.n = n; u.mode = opt_mode;
+    u.lr = lr; u.b1 = beta1; u.b2 = beta2; u.eps = eps; u.l1_clip = 0.0f; u.grad_scale = 1.0f;
+    const double b1 = (double)beta1, b2 = (double)beta2;  // python-side doubles of the reference optimiser, narrowed exactly like vaa_patch_update
+    u.one_m_b1 = (float)(1.0 - b1);
+    u.one_m_b2 = (float)(1.0 - b2);
+    u.step_size = (opt_mode == VAA_OPT_ADAMW_HF) ? (float)((double)lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step))) : 0.0f;
+    return step_epilogue_impl(who, partials, nparts, n, rowmap, R, B, L, V, mode, params, loss_ws, loss_ws_bytes, scalars, pred_tokens, pred_full_tokens, msg,
+                              &u, stat_part, stream);
 }

@@ -457,7 +457,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ __launch_bounds__(256) void patch_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gpatch,
                                                                  int n, int nparts) {
     __shared__ double sl[16][16][4];
-    partial_reduce_block(partial, gpatch, n, nparts, blockIdx.x, sl);
+    int oe;
+    float ov;
+    (void)partial_reduce_block(partial, gpatch, n, nparts, blockIdx.x, sl, oe, ov);
 }
 
 int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts, hipStream_t st, const char* who) {

@@ -13,30 +13,7 @@
 
 namespace vaa {
 
-struct UpdArgs {
-    float* patch;
-    const float* g;
-    float* m;
-    float* v;
-    float* stats;
-    int n, mode;
-    float lr, b1, b2, eps, step_size, one_m_b1, one_m_b2, l1_clip, grad_scale;
-};
-
 constexpr int kUpdRegs = 8;  // elements a thread keeps in registers: patches up to 8,192 elements (3x50x50 = 7,500) make ONE memory round trip
-
-__device__ __forceinline__ float update_one(const UpdArgs& a, float g, float p, float& m, float& v) {
-    if (a.mode == VAA_OPT_ADAMW_HF) {
-        m = __builtin_fmaf(g, a.one_m_b1, m * a.b1);      // exp_avg.mul_(b1).add_(g, alpha=1-b1)
-        v = v * a.b2 + (a.one_m_b2 * g) * g;              // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
-        const float denom = sqrtf(v) + a.eps;             // v.sqrt().add_(eps)
-        p = p + ((-a.step_size) * m) / denom;             // p.addcdiv_(m, denom, value=-step_size)
-    } else {
-        const float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
-        p = p - a.lr * sg;
-    }
-    return fminf(1.0f, fmaxf(0.0f, p));                   // patch.data.clamp(0, 1)
-}
 
 // SMALL: n <= 1024 * kUpdRegs — gradient, patch and both moments are requested at once and stay in registers across the statistics, so the
 // op is one load latency + one block reduction + the stores (7.2 -> 5.x us); larger patches re-read the gradient after the reduction.

@@ -619,10 +619,11 @@ def loss_rows_stats(logits, rowmap: LossRowMap, mode: int, w: float = 5.0, alpha
 
 
 def step_epilogue(partials, msg, scalars, rowmap: LossRowMap = None, R: int = 0, V: int = 32064, mode: int = LOSS_UADA_DDP, w: float = 5.0,
-                  alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0, loss_ws=None, want_pred: bool = True):
+                  alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0, loss_ws=None, want_pred: bool = True, update=None):
     """vaa_step_epilogue: msg[0..n) = fixed-order sum of K2's partial tiles [parts, n]; with `rowmap` (+ the workspace loss_rows_stats left)
     K3's statistics are folded into `scalars` (f32[8], output) and the prediction maps; msg[n..n+4) = {CE, w^2*MSE, UAD, total}.
-    Returns (pred_slice, pred_full) or (None, None)."""
+    update = dict(patch=, m=, v=, mode=, lr=, step=, beta1=, beta2=, eps=, stat_part= f64 [ceil(n/64), 2]) fuses K4 (single-GPU step:
+    vaa_step_epilogue_update). Returns (pred_slice, pred_full) or (None, None)."""
     _need(partials, torch.float32, "partials")
     parts, n = int(partials.shape[0]), int(partials.shape[1])
     _need(msg, torch.float32, "msg")
@@ -633,12 +634,25 @@ def step_epilogue(partials, msg, scalars, rowmap: LossRowMap = None, R: int = 0,
     if rowmap is not None and want_pred:
         pred = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=msg.device)
         pred_full = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=msg.device)
+    common = (partials.data_ptr(), parts, n, rowmap.buf.data_ptr() if rowmap is not None else None, int(R), rowmap.B if rowmap is not None else 0,
+              rowmap.L if rowmap is not None else 0, int(V), int(mode), _lib.f32x([w, alpha, beta, scale]),
+              loss_ws.data_ptr() if loss_ws is not None else None, loss_ws.numel() if loss_ws is not None else 0, scalars.data_ptr(),
+              pred.data_ptr() if pred is not None else None, pred_full.data_ptr() if pred_full is not None else None, msg.data_ptr())
     with _timed("EPI_step_epilogue", n=n, parts=parts):
-        rc = _lib.lib().vaa_step_epilogue(
-            partials.data_ptr(), parts, n, rowmap.buf.data_ptr() if rowmap is not None else None, int(R), rowmap.B if rowmap is not None else 0,
-            rowmap.L if rowmap is not None else 0, int(V), int(mode), _lib.f32x([w, alpha, beta, scale]),
-            loss_ws.data_ptr() if loss_ws is not None else None, loss_ws.numel() if loss_ws is not None else 0, scalars.data_ptr(),
-            pred.data_ptr() if pred is not None else None, pred_full.data_ptr() if pred_full is not None else None, msg.data_ptr(), _stream())
+        if update is None:
+            rc = _lib.lib().vaa_step_epilogue(*common, _stream())
+        else:
+            u = update
+            _need(u["patch"], torch.float32, "patch")
+            if u["patch"].numel() != n:
+                raise _lib.VaaError(f"update: patch has {u['patch'].numel()} elements, the gradient {n}")
+            sp = u.get("stat_part")
+            if sp is not None:
+                _need(sp, torch.float64, "stat_part", ((n + 63) // 64, 2))
+            rc = _lib.lib().vaa_step_epilogue_update(*common, u["patch"].data_ptr(), u["m"].data_ptr() if u.get("m") is not None else None,
+                                                     u["v"].data_ptr() if u.get("v") is not None else None, int(u["mode"]), float(u["lr"]),
+                                                     float(u.get("beta1", 0.9)), float(u.get("beta2", 0.999)), float(u.get("eps", 1e-6)), int(u["step"]),
+                                                     sp.data_ptr() if sp is not None else None, _stream())
     _lib.check(rc, "vaa_step_epilogue")
     return pred, pred_full
 

@@ -38,7 +38,33 @@ class PatchOptimizer:
         self.t = 0
         self.m = torch.zeros_like(patch, requires_grad=False) if self.mode == ops.OPT_ADAMW_HF else None
         self.v = torch.zeros_like(patch, requires_grad=False) if self.mode == ops.OPT_ADAMW_HF else None
-        self.last_stats = None  # device f32[2]: [sum|g|, mean g] of the most recent step
+        self._last_stats = None  # device f32[2]: [sum|g|, mean g] of the most recent step
+        self._stat_part = None   # fused steps (vaa_step_epilogue_update): per-block {sum|g|, sum g}, folded on demand
+
+    @property
+    def last_stats(self):
+        """device f32[2] = [sum|g|, mean g] of the most recent step (what K4 logs; after a fused step folded here from its block sums)."""
+        if self._last_stats is None and self._stat_part is not None:
+            t = self._stat_part.sum(dim=0)
+            self._last_stats = torch.stack([t[0], t[1] / self.patch.numel()]).to(torch.float32)
+        return self._last_stats
+
+    @last_stats.setter
+    def last_stats(self, v):
+        self._last_stats = v
+
+    def fused_update_args(self):
+        """Arguments of ONE step for ops.step_epilogue(update=...) — the single-GPU step applies K4 inside the epilogue launch. Advances the
+        step count like step(); only without L1 clip (the clip needs the whole gradient's norm first)."""
+        if self.l1_clip:
+            raise ValueError("the fused update has no L1 clip")
+        self.t += 1
+        grp = self.param_groups[0]
+        if self._stat_part is None:
+            self._stat_part = torch.zeros(((self.patch.numel() + 63) // 64, 2), dtype=torch.float64, device=self.patch.device)
+        self._last_stats = None
+        return dict(patch=self.patch.data, m=self.m, v=self.v, mode=self.mode, lr=grp["lr"], step=self.t, beta1=grp["betas"][0],
+                    beta2=grp["betas"][1], eps=grp["eps"], stat_part=self._stat_part)
 
     def step(self, grad: torch.Tensor | None = None, grad_scale: float = 1.0):
         g = grad if grad is not None else self.patch.grad
@@ -46,9 +72,9 @@ class PatchOptimizer:
             return None
         self.t += 1
         grp = self.param_groups[0]
-        self.last_stats = ops.patch_update(self.patch.data, g.contiguous(), self.m, self.v, self.mode, grp["lr"], self.t,
-                                           grp["betas"][0], grp["betas"][1], grp["eps"], self.l1_clip, grad_scale)
-        return self.last_stats
+        self._last_stats = ops.patch_update(self.patch.data, g.contiguous(), self.m, self.v, self.mode, grp["lr"], self.t,
+                                            grp["betas"][0], grp["betas"][1], grp["eps"], self.l1_clip, grad_scale)
+        return self._last_stats
 
     def zero_grad(self, set_to_none: bool = True):
         if set_to_none:

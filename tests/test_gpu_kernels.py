@@ -1252,6 +1252,20 @@ def test_step_epilogue_equals_separate_launches(ops, B, dtype):
     msg2 = torch.zeros(n + 4, device=DEV)
     ops.step_epilogue(parts, msg2, want_s)
     assert torch.equal(msg2[:n], msg[:n]) and torch.equal(msg2[n:], want_s[[1, 2, 7, 0]])
+    # the single-GPU form: K4 applied inside the epilogue == vaa_patch_update on the same gradient, bitwise in patch / m / v
+    for opt_mode in (ops.OPT_ADAMW_HF, ops.OPT_PGD_SIGN):
+        p_a, p_b = patch.clone(), patch.clone()
+        m_a, v_a = torch.rand_like(patch) * 1e-3, torch.rand_like(patch) * 1e-6
+        m_b, v_b = m_a.clone(), v_a.clone()
+        st = ops.patch_update(p_a, want_g, m_a, v_a, opt_mode, 2e-3, 7).clone()
+        sp = torch.zeros(((n + 63) // 64, 2), dtype=torch.float64, device=DEV)
+        msg3 = torch.zeros(n + 4, device=DEV)
+        ops.step_epilogue(parts, msg3, want_s, update=dict(patch=p_b, m=m_b, v=v_b, mode=opt_mode, lr=2e-3, step=7, stat_part=sp))
+        assert torch.equal(p_a, p_b) and torch.equal(msg3[:n], msg[:n]) and float((p_b - patch).abs().max()) > 0
+        if opt_mode == ops.OPT_ADAMW_HF:
+            assert torch.equal(m_a, m_b) and torch.equal(v_a, v_b)
+        tot = sp.sum(0)
+        assert torch.allclose(torch.stack([tot[0], tot[1] / n]).float(), st, rtol=1e-6, atol=0)
     # vaa_loss_rows_stats refuses modes whose gradient depends on the folded scalars
     from roboticattack_amd import _lib
 
