@@ -258,6 +258,17 @@ int vaa_patch_embed_grad_gather_tiles(const uint16_t* dy0, int D0, const uint16_
                                       const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
                                       const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
                                       int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream);
+/* EXPERIMENT (records): vaa_patch_apply_fwd_tiles_rec additionally writes records dev [B,256,196] x 16 B = {x0 | y0 << 9 | kept << 18, w, n, 0}
+ * for every pixel of the tiles its footprint role owns (the exact sample position K1 computed); vaa_patch_embed_grad_gather_tiles_rec walks
+ * the flagged tiles and reads them instead of rebuilding row tables and the coordinate chain. Same results bit for bit; kept out of the
+ * attack loops (measured, not adopted). */
+int vaa_patch_apply_fwd_tiles_rec(const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta, int B,
+                                  int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6, uint16_t* out0,
+                                  uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* records, void* stream);
+int vaa_patch_embed_grad_gather_tiles_rec(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
+                                          const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
+                                          const uint32_t* tile_flags, const void* records, int B, int ph, int pw, int geometry, int mask_mode,
+                                          const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream);
 /* the same with one patch per image (resize_patch=True; packed / pdesc / gpacked as in vaa_patch_grad_gather_multi):
  * ws >= vaa_patch_embed_grad_multi_ws_bytes(B); the resize adjoint then folds gpacked into the base patch's gradient */
 size_t vaa_patch_embed_grad_multi_ws_bytes(int B);

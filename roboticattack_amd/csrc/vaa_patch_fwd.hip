@@ -344,6 +344,7 @@ struct TileOut {
     uint16_t* out1;
     uint16_t* keep_t;
     uint32_t* flags;  // byte w of word t: wave w of the footprint workgroup saw a kept pixel in its rows of tile t
+    uint4* rec;       // experiment: [B,256,196] per-pixel records {x0 | y0 << 9 | kept << 18, w, n, 0} of the footprint tiles (nullptr: none)
 };
 
 constexpr int kTS = 14, kTPS = 16, kTElems = 3 * kTS * kTS;  // tile side, tiles per side, elements per tile and tower (588)
@@ -461,8 +462,11 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_tiles_kernel(const Fw
             const uint32_t by0 = sp[0], by1 = sp[1], by2 = sp[2];
             float cv[3];
             bool inside;
+            int rx0 = j, ry0 = i;
+            float rwf = 0.0f, rnf = 0.0f;
             if (a.geometry) {
-                const Samp s = sample_pos(bgrid[j], bgrid[i], th);
+                sample_pos_frac(bgrid[j], bgrid[i], th, rx0, ry0, rwf, rnf);
+                const Samp s = samp_from_frac(rx0, ry0, rwf, rnf);  // the products of sample_pos, bit for bit
                 const int u0 = s.x0 - px, v0 = s.y0 - py;
                 inside = !(u0 < -1 || u0 >= pw || v0 < -1 || v0 >= ph);
                 const int uc0 = min(max(u0, 0), pw - 1), uc1 = min(max(u0 + 1, 0), pw - 1);
@@ -504,6 +508,10 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_tiles_kernel(const Fw
                 o.out0[e + c * 196] = (uint16_t)(L[c] & 0xffffu);
                 o.out1[e + c * 196] = (uint16_t)(L[c] >> 16);
             }
+            if (o.rec)
+                o.rec[((size_t)b * 256 + t) * (kTS * kTS) + y * kTS + x] =
+                    make_uint4((uint32_t)rx0 | ((uint32_t)ry0 << 9) | ((kept[0] ? 1u : 0u) | (kept[1] ? 2u : 0u) | (kept[2] ? 4u : 0u)) << 18,
+                               __float_as_uint(rwf), __float_as_uint(rnf), 0u);
         }
         unsigned long long many = 0ull;
 #pragma unroll
@@ -583,11 +591,10 @@ extern "C" int vaa_patch_apply_fwd_multi(const uint8_t* img_u8, const float* pac
 }
 
 // K1 in tile-major form (see patch_apply_tiles_kernel): the operands of the two ViT patch-embed GEMMs + tile-major keep words + tile flags.
-extern "C" int vaa_patch_apply_fwd_tiles(const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta,
-                                         int B, int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
-                                         uint16_t* out0, uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* stream) {
-    using namespace vaa;
-    const char* who = "vaa_patch_apply_fwd_tiles";
+namespace vaa {
+static int patch_apply_tiles_impl(const char* who, const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                                  int B, int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6, uint16_t* out0,
+                                  uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, uint4* records, void* stream) {
     if (B == 0) return VAA_OK;
     if (!img_u8 || !patch || !xy || !out0 || !out1 || !mean6 || !std6 || (geometry && !theta)) {
         set_error("%s: null pointer argument", who);
@@ -610,7 +617,7 @@ extern "C" int vaa_patch_apply_fwd_tiles(const uint8_t* img_u8, const float* pat
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) { a.nrm.mean[q] = mean6[q]; a.nrm.stdv[q] = std6[q]; }
     TileOut o;
-    o.out0 = out0; o.out1 = out1; o.keep_t = keep_tiles; o.flags = tile_flags;
+    o.out0 = out0; o.out1 = out1; o.keep_t = keep_tiles; o.flags = tile_flags; o.rec = records;
     // footprint workgroups per image: each pays a ~2 us prologue (LUT, 224 row spans, tile list) before its first tile, so FEWER, longer-lived
     // workgroups win here — measured at bs=64 with 1024 / 512 / 256 / 128 in total: 18.7 / 16.2 / 18.6 / 25.8 us (a 50x50 footprint meets ~45
     // tiles: ~6 per workgroup at 8 per image); small batches keep 16 per image
@@ -619,4 +626,20 @@ extern "C" int vaa_patch_apply_fwd_tiles(const uint8_t* img_u8, const float* pat
     const long n_fp = (long)B * fsplit, n_bg = (long)B * 16;
     VAA_LAUNCH(patch_apply_tiles_kernel, dim3((unsigned)(n_fp + n_bg)), dim3(kFwdThreads), 0, (hipStream_t)stream, a, o, (int)n_fp, fsplit);
     return check_launch(who);
+}
+}  // namespace vaa
+
+extern "C" int vaa_patch_apply_fwd_tiles(const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                                         int B, int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
+                                         uint16_t* out0, uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* stream) {
+    return vaa::patch_apply_tiles_impl("vaa_patch_apply_fwd_tiles", img_u8, patch, pdesc, xy, theta, B, ph, pw, geometry, mask_mode, mean6, std6, out0, out1,
+                                       keep_tiles, tile_flags, nullptr, stream);
+}
+
+// EXPERIMENT: also emits per-pixel records for the footprint tiles, records dev [B,256,196] x 16 B.
+extern "C" int vaa_patch_apply_fwd_tiles_rec(const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                                             int B, int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
+                                             uint16_t* out0, uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* records, void* stream) {
+    return vaa::patch_apply_tiles_impl("vaa_patch_apply_fwd_tiles_rec", img_u8, patch, pdesc, xy, theta, B, ph, pw, geometry, mask_mode, mean6, std6, out0,
+                                       out1, keep_tiles, tile_flags, reinterpret_cast<uint4*>(records), stream);
 }

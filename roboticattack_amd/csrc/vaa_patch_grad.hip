@@ -51,6 +51,10 @@ struct GradArgs {
     const float* geff;
     const float* geff2;      // non-null: the tile kernel ran one tower per workgroup and `geff` holds {tower 0, tower 1} PAIRS per element: the gather adds the two
     const uint16_t* keep_t;  // TILED only: K1's tile-major keep words [B,3,256,14] (vaa_patch_apply_fwd_tiles) instead of `keep`
+    // REC (experiment): K1's per-pixel records [B,256,196] {x0 | y0 << 9 | kept << 18, w, n, 0} + its tile flag words [B,256]: the footprint is
+    // walked tile by tile from the flags and the exact sample position comes from the record instead of the row tables + coordinate chain
+    const uint4* rec;
+    const uint32_t* tflags;
 };
 
 constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTilePx;  // ViT patch-embed tiling of the 224x224 frame
@@ -82,13 +86,14 @@ __device__ __forceinline__ int round_half_up(float x) {
 // segments starting at an even column; one half-wave owns one (row, segment) slot at a time and a lane owns TWO adjacent
 // pixels of it (one 4-byte load per gradient plane, one keep byte), so a lane needs ONE LDS read (packed {jlo,len} of its
 // row) to know its pixels. Slots are dealt round-robin to the half-waves of the workgroup-row.
-template <int NCH, bool TILED, bool MULTI, bool HASK, int THREADS, int K>
+template <int NCH, bool TILED, bool MULTI, bool HASK, int THREADS, int K, bool REC = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void patch_grad_scatter_kernel(GradArgs a, int gx) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned long long* tile = reinterpret_cast<unsigned long long*>(smem_raw);  // [band_rows*pw][NCH] (channels interleaved)
     __shared__ float bgrid[VAA_IMG];
     __shared__ uint32_t row_word[kImgsPerPass][VAA_IMG];  // (jlo << 16) | len, jlo even
     __shared__ int row_min[kImgsPerPass], row_max[kImgsPerPass], len_max[kImgsPerPass];
+    __shared__ int tile_cnt[kImgsPerPass][4];  // REC: flagged tiles per (image, wave of 64 tiles)
     __shared__ uint32_t round_max[3];  // max |G| bits of a round, three slots in rotation (see the reset below)
     __shared__ int nonfinite;
     constexpr int HWS = THREADS / 32;  // half-waves per workgroup
@@ -166,52 +171,74 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
         __syncthreads();  // previous pass done with the tables (also orders the initial zero-fill)
         if (tid < kImgsPerPass) { row_min[tid] = VAA_IMG; row_max[tid] = -1; len_max[tid] = 0; }
         __syncthreads();
-        // ---- per-row column bounds of each footprint (conservative) ----
-        // threads cover images x 256 row slots (rows 224..255 idle), so a wave never straddles two images and the extent
-        // reduction is one shuffle tree + 3 LDS atomics per wave instead of 3 same-address atomics per row
-        for (int r0 = 0; r0 < nimg * 256; r0 += THREADS) {
-            const int r = r0 + tid;
-            const int q = r >> 8, i = r & 255;
-            int len = 0;
-            if (q < nimg && i < VAA_IMG) {
-                const int b = b0 + q * gx;
-                const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
-                const int ph = MULTI ? a.pdesc[4 * b] : a.ph, pw = MULTI ? a.pdesc[4 * b + 1] : a.pw;
-                int jlo = 0, jhi = -1;
-                if (a.geometry) {
-                    float th[6];
-#pragma unroll
-                    for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
-                    const PixAffine pa = pix_affine(th);
-                    // source x must fall in [px-1, px+pw) (corner x0 or x0+1 on the patch); a side that lies on the
-                    // frame edge also receives every clamped out-of-frame sample (padding_mode='border').
-                    const float xlo = (px == 0) ? -1e30f : (float)(px - 1);
-                    const float xhi = (px + pw == VAA_IMG) ? 1e30f : (float)(px + pw);
-                    // ... restricted to this workgroup's band of patch rows [v_lo, vb_hi): source y in [py + v_lo - 1, py + vb_hi)
-                    const int vb_hi = min(ph, v_lo + a.band_rows);
-                    const float ylo = (py == 0 && v_lo == 0) ? -1e30f : (float)(py + v_lo - 1);
-                    const float yhi = (py + ph == VAA_IMG && vb_hi == ph) ? 1e30f : (float)(py + vb_hi);
-                    float jl = -1e30f, jh = 1e30f;
-                    solve_interval(pa.a00, pa.a01 * (float)i + pa.c0, xlo, xhi, jl, jh);
-                    solve_interval(pa.a10, pa.a11 * (float)i + pa.c1, ylo, yhi, jl, jh);
-                    if (jl <= jh && v_lo < ph) {
-                        jlo = (int)fmaxf(0.0f, floorf(jl) - 1.0f);
-                        jhi = (int)fminf((float)(VAA_IMG - 1), ceilf(jh) + 1.0f);
+        if constexpr (REC) {
+            // ---- tile list of each image from K1's flag words: row_word[q][slot] = tile id, len_max[q] = count ----
+            for (int r0 = 0; r0 < nimg * 256; r0 += THREADS) {
+                const int r = r0 + tid;
+                const int q = r >> 8, t = r & 255;
+                const bool flag = q < nimg && a.tflags[(size_t)(b0 + q * gx) * 256 + t] != 0u;
+                const unsigned long long m = __ballot(flag);
+                if ((tid & 63) == 0 && q < nimg) tile_cnt[q][t >> 6] = __popcll(m);
+                __syncthreads();
+                if (q < nimg) {
+                    int base = 0, tot = 0;
+                    for (int w = 0; w < 4; ++w) { if (w < (t >> 6)) base += tile_cnt[q][w]; tot += tile_cnt[q][w]; }
+                    if (flag) {
+                        const int slot = base + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+                        if (slot < VAA_IMG) row_word[q][slot] = (uint32_t)t;
                     }
-                } else if (i >= py + v_lo && i < py + min(ph, v_lo + a.band_rows)) {
-                    jlo = px;
-                    jhi = px + pw - 1;
+                    if (t == 0) { len_max[q] = min(tot, VAA_IMG); row_min[q] = 0; row_max[q] = tot > 0 ? 0 : -1; }
                 }
-                if (jhi < jlo) { jlo = 0; jhi = -1; }  // an interval wholly beyond the frame (side open to infinity) is an empty row
-                jlo &= ~1;  // a lane's pixel pair starts at an even column: one aligned 4-byte load per plane
-                len = max(0, jhi - jlo + 1);
-                row_word[q][i] = ((uint32_t)jlo << 16) | (uint32_t)len;
+                __syncthreads();
             }
-            const int wmin = wave_min_i(len > 0 ? i : VAA_IMG), wmax = wave_max_i(len > 0 ? i : -1), wlen = wave_max_i(len);
-            if ((tid & 63) == 0 && q < nimg && wlen > 0) {
-                atomicMin(&row_min[q], wmin);
-                atomicMax(&row_max[q], wmax);
-                atomicMax(&len_max[q], wlen);
+        } else {
+        // ---- per-row column bounds of each footprint (conservative) ----
+            // threads cover images x 256 row slots (rows 224..255 idle), so a wave never straddles two images and the extent
+            // reduction is one shuffle tree + 3 LDS atomics per wave instead of 3 same-address atomics per row
+            for (int r0 = 0; r0 < nimg * 256; r0 += THREADS) {
+                const int r = r0 + tid;
+                const int q = r >> 8, i = r & 255;
+                int len = 0;
+                if (q < nimg && i < VAA_IMG) {
+                    const int b = b0 + q * gx;
+                    const int px = a.xy[2 * b], py = a.xy[2 * b + 1];
+                    const int ph = MULTI ? a.pdesc[4 * b] : a.ph, pw = MULTI ? a.pdesc[4 * b + 1] : a.pw;
+                    int jlo = 0, jhi = -1;
+                    if (a.geometry) {
+                        float th[6];
+    #pragma unroll
+                        for (int z = 0; z < 6; ++z) th[z] = a.theta[6 * b + z];
+                        const PixAffine pa = pix_affine(th);
+                        // source x must fall in [px-1, px+pw) (corner x0 or x0+1 on the patch); a side that lies on the
+                        // frame edge also receives every clamped out-of-frame sample (padding_mode='border').
+                        const float xlo = (px == 0) ? -1e30f : (float)(px - 1);
+                        const float xhi = (px + pw == VAA_IMG) ? 1e30f : (float)(px + pw);
+                        // ... restricted to this workgroup's band of patch rows [v_lo, vb_hi): source y in [py + v_lo - 1, py + vb_hi)
+                        const int vb_hi = min(ph, v_lo + a.band_rows);
+                        const float ylo = (py == 0 && v_lo == 0) ? -1e30f : (float)(py + v_lo - 1);
+                        const float yhi = (py + ph == VAA_IMG && vb_hi == ph) ? 1e30f : (float)(py + vb_hi);
+                        float jl = -1e30f, jh = 1e30f;
+                        solve_interval(pa.a00, pa.a01 * (float)i + pa.c0, xlo, xhi, jl, jh);
+                        solve_interval(pa.a10, pa.a11 * (float)i + pa.c1, ylo, yhi, jl, jh);
+                        if (jl <= jh && v_lo < ph) {
+                            jlo = (int)fmaxf(0.0f, floorf(jl) - 1.0f);
+                            jhi = (int)fminf((float)(VAA_IMG - 1), ceilf(jh) + 1.0f);
+                        }
+                    } else if (i >= py + v_lo && i < py + min(ph, v_lo + a.band_rows)) {
+                        jlo = px;
+                        jhi = px + pw - 1;
+                    }
+                    if (jhi < jlo) { jlo = 0; jhi = -1; }  // an interval wholly beyond the frame (side open to infinity) is an empty row
+                    jlo &= ~1;  // a lane's pixel pair starts at an even column: one aligned 4-byte load per plane
+                    len = max(0, jhi - jlo + 1);
+                    row_word[q][i] = ((uint32_t)jlo << 16) | (uint32_t)len;
+                }
+                const int wmin = wave_min_i(len > 0 ? i : VAA_IMG), wmax = wave_max_i(len > 0 ? i : -1), wlen = wave_max_i(len);
+                if ((tid & 63) == 0 && q < nimg && wlen > 0) {
+                    atomicMin(&row_min[q], wmin);
+                    atomicMax(&row_max[q], wmax);
+                    atomicMax(&len_max[q], wlen);
+                }
             }
         }
         __syncthreads();
@@ -224,9 +251,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
             const int plane = ph * pw;
             const int v_hi = min(ph, v_lo + a.band_rows);
             if (nrows > 0 && v_lo < ph) {
-                const int nseg = (len_max[q] + 63) >> 6;                   // <= 4
+                const int nseg = REC ? 4 : (len_max[q] + 63) >> 6;          // <= 4 (REC: four 4-row groups per tile)
                 const uint32_t inv_nseg = (65536u + nseg - 1) / nseg;      // exact floor(s/nseg) for s < 9362
-                const int nslots = nrows * nseg;
+                const int nslots = REC ? len_max[q] * 4 : nrows * nseg;
                 const int px = a.xy[2 * b], py = a.xy[2 * b + 1];          // workgroup-uniform -> scalar loads
                 float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
                 if (a.geometry) {
@@ -263,19 +290,37 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                         const int sc = min(sidx, nslots - 1);
                         const int r = (int)(((uint32_t)sc * inv_nseg) >> 16);
                         const int ks = sc - r * nseg;
-                        const int i = rmin + r;
-                        const uint32_t w = row_word[q][i];
-                        const int off = (ks << 6) + 2 * hl, len = (int)(w & 0xffffu);
+                        int i, j0, off, len;
+                        uint4 rc2[2];
+                        if constexpr (REC) {  // slot = (tile r of the list, 4-row group ks): a half-wave's first 28 lanes = 4 rows x 7 pixel pairs
+                            const int tl = (int)row_word[q][r];
+                            const int yy = 4 * ks + hl / 7, xp = hl - (hl / 7) * 7;
+                            const bool ok = hl < 28 && yy < kTilePx;
+                            i = (tl >> 4) * kTilePx + (ok ? yy : 0);
+                            j0 = (tl & 15) * kTilePx + (ok ? 2 * xp : 0);
+                            off = 0; len = ok ? 2 : 0;
+                            const uint4* rp = a.rec + ((size_t)b * 256 + tl) * (kTilePx * kTilePx) + (i - (tl >> 4) * kTilePx) * kTilePx + (j0 - (tl & 15) * kTilePx);
+                            rc2[0] = rp[0]; rc2[1] = rp[1];
+                        } else {
+                            i = rmin + r;
+                            const uint32_t w = row_word[q][i];
+                            off = (ks << 6) + 2 * hl; len = (int)(w & 0xffffu);
+                            j0 = min((int)(w >> 16) + off, VAA_IMG - 2);  // even
+                        }
                         const bool lane_in = sidx < nslots && off < len;
-                        const int j0 = min((int)(w >> 16) + off, VAA_IMG - 2);  // even
                         const int pix0 = i * VAA_IMG + j0;
-                        uint32_t f = ktiled ? 0u : (uint32_t)(pix0 & 7) << 16;  // tile-major keep words are shifted to bit 0 when they are loaded
+                        uint32_t f = (ktiled || REC) ? 0u : (uint32_t)(pix0 & 7) << 16;  // tile-major keep words are shifted to bit 0 when they are loaded
+                        uint32_t reckept = 0u;
 #pragma unroll
                         for (int p = 0; p < 2; ++p) {
                             const int j = j0 + p;
                             int x0 = j, y0 = i;
                             float wf = 0.0f, nf = 0.0f;
-                            if (a.geometry) sample_pos_frac(bgrid[j], bgrid[i], th, x0, y0, wf, nf);
+                            if constexpr (REC) {  // K1's own sample position of this pixel: no coordinate chain here
+                                x0 = (int)(rc2[p].x & 511u); y0 = (int)((rc2[p].x >> 9) & 511u);
+                                wf = __uint_as_float(rc2[p].y); nf = __uint_as_float(rc2[p].z);
+                                reckept |= ((rc2[p].x >> 18) & 7u) << (4 * p);
+                            } else if (a.geometry) sample_pos_frac(bgrid[j], bgrid[i], th, x0, y0, wf, nf);
                             fw[k][p] = wf; fn[k][p] = nf;
                             const int u0 = x0 - px, v0 = y0 - py;
                             // corners off the patch, off this workgroup's row band or off the frame get weight 0; a pixel without a live corner is skipped
@@ -323,7 +368,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             for (int cc = 0; cc < NCH; ++cc) {
                                 const int c = c_base + cc;
 #ifndef VAA_K2_ABLATE_NO_LOADS
-                                if (HASK) {
+                                if (REC) {
+                                    kb[k][cc] = ((reckept >> c) & 1u) | (((reckept >> (4 + c)) & 1u) << 1);  // the records carry the kept bits
+                                } else if (HASK) {
                                     if (ktiled) {  // word (c, tile, y), bit x: a lane's pixel pair never straddles a tile (14 is even)
                                         const int ty = i / kTilePx, tx = j0 / kTilePx;
                                         kb[k][cc] = (uint32_t)ktimg[((size_t)c * 256 + ty * kTilesPerSide + tx) * kTilePx + (i - ty * kTilePx)] >> (j0 - tx * kTilePx);
@@ -517,7 +564,8 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
         a.band_rows = (ph + gs.bands - 1) / gs.bands;
         const int nb = (ph + a.band_rows - 1) / a.band_rows;
         const size_t lds = 3 * (size_t)a.band_rows * pw * sizeof(long long);
-        if (a.keep) VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, true, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
+        if (TILED && a.rec) VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, true, 512, 3, TILED>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
+        else if (a.keep) VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, true, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
         else VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, false, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
     } else {  // one channel per workgroup (grid.y), row bands (grid.z) when even one plane exceeds the LDS (> 135x135)
         a.band_rows = band_rows_for(ph, pw, 3 * G);
@@ -608,7 +656,7 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode; a.band_rows = ph;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr; a.rec = nullptr; a.tflags = nullptr;
     return launch_scatter_reduce<false>(a, gpatch, st, "vaa_patch_grad_gather");
 }
 
@@ -639,7 +687,7 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.g = gout_bf16; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr; a.rec = nullptr; a.tflags = nullptr;
     return launch_scatter_multi<false>(a, max_h, max_w, (hipStream_t)stream, "vaa_patch_grad_gather_multi");
 }
 
@@ -1120,8 +1168,8 @@ namespace vaa {
 // fixed-order sum of the partial tiles (ws[0 .. parts*3*ph*pw), parts = vaa_patch_grad_partials(B)) to the caller's vaa_step_epilogue.
 static int embed_grad_gather_impl(const char* who, const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
                                   const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, const uint16_t* keep_tiles,
-                                  const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6, int round_bf16,
-                                  float* gpatch, bool defer_reduce, void* ws, size_t ws_bytes, void* stream) {
+                                  const uint32_t* tile_flags, const uint4* records, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
+                                  int round_bf16, float* gpatch, bool defer_reduce, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 && gpatch && ph > 0 && pw > 0) {
         if (hipMemsetAsync(gpatch, 0, (size_t)3 * ph * pw * sizeof(float), st) != hipSuccess) return check_launch(who);
@@ -1166,6 +1214,10 @@ static int embed_grad_gather_impl(const char* who, const uint16_t* dy0, int D0, 
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
     a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles;
+    // experiment: per-pixel records of K1 (only while a tile list fits the row-table storage: patches up to ~100 px)
+    const int tiles_bound = ((3 * ph / 2 + 13) / 14 + 2) * ((3 * pw / 2 + 13) / 14 + 2);
+    a.rec = (records && tiles_bound <= 128) ? records : nullptr;
+    a.tflags = tile_flags;
     if (keep_tiles) a.keep = reinterpret_cast<const uint8_t*>(keep_tiles);  // non-null selects the stored-mask instantiation
     return launch_scatter_reduce<true>(a, defer_reduce ? nullptr : gpatch, st, who);
 }
@@ -1176,8 +1228,8 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
                                            const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph,
                                            int pw, int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws,
                                            size_t ws_bytes, void* stream) {
-    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, keep_bits, nullptr, nullptr, B, ph, pw,
-                                       geometry, mask_mode, std6, round_bf16, gpatch, false, ws, ws_bytes, stream);
+    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, keep_bits, nullptr, nullptr, nullptr, B, ph,
+                                       pw, geometry, mask_mode, std6, round_bf16, gpatch, false, ws, ws_bytes, stream);
 }
 
 extern "C" int vaa_patch_grad_partials(int B) { return B > 0 ? vaa::grad_sched(B).gx : 0; }
@@ -1186,8 +1238,19 @@ extern "C" int vaa_patch_embed_grad_gather_tiles(const uint16_t* dy0, int D0, co
                                                  const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
                                                  const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
                                                  int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream) {
-    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather_tiles", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, nullptr, keep_tiles, tile_flags, B,
-                                       ph, pw, geometry, mask_mode, std6, round_bf16, gpatch, gpatch == nullptr, ws, ws_bytes, stream);
+    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather_tiles", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, nullptr, keep_tiles, tile_flags,
+                                       nullptr, B, ph, pw, geometry, mask_mode, std6, round_bf16, gpatch, gpatch == nullptr, ws, ws_bytes, stream);
+}
+
+// EXPERIMENT: the same with K1's per-pixel records (vaa_patch_apply_fwd_tiles_rec) — the gather walks the flagged
+// tiles and takes every pixel's exact sample position from its record instead of rebuilding row tables and the coordinate chain.
+extern "C" int vaa_patch_embed_grad_gather_tiles_rec(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
+                                                     const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
+                                                     const uint32_t* tile_flags, const void* records, int B, int ph, int pw, int geometry, int mask_mode,
+                                                     const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream) {
+    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather_tiles_rec", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, nullptr, keep_tiles, tile_flags,
+                                       reinterpret_cast<const uint4*>(records), B, ph, pw, geometry, mask_mode, std6, round_bf16, gpatch, gpatch == nullptr, ws,
+                                       ws_bytes, stream);
 }
 
 extern "C" size_t vaa_patch_embed_grad_multi_ws_bytes(int B) {
@@ -1236,6 +1299,6 @@ extern "C" int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, co
     a.g = nullptr; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = nullptr;
+    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = nullptr; a.rec = nullptr; a.tflags = nullptr;
     return launch_scatter_multi<true>(a, max_h, max_w, st, "vaa_patch_embed_grad_gather_multi");
 }

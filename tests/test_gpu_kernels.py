@@ -1271,3 +1271,47 @@ def test_step_epilogue_equals_separate_launches(ops, B, dtype):
 
     with pytest.raises(_lib.VaaError):
         ops.loss_rows_stats(logits, rm, ops.LOSS_UPA, grad=gsl)
+
+
+def test_records_experiment_entry_points_match_product(ops):
+    """The records experiment (vaa_patch_apply_fwd_tiles_rec / vaa_patch_embed_grad_gather_tiles_rec; measured and NOT adopted, DESIGN.md
+    section 4): same K1 outputs bit for bit, records = K1's own sample positions, gradient equal to the product path within the integer
+    accumulator's quantum (the slot order differs)."""
+    from roboticattack_amd import _lib, benchmarks
+
+    B = 6
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=DEV).manual_seed(3)
+    img = torch.from_numpy(synthetic.synth_images(5, B, "noise")).to(DEV)
+    patch = torch.rand(3, 50, 50, device=DEV, generator=g)
+    xy_n, th_n = benchmarks.random_params(B, 50, 50, 11)
+    xy, th = torch.from_numpy(xy_n).to(DEV), torch.from_numpy(th_n).to(DEV)
+    t0, t1, keep_t, flags = ops.patch_apply_fwd_tiles(img, patch, xy, th, True)
+    r0, r1 = torch.empty_like(t0), torch.empty_like(t1)
+    rk, rf = torch.empty_like(keep_t), torch.empty_like(flags)
+    rec = torch.zeros((B, 256, 196, 4), dtype=torch.int32, device=DEV)
+    _lib.check(L.vaa_patch_apply_fwd_tiles_rec(img.data_ptr(), patch.data_ptr(), None, xy.data_ptr(), th.data_ptr(), B, 50, 50, 1, 0, ops._MEAN, ops._STD,
+                                               r0.data_ptr(), r1.data_ptr(), rk.data_ptr(), rf.data_ptr(), rec.data_ptr(), st), "tiles_rec")
+    assert torch.equal(t0.view(torch.int16), r0.view(torch.int16)) and torch.equal(t1.view(torch.int16), r1.view(torch.int16))
+    assert torch.equal(keep_t, rk) and torch.equal(flags != 0, rf != 0)
+    # kept bits of the records == the keep words
+    rc = rec.cpu().numpy().astype(np.uint32)
+    kt = keep_t.cpu().numpy().view(np.uint16)
+    flagged = (flags.cpu().numpy() != 0)
+    kept_rec = ((rc[..., 0] >> 18) & 7).reshape(B, 256, 14, 14)
+    for c in range(3):
+        bits = (kt[:, c, :, :, None] >> np.arange(14)) & 1  # [B,256,14(y),14(x)]
+        assert np.array_equal(((kept_rec >> c) & 1)[flagged], bits[flagged])
+    D0, D1 = 64, 128
+    dy0 = (torch.randn(B, 256, D0, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    dy1 = (torch.randn(B, 256, D1, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    wp0 = ops.pack_embed_weights((torch.randn(588, D0, device=DEV, generator=g) * 0.05).to(torch.bfloat16))
+    wp1 = ops.pack_embed_weights((torch.randn(588, D1, device=DEV, generator=g) * 0.05).to(torch.bfloat16))
+    want = ops.patch_embed_grad_gather_tiles(dy0, dy1, wp0, wp1, patch, xy, th, keep_t, flags, True)
+    got = torch.empty_like(patch)
+    ws = torch.empty(L.vaa_patch_embed_grad_ws_bytes(B, 50, 50), dtype=torch.uint8, device=DEV)
+    _lib.check(L.vaa_patch_embed_grad_gather_tiles_rec(dy0.data_ptr(), D0, dy1.data_ptr(), D1, wp0.data_ptr(), wp1.data_ptr(), patch.data_ptr(), xy.data_ptr(),
+                                                       th.data_ptr(), keep_t.data_ptr(), flags.data_ptr(), rec.data_ptr(), B, 50, 50, 1, 0, ops._STD, 1,
+                                                       got.data_ptr(), ws.data_ptr(), ws.numel(), st), "gather_rec")
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) and float(want.abs().max()) > 0
