@@ -276,6 +276,11 @@ int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, const uint16_
                                       const float* packed, const int32_t* pdesc, const int32_t* xy, const float* theta,
                                       const uint8_t* keep_bits, int B, int max_h, int max_w, int geometry, int mask_mode, const float* std6,
                                       int round_bf16, float* gpacked, void* ws, size_t ws_bytes, void* stream);
+/* ... fed by the tile-major mask of vaa_patch_apply_fwd_tiles (called with pdesc) */
+int vaa_patch_embed_grad_gather_multi_tiles(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
+                                            const float* packed, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                                            const uint16_t* keep_tiles, const uint32_t* tile_flags, int B, int max_h, int max_w, int geometry,
+                                            int mask_mode, const float* std6, int round_bf16, float* gpacked, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * K4 — replaces transformers.AdamW.step + `patch.data.clamp(0,1)` + zero_grad (UADA.py:155-157; UADA_ddp.py:208-209),

@@ -51,6 +51,7 @@ EXPORTS = (
     "vaa_loss_rows_fwd_bwd",
     "vaa_patch_apply_fwd_tiles",
     "vaa_patch_grad_partials",
+    "vaa_patch_embed_grad_gather_multi_tiles",
     "vaa_patch_apply_fwd_tiles_rec",
     "vaa_patch_embed_grad_gather_tiles_rec",
     "vaa_patch_embed_grad_gather_tiles",
@@ -180,6 +181,8 @@ def lib() -> C.CDLL:
     L.vaa_patch_apply_fwd_tiles_rec.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, vp, vp, vp, vp]
     L.vaa_patch_embed_grad_gather_tiles_rec.restype = i32
     L.vaa_patch_embed_grad_gather_tiles_rec.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
+    L.vaa_patch_embed_grad_gather_multi_tiles.restype = i32
+    L.vaa_patch_embed_grad_gather_multi_tiles.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
     L.vaa_patch_grad_partials.restype = i32
     L.vaa_patch_grad_partials.argtypes = [i32]
     L.vaa_patch_embed_grad_gather_tiles.restype = i32

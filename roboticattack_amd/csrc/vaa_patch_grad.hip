@@ -1259,46 +1259,68 @@ extern "C" size_t vaa_patch_embed_grad_multi_ws_bytes(int B) {
 }
 
 // K2' with one patch per image (resize_patch=True): the tile gradients do not depend on the patches, the gather runs in MULTI mode.
-extern "C" int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
-                                                 const float* packed, const int32_t* pdesc, const int32_t* xy, const float* theta,
-                                                 const uint8_t* keep_bits, int B, int max_h, int max_w, int geometry, int mask_mode,
-                                                 const float* std6, int round_bf16, float* gpacked, void* ws, size_t ws_bytes, void* stream) {
-    using namespace vaa;
+namespace vaa {
+
+// K2' with one patch per image (resize_patch=True): the tile gradients do not depend on the patches, the gather runs in MULTI mode.
+static int embed_grad_gather_multi_impl(const char* who, const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
+                                        const float* packed, const int32_t* pdesc, const int32_t* xy, const float* theta, const uint8_t* keep_bits,
+                                        const uint16_t* keep_tiles, const uint32_t* tile_flags, int B, int max_h, int max_w, int geometry, int mask_mode,
+                                        const float* std6, int round_bf16, float* gpacked, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) return VAA_OK;
-    if (!dy0 || !dy1 || !wp0 || !wp1 || !pdesc || !xy || !std6 || !gpacked || !keep_bits || (geometry && !theta)) {
-        set_error("vaa_patch_embed_grad_gather_multi: null pointer argument (the keep bits of K1 are required)");
+    if (!dy0 || !dy1 || !wp0 || !wp1 || !pdesc || !xy || !std6 || !gpacked || (!keep_bits && !keep_tiles) || (keep_tiles && !tile_flags) || (geometry && !theta)) {
+        set_error("%s: null pointer argument (the keep mask of K1 is required)", who);
         return VAA_E_INVALID;
     }
     if (B < 0 || max_h <= 0 || max_w <= 0 || D0 <= 0 || D1 <= 0 || (D0 % 64) != 0 || (D1 % 64) != 0 ||
         (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100)) {
-        set_error("vaa_patch_embed_grad_gather_multi: bad sizes/mode (B=%d max_h=%d max_w=%d D0=%d D1=%d; D %% 64 == 0)", B, max_h, max_w, D0, D1);
+        set_error("%s: bad sizes/mode (B=%d max_h=%d max_w=%d D0=%d D1=%d; D %% 64 == 0)", who, B, max_h, max_w, D0, D1);
         return VAA_E_INVALID;
     }
     if (max_h > VAA_IMG || max_w > VAA_IMG) {
-        set_error("vaa_patch_embed_grad_gather_multi: patch bound %dx%d larger than the frame", max_h, max_w);
+        set_error("%s: patch bound %dx%d larger than the frame", who, max_h, max_w);
         return VAA_E_UNSUPPORTED;
     }
     if (geometry && mask_mode == VAA_MASK_NE_M100) {
-        set_error("vaa_patch_embed_grad_gather_multi: VAA_MASK_NE_M100 is defined for geometry=0 only");
+        set_error("%s: VAA_MASK_NE_M100 is defined for geometry=0 only", who);
         return VAA_E_UNSUPPORTED;
     }
     if (!ws || ws_bytes < vaa_patch_embed_grad_multi_ws_bytes(B)) {
-        set_error("vaa_patch_embed_grad_gather_multi: workspace %zu B < required %zu B", ws_bytes, vaa_patch_embed_grad_multi_ws_bytes(B));
+        set_error("%s: workspace %zu B < required %zu B", who, ws_bytes, vaa_patch_embed_grad_multi_ws_bytes(B));
         return VAA_E_WORKSPACE;
     }
     EmbedArgs e;
-    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wp0; e.wt1 = wp1; e.keep = keep_bits; e.flags = nullptr; e.geff = reinterpret_cast<float*>(ws);
+    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wp0; e.wt1 = wp1; e.keep = keep_bits; e.flags = tile_flags; e.geff = reinterpret_cast<float*>(ws);
     e.geff2 = e.geff + (size_t)B * 256 * kTileElems;
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
-    if (launch_embed_tiles(e, max_h, max_w, st, "vaa_patch_embed_grad_gather_multi") != VAA_OK) return VAA_E_LAUNCH;
-    int rc = check_launch("vaa_patch_embed_grad_gather_multi(tiles)");
+    if (launch_embed_tiles(e, max_h, max_w, st, who) != VAA_OK) return VAA_E_LAUNCH;
+    int rc = check_launch(who);
     if (rc != VAA_OK) return rc;
     GradArgs a;
     a.g = nullptr; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = nullptr; a.rec = nullptr; a.tflags = nullptr;
-    return launch_scatter_multi<true>(a, max_h, max_w, st, "vaa_patch_embed_grad_gather_multi");
+    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles; a.rec = nullptr; a.tflags = nullptr;
+    if (keep_tiles) a.keep = reinterpret_cast<const uint8_t*>(keep_tiles);  // non-null selects the stored-mask instantiation
+    return launch_scatter_multi<true>(a, max_h, max_w, st, who);
+}
+
+}  // namespace vaa
+
+extern "C" int vaa_patch_embed_grad_gather_multi(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
+                                                 const float* packed, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                                                 const uint8_t* keep_bits, int B, int max_h, int max_w, int geometry, int mask_mode,
+                                                 const float* std6, int round_bf16, float* gpacked, void* ws, size_t ws_bytes, void* stream) {
+    return vaa::embed_grad_gather_multi_impl("vaa_patch_embed_grad_gather_multi", dy0, D0, dy1, D1, wp0, wp1, packed, pdesc, xy, theta, keep_bits, nullptr, nullptr,
+                                             B, max_h, max_w, geometry, mask_mode, std6, round_bf16, gpacked, ws, ws_bytes, stream);
+}
+
+extern "C" int vaa_patch_embed_grad_gather_multi_tiles(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
+                                                       const float* packed, const int32_t* pdesc, const int32_t* xy, const float* theta,
+                                                       const uint16_t* keep_tiles, const uint32_t* tile_flags, int B, int max_h, int max_w, int geometry,
+                                                       int mask_mode, const float* std6, int round_bf16, float* gpacked, void* ws, size_t ws_bytes,
+                                                       void* stream) {
+    return vaa::embed_grad_gather_multi_impl("vaa_patch_embed_grad_gather_multi_tiles", dy0, D0, dy1, D1, wp0, wp1, packed, pdesc, xy, theta, nullptr, keep_tiles,
+                                             tile_flags, B, max_h, max_w, geometry, mask_mode, std6, round_bf16, gpacked, ws, ws_bytes, stream);
 }

@@ -285,6 +285,35 @@ def patch_embed_grad_gather_multi(dy0, dy1, wp0, wp1, packed, pdesc, max_hw, xy,
     return gpacked
 
 
+def patch_embed_grad_gather_multi_tiles(dy0, dy1, wp0, wp1, packed, pdesc, max_hw, xy, theta, keep_tiles, tile_flags, geometry: bool,
+                                        mask_mode: int = MASK_LT_M20, std6=None, round_bf16: bool = True):
+    """K2' with one patch per image, fed by the tile-major mask of patch_apply_fwd_tiles(pdesc=...)."""
+    B = dy0.shape[0]
+    D0, D1 = int(dy0.shape[2]), int(dy1.shape[2])
+    _need(dy0, torch.bfloat16, "dy0", (B, 256, D0))
+    _need(dy1, torch.bfloat16, "dy1", (B, 256, D1))
+    _need(wp0, torch.bfloat16, "wp0", (592 * D0,))
+    _need(wp1, torch.bfloat16, "wp1", (592 * D1,))
+    _need(packed, torch.float32, "packed")
+    _need(pdesc, torch.int32, "pdesc", (B, 4))
+    _need(xy, torch.int32, "xy", (B, 2))
+    if geometry:
+        _need(theta, torch.float32, "theta", (B, 6))
+    _need(keep_tiles, torch.int16, "keep_tiles", (B, 3, 256, 14))
+    _need(tile_flags, torch.int32, "tile_flags", (B, 256))
+    L = _lib.lib()
+    ws = _workspace(packed.device, L.vaa_patch_embed_grad_multi_ws_bytes(B), "k2e")
+    gpacked = torch.zeros_like(packed)
+    std_c = _STD if std6 is None else _lib.f32x(std6)
+    with _timed("K2_patch_embed_grad_gather_multi_tiles", B=B):
+        rc = L.vaa_patch_embed_grad_gather_multi_tiles(dy0.data_ptr(), D0, dy1.data_ptr(), D1, wp0.data_ptr(), wp1.data_ptr(), packed.data_ptr(), pdesc.data_ptr(),
+                                                       xy.data_ptr(), theta.data_ptr() if geometry else None, keep_tiles.data_ptr(), tile_flags.data_ptr(), B,
+                                                       int(max_hw[0]), int(max_hw[1]), int(bool(geometry)), int(mask_mode), std_c, int(bool(round_bf16)),
+                                                       gpacked.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "vaa_patch_embed_grad_gather_multi_tiles")
+    return gpacked
+
+
 class PatchApply(torch.autograd.Function):
     """Differentiable (w.r.t. `patch`) K1: PyTorch-ROCm autograd hands the model's bf16 pixel gradient to K2."""
 
@@ -471,19 +500,20 @@ class PatchApplyResizedEmbed(torch.autograd.Function):
         pdesc = torch.from_numpy(pdesc_np).to(p.device, non_blocking=True)
         max_hw = (int(pdesc_np[:, 0].max()), int(pdesc_np[:, 1].max()))
         packed = patch_resize_fwd(p, pdesc, total)
-        out, keep = patch_apply_fwd_multi(img_u8, packed, pdesc, max_hw, xy, theta, geometry, mask_mode, want_keep=True, mean6=mean6, std6=std6)
-        e0 = torch.nn.functional.linear(unfold_tiles(out[:, :3]), w0, b0)
-        e1 = torch.nn.functional.linear(unfold_tiles(out[:, 3:]), w1, b1)
-        ctx.save_for_backward(packed, pdesc, xy, theta if geometry else xy, keep, wp0, wp1)
+        # K1 with per-image patches, tile-major: the two GEMM operands directly (no [B,6,224,224] tensor, no im2col copies)
+        t0, t1, keep_t, flags = patch_apply_fwd_tiles(img_u8, packed, xy, theta, geometry, mask_mode, mean6=mean6, std6=std6, pdesc=pdesc, max_hw=max_hw)
+        e0 = torch.nn.functional.linear(t0, w0, b0)
+        e1 = torch.nn.functional.linear(t1, w1, b1)
+        ctx.save_for_backward(packed, pdesc, xy, theta if geometry else xy, keep_t, flags, wp0, wp1)
         ctx.geometry, ctx.mask_mode, ctx.std6, ctx.max_hw = bool(geometry), int(mask_mode), std6, max_hw
         ctx.base_hw = (int(p.shape[1]), int(p.shape[2]))
         return e0, e1
 
     @staticmethod
     def backward(ctx, d0, d1):
-        packed, pdesc, xy, theta, keep, wp0, wp1 = ctx.saved_tensors
-        gp = patch_embed_grad_gather_multi(d0.to(torch.bfloat16).contiguous(), d1.to(torch.bfloat16).contiguous(), wp0, wp1, packed, pdesc, ctx.max_hw, xy,
-                                           theta if ctx.geometry else None, keep, ctx.geometry, ctx.mask_mode, std6=ctx.std6)
+        packed, pdesc, xy, theta, keep_t, flags, wp0, wp1 = ctx.saved_tensors
+        gp = patch_embed_grad_gather_multi_tiles(d0.to(torch.bfloat16).contiguous(), d1.to(torch.bfloat16).contiguous(), wp0, wp1, packed, pdesc, ctx.max_hw,
+                                                 xy, theta if ctx.geometry else None, keep_t, flags, ctx.geometry, ctx.mask_mode, std6=ctx.std6)
         g = patch_resize_bwd(gp, pdesc, *ctx.base_hw)
         return (g,) + (None,) * 14
 

@@ -1315,3 +1315,25 @@ def test_records_experiment_entry_points_match_product(ops):
                                                        th.data_ptr(), keep_t.data_ptr(), flags.data_ptr(), rec.data_ptr(), B, 50, 50, 1, 0, ops._STD, 1,
                                                        got.data_ptr(), ws.data_ptr(), ws.numel(), st), "gather_rec")
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) and float(want.abs().max()) > 0
+
+
+def test_patch_embed_grad_gather_multi_tiles_equals_planar_mask_form(ops):
+    """K2' with one patch per image (resize_patch=True) fed by the tile-major mask == the planar-mask form, bitwise."""
+    rs = np.random.RandomState(4)
+    B, D0, D1 = 5, 64, 128
+    sizes = np.stack([rs.randint(40, 140, B), rs.randint(40, 140, B)], axis=1).astype(np.int32)
+    pdesc_n, total = ops.make_pdesc(sizes)
+    packed = _t(rs.rand(total).astype(np.float32))
+    imgs = _t(synthetic.synth_images(29, B, "noise"))
+    xy_n = np.stack([[rs.randint(0, 225 - w), rs.randint(0, 225 - h)] for h, w in sizes]).astype(np.int32)
+    _, th_n = _random_case(rs, B, 50, 50)
+    pdesc, xy, th = _t(pdesc_n), _t(xy_n, torch.int32), _t(th_n.reshape(B, 6))
+    max_hw = (int(sizes[:, 0].max()), int(sizes[:, 1].max()))
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    dy = [(torch.randn(B, 256, D, device=DEV, generator=gen) * 0.1).to(torch.bfloat16) for D in (D0, D1)]
+    wp = [ops.pack_embed_weights((torch.randn(588, D, device=DEV, generator=gen) * 0.05).to(torch.bfloat16)) for D in (D0, D1)]
+    _, keep = ops.patch_apply_fwd_multi(imgs, packed, pdesc, max_hw, xy, th, True, 0)
+    _, _, keep_t, flags = ops.patch_apply_fwd_tiles(imgs, packed, xy, th, True, 0, pdesc=pdesc, max_hw=max_hw)
+    ref = ops.patch_embed_grad_gather_multi(dy[0], dy[1], wp[0], wp[1], packed, pdesc, max_hw, xy, th, keep, True)
+    got = ops.patch_embed_grad_gather_multi_tiles(dy[0], dy[1], wp[0], wp[1], packed, pdesc, max_hw, xy, th, keep_t, flags, True)
+    assert torch.equal(ref, got) and float(ref.abs().max()) > 0
