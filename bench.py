@@ -395,7 +395,7 @@ def main():
         nb = op_bytes["K1"]
         roofline = {"kernel": k1name + " (K1)", "bound": "hbm", "achieved": nb / k1["mean_us"] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": nb / k1["mean_us"] / 1e3 / HBM_PEAK_GBS, "mean_us": k1["mean_us"], "min_us": k1["min_us"], "samples": k1["launches"],
-                    "algo_bytes": nb, "traffic": tr_ops.get("K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch"),
+                    "algo_bytes": nb, "traffic": tr_ops.get("K1t_patch_apply_fwd_tiles" if "tiles" in k1name else "K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch"),
                     "traffic_source": (tfile or "none") + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",
                     "timing": "IN-STEP, per dispatch: every K1 launch of the timed region goes through hipExtLaunchKernel with its own start/stop event pair, "
                               "which the runtime binds to that dispatch's begin/end timestamps — the quantity rocprofv3 --kernel-trace reports "
@@ -403,6 +403,20 @@ def main():
                               "no marker brackets, no subtraction",
                     "note": "dominant = the kernel of the hot path with the most algorithmic bytes (48.2 of ~69 MB per step); every hand-written kernel of the "
                             "timed region is listed in roofline_kernels, per-operator sums in hot_path_ops"}
+        # builder-side cross reference (NOT measured by this run): rocprofv3's average for the same kernel in the committed summary of the same command
+        ref = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
+        if os.path.exists(ref):
+            import csv
+
+            for row in csv.DictReader(open(ref)):
+                if k1name.split("(")[0] in row["Name"]:
+                    us = float(row["AverageNs"]) * 1e-3
+                    roofline["rocprofv3_reference"] = {"file": "profiles/r03_bench_kernel_stats.csv", "calls": int(row["Calls"]), "mean_us": us,
+                                                       "frac": nb / us / 1e3 / HBM_PEAK_GBS,
+                                                       "note": "committed rocprofv3 --kernel-trace --stats summary of `bench.py --steps 20 --warmup 3 --no-cpu-baseline "
+                                                               "--no-kernel-suite --no-per-rank`; the per-dispatch events of an un-profiled run read 0.3-1.8 us above it "
+                                                               "(they include the dispatch's start-up after the preceding command), so the line's frac is the lower one"}
+                    break
 
     extra = {"host_enqueue_ms_per_step": host_enqueue * 1e3, "host_cpu_ms_per_step": host_cpu * 1e3,
              "host_overhead_note": "host_cpu = CPU time of the launching thread per step (python + HIP launches): what N ranks on one host need N times in parallel; "

@@ -1,8 +1,8 @@
 #!/usr/bin/env bash
 # One measurement pass on the MI355X box (run through gpurun from the repo root): kernel-only rocprofv3 stats, PMC traffic, the bench
 # under rocprofv3, the bench line without and with the CPU baseline. Outputs land in gpurun_out/measure/; copy what is to be judged into
-# profiles/ (see profiles/README.md).
-#   gpurun --timeout 1500 -- 'bash tools/measure_round.sh'
+# profiles/ as rNN_* (see profiles/README.md).
+#   gpurun --timeout 2400 -- 'bash tools/measure_round.sh'
 set -uo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 out="${root}/gpurun_out/measure"
@@ -14,11 +14,18 @@ stats_csv() { find "$1" -name '*kernel_stats.csv' | head -1; }
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kb -o kb -- python tools/kbench.py --iters 20 > "${out}/kbench.json" 2> "${out}/kbench.err"
 cp "$(stats_csv /tmp/prof_kb)" "${out}/kbench_kernel_stats.csv" 2>/dev/null
 
-timeout 400 python tools/pmc_traffic.py > "${out}/traffic.log" 2>&1 && cp gpurun_out/traffic.json "${out}/traffic.json" && cp gpurun_out/traffic.json profiles/traffic_r02.json
+timeout 400 python tools/pmc_traffic.py > "${out}/traffic.log" 2>&1 && cp gpurun_out/traffic.json "${out}/traffic.json"
 
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-suite > "${out}/bench_under_rocprof.json" 2> "${out}/bench_under_rocprof.err"
+# the driver's N=1 command under rocprofv3 (20 steps like the driver's run; the CPU baseline and the stand-alone suite are not GPU work of the step)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank > "${out}/bench_under_rocprof.json" 2> "${out}/bench_under_rocprof.err"
 cp "$(stats_csv /tmp/prof_b)" "${out}/bench_kernel_stats.csv" 2>/dev/null
+# the same command un-profiled: its in-step per-dispatch figures are what the record carries
+timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank > "${out}/bench_same_cmd.json" 2> "${out}/bench_same_cmd.err"
 
-timeout 500 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > "${out}/bench_no_cpu.json" 2> "${out}/bench_no_cpu.err"
-timeout 900 python bench.py > "${out}/bench.json" 2> "${out}/bench.err"
+timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "${out}/bench_no_cpu.json" 2> "${out}/bench_no_cpu.err"
+timeout 1200 python bench.py > "${out}/bench.json" 2> "${out}/bench.err"
+# two ranks on the one GPU over gloo: the N > 1 code path at full size (functional evidence, not a scaling number)
+timeout 900 python bench.py --gpus 2 --steps 4 --warmup 1 --no-kernel-suite > "${out}/bench_2ranks_one_gpu.json" 2> "${out}/bench_2ranks_one_gpu.err"
+timeout 200 python tools/k3_onepass_check.py > "${out}/k3_onepass.txt" 2>&1
+timeout 200 python tools/k2_records_check.py 64 8 256 > "${out}/k2_records.txt" 2>&1
 ls -la "${out}"

@@ -74,10 +74,14 @@ def main():
                   "write_bytes": wm * 1024 * w_fac, "hbm_bytes_per_launch": fm * 1024 * f_fac + wm * 1024 * w_fac}
     # per hot-path op (what bench.py's event brackets cover): sum over the op's kernels
     ops = {"K1_patch_apply_fwd": ("patch_apply_fwd_kernel",),
+           "K1t_patch_apply_fwd_tiles": ("patch_apply_tiles_kernel",),                                            # K1 in tile-major form (what the attack step runs)
            "K2_patch_grad_gather": ("patch_grad_scatter_kernel<3, false, false", "patch_grad_reduce_kernel|30208"),
            "K2_patch_embed_grad_gather": ("embed_dgrad_tiles", "patch_grad_scatter_kernel<3, true, false", "patch_grad_reduce_kernel|30208"),
+           "K2et_deferred_reduce": ("embed_dgrad_tiles", "patch_grad_scatter_kernel<3, true, false"),             # tile GEMM + gather; the final sum is the epilogue's
            "K3_loss_rows_fwd_bwd": ("rows_stats_kernel", "rows_finish_kernel<unsigned short, 256>|256"),        # UADA_DDP: gradient slice, one finishing workgroup
+           "K3s_loss_rows_stats": ("rows_stats_kernel",),
            "K3_full_rows_fwd_bwd": ("rows_stats_kernel", "rows_finish_kernel<unsigned short, 256>|131072"),      # UADA: full-row gradient, R x split workgroups
+           "EPI_step_epilogue": ("step_epilogue_kernel",),
            "K4_patch_update": ("patch_update_kernel",)}
     # a kernel that belongs to two ops (reduce: K2 and K2'; stats: both K3 modes) ran once per op call, so its per-launch mean is counted once in each
     out["ops"] = {}
