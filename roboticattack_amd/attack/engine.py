@@ -135,6 +135,25 @@ class AttackBase:
                                          update=optimizer.fused_update_args() if optimizer is not None else None)
         return pred_full
 
+    # ---- single-GPU loops: K2's final sum + K4 as one launch after the backward ----
+    def fused_update_sink(self, optimizer):
+        """A gradient sink ({}) for `apply_random_patch_batch(grad_sink=...)` when the step can end with ONE launch that adds K2''s partial tiles
+        and applies the optimiser to every gradient element as it is produced (`fused_update`), else None: needs K2' (a model that exposes its
+        patch-embed weights), one patch per batch and no L1 clip (UPA's clip needs the whole gradient's norm first)."""
+        t = self.randomPatchTransform
+        ok = (os.environ.get("VAA_FUSED_EPILOGUE", "1") != "0" and self.use_rows and t.embed_with is not None and not t.resize_patch
+              and not optimizer.l1_clip)
+        return {} if ok else None
+
+    def fused_update(self, sink, patch, optimizer, scalars):
+        """After `total.backward()` of a step whose transform was given `sink`: vaa_step_epilogue_update in its pass-through form (the loss
+        scalars are final already) — patch / m / v get the bits `optimizer.step()` would write; patch.grad stays None."""
+        n = patch.numel()
+        msg = getattr(self, "_epi_msg", None)
+        if msg is None or msg.numel() != n + 4 or msg.device != patch.device:
+            msg = self._epi_msg = torch.zeros(n + 4, dtype=torch.float32, device=patch.device)
+        ops.step_epilogue(sink["partials"], msg, scalars, update=optimizer.fused_update_args())
+
     # ---- metrics (host, once per outer iteration) ----
     def decode_pred_gt(self, pred: torch.Tensor, labels: torch.Tensor):
         """Continuous predicted / ground-truth actions of the action rows, (b,k) order (UADA.py:165-175)."""

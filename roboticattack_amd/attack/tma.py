@@ -27,11 +27,12 @@ class OpenVLAAttacker(AttackBase):
         self.min_val_avg_CE_loss = 1000000
         self.min_val_avg_L1_loss = 1000000
 
-    def _images(self, pixel_values, patch, geometry, colorjitter):
+    def _images(self, pixel_values, patch, geometry, colorjitter, grad_sink=None):
         if not geometry and not colorjitter:
             return self.randomPatchTransform.paste_patch_fix(pixel_values, patch, mean=self.mean, std=self.std)
+        kw = {"grad_sink": grad_sink} if grad_sink is not None else {}
         return self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
-                                                                   geometry=geometry, colorjitter=colorjitter)
+                                                                   geometry=geometry, colorjitter=colorjitter, **kw)
 
     def calculate_relative_distance_target(self, pred, gt):
         """TMA.py:470-483."""
@@ -80,11 +81,18 @@ class OpenVLAAttacker(AttackBase):
             newlabels = tma_target_labels(labels, target)  # TMA.py:124-129
             do_step = (i + 1) % accumulate_steps == 0 or (i + 1) == len(train_dataloader)
             rel = []
+            fused_row = None
             for inner_loop in range(innerLoop):
-                pix = self._images(pixel_values, patch, geometry, colorjitter)
+                # without gradient accumulation the step ends with ONE launch: K2's final sum + the optimiser (AdamW or PGD sign step) + clamp
+                sink = self.fused_update_sink(optimizer) if (accumulate_steps == 1 and geometry) else None
+                pix = self._images(pixel_values, patch, geometry, colorjitter, grad_sink=sink)
                 total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, newlabels, ops.LOSS_CE, scale=1.0 / accumulate_steps)
                 total.backward()
-                if do_step:
+                if sink is not None and "partials" in sink:
+                    self.fused_update(sink, patch, optimizer, scalars)
+                    fused_row = inner_loop
+                    optimizer.zero_grad()
+                elif do_step:
                     stats = optimizer.step()
                     scal[inner_loop, 8:10] = stats
                     optimizer.zero_grad()
@@ -92,6 +100,8 @@ class OpenVLAAttacker(AttackBase):
                 rel.append(pred)
             if scheduler is not None and do_step:
                 scheduler.step()
+            if fused_row is not None:
+                scal[fused_row, 8:10] = optimizer.last_stats
             host = scal[:innerLoop].cpu().numpy()
             inner_avg_loss = float(host[:, 0].mean())
             inner_rel = 0.0

@@ -31,13 +31,19 @@ class OpenVLAAttacker(AttackBase):
 
     # ------------------------------------------------------------------------------------------
     def inner_step(self, patch, optimizer, pixel_values, input_ids, attention_mask, labels, geometry, scalars_out, k):
-        """One iteration of the hot inner loop (UADA.py:133-159)."""
-        pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std, geometry=geometry)
+        """One iteration of the hot inner loop (UADA.py:133-159). With K2' (a model that exposes its patch-embed weights) the step ends with ONE
+        launch that adds K2''s partial tiles and applies AdamW + clamp; the logged gradient statistics are then folded once per outer iteration."""
+        sink = self.fused_update_sink(optimizer)
+        pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std, geometry=geometry, **({"grad_sink": sink} if sink is not None else {}))
         total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, self.loss_mode, w=self.mse_weight)
         total.backward()
-        stats = optimizer.step()  # K4: AdamW + clamp(0,1); patch.data updated in place
         scalars_out[k, :8] = scalars
-        scalars_out[k, 8:10] = stats
+        if sink is not None and "partials" in sink:
+            self.fused_update(sink, patch, optimizer, scalars)  # K2's final sum + K4 (AdamW + clamp(0,1)) in one launch
+            self._stats_row = k
+        else:
+            scalars_out[k, 8:10] = optimizer.step()  # K4: AdamW + clamp(0,1); patch.data updated in place
+            self._stats_row = None
         optimizer.zero_grad()
         return pred, pix
 
@@ -75,6 +81,8 @@ class OpenVLAAttacker(AttackBase):
             if scheduler is not None and ((i + 1) % accumulate_steps == 0 or (i + 1) == len(train_dataloader)):
                 scheduler.step()
 
+            if getattr(self, "_stats_row", None) is not None:  # fused update: the last step's {sum|g|, mean g} from its block sums
+                scal[self._stats_row, 8:10] = optimizer.last_stats
             # one read-back per outer iteration (the reference syncs 4-5 times per inner step)
             host = scal[:innerLoop].cpu().numpy()
             self.train_CE_loss.extend(host[:, 1].tolist())

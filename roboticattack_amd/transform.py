@@ -100,9 +100,34 @@ class RandomPatchTransform:
             theta[b] = m[:2].reshape(6)
         return xy, theta
 
+    _RING = 8  # staging slots: the host may run several steps ahead of the GPU
+
     def _to_dev(self, xy, theta):
+        """(x, y) and theta of one step -> device tensors through ONE pinned staging buffer and ONE async copy (the only host->device traffic
+        of a step: 32 B per image). A ring of slots, each guarded by an event, keeps a slot's host and device memory untouched until the
+        copy that read it has completed and for the steps that may still hold its tensors."""
         self.last_params = (xy, theta)
-        return torch.from_numpy(xy).to(self.device, non_blocking=True), torch.from_numpy(theta).to(self.device, non_blocking=True)
+        if self.device.type != "cuda":
+            return torch.from_numpy(xy).to(self.device), torch.from_numpy(theta).to(self.device)
+        B = int(xy.shape[0])
+        ring = getattr(self, "_ring", None)
+        if ring is None or ring["B"] != B:
+            ring = self._ring = {"B": B, "i": 0, "host": [torch.empty(8 * B, dtype=torch.int32).pin_memory() for _ in range(self._RING)],
+                                 "dev": [torch.empty(8 * B, dtype=torch.int32, device=self.device) for _ in range(self._RING)],
+                                 "ev": [None] * self._RING}
+        k = ring["i"]
+        ring["i"] = (k + 1) % self._RING
+        if ring["ev"][k] is not None:
+            ring["ev"][k].synchronize()  # the copy that last read this slot is done (it was enqueued _RING steps ago)
+        h, d = ring["host"][k], ring["dev"][k]
+        hn = h.numpy()
+        hn[: 2 * B] = xy.reshape(-1)
+        hn[2 * B :].view(np.float32)[:] = theta.reshape(-1)
+        d.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["ev"][k] = ev
+        return d[: 2 * B].view(B, 2), d[2 * B :].view(torch.float32).view(B, 6)
 
     # ---- the operators ----
     def apply_random_patch_batch(self, images, patch, mean, std, geometry, colorjitter=False, out_dtype=torch.bfloat16, grad_sink=None):

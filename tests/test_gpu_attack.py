@@ -690,3 +690,70 @@ def test_fused_epilogue_step_equals_separate_launches(monkeypatch):
         # the update applied inside the epilogue: same bits in the patch (and so in every later step), the logged statistics to fp32 rounding
         assert torch.equal(p1, p3) and torch.equal(s1, s3) and torch.equal(b1, b3) and torch.allclose(st1, st3, rtol=1e-6, atol=0)
     assert float((runs[0][-1][0] - runs[0][0][0]).abs().max()) > 0 and bool(torch.isfinite(runs[0][-1][1]).all())
+
+
+@pytest.mark.parametrize("which,opt", [("uada", "adamW"), ("tma", "adamW"), ("tma", "pgd")])
+def test_single_gpu_loops_fused_update_equals_separate_launches(tmp_path, monkeypatch, which, opt):
+    """The single-GPU UADA / TMA loops on a model that exposes its patch-embed weights end every step with ONE launch (K2''s final sum + the
+    optimiser + clamp, vaa_step_epilogue_update in pass-through form): the patch after every inner step, the logged losses and the saved
+    `last/patch.pt` are BITWISE those of the run through patch.grad + optimizer.step() (VAA_FUSED_EPILOGUE=0)."""
+    import types
+
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+
+    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, False, True), siglip=VitCfg(192, 3, 2, 384, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=9)
+    if which == "uada":
+        from roboticattack_amd.attack.uada import OpenVLAAttacker
+    else:
+        from roboticattack_amd.attack.tma import OpenVLAAttacker
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VAA_FUSED_EPILOGUE", fused)
+        out = tmp_path / f"{which}_{opt}_{fused}"
+        out.mkdir()
+        att = OpenVLAAttacker(m, None, str(out), optimizer=opt, resize_patch=False)
+        att.val_batches = 1
+        snaps = []
+        from roboticattack_amd import optim
+
+        orig_args, orig_step = optim.PatchOptimizer.fused_update_args, optim.PatchOptimizer.step
+        hits = {"fused": 0, "step": 0}
+
+        def fa(self):
+            hits["fused"] += 1
+            return orig_args(self)
+
+        def st(self, *a, **k):
+            hits["step"] += 1
+            return orig_step(self, *a, **k)
+
+        monkeypatch.setattr(optim.PatchOptimizer, "fused_update_args", fa)
+        monkeypatch.setattr(optim.PatchOptimizer, "step", st)
+        if which == "uada":
+            orig = att.inner_step
+
+            def rec(patch, *a, **k):
+                r = orig(patch, *a, **k)
+                snaps.append(patch.detach().cpu().numpy().copy())
+                return r
+
+            att.inner_step = rec
+        _seed()
+        train, val = _Fresh([11, 12, 13], 3), _Fresh([21], 1)
+        kw = dict(num_iter=3, patch_size=[3, 50, 50], accumulate_steps=1, maskidx=[0, 1], warmup=1, filterGripTrainTo1=False, geometry=True,
+                  innerLoop=2, args=types.SimpleNamespace(wandb_project="false"))
+        if which == "uada":
+            att.patchattack_unconstrained(train, val, target_action=np.zeros(7), lr=0.02, **kw)
+            logs = (list(att.train_CE_loss), list(att.train_MSE_distance_loss), att.last_train_log["TRAIN_patch_gradient"])
+        else:
+            att.patchattack_unconstrained(train, val, target_action=0.3 * np.ones(7), alpha=0.02, **kw)
+            logs = (list(att.train_CE_loss), att.last_train_log["TRAIN_patch_gradient"])
+        monkeypatch.undo()
+        assert (hits["fused"] > 0 and hits["step"] == 0) if fused == "1" else (hits["fused"] == 0 and hits["step"] > 0), hits
+        runs.append((snaps, torch.load(os.path.join(str(out), "last", "patch.pt")).numpy(), logs))
+    (s1, p1, l1), (s0, p0, l0) = runs
+    assert np.array_equal(p1, p0) and len(s1) == len(s0) and all(np.array_equal(a, b) for a, b in zip(s1, s0))
+    assert l1[0] == l0[0] and np.allclose(np.asarray(l1[-1], np.float64), np.asarray(l0[-1], np.float64), rtol=1e-5, atol=1e-12)
+    assert float(np.abs(p1 - 0.5).max()) <= 0.5 + 1e-6
