@@ -119,7 +119,8 @@ int vaa_patch_apply_fwd_tiles(const uint8_t* img_u8, const float* patch, const i
  *   patch, xy, theta, geometry, mask_mode: as given to K1 for the same step
  *   keep_bits dev: K1's mask output, or NULL to recompute the mask from `patch`
  *   std6     host [6]
- *   gpatch   dev  [3,ph,pw] float32, overwritten with dL/d patch (sum over the B images)
+ *   gpatch   dev  [3,ph,pw] float32, overwritten with dL/d patch (sum over the B images); NULL leaves the final fixed-order sum to
+ *             vaa_step_epilogue[_update]: the vaa_patch_grad_partials(B) partial tiles [parts][3*ph*pw] f32 then sit at the start of ws
  *   ws       dev  scratch of at least vaa_patch_grad_ws_bytes(B,ph,pw) bytes (contents undefined on entry and exit)
  * Numerics: every bilinear contribution fl(G*w) is accumulated as an integer (quantum 2^-30 of the largest |G| a workgroup meets), the
  * partial tiles are added in a fixed order: the same arguments give the same bits, for every patch size up to 224x224 (no global or

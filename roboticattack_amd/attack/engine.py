@@ -138,11 +138,11 @@ class AttackBase:
     # ---- single-GPU loops: K2's final sum + K4 as one launch after the backward ----
     def fused_update_sink(self, optimizer):
         """A gradient sink ({}) for `apply_random_patch_batch(grad_sink=...)` when the step can end with ONE launch that adds K2''s partial tiles
-        and applies the optimiser to every gradient element as it is produced (`fused_update`), else None: needs K2' (a model that exposes its
-        patch-embed weights), one patch per batch and no L1 clip (UPA's clip needs the whole gradient's norm first)."""
+        and applies the optimiser to every gradient element as it is produced (`fused_update`), else None: needs one patch per batch and no
+        L1 clip (UPA's clip needs the whole gradient's norm first). Works behind both boundaries: K2' (a model that exposes its patch-embed
+        weights) and K2 on a black-box model's pixel gradient."""
         t = self.randomPatchTransform
-        ok = (os.environ.get("VAA_FUSED_EPILOGUE", "1") != "0" and self.use_rows and t.embed_with is not None and not t.resize_patch
-              and not optimizer.l1_clip)
+        ok = os.environ.get("VAA_FUSED_EPILOGUE", "1") != "0" and not t.resize_patch and not optimizer.l1_clip
         return {} if ok else None
 
     def fused_update(self, sink, patch, optimizer, scalars):

@@ -631,7 +631,7 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
             return check_launch("vaa_patch_grad_gather(memset)");
         return VAA_OK;
     }
-    if (!gout_bf16 || !xy || !std6 || !gpatch || (geometry && !theta) || (!keep_bits && !patch)) {
+    if (!gout_bf16 || !xy || !std6 || (geometry && !theta) || (!keep_bits && !patch)) {  // gpatch == NULL: the final sum is left to vaa_step_epilogue
         set_error("vaa_patch_grad_gather: null pointer argument");
         return VAA_E_INVALID;
     }

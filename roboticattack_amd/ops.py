@@ -156,8 +156,9 @@ def patch_apply_fwd_tiles(img_u8, patch, xy, theta, geometry: bool, mask_mode: i
     return out0, out1, keep_t, flags
 
 
-def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None):
-    """K2. gout_bf16 [B,6,224,224] bf16 -> dL/d patch [3,ph,pw] f32 (sum over the batch)."""
+def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None, defer_reduce: bool = False):
+    """K2. gout_bf16 [B,6,224,224] bf16 -> dL/d patch [3,ph,pw] f32 (sum over the batch). defer_reduce=True returns the partial tiles
+    [parts, 3*ph*pw] (a view of the workspace) for ops.step_epilogue to add."""
     B = gout_bf16.shape[0]
     _need(gout_bf16, torch.bfloat16, "gout_bf16", (B, 6, IMG, IMG))
     _need(patch, torch.float32, "patch")
@@ -170,14 +171,17 @@ def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, ma
     L = _lib.lib()
     nbytes = L.vaa_patch_grad_ws_bytes(B, ph, pw)
     ws = _workspace(patch.device, nbytes)
-    gpatch = torch.empty_like(patch)
+    gpatch = None if defer_reduce else torch.empty_like(patch)
     std_c = _STD if std6 is None else _lib.f32x(std6)
     with _timed("K2_patch_grad_gather", B=B, ph=ph, pw=pw):
         rc = L.vaa_patch_grad_gather(
             gout_bf16.data_ptr(), patch.data_ptr(), xy.data_ptr(), theta.data_ptr() if geometry else None,
             keep_bits.data_ptr() if keep_bits is not None else None, B, ph, pw, int(bool(geometry)), int(mask_mode), std_c,
-            gpatch.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+            gpatch.data_ptr() if gpatch is not None else None, ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "vaa_patch_grad_gather")
+    if defer_reduce:
+        parts, n = L.vaa_patch_grad_partials(B), 3 * ph * pw
+        return ws[: parts * n * 4].view(torch.float32).view(parts, n)
     return gpatch
 
 
@@ -318,19 +322,23 @@ class PatchApply(torch.autograd.Function):
     """Differentiable (w.r.t. `patch`) K1: PyTorch-ROCm autograd hands the model's bf16 pixel gradient to K2."""
 
     @staticmethod
-    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode, mean6=None, std6=None):
+    def forward(ctx, patch, img_u8, xy, theta, geometry, mask_mode, mean6=None, std6=None, sink=None):
+        """sink (dict, optional): as in PatchApplyEmbed — the backward leaves K2's partial tiles in sink["partials"] and no patch gradient."""
         p = patch.detach().contiguous()
         out, keep = patch_apply_fwd(img_u8, p, xy, theta, geometry, mask_mode, want_keep=True, mean6=mean6, std6=std6)
         ctx.save_for_backward(p, xy, theta if geometry else xy, keep)
-        ctx.geometry, ctx.mask_mode, ctx.std6 = bool(geometry), int(mask_mode), std6
+        ctx.geometry, ctx.mask_mode, ctx.std6, ctx.sink = bool(geometry), int(mask_mode), std6, sink
         return out
 
     @staticmethod
     def backward(ctx, gout):
         patch, xy, theta, keep = ctx.saved_tensors
         g = patch_grad_gather(gout.to(torch.bfloat16).contiguous(), patch, xy, theta if ctx.geometry else None, keep,
-                              ctx.geometry, ctx.mask_mode, std6=ctx.std6)
-        return g, None, None, None, None, None, None, None
+                              ctx.geometry, ctx.mask_mode, std6=ctx.std6, defer_reduce=ctx.sink is not None)
+        if ctx.sink is not None:
+            ctx.sink["partials"] = g
+            g = None
+        return g, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------

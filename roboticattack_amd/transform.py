@@ -133,8 +133,8 @@ class RandomPatchTransform:
     def apply_random_patch_batch(self, images, patch, mean, std, geometry, colorjitter=False, out_dtype=torch.bfloat16, grad_sink=None):
         """Paste `patch` at a random position of every image, optionally warp it by a random rotation+shear, composite
         where the warped canvas is >= -20, normalise twice and stack to 6 channels (:104-136). Differentiable w.r.t. patch.
-        grad_sink (dict, only with `embed_with` and one patch for the batch): the backward leaves K2''s partial tiles in
-        grad_sink["partials"] instead of a patch gradient — the data-parallel step folds them with ops.step_epilogue."""
+        grad_sink (dict, one patch for the batch): the backward leaves K2's (or K2''s) partial tiles in grad_sink["partials"] instead of a
+        patch gradient — the caller adds them with ops.step_epilogue (into the DDP message and / or straight through the optimiser)."""
         mean6, std6 = _six(mean, std)
         img = self.stage_images(images)
         B = img.shape[0]
@@ -147,9 +147,7 @@ class RandomPatchTransform:
         emb = self._embed_params(patch, out_dtype)
         if emb is not None:
             return ops.PatchEmbeds(ops.PatchApplyEmbed.apply(patch, img, xy, theta, bool(geometry), ops.MASK_LT_M20, mean6, std6, *emb, grad_sink))
-        if grad_sink is not None:
-            raise ValueError("grad_sink needs a model that exposes its patch-embed weights (embed_with)")
-        out = ops.PatchApply.apply(patch, img, xy, theta, bool(geometry), ops.MASK_LT_M20, mean6, std6)
+        out = ops.PatchApply.apply(patch, img, xy, theta, bool(geometry), ops.MASK_LT_M20, mean6, std6, grad_sink)
         return out if out_dtype == torch.bfloat16 else out.to(out_dtype)
 
     def _embed_params(self, patch, out_dtype):
