@@ -248,8 +248,13 @@ def rank_shapes(iters=20, device="cuda:0"):
     wp0 = ops.pack_embed_weights((torch.randn(588, 1024, device=dev) * 0.05).to(torch.bfloat16))
     wp1 = ops.pack_embed_weights((torch.randn(588, 1152, device=dev) * 0.05).to(torch.bfloat16))
     ntile = int(sum(((int(h) + 13) // 14 + 1) * ((int(w) + 13) // 14 + 1) for h, w in sizes))  # ~tiles under the (warped) patches
+    _, _, keep_t, tflags = ops.patch_apply_fwd_tiles(img, packed, xy, th, True, pdesc=pdesc, max_hw=max_hw)
     c5 = {}
     for name, fn, nb in (
+        ("K1t_patch_apply_fwd_tiles_multi", lambda: ops.patch_apply_fwd_tiles(img, packed, xy, th, True, pdesc=pdesc, max_hw=max_hw), B * (150528 + 602112) + 4 * total),
+        ("K2et_patch_embed_grad_gather_multi_tiles",
+         lambda: ops.patch_embed_grad_gather_multi_tiles(dy0, dy1, wp0, wp1, packed, pdesc, max_hw, xy, th, keep_t, tflags, True),
+         ntile * (1024 + 1152) * 2 + 588 * (1024 + 1152) * 2 + 4 * total),
         ("K2e_patch_embed_grad_gather_multi",
          lambda: ops.patch_embed_grad_gather_multi(dy0, dy1, wp0, wp1, packed, pdesc, max_hw, xy, th, keep, True),
          ntile * (1024 + 1152) * 2 + 588 * (1024 + 1152) * 2 + 4 * total),

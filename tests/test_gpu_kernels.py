@@ -1337,3 +1337,53 @@ def test_patch_embed_grad_gather_multi_tiles_equals_planar_mask_form(ops):
     ref = ops.patch_embed_grad_gather_multi(dy[0], dy[1], wp[0], wp[1], packed, pdesc, max_hw, xy, th, keep, True)
     got = ops.patch_embed_grad_gather_multi_tiles(dy[0], dy[1], wp[0], wp[1], packed, pdesc, max_hw, xy, th, keep_t, flags, True)
     assert torch.equal(ref, got) and float(ref.abs().max()) > 0
+
+
+def test_round3_entry_points_error_paths_and_empty_batches(ops):
+    """Argument checking of the round-3 entry points through the C-ABI: null pointers, bad sizes, the un-warped mask rule with a warp,
+    workspace too small, modes the split K3 form does not cover, empty batches (no-ops), and the per-dispatch timer's bookkeeping."""
+    import ctypes as C
+
+    from roboticattack_amd import _lib
+
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    d = torch.zeros(1 << 16, dtype=torch.float32, device=DEV)
+    p = d.data_ptr()
+    f6 = _lib.f32x([0.5] * 6)
+    # K1 tile-major
+    assert L.vaa_patch_apply_fwd_tiles(p, p, None, p, p, 0, 50, 50, 1, 0, f6, f6, p, p, p, p, st) == 0                      # empty batch
+    assert L.vaa_patch_apply_fwd_tiles(None, p, None, p, p, 2, 50, 50, 1, 0, f6, f6, p, p, p, p, st) == -1                   # null image
+    assert L.vaa_patch_apply_fwd_tiles(p, p, None, p, None, 2, 50, 50, 1, 0, f6, f6, p, p, p, p, st) == -1                   # geometry without theta
+    assert L.vaa_patch_apply_fwd_tiles(p, p, None, p, p, 2, 225, 50, 1, 0, f6, f6, p, p, p, p, st) == -2                     # patch larger than the frame
+    assert L.vaa_patch_apply_fwd_tiles(p, p, None, p, p, 2, 50, 50, 1, 1, f6, f6, p, p, p, p, st) == -2 and b"geometry=0" in L.vaa_last_error()
+    # K2' tile-major: keep words without flags, widths, workspace
+    a = (p, 64, p, 64, p, p, p, p, p)
+    assert L.vaa_patch_embed_grad_gather_tiles(*a, p, None, 2, 50, 50, 1, 0, f6, 1, p, p, 1 << 30, st) == -1
+    assert L.vaa_patch_embed_grad_gather_tiles(p, 96, p, 64, p, p, p, p, p, p, p, 2, 50, 50, 1, 0, f6, 1, p, p, 1 << 30, st) == -1
+    assert L.vaa_patch_embed_grad_gather_tiles(*a, p, p, 2, 50, 50, 1, 0, f6, 1, p, p, 1024, st) == -4 and b"workspace" in L.vaa_last_error()
+    assert L.vaa_patch_grad_partials(0) == 0 and L.vaa_patch_grad_partials(64) == 64 and L.vaa_patch_grad_partials(5000) == 512
+    # split K3 form + epilogue
+    prm = _lib.f32x([5.0, 0.8, 0.2, 1.0])
+    assert L.vaa_loss_rows_stats(p, 1, p, 8, 4, 10, 32064, ops.LOSS_UPA, prm, p, 1, p, 1 << 20, st) == -1 and b"VAA_LOSS_UADA_DDP" in L.vaa_last_error()
+    assert L.vaa_loss_rows_stats(p, 1, p, 8, 4, 10, 32064, ops.LOSS_UADA_DDP, prm, p, 1, p, 16, st) == -4
+    assert L.vaa_loss_rows_stats(p, 1, p, 100, 4, 10, 32064, ops.LOSS_UADA_DDP, prm, p, 1, p, 1 << 20, st) == -1             # R > B*(L-1)
+    assert L.vaa_step_epilogue(None, 4, 7500, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, st) == -1
+    assert L.vaa_step_epilogue(p, 0, 7500, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, st) == -1
+    assert L.vaa_step_epilogue_update(p, 4, 100, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, None, p, p, 0, 1e-3, 0.9, 0.999, 1e-6, 1, None, st) == -1
+    assert L.vaa_step_epilogue_update(p, 4, 100, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, p, p, p, 0, 1e-3, 0.9, 0.999, 1e-6, 0, None, st) == -1  # AdamW step 0
+    assert L.vaa_step_epilogue_update(p, 4, 100, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, p, p, p, 7, 1e-3, 0.9, 0.999, 1e-6, 1, None, st) == -1  # unknown mode
+    # per-dispatch timer: records exactly the launches made while armed, capacity respected, names are the kernels'
+    patch = torch.rand(3, 8, 8, device=DEV)
+    g = torch.rand_like(patch)
+    m, v = torch.zeros_like(patch), torch.zeros_like(patch)
+    ops.prof_start(2)
+    for t in range(1, 4):
+        ops.patch_update(patch, g, m, v, ops.OPT_ADAMW_HF, 1e-3, t)
+    recs = ops.prof_collect()
+    assert len(recs) == 2 and all("patch_update_kernel" in n and 0.5 < us < 500 for n, us in recs)
+    ops.patch_update(patch, g, m, v, ops.OPT_ADAMW_HF, 1e-3, 4)   # disarmed: nothing recorded
+    assert L.vaa_prof_stop() == 2 and L.vaa_prof_get(5, None, C.byref(C.c_float())) == -1 and L.vaa_prof_start(-1) == -1
+    ops.prof_start(0)
+    assert ops.prof_collect() == []
+    torch.cuda.synchronize()
