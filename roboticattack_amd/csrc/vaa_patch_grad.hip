@@ -514,6 +514,15 @@ int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts
     return check_launch(who);
 }
 
+// gpatch[e] = sum over the channel planes the fused tile kernel left (plane_reduce_block, vaa_common.h), fixed order
+__global__ __launch_bounds__(256) void patch_grad_reduce_planes_kernel(const float* __restrict__ planes, float* __restrict__ gpatch, int plane, int nparts,
+                                                                        int nch) {
+    __shared__ double sl[16][16][4];
+    int oe;
+    float ov;
+    (void)plane_reduce_block(planes, gpatch, plane, nparts, nch, blockIdx.x, sl, oe, ov);
+}
+
 struct GradSched {
     int gx, bands;
 };
@@ -938,10 +947,25 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
 constexpr int kEmbedFastThreads = VAA_EMBED_WAVES * 64;
 constexpr int kEmbedStageMax = ((64 * 1160 / 8 + kEmbedFastThreads - 1) / kEmbedFastThreads + 1) / 2 * 2;  // 16-byte chunks a thread stages per tower (even)
 
+// FUSE (with SPLIT): the gather runs HERE, from the registers the k-loop leaves — no tile-gradient buffer, no second launch. The gather is linear
+// in the two towers, so a workgroup scatters its own tower's scaled contribution of its own columns: kept bit from K1's keep words (staged in
+// LDS), the exact sample position recomputed per (pixel, channel), fl(G * w) rounded to the integer quantum of the workgroup's exponent and
+// added into a patch-shaped int64 accumulator in LDS (aliases the staging buffer once the k-loop is over). A column range of <= 19 blocks
+// covers at most two channels: the accumulator and the output are two channel PLANES per workgroup,
+//   planes[((b * 2 + tower) * nch + ch) * 2 + slot][ph * pw],  slot = channel - cbase(ch),  cbase(ch) = first column of the range / 196,
+// which vaa_step_epilogue (part_layout = nch) / patch_grad_reduce_planes_kernel add per channel in a fixed order.
+struct FuseArgs {
+    const int32_t* xy;
+    const float* theta;
+    const uint16_t* keep_t;  // [B,3,256,14]
+    float* planes;
+    int ph, pw, geometry;
+};
+
 // SPLIT: one tower per workgroup (blockIdx.z), its tile gradients into geff / geff2 (the gather adds the two); else both towers, summed.
 // NB: most column blocks a wave owns (ceil(ceil(37 / nch) / 8)).
-template <bool SPLIT, int NB>
-__global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kernel(EmbedArgs a, int nch) {
+template <bool SPLIT, int NB, bool FUSE = false>
+__global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kernel(EmbedArgs a, int nch, FuseArgs fz) {
     extern __shared__ __align__(16) unsigned char embed_smem[];
     uint16_t* sA = reinterpret_cast<uint16_t*>(embed_smem);
     __shared__ int16_t tiles[256];
@@ -967,6 +991,15 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     __syncthreads();
 
     K2_STAMP(0)
+    if constexpr (FUSE) {
+        if (M == 0 || M > 64) {  // nothing kept in this image: zero planes; a tile list beyond one row group cannot be fused (the host's bound keeps it away): NaN, never silent
+            const int plane = fz.ph * fz.pw;
+            float* outp = fz.planes + ((((size_t)b * 2 + (int)blockIdx.z) * nch + ch) * 2) * plane;
+            const float fill = M == 0 ? 0.0f : __uint_as_float(0x7fc00000u);
+            for (int e = tid; e < plane * 2; e += kEmbedFastThreads) outp[e] = fill;
+            return;
+        }
+    }
     // this wave's column blocks: [nb0, nb0 + nbw) of the workgroup's range [ch * per, min(37, (ch + 1) * per))
     const int per = (kNBlocks + nch - 1) / nch;
     const int wg_lo = ch * per, wg_n = max(0, min(kNBlocks, wg_lo + per) - wg_lo);
@@ -1067,6 +1100,107 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                     }
             K2_STAMP(2 + 2 * tower)
         }
+        if constexpr (FUSE) {
+            // ================= the gather, from registers (mg == 0: the host only fuses while a tile list fits one row group) =================
+            __shared__ float bgrid[VAA_IMG];
+            __shared__ uint32_t fmax_bits;
+            __shared__ int fbad;
+            const int ph = fz.ph, pw = fz.pw, plane = ph * pw;
+            const int cbase = (wg_lo * 16) / (kTilePx * kTilePx);  // first channel of this workgroup's column range
+            __syncthreads();                                        // every wave is done with the staged rows: the LDS is free
+            unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(embed_smem);       // [plane][2 slots], channel slots interleaved
+            uint16_t* keepw = reinterpret_cast<uint16_t*>(embed_smem + (size_t)plane * 2 * 8);    // [3][M][14] keep words of the listed tiles
+            for (int e = tid; e < plane * 2; e += kEmbedFastThreads) acc64[e] = 0ull;
+            for (int e = tid; e < 3 * M * kTilePx; e += kEmbedFastThreads) {
+                const int c3 = e / (M * kTilePx), rem = e - c3 * (M * kTilePx), sl = rem / kTilePx, y = rem - sl * kTilePx;
+                keepw[e] = fz.keep_t[(((size_t)b * 3 + c3) * 256 + tiles[sl]) * kTilePx + y];
+            }
+            if (tid < VAA_IMG) bgrid[tid] = base_coord(tid);
+            if (tid == 0) { fmax_bits = 0u; fbad = 0; }
+            __syncthreads();
+            const int px = fz.xy[2 * b], py = fz.xy[2 * b + 1];
+            float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+            if (fz.geometry) {
+#pragma unroll
+                for (int z = 0; z < 6; ++z) th[z] = fz.theta[6 * b + z];
+            }
+            // ---- pass A: kept bits and the largest kept |G| of the workgroup (fixes the accumulator's exponent) ----
+            uint32_t keptm[NB];  // bit q*4 + r
+            float lmax = 0.0f;
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                keptm[j] = 0u;
+                if (!nv[j]) continue;
+                const int c3 = n[j] / (kTilePx * kTilePx), rem = n[j] - c3 * (kTilePx * kTilePx), y = rem / kTilePx, x = rem - y * kTilePx;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int sl = q * 16 + g * 4 + r;
+                        if (sl >= M) continue;
+                        if ((keepw[(c3 * M + sl) * kTilePx + y] >> x) & 1u) {
+                            const float G = res[j][q][r];
+                            if ((__float_as_uint(G) & 0x7fffffffu) >= 0x7f800000u) bad = true;
+                            else { keptm[j] |= 1u << (q * 4 + r); lmax = fmaxf(lmax, fabsf(G)); }
+                        }
+                    }
+            }
+            lmax = wave_max(lmax);
+            if (lane == 0 && lmax > 0.0f) atomicMax(&fmax_bits, __float_as_uint(lmax));
+            if (bad) fbad = 1;
+            __syncthreads();
+            const uint32_t mbits = fmax_bits;
+            const int E = max((int)(mbits >> 23) - 127, -96);
+            const float gscale = __uint_as_float((uint32_t)(kCBits - 1 - E + 127) << 23);
+            // ---- pass B: exact sample position per kept (pixel, channel), four integer contributions each ----
+            if (mbits != 0u) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (keptm[j] == 0u) continue;
+                    const int c3 = n[j] / (kTilePx * kTilePx), rem = n[j] - c3 * (kTilePx * kTilePx), y = rem / kTilePx, x = rem - y * kTilePx;
+                    const int slot = c3 - cbase;  // 0 or 1
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (!((keptm[j] >> (q * 4 + r)) & 1u)) continue;
+                            const int tl = tiles[q * 16 + g * 4 + r];
+                            const int i = (tl >> 4) * kTilePx + y, jx = (tl & 15) * kTilePx + x;
+                            int x0 = jx, y0 = i;
+                            float wf = 0.0f, nf = 0.0f;
+                            if (fz.geometry) sample_pos_frac(bgrid[jx], bgrid[i], th, x0, y0, wf, nf);
+                            const int u0 = x0 - px, v0 = y0 - py;
+                            const bool uin0 = (unsigned)u0 < (unsigned)pw, uin1 = ((unsigned)(u0 + 1) < (unsigned)pw) && (x0 + 1 < VAA_IMG);
+                            const bool vin0 = (unsigned)v0 < (unsigned)ph, vin1 = ((unsigned)(v0 + 1) < (unsigned)ph) && (y0 + 1 < VAA_IMG);
+                            if (!((uin0 || uin1) && (vin0 || vin1))) continue;
+                            const float ee = 1.0f - wf, so = 1.0f - nf;
+                            const float wx0 = uin0 ? ee : 0.0f, wx1 = uin1 ? wf : 0.0f, wy0 = vin0 ? so : 0.0f, wy1 = vin1 ? nf : 0.0f;
+                            const float wt[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};  // the fp32 weights grid_sample's backward uses
+                            const int u0c = min(max(u0, 0), pw - 1), u1c = min(max(u0 + 1, 0), pw - 1);
+                            const int v0c = min(max(v0, 0), ph - 1) * pw, v1c = min(max(v0 + 1, 0), ph - 1) * pw;
+                            const int offs[4] = {v0c + u0c, v0c + u1c, v1c + u0c, v1c + u1c};
+                            const float Gs = res[j][q][r] * gscale;
+#pragma unroll
+                            for (int cn = 0; cn < 4; ++cn) {
+                                const int ci = round_half_up(Gs * wt[cn]);
+                                if (ci != 0) atomicAdd(acc64 + offs[cn] * 2 + slot, (unsigned long long)(long long)ci);
+                            }
+                        }
+                }
+            }
+            __syncthreads();
+            // ---- drain: the two channel planes of this workgroup ----
+            const double quantum = (mbits == 0u) ? 0.0 : __longlong_as_double((long long)(E + 1 - kCBits + 1023) << 52);
+            const bool poison = fbad != 0;
+            float* outp = fz.planes + ((((size_t)b * 2 + t_lo) * nch + ch) * 2) * plane;
+            for (int e = tid; e < plane * 2; e += kEmbedFastThreads) {
+                const int slot = e / plane, t = e - slot * plane;
+                const unsigned long long raw = acc64[t * 2 + slot];
+                const double d = __builtin_fma((double)(int)(raw >> 32), 4294967296.0, (double)(unsigned)raw);
+                outp[e] = poison ? __uint_as_float(0x7fc00000u) : (float)(d * quantum);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (!nv[j]) continue;
@@ -1081,6 +1215,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                         else a.geff[el] = res[j][q][r];
                     }
                 }
+        }
         }
         K2_STAMP(5)
     }
@@ -1124,10 +1259,10 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
             return VAA_E_LAUNCH;
         }
         const dim3 grid((unsigned)Bpad * nch, ny, e.tower_split ? 2 : 1), blk(kEmbedFastThreads);
-        if (!e.tower_split) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<false, 2>), grid, blk, lds_fast, st, e, nch);
-        else if (nbmax == 1) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 1>), grid, blk, lds_fast, st, e, nch);
-        else if (nbmax == 2) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 2>), grid, blk, lds_fast, st, e, nch);
-        else VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 3>), grid, blk, lds_fast, st, e, nch);
+        if (!e.tower_split) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<false, 2>), grid, blk, lds_fast, st, e, nch, FuseArgs{});
+        else if (nbmax == 1) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 1>), grid, blk, lds_fast, st, e, nch, FuseArgs{});
+        else if (nbmax == 2) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 2>), grid, blk, lds_fast, st, e, nch, FuseArgs{});
+        else VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 3>), grid, blk, lds_fast, st, e, nch, FuseArgs{});
     } else {  // wide towers: fragments straight from global memory
         const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
         VAA_LAUNCH(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedThreads), 0, st, e, nch);
@@ -1259,6 +1394,81 @@ extern "C" size_t vaa_patch_embed_grad_multi_ws_bytes(int B) {
 }
 
 // K2' with one patch per image (resize_patch=True): the tile gradients do not depend on the patches, the gather runs in MULTI mode.
+namespace vaa {
+
+// workgroups per image and tower of the fused form (0: not applicable — the caller takes vaa_patch_embed_grad_gather_tiles)
+static int fused_nch(int B, int ph, int pw, int D0, int D1) {
+    const int Dmax = D0 > D1 ? D0 : D1;
+    const int tiles_bound = ((3 * ph / 2 + 13) / 14 + 2) * ((3 * pw / 2 + 13) / 14 + 2);
+    const long Bpad = (B + 7) / 8 * 8;
+    const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
+    const size_t lds_acc = (size_t)ph * pw * 2 * sizeof(long long) + 3 * 64 * kTilePx * sizeof(uint16_t) + 64;
+    if (B <= 0 || tiles_bound > 64 || Bpad > 64 || lds_fast > 150 * 1024 || lds_acc > 150 * 1024 ||
+        (size_t)64 * (Dmax / 8) > (size_t)kEmbedStageMax * kEmbedFastThreads)
+        return 0;
+    return Bpad <= 24 ? 5 : (Bpad <= 40 ? 3 : 2);
+}
+
+}  // namespace vaa
+
+extern "C" int vaa_patch_embed_grad_fused_layout(int B, int ph, int pw, int D0, int D1) { return vaa::fused_nch(B, ph, pw, D0, D1); }
+
+// K2' in ONE launch: tile GEMM + gather from its registers (embed_dgrad_tiles_lds_kernel<true, NB, true>). Output: the channel planes
+// [B*2][nch][2][ph*pw] f32 at the start of ws (nch = vaa_patch_embed_grad_fused_layout(...) > 0 required); gpatch != NULL adds them here
+// (second launch), NULL leaves that to vaa_step_epilogue(part_layout = nch).
+extern "C" int vaa_patch_embed_grad_fused(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
+                                          const int32_t* xy, const float* theta, const uint16_t* keep_tiles, const uint32_t* tile_flags, int B, int ph,
+                                          int pw, int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    using namespace vaa;
+    const char* who = "vaa_patch_embed_grad_fused";
+    hipStream_t st = (hipStream_t)stream;
+    if (!dy0 || !dy1 || !wt0 || !wt1 || !xy || !std6 || !keep_tiles || !tile_flags || (geometry && !theta)) {
+        set_error("%s: null pointer argument", who);
+        return VAA_E_INVALID;
+    }
+    if (B <= 0 || ph <= 0 || pw <= 0 || D0 <= 0 || D1 <= 0 || (D0 % 64) != 0 || (D1 % 64) != 0 ||
+        (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100) || (geometry && mask_mode == VAA_MASK_NE_M100)) {
+        set_error("%s: bad sizes/mode (B=%d ph=%d pw=%d D0=%d D1=%d mask_mode=%d)", who, B, ph, pw, D0, D1, mask_mode);
+        return VAA_E_INVALID;
+    }
+    const int nch = fused_nch(B, ph, pw, D0, D1);
+    if (nch == 0) {
+        set_error("%s: the fused form does not cover B=%d, patch %dx%d, towers %d/%d (vaa_patch_embed_grad_fused_layout == 0)", who, B, ph, pw, D0, D1);
+        return VAA_E_UNSUPPORTED;
+    }
+    const size_t plane = (size_t)ph * pw, need = (size_t)B * 2 * nch * 2 * plane * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        set_error("%s: workspace %zu B < required %zu B", who, ws_bytes, need);
+        return VAA_E_WORKSPACE;
+    }
+    EmbedArgs e = {};
+    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wt0; e.wt1 = wt1; e.keep = nullptr; e.flags = tile_flags; e.geff = nullptr; e.geff2 = nullptr;
+    e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0; e.tower_split = 1;
+    for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
+    FuseArgs fz;
+    fz.xy = xy; fz.theta = theta; fz.keep_t = keep_tiles; fz.planes = (float*)ws; fz.ph = ph; fz.pw = pw; fz.geometry = geometry ? 1 : 0;
+    const int Dmax = D0 > D1 ? D0 : D1;
+    const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
+    const size_t lds_acc = plane * 2 * sizeof(long long) + 3 * 64 * kTilePx * sizeof(uint16_t) + 64;
+    const size_t lds = lds_fast > lds_acc ? lds_fast : lds_acc;
+    const int nbmax = ((kNBlocks + nch - 1) / nch + VAA_EMBED_WAVES - 1) / VAA_EMBED_WAVES;
+    const void* fn = nbmax == 1 ? (const void*)embed_dgrad_tiles_lds_kernel<true, 1, true>
+                                : (nbmax == 2 ? (const void*)embed_dgrad_tiles_lds_kernel<true, 2, true> : (const void*)embed_dgrad_tiles_lds_kernel<true, 3, true>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute failed", who);
+        return VAA_E_LAUNCH;
+    }
+    const dim3 grid((unsigned)((B + 7) / 8 * 8) * nch, 1, 2), blk(kEmbedFastThreads);
+    if (nbmax == 1) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 1, true>), grid, blk, lds, st, e, nch, fz);
+    else if (nbmax == 2) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 2, true>), grid, blk, lds, st, e, nch, fz);
+    else VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 3, true>), grid, blk, lds, st, e, nch, fz);
+    int rc = check_launch(who);
+    if (rc != VAA_OK || !gpatch) return rc;
+    VAA_LAUNCH(patch_grad_reduce_planes_kernel, dim3((unsigned)((3 * plane + 63) / 64)), dim3(256), 0, st, (const float*)ws, gpatch, (int)plane, B * 2, nch);
+    return check_launch(who);
+}
+
 namespace vaa {
 
 // K2' with one patch per image (resize_patch=True): the tile gradients do not depend on the patches, the gather runs in MULTI mode.
