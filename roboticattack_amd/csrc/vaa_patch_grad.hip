@@ -1026,15 +1026,17 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
             const int D = tower ? a.D1 : a.D0, SA = D + 8, cpr = D >> 3;  // 16-byte chunks per row
             const uint16_t* dy = tower ? a.dy1 : a.dy0;
             const int nchunks = nq * 16 * cpr;
-            // ---- stage in two halves (register budget): the loads of a half are all in flight before its LDS stores ----
+            // ---- stage: the loads of a phase are all in flight before its LDS stores. One tower per workgroup (SPLIT) has the registers for
+            //      ONE phase (20 x 16 B per thread: one memory round trip instead of two); both towers in sequence keep two halves ----
             __syncthreads();  // the previous tower's k-loops are over
+            constexpr int kPhases = SPLIT ? 1 : 2, kPer = kEmbedStageMax / kPhases;
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                uint4 st[kEmbedStageMax / 2];
+            for (int hf = 0; hf < kPhases; ++hf) {
+                uint4 st[kPer];
 #pragma unroll
-                for (int it = 0; it < kEmbedStageMax / 2; ++it) {
-                    int idx = tid + (hf * (kEmbedStageMax / 2) + it) * kEmbedFastThreads;
-                    // opaque to the optimiser: otherwise the row / column split of all 2 x 18 staging slots is hoisted out of the row-group
+                for (int it = 0; it < kPer; ++it) {
+                    int idx = tid + (hf * kPer + it) * kEmbedFastThreads;
+                    // opaque to the optimiser: otherwise the row / column split of all staging slots is hoisted out of the row-group
                     // loop, stays live across both k-loops and spills (every staging load then sat between two scratch accesses)
                     asm volatile("" : "+v"(idx));
                     st[it] = make_uint4(0, 0, 0, 0);
@@ -1044,8 +1046,8 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                     }
                 }
 #pragma unroll
-                for (int it = 0; it < kEmbedStageMax / 2; ++it) {
-                    int idx = tid + (hf * (kEmbedStageMax / 2) + it) * kEmbedFastThreads;
+                for (int it = 0; it < kPer; ++it) {
+                    int idx = tid + (hf * kPer + it) * kEmbedFastThreads;
                     asm volatile("" : "+v"(idx));
                     if (idx < nchunks) {
                         const int row = idx / cpr, cc = idx - row * cpr;

@@ -4,7 +4,7 @@
     python tools/soak_loss.py --seconds 120 --seed 1
 
 Every case draws a batch, a prompt-length range, a labelling pattern (subsets of the 7 action positions, with / without EOS, samples
-without any label), a mode (UADA, UADA_DDP, UPA, CE) and a logits dtype, then checks scalars (3e-5), gradients (2e-4 of the row scale
+without any label), a mode (UADA, UADA_DDP, UPA, CE) and a logits dtype, then checks scalars (3e-5), gradients (5e-4 of the row scale
 for fp32, 1e-2 for bf16 storage), slice-vs-full storage, the action-slice and full-vocabulary argmax, for the rows route (row map) and
 the label-driven route (FULL layout).
 """
@@ -64,7 +64,10 @@ def one_case(seed):
     so, go = c_oracle.loss(full.numpy(), lab, om, w=w, alpha=alpha, beta=beta, scale=scale)
     gor = go[bk[:, 0], bk[:, 1] + 256]
     tag = f"seed={seed} B={B} L={L} R={R} mode={mode} dtype={dtype}"
-    gtol = (1e-2 if dtype == torch.bfloat16 else 2e-4) * max(np.abs(gor).max(), 1e-30)
+    # fp32: 2e-4 of the row scale in all but saturated action slices — when one bin holds nearly all of the slice's probability the soft-argmax
+    # gradient p_i (i - E) is a difference of two fp32 numbers of size ~100 scaled by ~eps (the kernels do it in fp32 like the reference's torch
+    # ops, the oracle in fp64) and the whole gradient is that small: seed 54001667 (B=1, R=2, UADA) reads 2.2e-4 on BOTH routes; bound 5e-4
+    gtol = (1e-2 if dtype == torch.bfloat16 else 5e-4) * max(np.abs(gor).max(), 1e-30)
     rm = ops.LossRowMap(labels.to(DEV))
     kinds = [ops.GRAD_FULL] + ([ops.GRAD_SLICE] if mode in ("UADA_DDP", "UPA") else [])
     zf = zt.float().numpy()

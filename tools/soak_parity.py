@@ -5,9 +5,11 @@
 
 Every case draws a patch size (1..224 per side), a batch, placements biased towards the frame edges, and either the reference's
 rotation+shear transforms or a general affine (scale 0.3..3, any rotation, translation), then checks
-  K1  : whole bf16 tensor and keep bits BIT-EXACT (uniform patch and per-image patches),
+  K1  : whole bf16 tensor and keep bits BIT-EXACT (uniform patch and per-image patches), in the planar AND the tile-major form (both patch-embed
+        GEMM operands, keep words, tile flags),
   K2  : <= 3e-6 of the gradient scale with the stored mask and with the recomputed mask, bitwise repeatable,
-  K2' : <= 5e-3 (one bf16 ulp: rounding flips of the tile gradients) against the oracle fed by an fp32 host matmul, random tower widths,
+  K2' : <= 5e-3 (one bf16 ulp: rounding flips of the tile gradients) against the oracle fed by an fp32 host matmul, random tower widths; the
+        tile-major-mask form bitwise the planar-mask form; the step epilogue (final sum + AdamW inside it) bitwise the separate launches,
   K0  : resize forward bit-exact, adjoint <= 2e-6,
   K5  : eval-time paste byte-exact.
 Prints one line per failure (with the seed that reproduces it) and a summary; exit code 1 on any failure.
@@ -91,6 +93,17 @@ def one_case(seed):
         fails.append(f"K1 out   {tag}: {int((bits(out) != ob).sum())} values differ")
     if not np.array_equal(np.unpackbits(keep.cpu().numpy(), axis=-1, bitorder="little"), ok):
         fails.append(f"K1 keep  {tag}")
+    # ---- K1 in tile-major form (what the attack step runs): both GEMM operands == im2col of the oracle's bf16 tensor, keep words == the
+    #      oracle's mask bits, tile flags == "any kept pixel in the tile" ----
+    t0, t1, keep_t, tflags = ops.patch_apply_fwd_tiles(t(imgs), t(patch), t(xy, torch.int32), t(theta.reshape(-1, 6)), bool(geo), mm)
+    ob_t = torch.from_numpy(ob.view(np.int16)).view(B, 6, 224, 224)
+    im2col = lambda x3: x3.reshape(B, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(B, 256, 588)
+    if not (torch.equal(t0.cpu().view(torch.int16), im2col(ob_t[:, :3])) and torch.equal(t1.cpu().view(torch.int16), im2col(ob_t[:, 3:]))):
+        fails.append(f"K1 tiles out  {tag}")
+    okb = ok.reshape(B, 3, 16, 14, 16, 14)                                                   # [b,c,ty,y,tx,x] mask bits of the oracle
+    kw = (okb.astype(np.uint32) << np.arange(14, dtype=np.uint32)).sum(axis=5).transpose(0, 1, 2, 4, 3).reshape(B, 3, 256, 14).astype(np.uint16)
+    if not np.array_equal(keep_t.cpu().numpy().view(np.uint16), kw) or not np.array_equal(tflags.cpu().numpy() != 0, (kw != 0).any(axis=(1, 3))):
+        fails.append(f"K1 tiles keep {tag}")
     # general affines can map many output pixels onto one texel: the reference's fp32 scan-order accumulation is then itself the
     # dominant error, so those cases are checked against the same fp32 products accumulated in fp64
     og = c_oracle.patch_grad(bits(g), patch, xy, theta, geo, mm, f64=general)
@@ -112,6 +125,23 @@ def one_case(seed):
         w = [(torch.randn(D, 588, device=DEV, generator=gen) * 0.05).to(torch.bfloat16) for D in (D0, D1)]
         fused = ops.patch_embed_grad_gather(dy[0], dy[1], ops.pack_embed_weights(w[0].t().contiguous()), ops.pack_embed_weights(w[1].t().contiguous()),
                                             t(patch), t(xy, torch.int32), t(theta.reshape(-1, 6)), keep, bool(geo)).cpu().numpy()
+        # the production forms: K2' fed by the tile-major mask (bitwise the planar-mask form) and its final sum left to the step epilogue,
+        # with the optimiser applied inside it (bitwise vaa_patch_update on the same gradient)
+        wps = (ops.pack_embed_weights(w[0].t().contiguous()), ops.pack_embed_weights(w[1].t().contiguous()))
+        pa = (t(patch), t(xy, torch.int32), t(theta.reshape(-1, 6)))
+        ft = ops.patch_embed_grad_gather_tiles(dy[0], dy[1], *wps, *pa, keep_t, tflags, bool(geo))
+        if not np.array_equal(ft.cpu().numpy(), fused):
+            fails.append(f"K2' tiles {tag} D={D0}+{D1}: differs from the planar-mask form")
+        parts = ops.patch_embed_grad_gather_tiles(dy[0], dy[1], *wps, *pa, keep_t, tflags, bool(geo), defer_reduce=True)
+        n_el = 3 * ph * pw
+        msg, sc8 = torch.zeros(n_el + 4, device=DEV), torch.arange(8, dtype=torch.float32, device=DEV)
+        p_a, m_a, v_a = (torch.from_numpy(x).to(DEV) for x in (rs.rand(3, ph, pw).astype(np.float32), (rs.rand(3, ph, pw) * 1e-3).astype(np.float32),
+                                                                (rs.rand(3, ph, pw) * 1e-6).astype(np.float32)))
+        p_b, m_b, v_b = p_a.clone(), m_a.clone(), v_a.clone()
+        ops.step_epilogue(parts, msg, sc8, update=dict(patch=p_b, m=m_b, v=v_b, mode=ops.OPT_ADAMW_HF, lr=2e-3, step=3))
+        ops.patch_update(p_a, ft, m_a, v_a, ops.OPT_ADAMW_HF, 2e-3, 3)
+        if not (torch.equal(msg[:n_el].view_as(ft), ft) and torch.equal(p_a, p_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b)):
+            fails.append(f"epilogue {tag} D={D0}+{D1}: sum / fused update differ from the separate launches")
         fold = lambda d, ww: (d.float().cpu() @ ww.float().cpu()).to(torch.bfloat16).view(B, 16, 16, 3, 14, 14).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 224, 224)
         gcat = torch.cat([fold(dy[0], w[0]), fold(dy[1], w[1])], dim=1).contiguous()
         oge = c_oracle.patch_grad(bits(gcat), patch, xy, theta, geo, 0, f64=general)
