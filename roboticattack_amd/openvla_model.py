@@ -373,6 +373,8 @@ class OpenVLAShaped(nn.Module):
 
         f = (lambda m, x: m(None, embedded=x)) if embedded else (lambda m, x: m(x))
         mode = os.environ.get("VAA_TOWER_STREAMS", "auto")
+        if mode == "auto" and os.environ.get("VAA_DIST_BACKEND") == "gloo" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            mode = "0"  # test mode, several ranks share one GPU: their four queues time-slice badly (strong region 609 -> 2,270+ ms per step measured)
         if not in0.is_cuda or mode == "0":
             return f(self.featurizer, in0), f(self.fused_featurizer, in1)
         cur = torch.cuda.current_stream(in0.device)
@@ -485,8 +487,8 @@ class OpenVLAShaped(nn.Module):
 
 def enable_tuned_gemms() -> bool:
     """Point PyTorch-ROCm's TunableOp at the GEMM selections recorded on an MI355X for the OpenVLA-7B step at the per-rank batches of the
-    BASELINE configs — bs = 64 (weak scaling), 8 (configs 3 / 4: 64 or 32 images over 8 or 4 ranks) and 4 (config 5) with prompts
-    bucketed to 44 tokens (cfg.seq_floor) — (roboticattack_amd/tunableop/*.csv, one identical copy per device ordinal; made by
+    BASELINE configs — bs = 64 (weak scaling), 32 / 16 / 8 (strong scaling of config 3 over 2 / 4 / 8 ranks; config 4: 32 over 4 ranks) and
+    4 (config 5) with prompts bucketed to 44 tokens (cfg.seq_floor) — (roboticattack_amd/tunableop/*.csv, one identical copy per device ordinal; made by
     tools/tune_gemms.sh). Tuning itself stays off: unknown shapes fall back to the default hipBLASLt heuristic, a validator mismatch
     (different ROCm / hipBLASLt build) ignores the file. Worth ~3 % of the step; honours a user's own PYTORCH_TUNABLEOP_* env."""
     import os
