@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -36,10 +37,10 @@ struct ProfRec {
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;   // pool of event pairs; the first g_prof_used are recorded
 static int g_prof_used = 0;
-static bool g_prof_armed = false;
+static std::atomic<bool> g_prof_armed{false};  // read without the lock on every launch
 
 bool prof_next(const char* name, hipEvent_t* start, hipEvent_t* stop) {
-    if (!g_prof_armed) return false;  // unlocked fast path: arming/disarming happens between steps, on the launching thread
+    if (!g_prof_armed.load(std::memory_order_acquire)) return false;  // fast path of every un-profiled launch
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_armed || g_prof_used >= (int)g_prof.size()) return false;  // pool exhausted: later dispatches run unprofiled
     ProfRec& r = g_prof[g_prof_used++];

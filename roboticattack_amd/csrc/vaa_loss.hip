@@ -1275,6 +1275,28 @@ static unsigned* rows_bar_for(hipStream_t st) {
     return base + 32 * used++;
 }
 
+// The one-pass form waits on a grid-wide hand-over, so every workgroup of the launch has to be resident at once: the grid is admitted
+// only when the occupancy the runtime reports for that instantiation (x the device's CU count) covers it; otherwise two launches.
+template <typename K>
+static bool rows_grid_resident(K kernel, int threads, long grid) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return grid <= (long)cus * per_cu;
+}
+
+static bool rows_one_pass_fits(const RowsArgs& a, int dtype) {
+    const long grid = (long)a.R * a.split;
+    if (rows_threads(a.V) == 256)
+        return dtype == VAA_DTYPE_F32 ? rows_grid_resident(rows_stats_kernel<float, 256, true>, 256, grid)
+                                      : rows_grid_resident(rows_stats_kernel<uint16_t, 256, true>, 256, grid);
+    return dtype == VAA_DTYPE_F32 ? rows_grid_resident(rows_stats_kernel<float, 512, true>, 512, grid)
+                                  : rows_grid_resident(rows_stats_kernel<uint16_t, 512, true>, 512, grid);
+}
+
 static int launch_rows_stats(const RowsArgs& a, int dtype, hipStream_t st, const char* who, unsigned* bar = nullptr) {
     const int nt = rows_threads(a.V);
     const dim3 gs((unsigned)(a.R * a.split));
@@ -1330,7 +1352,7 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
         const hipError_t ce = hipStreamIsCapturing(st, &cs);
         if (ce != hipSuccess) (void)hipGetLastError();
         const bool capturing = ce != hipSuccess || cs != hipStreamCaptureStatusNone;
-        unsigned* bar = capturing ? nullptr : rows_bar_for(st);
+        unsigned* bar = (capturing || !rows_one_pass_fits(a, dtype)) ? nullptr : rows_bar_for(st);
         if (bar) return launch_rows_stats(a, dtype, st, "vaa_loss_rows_fwd_bwd(one pass)", bar);
     }
     rc = launch_rows_stats(a, dtype, st, "vaa_loss_rows_fwd_bwd(stats)");
