@@ -283,6 +283,7 @@ def self_launch(args):
 
 
 def main():
+    t_main = time.perf_counter()
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)  # does not return
@@ -325,7 +326,9 @@ def main():
     stage_ms = (time.perf_counter() - t_stage) * 1e3
 
     # ---- the timed region: weak scaling, bs = args.bs PER RANK (reference semantics, UADA_ddp.py:158) ----
+    t_setup = time.perf_counter() - t_main
     dt, host_enqueue, host_cpu, recs = timed_steps(runner, args.steps, args.warmup, world, dev, profile=True)
+    t_region = time.perf_counter() - t_main - t_setup
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
     finite = bool(torch.isfinite(runner.scal).all())
 
@@ -468,6 +471,8 @@ def main():
         "peak_mem_GiB": peak_mem, "loss_finite": finite,
     }
     line.update(extra)
+    # where this process's wall time went (imports excluded): model + batch set-up, warm-up + timed region, everything reported beside it
+    line["wall_s"] = {"setup": t_setup, "warmup_and_timed_region": t_region, "total": time.perf_counter() - t_main}
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)
     os.close(stdout_fd)
