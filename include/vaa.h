@@ -197,7 +197,11 @@ int vaa_loss_fwd_bwd_ex(const void* logits, int dtype, int layout, const int64_t
  *             grad dev or NULL, grad_kind VAA_GRAD_FULL [R,V] | VAA_GRAD_SLICE [R,256] (only for UADA_DDP / UPA, whose gradient is
  *                              confined to the action columns: the LM-head backward then contracts over 256 columns, not 32,064)
  *             ws >= vaa_loss_rows_ws_bytes(R). Rows are split over 2-4 workgroups so that 128 rows fill the 256 CUs; in UADA_DDP
- *             mode the gradient is written by the same pass that reads the logits.
+ *             mode the gradient is written by the same pass that reads the logits. Full-row gradients whose scale needs the folded
+ *             scalars (UADA's 1/CE^2 term, UADA.py:145-148; CE, TMA.py:148) are ONE launch too — statistics, grid-wide hand-over,
+ *             gradient from the registers, every row read once — when the grid takes at most half of the device's resident slots,
+ *             the stream is not being captured and no other stream of the process has such a launch in flight; else (and with
+ *             VAA_K3_ONE_PASS=0 in the environment) two launches with the same bits in every output.
  */
 size_t vaa_loss_rowmap_bytes(int B, int L);
 int vaa_loss_rowmap_build(const int64_t* labels, int B, int L, void* rowmap, size_t rowmap_bytes, void* stream);

@@ -54,6 +54,26 @@ def random_params(B, ph, pw, seed=0):
     return xy, th
 
 
+def _time_in_stream(fn, iters, warmup=3, reps=5):
+    """Mean GPU time of one `fn()` call launched back to back in the current stream: `iters` calls between two HIP events, `reps` times. For
+    ops that cannot be captured into a graph (K3's one-pass form: its hand-over generation is a launch argument). The host enqueues faster
+    than these kernels run once a few are queued, so the bracket is GPU time."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) * 1e-3 / iters)
+    t = np.array(ts)
+    return float(t.mean()), float(np.median(t)), float(t.min())
+
+
 def _time(fn, iters, warmup=3, per_graph=10):
     """Mean GPU time of one `fn()` call. The launch sequence is captured `per_graph` times into a hipGraph and the
     graph is replayed `iters` times between two HIP events on the replay stream, so host launch overhead (python +
@@ -119,8 +139,8 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
     gp = torch.randn_like(patch) * 1e-3
     res = {}
 
-    def rec(name, key, fn, nbytes, **extra):
-        mean, med, mn = _time(fn, iters)
+    def rec(name, key, fn, nbytes, in_stream=False, **extra):
+        mean, med, mn = _time_in_stream(fn, max(iters, 100)) if in_stream else _time(fn, iters)
         res[name] = dict(mean_us=mean * 1e6, median_us=med * 1e6, min_us=mn * 1e6, algo_bytes=nbytes,
                          achieved_GBs=nbytes / mean / 1e9, frac_of_8TBs=nbytes / mean / 1e9 / HBM_PEAK_GBS, **extra)
 
@@ -149,7 +169,26 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
         note="the bench step's mode (UADA_DDP): row map prebuilt, gradient = the 256 action columns; 16.4 MB figure of SURVEY 8d = full-row storage, see K3_full")
     rec("K3_full_rows_fwd_bwd", "K3",
         lambda: ops.loss_rows_fwd_bwd(logits, rowmap, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=glog),
-        algo_bytes("K3", B, rows=R, esize=logits.element_size()), rows=R, note="UADA (1/CE term): full-row gradient, SURVEY 8d's 2*R'*V*e")
+        algo_bytes("K3", B, rows=R, esize=logits.element_size()), in_stream=True, rows=R,
+        note="UADA (1/CE term): full-row gradient, SURVEY 8d's 2*R'*V*e; ONE launch (statistics, grid-wide hand-over, gradient from the registers), "
+             "timed as back-to-back calls in a stream (the form is not graph-capturable)")
+
+    def k3_two_launches():
+        import os
+
+        old = os.environ.get("VAA_K3_ONE_PASS")
+        os.environ["VAA_K3_ONE_PASS"] = "0"
+        try:
+            ops.loss_rows_fwd_bwd(logits, rowmap, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=glog)
+        finally:
+            if old is None:
+                del os.environ["VAA_K3_ONE_PASS"]
+            else:
+                os.environ["VAA_K3_ONE_PASS"] = old
+
+    rec("K3_full_two_launches", "K3", k3_two_launches, algo_bytes("K3", B, rows=R, esize=logits.element_size()), in_stream=True, rows=R,
+        note="the same with VAA_K3_ONE_PASS=0 (statistics launch + finishing launch that reads every row again): what stream capture and grids beyond "
+             "half the device's residency take")
     parts = ops.patch_embed_grad_gather_tiles(dy0, dy1, wt0, wt1, patch, xy, th, keep_t, tflags, True, defer_reduce=True)
     msg, scal8 = torch.zeros(3 * ph * pw + 4, device=dev), torch.zeros(8, device=dev)
     ws3 = ops.loss_rows_stats(logits, rowmap, ops.LOSS_UADA_DDP, w=5.0, grad=gslice)

@@ -577,13 +577,20 @@ struct FoldOut {
     double nrow, nact, CE, MSE, UAD, total, aux0, aux1, dce;
     int Rn;
 };
+// one-pass hand-over (rows_stats_kernel<.., true>): the folding workgroup leaves every row's log-sum-exp beside its slice statistics
+// (SliceStat::pad) and publishes what every gradient needs as two SELF-VALIDATING 64-bit words {generation, payload} — a waiting workgroup
+// polls exactly those two words and needs no ordering between them — BEFORE it writes the scalars and prediction maps nobody waits for
+struct Handover {
+    unsigned long long* words;  // [0] = {gen, bits of kce = dce / nrow as fp32}, [1] = {gen, nact | Rn << 16}
+    unsigned gen;
+};
 template <int kRowsT, bool COH = false>
-__device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, double (*sh)[7]);
+__device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, double (*sh)[7], Handover ho = Handover{nullptr, 0u});
 
 struct SliceStat;
 template <typename T, int kRowsT>
-__device__ __forceinline__ void rows_full_gradient(const RowsArgs& a, const FoldOut& f, int r, int v_lo, int v_hi, const float (&v)[32 / Vec<T>::N][Vec<T>::N],
-                                                   float lse, float alse, float E);
+__device__ __forceinline__ void rows_full_gradient(const RowsArgs& a, float kce, double nact, int r, int v_lo, int v_hi,
+                                                   const float (&v)[32 / Vec<T>::N][Vec<T>::N], float lse, float alse, float E);
 
 // statistics words another workgroup of the SAME launch wrote: agent-scope atomics go past the per-XCD L2 (COH); plain accesses otherwise
 template <bool COH, typename S>
@@ -611,7 +618,7 @@ __device__ __forceinline__ void stat_store(S* p, const S& v) {
 // registers across a grid-wide barrier, folds the statistics and writes the gradient from them — the logits are read ONCE (the two-launch
 // form reads every row again in its finishing launch). bar: two zeroed words owned by this launch's stream, left zero.
 template <typename T, int kRowsT, bool ONEPASS>
-__global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a, unsigned* bar) {
+__global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a, unsigned* bar, unsigned gen) {
     constexpr int N = Vec<T>::N;
     constexpr int MAXV = 32 / N;  // 32 logits per thread in registers: covers V/split <= 16384
     const int r = blockIdx.x / a.split, h = blockIdx.x - r * a.split;
@@ -750,85 +757,72 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a, unsigned
     }
     if (!ONEPASS) return;
     // ---- grid-wide hand-over without cache-wide fences: every cross-workgroup word travels through agent-scope atomics (they bypass the
-    // per-XCD L2), the LAST workgroup to arrive folds the statistics once and raises a flag, everybody else waits for the flag only.
-    // (A release/acquire fence pair per workgroup — L2 write-back + invalidate, after which 512 workgroups each re-fetched all statistics
-    // through the fabric — made this form 2x SLOWER than two launches: 42 vs 20 us at R' = 128.) ----
+    // per-XCD L2). Arrival is counted in two levels, each counter on its own 128-byte line — eight counters by blockIdx & 7, then one — so no
+    // line takes more than nwg / 8 read-modify-writes. The LAST workgroup folds the statistics once, leaves every row's log-sum-exp beside
+    // its slice statistics and publishes {kce, nact, Rn} as two self-validating 64-bit words {generation, payload} on a line of their own;
+    // everybody else polls those two words (two lanes, one instruction per round), then fetches ONE 16-byte record of its own row.
+    // What was measured on the way, R' = 128, bf16 (two launches: 20.3 us): release/acquire fences per workgroup 42 us; ticket, flag, leave
+    // count and results on one line 33 us; separate lines + a flag + a fetch of seven words and the row's record 19.6 us; a 64-byte record
+    // per row polled by 16 lanes 22.3 us; row cells as the first arrival level + the row's statistics fetched while waiting 20.8 us (every
+    // extra polling lane costs more than the round trip it saves); this form 20.0 us (fp32, R' = 256: 25.8 against 30.2). ----
     __shared__ int bar_ok, am_last;
-    __shared__ float row_sh[8];
     __shared__ double shf[kRowsT / 64][7];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's statistics stores (agent-scope atomic stores below) have completed
+    __shared__ unsigned hand[16];  // 0: kce, 1: nact | Rn << 16; 8..11: the row's {alse, E, pred, log-sum-exp}
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's statistics stores (agent-scope atomic stores above) have completed
     __syncthreads();
-    unsigned* res = bar + 4;  // 16 words: the folded quantities the gradient needs
+    unsigned long long* pub = reinterpret_cast<unsigned long long*>(bar + 32 * 9);
     if (tid == 0) {
-        const unsigned nwg = gridDim.x;
-        const unsigned old = atomicAdd(&bar[0], 1u);
-        am_last = old == nwg - 1;
+        const unsigned nwg = gridDim.x, sub = blockIdx.x & 7u;
+        const unsigned nres = (nwg + 7u - sub) >> 3, ntop = nwg < 8u ? nwg : 8u;
+        unsigned* subc = bar + 32 * (1 + sub);
+        bool last = false;
+        if (atomicAdd(subc, 1u) == nres - 1u) {  // everybody of this residue has arrived: re-arm the counter, report upwards
+            __hip_atomic_store(subc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (atomicAdd(bar, 1u) == ntop - 1u) {
+                __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = true;
+            }
+        }
+        am_last = last ? 1 : 0;
         bar_ok = 1;
     }
     __syncthreads();
-    FoldOut f;
-    if (am_last) {
-        f = rows_fold<kRowsT, true>(a, true, shf);  // coherent loads; publishes scalars[8] + the prediction maps like rows_finish_kernel's block 0
-        if (tid == 0) {
-            const double pub[4] = {f.nrow, f.nact, f.dce, 0.0};
-            const unsigned* pw = reinterpret_cast<const unsigned*>(pub);
-#pragma unroll
-            for (int z = 0; z < 6; ++z) __hip_atomic_store(&res[z], pw[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&res[6], (unsigned)f.Rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // everybody has arrived: re-arm the ticket
-            __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the flag
+    // coherent loads; scalars[8] + the prediction maps like rows_finish_kernel's block 0
+    if (am_last) (void)rows_fold<kRowsT, true>(a, true, shf, Handover{pub, gen});
+    if (wv == 0) {
+        unsigned long long w = 0ull;
+        int it = 0;
+        for (;;) {  // (the folding workgroup finds its own words at once)
+            if (lane < 2) w = __hip_atomic_load(&pub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = lane >= 2 || (unsigned)(w >> 32) == gen;
+            if (__all(ok) || ++it >= (1 << 22)) break;  // wave-uniform
+            __builtin_amdgcn_s_sleep(4);
         }
-    } else {
-        if (tid == 0) {
-            int it = 0;
-            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && it < (1 << 22)) { __builtin_amdgcn_s_sleep(2); ++it; }
-            bar_ok = it < (1 << 22);  // a launch that never became fully resident gives up instead of hanging: NaN gradient
-        }
-        __syncthreads();
-        unsigned w6[7];
-#pragma unroll
-        for (int z = 0; z < 7; ++z) w6[z] = __hip_atomic_load(&res[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double pub[3];
-        __builtin_memcpy(pub, w6, 24);
-        f.nrow = pub[0]; f.nact = pub[1]; f.dce = pub[2]; f.Rn = (int)w6[6];
-    }
-    if (!bar_ok) f.dce = __longlong_as_double(0x7ff8000000000000ll);
-    if (tid == 0 && r < f.Rn) {  // this row's own statistics (its other parts belong to sibling workgroups): one thread fetches, LDS broadcasts
-        const SliceStat ms = stat_load<true>(&a.slice[r]);
-        float M = -INFINITY, tot = 0.0f;
-        for (int q = 0; q < a.split; ++q) M = fmaxf(M, stat_load<true>(&a.part[(size_t)r * a.split + q]).m);
-        for (int q = 0; q < a.split; ++q) {
-            const PartStat p = stat_load<true>(&a.part[(size_t)r * a.split + q]);
-            tot += p.s * expf(p.m - M);
-        }
-        row_sh[0] = M + logf(tot); row_sh[1] = ms.alse; row_sh[2] = ms.E;
+        if (lane < 2) hand[lane] = (unsigned)w;
+        if (lane == 0) bar_ok = it < (1 << 22);  // a launch that never became fully resident gives up instead of hanging (the host admits resident grids only): NaN gradient
+        if (lane >= 8 && lane < 12) hand[lane] = __hip_atomic_load(reinterpret_cast<const unsigned*>(&a.slice[r]) + (lane - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (a.grad && r < f.Rn) rows_full_gradient<T, kRowsT>(a, f, r, v_lo, v_hi, v, row_sh[0], row_sh[1], row_sh[2]);
-    // the last workgroup to LEAVE lowers the flag: the words are zero again when the launch ends
-    __syncthreads();
-    if (tid == 0 && atomicAdd(&bar[2], 1u) == gridDim.x - 1) {
-        __hip_atomic_store(&bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    float kce = __uint_as_float(hand[0]);
+    const int nact_all = (int)(hand[1] & 0xffffu), Rn = (int)(hand[1] >> 16);
+    if (!bar_ok) kce = __uint_as_float(0x7fc00000u);
+    if (a.grad && r < Rn) rows_full_gradient<T, kRowsT>(a, kce, (double)nact_all, r, v_lo, v_hi, v, __uint_as_float(hand[11]), __uint_as_float(hand[8]), __uint_as_float(hand[9]));
 }
 
 // d total / d logits of row r, part [v_lo, v_hi), from the logits a thread holds (v[c] = vector v_lo + tid + c * kRowsT): full-row modes
 // (UADA: 1/CE^2 term + the action-slice term, CE).
 template <typename T, int kRowsT>
-__device__ __forceinline__ void rows_full_gradient(const RowsArgs& a, const FoldOut& f, int r, int v_lo, int v_hi, const float (&v)[32 / Vec<T>::N][Vec<T>::N],
-                                                   float lse, float alse, float E) {
+__device__ __forceinline__ void rows_full_gradient(const RowsArgs& a, float kce, double nact, int r, int v_lo, int v_hi,
+                                                   const float (&v)[32 / Vec<T>::N][Vec<T>::N], float lse, float alse, float E) {
     constexpr int N = Vec<T>::N;
     constexpr int MAXV = 32 / N;
     const int tid = threadIdx.x;
     const RowMap me = reinterpret_cast<const RowMap*>(a.rowmap + 4)[r];
     struct { float alse, E; } ms = {alse, E};
-    const float kce = f.nrow > 0 ? (float)(f.dce / f.nrow) : 0.0f;
     float kE = 0.0f;
     if (a.mode != VAA_LOSS_CE && me.lab > 2) {
         const double q = (double)ms.E / 256.0, t = (me.lab > 31872) ? 0.0 : 1.0;
-        kE = (float)((double)a.w * a.w * 2.0 * (q - t) / f.nact / 256.0);
+        kE = (float)((double)a.w * a.w * 2.0 * (q - t) / nact / 256.0);
     }
     T* g = reinterpret_cast<T*>(a.grad) + (size_t)r * a.V;
 #pragma unroll
@@ -852,17 +846,34 @@ __device__ __forceinline__ void rows_full_gradient(const RowsArgs& a, const Fold
 // Folds the R compact row statistics into the loss scalars in a fixed order (thread t takes rows t, t + kRowsT, ...; block_sums), and — for
 // the publishing workgroup — writes scalars[8] and the two prediction maps. Shared by rows_finish_kernel and the step epilogue.
 template <int kRowsT, bool COH>
-__device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, double (*sh)[7]) {
+__device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, double (*sh)[7], Handover ho) {
     const int tid = threadIdx.x;
     const RowMap* rm = reinterpret_cast<const RowMap*>(a.rowmap + 4);
     const int Rdev = a.rowmap[0];
     const int Rn = min(a.R, Rdev);  // rows both the caller and the map know: a mismatch publishes NaN and never leaves the map
     auto row_lse = [&](int rr, float& zlab, int& amax) {  // combine the parts of row rr
-        float M = -INFINITY;
-        for (int q = 0; q < a.split; ++q) M = fmaxf(M, stat_load<COH>(&a.part[(size_t)rr * a.split + q]).m);
-        float tot = 0.0f, best = -INFINITY;
+        float M = -INFINITY, tot = 0.0f, best = -INFINITY;
         zlab = -INFINITY;
         amax = 0x7fffffff;
+        constexpr int kHeld = 8;
+        if (COH && a.split <= kHeld) {  // coherent loads are not merged by the compiler: fetch every part ONCE, all requests in flight together
+            PartStat ps[kHeld];
+#pragma unroll
+            for (int q = 0; q < kHeld; ++q)
+                if (q < a.split) ps[q] = stat_load<COH>(&a.part[(size_t)rr * a.split + q]);
+#pragma unroll
+            for (int q = 0; q < kHeld; ++q)
+                if (q < a.split) M = fmaxf(M, ps[q].m);
+#pragma unroll
+            for (int q = 0; q < kHeld; ++q)
+                if (q < a.split) {
+                    tot += ps[q].s * expf(ps[q].m - M);
+                    zlab = fmaxf(zlab, ps[q].zlab);
+                    if (ps[q].m > best || (ps[q].m == best && ps[q].amax < amax)) { best = ps[q].m; amax = ps[q].amax; }
+                }
+            return M + logf(tot);
+        }
+        for (int q = 0; q < a.split; ++q) M = fmaxf(M, stat_load<COH>(&a.part[(size_t)rr * a.split + q]).m);
         for (int q = 0; q < a.split; ++q) {
             const PartStat p = stat_load<COH>(&a.part[(size_t)rr * a.split + q]);
             tot += p.s * expf(p.m - M);
@@ -871,24 +882,32 @@ __device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, do
         }
         return M + logf(tot);
     };
-    if (publish) {  // the publishing workgroup clears the prediction maps NOW, under the statistics' load latency; the barriers of the
-                    // block reduction below order these stores before the per-row stores that follow it
+    const bool handing = COH && ho.words != nullptr;
+    auto clear_maps = [&]() {
         const int P0 = a.B * (a.L - 1);
         if (a.pred_tokens) for (int q = tid; q < P0; q += kRowsT) a.pred_tokens[q] = -1;
         if (a.pred_full) for (int q = tid; q < P0; q += kRowsT) a.pred_full[q] = -1;
-    }
+    };
+    // the publishing workgroup clears the prediction maps NOW, under the statistics' load latency (the barriers of the block reduction below
+    // order these stores before the per-row stores that follow it) — unless a grid is waiting for this fold: then nothing is queued in front
+    // of the statistics loads and the maps are cleared after the hand-over
+    if (publish && !handing) clear_maps();
     int first_am = 0;  // full-vocabulary argmax of this thread's first row (rr = tid), kept for the publication
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // ce, mse, uad, nrow, nact, upa sum(cos+1), upa sum ||e'-l'||
     for (int rr = tid; rr < Rn; rr += kRowsT) {
         const RowMap m = rm[rr];
         float zl;
         int am;
+        SliceStat ss_early = {0.f, 0.f, 0, 0};
+        if (handing) ss_early = stat_load<COH>(&a.slice[rr]);  // requested together with the parts: one round trip for the whole row
         const float lse = row_lse(rr, zl, am);
+        if (handing)  // the row's workgroups take their log-sum-exp from here instead of combining the parts again
+            __hip_atomic_store(reinterpret_cast<unsigned*>(&a.slice[rr].pad), __float_as_uint(lse), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (rr == tid) first_am = am;
         acc[3] += 1.0;
         acc[0] += (double)lse - (double)zl;
         if (m.lab > 2) {
-            const SliceStat ss = stat_load<COH>(&a.slice[rr]);
+            const SliceStat ss = handing ? ss_early : stat_load<COH>(&a.slice[rr]);
             acc[4] += 1.0;
             const double q = (double)ss.E / 256.0, t = (m.lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10: 1/256 -> 0)
             acc[1] += (q - t) * (q - t);
@@ -925,6 +944,20 @@ __device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, do
     } else if (a.mode == VAA_LOSS_UADA) { f.total = f.MSE + 1.0 / f.CE; f.dce = -1.0 / (f.CE * f.CE); }  // UADA.py:147
     else if (a.mode == VAA_LOSS_UADA_DDP) { f.total = f.MSE; }                                           // UADA_ddp.py:203-206
     else { f.total = (double)a.scale * f.CE; f.dce = (double)a.scale; }                                 // TMA.py:148
+    if (handing) {  // the waiting workgroups need {kce, nact, Rn}: hand over now, publish afterwards
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's log-sum-exp words (issued a reduction ago) have completed
+        __syncthreads();
+        if (tid == 0) {
+            const float kce = f.nrow > 0 ? (float)(f.dce / f.nrow) : 0.0f;
+            const unsigned long long g = (unsigned long long)ho.gen << 32;
+            __hip_atomic_store(&ho.words[0], g | __float_as_uint(kce), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ho.words[1], g | ((unsigned)f.nact & 0xffffu) | ((unsigned)f.Rn << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (publish && handing) {
+        clear_maps();
+        __syncthreads();
+    }
     if (publish) {
         if (tid == 0) {
             const bool ok = Rdev == a.R;  // the caller's row count must be the row map's
@@ -1252,14 +1285,17 @@ static int rows_args(const char* who, const void* logits, int dtype, const void*
     return VAA_OK;
 }
 
-// Barrier words of the one-pass form: two zero-initialised words per stream that uses it (the launch leaves them zero), in the library's
-// own device image — nothing is allocated, the caller's workspace keeps its "contents undefined" contract.
-constexpr int kBarSlots = 64;
-__device__ unsigned g_rows_bar[kBarSlots][32];  // {ticket, flag, leave count, -, 16 words of folded results}
+// Hand-over words of the one-pass form, in the library's own device image (nothing is allocated, the caller's workspace keeps its
+// "contents undefined" contract): per stream that uses it twelve 128-byte lines — line 0 the second-level arrival counter, lines 1..8 the
+// first-level counters (blockIdx & 7), line 9 the two published words. The counters are re-armed by their last arrival, the published
+// words carry a per-slot launch generation, so a launch leaves nothing to clean up.
+constexpr int kBarSlots = 64, kBarWords = 32 * 12;
+__device__ unsigned g_rows_bar[kBarSlots][kBarWords];
 
-static unsigned* rows_bar_for(hipStream_t st) {
+static unsigned* rows_bar_for(hipStream_t st, unsigned* gen) {
     static std::mutex mu;
     static hipStream_t owner[kBarSlots];
+    static unsigned gens[kBarSlots];
     static int used = 0;
     static unsigned* base = nullptr;
     std::lock_guard<std::mutex> lk(mu);
@@ -1268,11 +1304,16 @@ static unsigned* rows_bar_for(hipStream_t st) {
         base = nullptr;
         return nullptr;
     }
-    for (int i = 0; i < used; ++i)
-        if (owner[i] == st) return base + 32 * i;
-    if (used == kBarSlots) return nullptr;  // more streams than slots: the caller falls back to the two-launch form
-    owner[used] = st;
-    return base + 32 * used++;
+    int i = 0;
+    while (i < used && owner[i] != st) ++i;
+    if (i == used) {
+        if (used == kBarSlots) return nullptr;  // more streams than slots: the caller falls back to the two-launch form
+        owner[used] = st;
+        gens[used++] = 0u;
+    }
+    if (++gens[i] == 0u) ++gens[i];  // never 0: the words start zeroed
+    *gen = gens[i];
+    return base + (size_t)kBarWords * i;
 }
 
 // The one-pass form waits on a grid-wide hand-over, so every workgroup of the launch has to be resident at once: the grid is admitted
@@ -1285,7 +1326,33 @@ static bool rows_grid_resident(K kernel, int threads, long grid) {
         (void)hipGetLastError();
         return false;
     }
-    return grid <= (long)cus * per_cu;
+    // half of what fits: a second launch of the same shape from ANOTHER process (the GPU shared by two ranks or tenants) still finds room,
+    // so two waiting grids can never hold the slots each other's last workgroups need
+    return 2 * grid <= (long)cus * per_cu;
+}
+
+// Inside this process at most ONE stream has one-pass launches in flight: a request from another stream is admitted only once the owner
+// stream has drained (hipStreamQuery), else it takes the two-launch form — two half-resident waiting grids would otherwise be possible.
+static bool rows_one_pass_stream_ok(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t owner = nullptr;
+    static bool owned = false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (owned && owner != st) {
+        if (hipStreamQuery(owner) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    owner = st;
+    owned = true;
+    return true;
+}
+
+constexpr bool kOnePassDefault = true;
+static bool rows_one_pass_wanted() {  // VAA_K3_ONE_PASS=1 / 0 overrides the default
+    const char* ev = getenv("VAA_K3_ONE_PASS");
+    return ev && *ev ? (ev[0] != '0') : kOnePassDefault;
 }
 
 static bool rows_one_pass_fits(const RowsArgs& a, int dtype) {
@@ -1297,24 +1364,24 @@ static bool rows_one_pass_fits(const RowsArgs& a, int dtype) {
                                   : rows_grid_resident(rows_stats_kernel<uint16_t, 512, true>, 512, grid);
 }
 
-static int launch_rows_stats(const RowsArgs& a, int dtype, hipStream_t st, const char* who, unsigned* bar = nullptr) {
+static int launch_rows_stats(const RowsArgs& a, int dtype, hipStream_t st, const char* who, unsigned* bar = nullptr, unsigned gen = 0u) {
     const int nt = rows_threads(a.V);
     const dim3 gs((unsigned)(a.R * a.split));
     unsigned* nobar = nullptr;
     if (bar) {  // one pass: statistics, grid barrier, fold, full-row gradient from the registers
         if (dtype == VAA_DTYPE_F32) {
-            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, true>), gs, dim3(256), 0, st, a, bar);
-            else VAA_LAUNCH((rows_stats_kernel<float, 512, true>), gs, dim3(512), 0, st, a, bar);
+            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, true>), gs, dim3(256), 0, st, a, bar, gen);
+            else VAA_LAUNCH((rows_stats_kernel<float, 512, true>), gs, dim3(512), 0, st, a, bar, gen);
         } else {
-            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, true>), gs, dim3(256), 0, st, a, bar);
-            else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, true>), gs, dim3(512), 0, st, a, bar);
+            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, true>), gs, dim3(256), 0, st, a, bar, gen);
+            else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, true>), gs, dim3(512), 0, st, a, bar, gen);
         }
     } else if (dtype == VAA_DTYPE_F32) {
-        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, false>), gs, dim3(256), 0, st, a, nobar);
-        else VAA_LAUNCH((rows_stats_kernel<float, 512, false>), gs, dim3(512), 0, st, a, nobar);
+        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, false>), gs, dim3(256), 0, st, a, nobar, 0u);
+        else VAA_LAUNCH((rows_stats_kernel<float, 512, false>), gs, dim3(512), 0, st, a, nobar, 0u);
     } else {
-        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, false>), gs, dim3(256), 0, st, a, nobar);
-        else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, false>), gs, dim3(512), 0, st, a, nobar);
+        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, false>), gs, dim3(256), 0, st, a, nobar, 0u);
+        else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, false>), gs, dim3(512), 0, st, a, nobar, 0u);
     }
     return check_launch(who);
 }
@@ -1342,18 +1409,20 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
     int rc = rows_args(who, logits, dtype, rowmap, R, B, L, V, mode, params, scalars, pred_tokens, pred_full_tokens, grad, grad_kind, ws, ws_bytes, a);
     if (rc != VAA_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    // EXPERIMENT, off by default (VAA_K3_ONE_PASS=1): full-row gradients (UADA's 1/CE^2, CE) in ONE launch — the statistics pass keeps its
-    // logits in registers across a grid-wide hand-over and writes the gradient from them, so every row is read once (16.4 MB instead of
-    // 25.4 MB at R' = 128). Measured on MI355X (tools/k3_onepass_check.py, profiles/r03_k3_onepass.txt): bitwise the same outputs, but 33 us
-    // against 20 us for the two launches (42 us with release/acquire fences instead of agent-scope atomics): a device-scope round trip
-    // across the XCDs costs more than the kernel boundary it replaces. The two-launch form stays the product path.
-    if (getenv("VAA_K3_ONE_PASS") && grad && grad_kind == VAA_GRAD_FULL && (mode == VAA_LOSS_UADA || mode == VAA_LOSS_CE) && (long)R * a.split <= 1024) {
+    // Full-row gradients (UADA's 1/CE^2, CE) in ONE launch: the statistics pass keeps its logits in registers across a grid-wide hand-over
+    // and writes the gradient from them, so every row is read once (16.4 MB instead of 25.4 MB at R' = 128) — bitwise the outputs of the
+    // two launches below, 19.2 against 21.1 us per call in a stream at R' = 128 (tools/k3_onepass_check.py, profiles/r03_k3_onepass.txt).
+    // Admitted when the grid takes at most HALF of the slots the runtime reports (residency is what a waiting grid relies on), outside
+    // stream capture (the hand-over generation is a launch argument) and while no OTHER stream of this process has such launches in
+    // flight; anything else takes the two launches. VAA_K3_ONE_PASS=0 turns it off.
+    if (rows_one_pass_wanted() && grad && grad_kind == VAA_GRAD_FULL && (mode == VAA_LOSS_UADA || mode == VAA_LOSS_CE) && (long)R * a.split <= 1024 && R < 65536) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const hipError_t ce = hipStreamIsCapturing(st, &cs);
         if (ce != hipSuccess) (void)hipGetLastError();
         const bool capturing = ce != hipSuccess || cs != hipStreamCaptureStatusNone;
-        unsigned* bar = (capturing || !rows_one_pass_fits(a, dtype)) ? nullptr : rows_bar_for(st);
-        if (bar) return launch_rows_stats(a, dtype, st, "vaa_loss_rows_fwd_bwd(one pass)", bar);
+        unsigned gen = 0u;
+        unsigned* bar = (capturing || !rows_one_pass_fits(a, dtype) || !rows_one_pass_stream_ok(st)) ? nullptr : rows_bar_for(st, &gen);
+        if (bar) return launch_rows_stats(a, dtype, st, "vaa_loss_rows_fwd_bwd(one pass)", bar, gen);
     }
     rc = launch_rows_stats(a, dtype, st, "vaa_loss_rows_fwd_bwd(stats)");
     if (rc != VAA_OK) return rc;

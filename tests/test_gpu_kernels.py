@@ -3,6 +3,7 @@
   (2) the plain-C oracle on the same seeded inputs (oracle/vaa_oracle.c, itself pinned to the golden vectors).
 Bars: paste/warp mask indices and the whole bf16 model input bit-exact; fp32 gradients/losses to the stated tolerance.
 """
+import contextlib
 import os
 import zlib
 
@@ -1436,3 +1437,49 @@ def test_patch_embed_grad_fused_one_launch(ops, B, ph, pw, geo, D0, D1):
     assert np.abs(got.cpu().numpy() - og).max() <= 2e-3 * np.abs(og).max() + 1e-7
     # beyond the form's reach the layout query says so and the entry point refuses
     assert _lib.lib().vaa_patch_embed_grad_fused_layout(128, 50, 50, D0, D1) == 0 and _lib.lib().vaa_patch_embed_grad_fused_layout(4, 100, 100, D0, D1) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,maskidx,mode,dtype", [(64, [0], "UADA", torch.bfloat16), (16, [0, 3], "UADA", torch.float32), (8, list(range(7)), "CE", torch.bfloat16),
+                                                  (3, [0], "UADA", torch.bfloat16)])
+def test_k3_one_pass_equals_two_launches(ops, monkeypatch, B, maskidx, mode, dtype):
+    """K3 full-row gradients (single-GPU UADA: 1/CE, UADA.py:145-148; TMA's CE, TMA.py:148) as ONE launch — statistics, grid-wide hand-over,
+    gradient from the registers — are bit for bit the two-launch form's: scalars, both prediction maps, the gradient; repeated launches on one
+    stream (the hand-over words re-arm themselves) and launches on a second stream (its own words) included."""
+    from roboticattack_amd.labels import mask_labels
+
+    _, labels, _ = synthetic.synth_text_batch(4242 + B, B)
+    labels = mask_labels(labels, maskidx).to(DEV)
+    R = int((labels[:, 1:] != -100).sum())
+    g0 = torch.Generator(device=DEV).manual_seed(B)
+    logits = (torch.randn(R, 32064, device=DEV, generator=g0) * 2).to(dtype)
+    rm = ops.LossRowMap(labels)
+    kmode = {"UADA": ops.LOSS_UADA, "CE": ops.LOSS_CE}[mode]
+
+    def run(stream=None):
+        g = torch.full_like(logits, float("nan"))
+        with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+            sc, pred, pred_full, _ = ops.loss_rows_fwd_bwd(logits, rm, kmode, w=5.0, grad_kind=ops.GRAD_FULL, grad=g)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (sc, pred, pred_full, g)]
+
+    def same(a, b):
+        return all(torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y) or
+                   (x.is_floating_point() and torch.equal(torch.isnan(x), torch.isnan(y)) and torch.equal(torch.nan_to_num(x.float()), torch.nan_to_num(y.float())))
+                   for x, y in zip(a, b))
+
+    monkeypatch.setenv("VAA_K3_ONE_PASS", "0")
+    ref = run()
+    assert torch.isfinite(ref[3].float()).all()
+    monkeypatch.setenv("VAA_K3_ONE_PASS", "1")
+    ops.prof_start(16)
+    one = run()
+    names = [n for n, _ in ops.prof_collect()]
+    assert len(names) == 1 and "rows_stats_kernel" in names[0], names  # really one launch
+    assert same(ref, one)
+    for _ in range(5):
+        assert same(ref, run())
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    assert same(ref, run(side))
+    assert same(ref, run())

@@ -19,12 +19,9 @@ for B, maskidx, mode, dtype in ((64, [0], ops.LOSS_UADA, torch.bfloat16), (16, [
     R = int((labels[:, 1:] != -100).sum())
     logits = (torch.randn(R, 32064, device=dev) * 2).to(dtype)
     rm = ops.LossRowMap(labels)
-    res, times = {}, {}
-    for tag, env in (("two_launch", ""), ("one_pass", "1")):
-        if env:
-            os.environ["VAA_K3_ONE_PASS"] = env
-        else:
-            os.environ.pop("VAA_K3_ONE_PASS", None)
+    res, times, wall = {}, {}, {}
+    for tag, env in (("two_launch", "0"), ("one_pass", "1")):
+        os.environ["VAA_K3_ONE_PASS"] = env
         g = torch.empty_like(logits)
         for _ in range(3):
             out = ops.loss_rows_fwd_bwd(logits, rm, mode, w=5.0, grad_kind=ops.GRAD_FULL, grad=g)
@@ -38,8 +35,15 @@ for B, maskidx, mode, dtype in ((64, [0], ops.LOSS_UADA, torch.bfloat16), (16, [
         for n, us in recs:
             per.setdefault(n, []).append(us)
         times[tag] = {n: float(np.mean(v)) for n, v in per.items()}
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            out = ops.loss_rows_fwd_bwd(logits, rm, mode, w=5.0, grad_kind=ops.GRAD_FULL, grad=g)
+        e1.record()
+        torch.cuda.synchronize()
+        wall[tag] = e0.elapsed_time(e1) * 1e3 / 200
         res[tag] = (out[0].clone(), out[1].clone(), out[2].clone(), g.clone())
     same = all(torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
                for a, b in zip(res["two_launch"], res["one_pass"]))
     t2, t1 = sum(times["two_launch"].values()), sum(times["one_pass"].values())
-    print(f"B={B} R={R} mode={mode} {dtype}: bitwise equal {same}; two launches {t2:.2f} us {[round(v, 2) for v in times['two_launch'].values()]}, one pass {t1:.2f} us")
+    print(f"B={B} R={R} mode={mode} {dtype}: bitwise equal {same}; two launches {t2:.2f} us {[round(v, 2) for v in times['two_launch'].values()]}, one pass {t1:.2f} us; in-stream per call (200 calls between two events): {wall['two_launch']:.2f} vs {wall['one_pass']:.2f} us")
