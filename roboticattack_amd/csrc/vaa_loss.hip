@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "vaa_common.h"
@@ -1319,16 +1320,29 @@ static unsigned* rows_bar_for(hipStream_t st, unsigned* gen) {
 // The one-pass form waits on a grid-wide hand-over, so every workgroup of the launch has to be resident at once: the grid is admitted
 // only when the occupancy the runtime reports for that instantiation (x the device's CU count) covers it; otherwise two launches.
 template <typename K>
-static bool rows_grid_resident(K kernel, int threads, long grid) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) {
+static bool rows_grid_resident(K kernel, int threads, long grid, int variant) {
+    static std::atomic<long> slots[4][16];  // [kernel variant][device]: resident workgroups, queried once (0 = not yet, -1 = query failed)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
         (void)hipGetLastError();
         return false;
     }
+    long have = slots[variant][dev].load(std::memory_order_relaxed);
+    if (have == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            have = -1;
+        } else {
+            have = (long)cus * per_cu;
+        }
+        slots[variant][dev].store(have, std::memory_order_relaxed);
+    }
+    const long cus_per_cu = have;
     // half of what fits: a second launch of the same shape from ANOTHER process (the GPU shared by two ranks or tenants) still finds room,
     // so two waiting grids can never hold the slots each other's last workgroups need
-    return 2 * grid <= (long)cus * per_cu;
+    return cus_per_cu > 0 && 2 * grid <= cus_per_cu;
 }
 
 // Inside this process at most ONE stream has one-pass launches in flight: a request from another stream is admitted only once the owner
@@ -1339,10 +1353,9 @@ static bool rows_one_pass_stream_ok(hipStream_t st) {
     static bool owned = false;
     std::lock_guard<std::mutex> lk(mu);
     if (owned && owner != st) {
-        if (hipStreamQuery(owner) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
+        const hipError_t q = hipStreamQuery(owner);
+        if (q == hipErrorNotReady) return false;
+        if (q != hipSuccess) (void)hipGetLastError();  // the owner stream no longer exists: nothing of it is in flight
     }
     owner = st;
     owned = true;
@@ -1358,10 +1371,10 @@ static bool rows_one_pass_wanted() {  // VAA_K3_ONE_PASS=1 / 0 overrides the def
 static bool rows_one_pass_fits(const RowsArgs& a, int dtype) {
     const long grid = (long)a.R * a.split;
     if (rows_threads(a.V) == 256)
-        return dtype == VAA_DTYPE_F32 ? rows_grid_resident(rows_stats_kernel<float, 256, true>, 256, grid)
-                                      : rows_grid_resident(rows_stats_kernel<uint16_t, 256, true>, 256, grid);
-    return dtype == VAA_DTYPE_F32 ? rows_grid_resident(rows_stats_kernel<float, 512, true>, 512, grid)
-                                  : rows_grid_resident(rows_stats_kernel<uint16_t, 512, true>, 512, grid);
+        return dtype == VAA_DTYPE_F32 ? rows_grid_resident(rows_stats_kernel<float, 256, true>, 256, grid, 0)
+                                      : rows_grid_resident(rows_stats_kernel<uint16_t, 256, true>, 256, grid, 1);
+    return dtype == VAA_DTYPE_F32 ? rows_grid_resident(rows_stats_kernel<float, 512, true>, 512, grid, 2)
+                                  : rows_grid_resident(rows_stats_kernel<uint16_t, 512, true>, 512, grid, 3);
 }
 
 static int launch_rows_stats(const RowsArgs& a, int dtype, hipStream_t st, const char* who, unsigned* bar = nullptr, unsigned gen = 0u) {
