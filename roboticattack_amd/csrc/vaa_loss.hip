@@ -805,8 +805,12 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a, unsigned
     }
     __syncthreads();
     float kce = __uint_as_float(hand[0]);
-    const int nact_all = (int)(hand[1] & 0xffffu), Rn = (int)(hand[1] >> 16);
-    if (!bar_ok) kce = __uint_as_float(0x7fc00000u);
+    int nact_all = (int)(hand[1] & 0xffffu), Rn = (int)(hand[1] >> 16);
+    if (!bar_ok) {  // the words never came: every row of the launch gets a NaN gradient (never a stale one, never nothing)
+        kce = __uint_as_float(0x7fc00000u);
+        Rn = a.R;
+        nact_all = 1;
+    }
     if (a.grad && r < Rn) rows_full_gradient<T, kRowsT>(a, kce, (double)nact_all, r, v_lo, v_hi, v, __uint_as_float(hand[11]), __uint_as_float(hand[8]), __uint_as_float(hand[9]));
 }
 
