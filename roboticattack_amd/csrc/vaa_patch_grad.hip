@@ -878,7 +878,8 @@ constexpr int kEmbedGroup = VAA_EMBED_GROUP;  // 64-wide k-chunks whose weight f
 //     together), so the LDS latency is covered by twelve MFMAs instead of being paid in front of every pair.
 //   * MFMA order: all row blocks against the first k-half, then the second: consecutive MFMAs never share an accumulator.
 template <int NQ, int NB>
-__device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const uint16_t* const (&wp)[NB], int nchunk, v4f_e (&acc)[NB][4]) {
+__device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const uint16_t* const (&wp)[NB], int nchunk, v4f_e (&acc)[NB][4],
+                                            const v8s_e (*pre)[NB][2] = nullptr) {
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -925,7 +926,16 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
     };
     // two register sets in ping-pong: the requests of the next group are in flight while this group's MFMAs run
     v8s_e bfa[kEmbedGroup][NB][2], bfb[kEmbedGroup][NB][2];
-    load_group(bfa, 0);
+    if (pre) {  // the first group was requested by the caller, under its staging round trip
+#pragma unroll
+        for (int u = 0; u < kEmbedGroup; ++u)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bfa[u][j][h] = pre[u][j][h];
+    } else {
+        load_group(bfa, 0);
+    }
     for (int k0 = 0; k0 < nchunk; k0 += 2 * kEmbedGroup) {
         load_group(bfb, k0 + kEmbedGroup);
         __builtin_amdgcn_sched_barrier(0);
@@ -1030,6 +1040,17 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
             //      ONE phase (20 x 16 B per thread: one memory round trip instead of two); both towers in sequence keep two halves ----
             __syncthreads();  // the previous tower's k-loops are over
             constexpr int kPhases = SPLIT ? 1 : 2, kPer = kEmbedStageMax / kPhases;
+            const uint16_t* wt = tower ? a.wt1 : a.wt0;
+            // blocks beyond this wave's count (or beyond the 37th) re-read its last block: loads stay unconditional, results are never stored
+            const uint16_t* wp[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                wp[j] = wt + packed_frag_offset(min(nb0 + min(j, max(nbw - 1, 0)), kNBlocks - 1), D >> 6, 0, 0, lane);
+            // the k-loop's first weight group is requested right behind the staging loads — one memory round trip for both instead of two
+            // (B=24: 11.6 -> 10.6 us warm, 14.7 -> 12.7 us with cold caches, profiles/r03_cold_probe.txt) — where the registers allow it: with
+            // three column blocks per wave the group's 48 VGPRs spill (B=64: 17.7 -> 20.4 us), so that instantiation requests it in the loop
+            constexpr bool kEarly = SPLIT && !FUSE && NB <= 2;
+            v8s_e pre[kEmbedGroup][NB][2];
 #pragma unroll
             for (int hf = 0; hf < kPhases; ++hf) {
                 uint4 st[kPer];
@@ -1045,6 +1066,16 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                         if (r < M) st[it] = *reinterpret_cast<const uint4*>(dy + ((size_t)b * 256 + tiles[r]) * D + cc * 8);
                     }
                 }
+                if constexpr (kEarly) {
+#pragma unroll
+                    for (int u = 0; u < kEmbedGroup; ++u) {
+                        const int kc = min(u, (D >> 6) - 1);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) pre[u][j][h] = *reinterpret_cast<const v8s_e*>(wp[j] + (size_t)kc * 1024 + h * 512);
+                    }
+                }
 #pragma unroll
                 for (int it = 0; it < kPer; ++it) {
                     int idx = tid + (hf * kPer + it) * kEmbedFastThreads;
@@ -1058,12 +1089,6 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
             __syncthreads();
             K2_STAMP(1 + 2 * tower)
             // ---- barrier-free k-loop ----
-            const uint16_t* wt = tower ? a.wt1 : a.wt0;
-            // blocks beyond this wave's count (or beyond the 37th) re-read its last block: loads stay unconditional, results are never stored
-            const uint16_t* wp[NB];
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-                wp[j] = wt + packed_frag_offset(min(nb0 + min(j, max(nbw - 1, 0)), kNBlocks - 1), D >> 6, 0, 0, lane);
             v4f_e acc[NB][4];
 #pragma unroll
             for (int j = 0; j < NB; ++j)
@@ -1075,13 +1100,23 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                 constexpr int NBW = decltype(nbtag)::value;
                 const uint16_t* wq[NBW];
                 v4f_e ac[NBW][4];
+                v8s_e pq[kEmbedGroup][NBW][2];
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) wq[j] = wp[j];
+                for (int j = 0; j < NBW; ++j) {
+                    wq[j] = wp[j];
+                    if constexpr (kEarly) {
+#pragma unroll
+                        for (int u = 0; u < kEmbedGroup; ++u)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) pq[u][j][h] = pre[u][j][h];
+                    }
+                }
+                const v8s_e (*pp)[NBW][2] = kEarly ? pq : nullptr;
                 switch (nq) {
-                    case 1: embed_kloop<1, NBW>(ap, SA, wq, D >> 6, ac); break;
-                    case 2: embed_kloop<2, NBW>(ap, SA, wq, D >> 6, ac); break;
-                    case 3: embed_kloop<3, NBW>(ap, SA, wq, D >> 6, ac); break;
-                    default: embed_kloop<4, NBW>(ap, SA, wq, D >> 6, ac); break;
+                    case 1: embed_kloop<1, NBW>(ap, SA, wq, D >> 6, ac, pp); break;
+                    case 2: embed_kloop<2, NBW>(ap, SA, wq, D >> 6, ac, pp); break;
+                    case 3: embed_kloop<3, NBW>(ap, SA, wq, D >> 6, ac, pp); break;
+                    default: embed_kloop<4, NBW>(ap, SA, wq, D >> 6, ac, pp); break;
                 }
 #pragma unroll
                 for (int j = 0; j < NBW; ++j)
