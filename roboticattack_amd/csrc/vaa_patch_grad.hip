@@ -877,16 +877,16 @@ constexpr int kEmbedGroup = VAA_EMBED_GROUP;  // 64-wide k-chunks whose weight f
 //   * the A fragments of chunk u+1 are read from LDS before the MFMAs of chunk u (one ds_read per row block and k-half, all issued
 //     together), so the LDS latency is covered by twelve MFMAs instead of being paid in front of every pair.
 //   * MFMA order: all row blocks against the first k-half, then the second: consecutive MFMAs never share an accumulator.
-template <int NQ, int NB>
+template <int NQ, int NB, int G = kEmbedGroup>
 __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const uint16_t* const (&wp)[NB], int nchunk, v4f_e (&acc)[NB][4],
                                             const v8s_e (*pre)[NB][2] = nullptr) {
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[j][q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
-    auto load_group = [&](v8s_e (&bf)[kEmbedGroup][NB][2], int k0) {
+    auto load_group = [&](v8s_e (&bf)[G][NB][2], int k0) {
 #pragma unroll
-        for (int u = 0; u < kEmbedGroup; ++u) {
+        for (int u = 0; u < G; ++u) {
             const int kc = min(k0 + u, nchunk - 1);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -894,7 +894,7 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
                 for (int j = 0; j < NB; ++j) bf[u][j][h] = *reinterpret_cast<const v8s_e*>(wp[j] + (size_t)kc * 1024 + h * 512);
         }
     };
-    auto compute_group = [&](const v8s_e (&bf)[kEmbedGroup][NB][2], int k0) {
+    auto compute_group = [&](const v8s_e (&bf)[G][NB][2], int k0) {
         if (k0 >= nchunk) return;  // wave-uniform
         v8s_e af[2][NQ][2];
 #pragma unroll
@@ -902,10 +902,10 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
 #pragma unroll
             for (int h = 0; h < 2; ++h) af[0][q][h] = *reinterpret_cast<const v8s_e*>(ap + q * 16 * SA + k0 * 64 + h * 8);
 #pragma unroll
-        for (int u = 0; u < kEmbedGroup; ++u) {
+        for (int u = 0; u < G; ++u) {
             const int kc = k0 + u;
             if (kc < nchunk) {  // wave-uniform
-                if (u + 1 < kEmbedGroup) {
+                if (u + 1 < G) {
                     const int kn = min(kc + 1, nchunk - 1);
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
@@ -925,10 +925,10 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
         }
     };
     // two register sets in ping-pong: the requests of the next group are in flight while this group's MFMAs run
-    v8s_e bfa[kEmbedGroup][NB][2], bfb[kEmbedGroup][NB][2];
+    v8s_e bfa[G][NB][2], bfb[G][NB][2];
     if (pre) {  // the first group was requested by the caller, under its staging round trip
 #pragma unroll
-        for (int u = 0; u < kEmbedGroup; ++u)
+        for (int u = 0; u < G; ++u)
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -936,13 +936,13 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
     } else {
         load_group(bfa, 0);
     }
-    for (int k0 = 0; k0 < nchunk; k0 += 2 * kEmbedGroup) {
-        load_group(bfb, k0 + kEmbedGroup);
+    for (int k0 = 0; k0 < nchunk; k0 += 2 * G) {
+        load_group(bfb, k0 + G);
         __builtin_amdgcn_sched_barrier(0);
         compute_group(bfa, k0);
-        load_group(bfa, k0 + 2 * kEmbedGroup);
+        load_group(bfa, k0 + 2 * G);
         __builtin_amdgcn_sched_barrier(0);
-        compute_group(bfb, k0 + kEmbedGroup);
+        compute_group(bfb, k0 + G);
     }
 }
 
@@ -1047,10 +1047,12 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
             for (int j = 0; j < NB; ++j)
                 wp[j] = wt + packed_frag_offset(min(nb0 + min(j, max(nbw - 1, 0)), kNBlocks - 1), D >> 6, 0, 0, lane);
             // the k-loop's first weight group is requested right behind the staging loads — one memory round trip for both instead of two
-            // (B=24: 11.6 -> 10.6 us warm, 14.7 -> 12.7 us with cold caches, profiles/r03_cold_probe.txt) — where the registers allow it: with
-            // three column blocks per wave the group's 48 VGPRs spill (B=64: 17.7 -> 20.4 us), so that instantiation requests it in the loop
-            constexpr bool kEarly = SPLIT && !FUSE && NB <= 2;
-            v8s_e pre[kEmbedGroup][NB][2];
+            // (B=24: 11.6 -> 10.6 us warm, 14.7 -> 12.7 us with cold caches, profiles/r03_cold_probe.txt)
+            constexpr bool kEarly = SPLIT && !FUSE;
+            // weight fragments requested together per k-loop group: two 64-wide chunks where a wave owns <= 2 column blocks; ONE with three
+            // blocks (the second chunk's 24 VGPRs per register set are what spilled: B=64 18.1 -> 16.9 us warm, 21.7 -> 19.7 us cold)
+            constexpr int GRP = (SPLIT && NB >= 3) ? 1 : kEmbedGroup;
+            v8s_e pre[GRP][NB][2];
 #pragma unroll
             for (int hf = 0; hf < kPhases; ++hf) {
                 uint4 st[kPer];
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                 }
                 if constexpr (kEarly) {
 #pragma unroll
-                    for (int u = 0; u < kEmbedGroup; ++u) {
+                    for (int u = 0; u < GRP; ++u) {
                         const int kc = min(u, (D >> 6) - 1);
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
@@ -1100,23 +1102,23 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                 constexpr int NBW = decltype(nbtag)::value;
                 const uint16_t* wq[NBW];
                 v4f_e ac[NBW][4];
-                v8s_e pq[kEmbedGroup][NBW][2];
+                v8s_e pq[GRP][NBW][2];
 #pragma unroll
                 for (int j = 0; j < NBW; ++j) {
                     wq[j] = wp[j];
                     if constexpr (kEarly) {
 #pragma unroll
-                        for (int u = 0; u < kEmbedGroup; ++u)
+                        for (int u = 0; u < GRP; ++u)
 #pragma unroll
                             for (int h = 0; h < 2; ++h) pq[u][j][h] = pre[u][j][h];
                     }
                 }
                 const v8s_e (*pp)[NBW][2] = kEarly ? pq : nullptr;
                 switch (nq) {
-                    case 1: embed_kloop<1, NBW>(ap, SA, wq, D >> 6, ac, pp); break;
-                    case 2: embed_kloop<2, NBW>(ap, SA, wq, D >> 6, ac, pp); break;
-                    case 3: embed_kloop<3, NBW>(ap, SA, wq, D >> 6, ac, pp); break;
-                    default: embed_kloop<4, NBW>(ap, SA, wq, D >> 6, ac, pp); break;
+                    case 1: embed_kloop<1, NBW, GRP>(ap, SA, wq, D >> 6, ac, pp); break;
+                    case 2: embed_kloop<2, NBW, GRP>(ap, SA, wq, D >> 6, ac, pp); break;
+                    case 3: embed_kloop<3, NBW, GRP>(ap, SA, wq, D >> 6, ac, pp); break;
+                    default: embed_kloop<4, NBW, GRP>(ap, SA, wq, D >> 6, ac, pp); break;
                 }
 #pragma unroll
                 for (int j = 0; j < NBW; ++j)
