@@ -354,10 +354,15 @@ def main():
             torch.cuda.empty_cache()
             rb = StepRunner(model, dev, b, patch_shape, rank, world)
             n_b = max(args.steps, 10) if b <= 8 else max(args.steps // 2, 6)
-            dt_b, enq_b, cpu_b, _ = timed_steps(rb, n_b, 3, world, dev)
+            dt_b, enq_b, cpu_b, recs_b = timed_steps(rb, n_b, 3, world, dev, profile=True)
+            hot_b = {}
+            for name, us in recs_b:  # the hand-written launches of the step at this batch, per dispatch (vaa_prof_*)
+                op = next((o for sub, o in KERNEL_OPS if sub in name), "other")
+                hot_b[op] = hot_b.get(op, 0.0) + us / n_b
             per_rank[f"bs{b}"] = {"ms_per_step": dt_b / n_b * 1e3, "images_per_s": b * n_b / dt_b, "images_per_s_vs_bs%d" % B: (b * n_b / dt_b) / ips64,
                                   "projected_speedup_%d_ranks_before_comm" % (B // b): (B // b) * (b * n_b / dt_b) / ips64,
-                                  "host_cpu_ms_per_step": cpu_b * 1e3, "host_enqueue_ms_per_step": enq_b * 1e3, "labelled_rows": rb.R}
+                                  "host_cpu_ms_per_step": cpu_b * 1e3, "host_enqueue_ms_per_step": enq_b * 1e3, "labelled_rows": rb.R,
+                                  "hot_path_us_per_step": sum(hot_b.values()), "hot_path_ops_us": hot_b}
             del rb
         per_rank["note"] = ("full-model step (same code path as the timed region) at the per-rank batches of the strong-scaling runs — global 64 over 2 / 4 / 8 "
                             "ranks -> bs = 32 / 16 / 8 (BASELINE config 3; config 4: 32 over 4 -> 8), config 5: 32 over 8 -> bs=4 — on this one GPU; projected "
