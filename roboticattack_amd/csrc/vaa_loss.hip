@@ -1302,11 +1302,16 @@ static unsigned* rows_bar_for(hipStream_t st, unsigned* gen) {
     static hipStream_t owner[kBarSlots];
     static unsigned gens[kBarSlots];
     static int used = 0;
-    static unsigned* base = nullptr;
+    static unsigned* base[16];  // the array's address on each device of the process
     std::lock_guard<std::mutex> lk(mu);
-    if (!base && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_rows_bar)) != hipSuccess) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
         (void)hipGetLastError();
-        base = nullptr;
+        return nullptr;
+    }
+    if (!base[dev] && hipGetSymbolAddress(reinterpret_cast<void**>(&base[dev]), HIP_SYMBOL(g_rows_bar)) != hipSuccess) {
+        (void)hipGetLastError();
+        base[dev] = nullptr;
         return nullptr;
     }
     int i = 0;
@@ -1318,7 +1323,7 @@ static unsigned* rows_bar_for(hipStream_t st, unsigned* gen) {
     }
     if (++gens[i] == 0u) ++gens[i];  // never 0: the words start zeroed
     *gen = gens[i];
-    return base + (size_t)kBarWords * i;
+    return base[dev] + (size_t)kBarWords * i;
 }
 
 // The one-pass form waits on a grid-wide hand-over, so every workgroup of the launch has to be resident at once: the grid is admitted
