@@ -265,6 +265,29 @@ class RopeAttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None
 
 
+class RopePackedAttentionFn(torch.autograd.Function):
+    """rope(q), rope(k) -> causal attention on a packed qkv [B,T,3,H,hd] — the output of ONE q/k/v GEMM over row-concatenated weights — with
+    the gradient coming back as one [B,T,3,H,hd] buffer (dq | dk | dv slices, rotary adjoint applied in the backward kernels' epilogues): the
+    layer's q/k/v data-gradient is then ONE GEMM with K = 3D as well. Same kernels as RopeAttentionFn, strided operands."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, causal, scale, cu_seqlens=None, max_len=0):
+        scale = float(qkv.shape[-1]) ** -0.5 if scale is None else float(scale)
+        qr, kr = _rope_launch(qkv[:, :, 0], cos, sin, 1.0), _rope_launch(qkv[:, :, 1], cos, sin, 1.0)
+        v = qkv[:, :, 2]
+        o, lse = attention_fwd(qr, kr, v, causal, scale, cu_seqlens, max_len)
+        ctx.save_for_backward(qr, kr, qkv, o, lse, cos, sin, *([cu_seqlens] if cu_seqlens is not None else []))
+        ctx.causal, ctx.scale, ctx.max_len = bool(causal), scale, int(max_len)
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        qr, kr, qkv, o, lse, cos, sin, *cu = ctx.saved_tensors
+        buf = attention_bwd(qr, kr, qkv[:, :, 2], o, lse, dout, ctx.causal, ctx.scale, packed_grad=True, rope=(cos, sin),
+                            cu_seqlens=cu[0] if cu else None, max_len=ctx.max_len)
+        return buf, None, None, None, None, None, None
+
+
 class PackedAttentionFn(torch.autograd.Function):
     """Same on a packed qkv [B,T,3,H,hd] (the ViT blocks' fused projection); the gradient comes back packed, in one buffer."""
 

@@ -210,6 +210,29 @@ class LlamaLayer(nn.Module):
             self._wt_cache[name] = hit
         return hit[2]
 
+    def _wcat(self, names):
+        """Row-concatenated frozen weights of several projections that share their input ([sum out, in]) and the transposed copy, built once."""
+        ws = [getattr(self, n).weight for n in names]
+        key = "+".join(names)
+        ver = tuple(w._version for w in ws)
+        hit = self._wt_cache.get(key)
+        if hit is None or hit[0] != ver or any(a is not b for a, b in zip(hit[1], ws)):
+            w = torch.cat([w.detach() for w in ws], 0).contiguous()
+            hit = (ver, ws, w, w.t().contiguous())
+            self._wt_cache[key] = hit
+        return hit[2], hit[3]
+
+    @staticmethod
+    def _fuse_qkv(rows: int) -> bool:
+        """q/k/v as ONE GEMM over the concatenated weights (and one data-gradient GEMM with K = 3D): at the per-rank batches of the
+        strong-scaling configs (M = B*T = 1,200 / 2,400 rows) three [M,4096]x[4096,4096] products run at 0.8-1.05 PFLOP/s, the single
+        [M,4096]x[4096,12288] at 1.3-1.36 (tools/gemm_overlap_probe.py); at M = 19,200 the two forms are level, so the separate, tuned GEMMs
+        stay. VAA_FUSED_QKV=1 / 0 forces it on / off."""
+        import os
+
+        mode = os.environ.get("VAA_FUSED_QKV", "auto")
+        return mode == "1" or (mode != "0" and rows < 8192)
+
     def _lin(self, x, names, res=None):
         from . import model_ops
 
@@ -231,11 +254,26 @@ class LlamaLayer(nn.Module):
             x, h = model_ops.ResidualRMSNormFn.apply(x, self.input_layernorm.weight, self.input_layernorm.eps)
         else:
             h = self.input_layernorm(x)
-        if tn:
+        if tn and hd in (64, 128) and self._fuse_qkv(B * T):
+            wqkv, wqkv_t = self._wcat(("q_proj", "k_proj", "v_proj"))
+            (qkv,) = model_ops.FrozenLinearsFn.apply(h, None, wqkv, wqkv_t)
+            qkv = qkv.view(B, T, 3, self.heads, hd)
+            if model_ops.attention_enabled(qkv[:, :, 0]):
+                a = model_ops.RopePackedAttentionFn.apply(qkv, *rope_tab, True, None, pack.cu if pack is not None else None,
+                                                          pack.max_len if pack is not None else 0).view(B, T, D)
+                q = k = v = None
+            else:
+                q, k, v = (qkv[:, :, z].reshape(B, T, D) for z in range(3))
+                a = None
+        elif tn:
             q, k, v = self._lin(h, ("q_proj", "k_proj", "v_proj"))
+            a = None
         else:
             q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
-        if fused and model_ops.attention_enabled(q.view(B, T, self.heads, hd)):
+            a = None
+        if a is not None:
+            pass
+        elif fused and model_ops.attention_enabled(q.view(B, T, self.heads, hd)):
             sh = (B, T, self.heads, hd)
             if hd in (64, 128):  # rotary adjoint of dq/dk runs in the attention backward's epilogues
                 a = model_ops.RopeAttentionFn.apply(q.view(sh), k.view(sh), v.view(sh), *rope_tab, True, None,

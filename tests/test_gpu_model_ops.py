@@ -344,3 +344,60 @@ def test_model_sequence_packing_matches_padded(monkeypatch):
     (r1, g1), (r2, g2) = res
     assert (r1 - r2).abs().max() <= 2e-2 * r2.abs().max() + 1e-3   # same math; GEMM row count differs -> different kernel selections
     assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.999
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hd", [64, 128])
+def test_rope_packed_attention_equals_separate_operands(hd):
+    """RopePackedAttentionFn on one [B,T,3,H,hd] buffer (a fused q/k/v projection's output) == RopeAttentionFn on three tensors, bit for bit:
+    output and the packed gradient's dq | dk | dv slices (same kernels, strided operands)."""
+    from roboticattack_amd import model_ops
+
+    B, T, H = 2, 75, 3
+    g = torch.Generator(device=DEV).manual_seed(hd + 1)
+    ang = torch.outer(torch.arange(T, device=DEV, dtype=torch.float32), 1.0 / (10000 ** (torch.arange(0, hd, 2, device=DEV, dtype=torch.float32) / hd)))
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    qkv0 = torch.randn(B, T, 3, H, hd, device=DEV, generator=g).to(torch.bfloat16)
+    go = torch.randn(B, T, H, hd, device=DEV, generator=g).to(torch.bfloat16)
+    qkv = qkv0.clone().requires_grad_(True)
+    o1 = model_ops.RopePackedAttentionFn.apply(qkv, cos, sin, True, None)
+    o1.backward(go)
+    q, k, v = [qkv0[:, :, z].contiguous().requires_grad_(True) for z in range(3)]
+    o2 = model_ops.RopeAttentionFn.apply(q, k, v, cos, sin, True, None)
+    o2.backward(go)
+    assert torch.equal(o1, o2)
+    for z, t in enumerate((q, k, v)):
+        assert torch.equal(qkv.grad[:, :, z], t.grad)
+
+
+@pytest.mark.gpu
+def test_model_fused_qkv_matches_separate_projections(monkeypatch):
+    """q/k/v as ONE GEMM over the concatenated weights (the default below 8,192 rows) against three GEMMs: same logits rows and pixel gradient up
+    to GEMM summation order; the concatenated copy follows a weight update."""
+    from roboticattack_amd import synthetic
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+
+    cfg = OpenVLACfg(dino=VitCfg(32, 3, 2, 64, 5, True, True), siglip=VitCfg(48, 3, 2, 80, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)  # head dim 128
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=4)
+    ids, labels, _ = synthetic.synth_text_batch(6, 2, 18, 22)
+    labels = mask_labels(labels, [0]).to(DEV)
+    pix0 = torch.randn(2, 6, 224, 224, device=DEV).to(torch.bfloat16)
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VAA_FUSED_QKV", mode)
+        pix = pix0.clone().requires_grad_(True)
+        rows = m.forward_rows(ids.to(DEV), pix, labels)
+        rows.float().square().mean().backward()
+        outs.append((rows.detach().float(), pix.grad.detach().float()))
+    (r1, g1), (r2, g2) = outs
+    assert (r1 - r2).abs().max() <= 1e-2 * r2.abs().max() + 1e-4
+    assert torch.nn.functional.cosine_similarity(g1.flatten(), g2.flatten(), dim=0) > 0.999
+    monkeypatch.setenv("VAA_FUSED_QKV", "1")
+    lyr = m.layers[0]
+    w_old, _ = lyr._wcat(("q_proj", "k_proj", "v_proj"))
+    with torch.no_grad():
+        lyr.k_proj.weight.mul_(2.0)
+    w_new, wt_new = lyr._wcat(("q_proj", "k_proj", "v_proj"))
+    assert w_new is not w_old and torch.equal(w_new[256:512], lyr.k_proj.weight) and torch.equal(wt_new, w_new.t())
