@@ -558,7 +558,8 @@ def build_openvla(cfg: OpenVLACfg | None = None, device="cuda", dtype=torch.bflo
 def load_hf_openvla(model: OpenVLAShaped, ckpt_dir: str) -> OpenVLAShaped:
     """Map a local HF `openvla/openvla-7b` safetensors checkpoint onto this module tree (names follow
     modeling_prismatic.py: vision_backbone.{featurizer,fused_featurizer}.*, projector.fc{1,2,3}, language_model.model.*).
-    Untested in this image (no weights, no network)."""
+    The name mapping is exercised on a synthetic checkpoint written with the HF module names (tests/test_host_logic.py); the released
+    weights themselves are not in this image (no network), so no numerical check against them exists."""
     import glob
     import os
 
