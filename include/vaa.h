@@ -216,9 +216,8 @@ int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int
  *             need the folded scalars for their gradient and must use vaa_loss_rows_fwd_bwd). ws as in vaa_loss_rows_fwd_bwd.
  *   vaa_step_epilogue   : ONE launch between the backward and the gradient exchange — replaces K2's final reduce launch, K3's finishing
  *             launch and the packing of the DDP message (dist.PatchGradSync):
- *               msg[0..n)    = sum of K2's `nparts` partial tiles [nparts][n] (n = 3*ph*pw; part_layout = 0), the fixed order of
- *                              vaa_patch_grad_gather: bitwise the gradient that call would have written — or (part_layout = nch > 0) of the channel
- *                              planes [nparts = 2 B][nch][2][n/3] vaa_patch_embed_grad_fused left
+ *               msg[0..n)    = sum of K2's `nparts` partial tiles [nparts][n] (n = 3*ph*pw), the fixed order of
+ *                              vaa_patch_grad_gather: bitwise the gradient that call would have written
  *               rowmap != NULL: the statistics in loss_ws (left by vaa_loss_rows_stats with the same R, B, L, V, mode, params) are folded:
  *                              scalars[8], pred_tokens, pred_full_tokens as vaa_loss_rows_fwd_bwd writes them
  *               rowmap == NULL: scalars is an INPUT (already final)
@@ -226,14 +225,14 @@ int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* rowmap, int
  */
 int vaa_loss_rows_stats(const void* logits, int dtype, const void* rowmap, int R, int B, int L, int V, int mode, const float* params, void* grad,
                         int grad_kind, void* ws, size_t ws_bytes, void* stream);
-int vaa_step_epilogue(const float* partials, int nparts, int n, int part_layout, const void* rowmap, int R, int B, int L, int V, int mode,
+int vaa_step_epilogue(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
                       const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
                       int32_t* pred_full_tokens, float* msg, void* stream);
 /* Single-GPU form (UADA.py:148-157: nothing sits between the gradient and optimizer.step()): the epilogue also applies K4 — vaa_patch_update
  * with grad_scale = 1 and no L1 clip — to every gradient element as it is produced (same per-element arithmetic: patch / m / v get the
  * bits the separate launch would write). stat_part dev f64 [ceil(n/64)][2] or NULL: per-block {sum |g|, sum g}; their sums give K4's
  * logged {sum|g|, mean g = sum g / n}. */
-int vaa_step_epilogue_update(const float* partials, int nparts, int n, int part_layout, const void* rowmap, int R, int B, int L, int V, int mode,
+int vaa_step_epilogue_update(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
                              const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
                              int32_t* pred_full_tokens, float* msg, float* patch, float* m, float* v, int opt_mode, float lr, float beta1,
                              float beta2, float eps, int step, double* stat_part, void* stream);
@@ -264,29 +263,6 @@ int vaa_patch_embed_grad_gather_tiles(const uint16_t* dy0, int D0, const uint16_
                                       const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
                                       const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
                                       int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream);
-/* K2' in ONE launch (what the fused data-parallel step runs): the gather happens inside the tile kernel, from the registers its k-loop leaves —
- * no tile-gradient buffer, no second launch. The gather is linear in the two towers, so every workgroup (image, tower, column range) scatters
- * its own tower's contribution of its own columns into an LDS accumulator and leaves two channel planes;
- *   vaa_patch_embed_grad_fused_layout(B, ph, pw, D0, D1) = nch > 0 (column ranges per image and tower) when the form applies — B <= 64, a
- *   tile list of <= 64 tiles (patches up to ~60 px), towers that fit the LDS-resident tile kernel — else 0 (use ..._gather_tiles);
- *   ws >= 2*B*nch*2*ph*pw*4 bytes receives the planes [2 B][nch][2][ph*pw]; gpatch != NULL adds them here (a second launch), NULL leaves
- *   that to vaa_step_epilogue[_update](nparts = 2 B, part_layout = nch). Differs from the two-launch form by the fp32 rounding of
- *   fl(t0 s0 w) + fl(t1 s1 w) against fl((t0 s0 + t1 s1) w): <= 1e-6 of the gradient scale. */
-int vaa_patch_embed_grad_fused_layout(int B, int ph, int pw, int D0, int D1);
-int vaa_patch_embed_grad_fused(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1, const int32_t* xy,
-                               const float* theta, const uint16_t* keep_tiles, const uint32_t* tile_flags, int B, int ph, int pw, int geometry,
-                               int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream);
-/* EXPERIMENT (records): vaa_patch_apply_fwd_tiles_rec additionally writes records dev [B,256,196] x 16 B = {x0 | y0 << 9 | kept << 18, w, n, 0}
- * for every pixel of the tiles its footprint role owns (the exact sample position K1 computed); vaa_patch_embed_grad_gather_tiles_rec walks
- * the flagged tiles and reads them instead of rebuilding row tables and the coordinate chain. Same results bit for bit; kept out of the
- * attack loops (measured, not adopted). */
-int vaa_patch_apply_fwd_tiles_rec(const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta, int B,
-                                  int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6, uint16_t* out0,
-                                  uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* records, void* stream);
-int vaa_patch_embed_grad_gather_tiles_rec(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
-                                          const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
-                                          const uint32_t* tile_flags, const void* records, int B, int ph, int pw, int geometry, int mask_mode,
-                                          const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream);
 /* the same with one patch per image (resize_patch=True; packed / pdesc / gpacked as in vaa_patch_grad_gather_multi):
  * ws >= vaa_patch_embed_grad_multi_ws_bytes(B); the resize adjoint then folds gpacked into the base patch's gradient */
 size_t vaa_patch_embed_grad_multi_ws_bytes(int B);

@@ -51,11 +51,7 @@ EXPORTS = (
     "vaa_loss_rows_fwd_bwd",
     "vaa_patch_apply_fwd_tiles",
     "vaa_patch_grad_partials",
-    "vaa_patch_embed_grad_fused_layout",
-    "vaa_patch_embed_grad_fused",
     "vaa_patch_embed_grad_gather_multi_tiles",
-    "vaa_patch_apply_fwd_tiles_rec",
-    "vaa_patch_embed_grad_gather_tiles_rec",
     "vaa_patch_embed_grad_gather_tiles",
     "vaa_loss_rows_stats",
     "vaa_step_epilogue",
@@ -179,14 +175,6 @@ def lib() -> C.CDLL:
     L.vaa_patch_apply_eval.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.vaa_patch_apply_fwd_tiles.restype = i32
     L.vaa_patch_apply_fwd_tiles.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, vp, vp, vp]
-    L.vaa_patch_apply_fwd_tiles_rec.restype = i32
-    L.vaa_patch_apply_fwd_tiles_rec.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, vp, vp, vp, vp]
-    L.vaa_patch_embed_grad_gather_tiles_rec.restype = i32
-    L.vaa_patch_embed_grad_gather_tiles_rec.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
-    L.vaa_patch_embed_grad_fused_layout.restype = i32
-    L.vaa_patch_embed_grad_fused_layout.argtypes = [i32, i32, i32, i32, i32]
-    L.vaa_patch_embed_grad_fused.restype = i32
-    L.vaa_patch_embed_grad_fused.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
     L.vaa_patch_embed_grad_gather_multi_tiles.restype = i32
     L.vaa_patch_embed_grad_gather_multi_tiles.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
     L.vaa_patch_grad_partials.restype = i32
@@ -196,9 +184,9 @@ def lib() -> C.CDLL:
     L.vaa_loss_rows_stats.restype = i32
     L.vaa_loss_rows_stats.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, i32, vp, sz, vp]
     L.vaa_step_epilogue.restype = i32
-    L.vaa_step_epilogue.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp]
+    L.vaa_step_epilogue.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp]
     L.vaa_step_epilogue_update.restype = i32
-    L.vaa_step_epilogue_update.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32,
+    L.vaa_step_epilogue_update.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32,
                                            i32, vp, vp]
     L.vaa_prof_start.restype = i32
     L.vaa_prof_start.argtypes = [i32]

@@ -131,7 +131,7 @@ class AttackBase:
         ws = ops.loss_rows_stats(logits, self._row_map, ops.LOSS_UADA_DDP, w, grad=gsl)      # K3: statistics + d loss / d action logits
         h.backward(gsl @ W[ops.ACTION_LO : ops.ACTION_LO + ops.N_ACTION])                     # head backward over 256 columns, model backward, K2'
         _, pred_full = ops.step_epilogue(sink["partials"], msg, scalars, rowmap=self._row_map, R=int(logits.shape[0]), V=int(W.shape[0]),
-                                         mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws, part_layout=sink.get("part_layout", 0),
+                                         mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws,
                                          update=optimizer.fused_update_args() if optimizer is not None else None)
         return pred_full
 
@@ -152,7 +152,7 @@ class AttackBase:
         msg = getattr(self, "_epi_msg", None)
         if msg is None or msg.numel() != n + 4 or msg.device != patch.device:
             msg = self._epi_msg = torch.zeros(n + 4, dtype=torch.float32, device=patch.device)
-        ops.step_epilogue(sink["partials"], msg, scalars, update=optimizer.fused_update_args(), part_layout=sink.get("part_layout", 0))
+        ops.step_epilogue(sink["partials"], msg, scalars, update=optimizer.fused_update_args())
 
     # ---- metrics (host, once per outer iteration) ----
     def decode_pred_gt(self, pred: torch.Tensor, labels: torch.Tensor):

@@ -225,52 +225,6 @@ __device__ __forceinline__ bool partial_reduce_block(const float* __restrict__ p
     return false;
 }
 
-// The same for the channel planes the fused tile kernel leaves: P[p][w][s][t] (p < nparts = 2 B, w < nch column ranges, s < 2 slots, t < plane);
-// plane (w, s) holds channel cbase(w) + s with cbase(w) = first column of range w / 196 (ranges of ceil(37 / nch) 16-column blocks). Element e of
-// the gradient (channel c = e / plane) is the sum over p and over the (at most two) ranges whose slot c - cbase(w) is 0 or 1, in a fixed order.
-__device__ __forceinline__ bool plane_reduce_block(const float* __restrict__ P, float* __restrict__ out, int plane, int nparts, int nch, int blk,
-                                                   double (*sl)[16][4], int& oe, float& ov) {
-    const int el = threadIdx.x & 15, s = threadIdx.x >> 4;
-    const int n = 3 * plane, e = (blk * 16 + el) * 4;
-    const int per16 = ((37 + nch - 1) / nch) * 16;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const bool quad = (plane & 3) == 0 && e + 3 < n;  // four consecutive elements of one channel
-    for (int p = s; p < nparts; p += 16)
-        for (int w = 0; w < nch; ++w) {
-            const int cb = (w * per16) / 196;
-            if (quad) {
-                const int c = e / plane, slot = c - cb;
-                if (slot == 0 || slot == 1) {
-                    const float4 v = *reinterpret_cast<const float4*>(P + (((size_t)p * nch + w) * 2 + slot) * plane + (e - c * plane));
-                    acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
-                }
-            } else {
-#pragma unroll
-                for (int z = 0; z < 4; ++z)
-                    if (e + z < n) {
-                        const int c = (e + z) / plane, slot = c - cb;
-                        if (slot == 0 || slot == 1) acc[z] += (double)P[(((size_t)p * nch + w) * 2 + slot) * plane + (e + z - c * plane)];
-                    }
-            }
-        }
-#pragma unroll
-    for (int z = 0; z < 4; ++z) sl[s][el][z] = acc[z];
-    __syncthreads();
-    if (s < 4) {
-        const int z = s;
-        if (e + z < n) {
-            double t = 0.0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t += sl[q][el][z];
-            out[e + z] = (float)t;
-            oe = e + z;
-            ov = (float)t;
-            return true;
-        }
-    }
-    return false;
-}
-
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -1104,7 +1104,6 @@ struct EpiArgs {
     float* msg;
     const float* scalars_in;  // fold == 0: final scalars of an earlier vaa_loss_rows_fwd_bwd, only copied into the message
     int n, nparts, nred, fold;
-    int part_layout;          // 0: partial tiles [nparts][n]; nch > 0: the fused tile kernel's channel planes [nparts][nch][2][n/3]
     int fuse_update;          // single-GPU step: K4's per-element update applied right where the gradient element is produced
     UpdArgs upd;
     double* stat_part;        // fuse_update: [nred][2] = {sum |g|, sum g} over the block's 64 elements (the caller adds them for the log)
@@ -1115,8 +1114,7 @@ __global__ __launch_bounds__(256) void step_epilogue_kernel(EpiArgs e, RowsArgs 
     if ((int)blockIdx.x < e.nred) {
         int oe = 0;
         float g = 0.0f;
-        const bool own = e.part_layout ? plane_reduce_block(e.partials, e.msg, e.n / 3, e.nparts, e.part_layout, blockIdx.x, sl, oe, g)
-                                       : partial_reduce_block(e.partials, e.msg, e.n, e.nparts, blockIdx.x, sl, oe, g);
+        const bool own = partial_reduce_block(e.partials, e.msg, e.n, e.nparts, blockIdx.x, sl, oe, g);
         if (!e.fuse_update) return;
         // K4 on the element this thread just produced (grad_scale = 1, no L1 clip: vaa_step_epilogue_update checks): same arithmetic, same bits
         if (own) {
@@ -1486,15 +1484,14 @@ extern "C" int vaa_loss_rows_stats(const void* logits, int dtype, const void* ro
 
 namespace vaa {
 
-static int step_epilogue_impl(const char* who, const float* partials, int nparts, int n, int part_layout, const void* rowmap, int R, int B, int L, int V, int mode,
+static int step_epilogue_impl(const char* who, const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
                               const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
                               int32_t* pred_full_tokens, float* msg, const UpdArgs* upd, double* stat_part, void* stream) {
-    if (!partials || !msg || !scalars || nparts <= 0 || n <= 0 || part_layout < 0 || part_layout > 37 || (part_layout && n % 3)) {
-        set_error("%s: bad arguments (nparts=%d n=%d part_layout=%d)", who, nparts, n, part_layout);
+    if (!partials || !msg || !scalars || nparts <= 0 || n <= 0) {
+        set_error("%s: bad arguments (nparts=%d n=%d)", who, nparts, n);
         return VAA_E_INVALID;
     }
     EpiArgs e = {};
-    e.part_layout = part_layout;
     e.partials = partials; e.msg = msg; e.scalars_in = scalars; e.n = n; e.nparts = nparts; e.nred = (n + 63) / 64; e.fold = rowmap ? 1 : 0;
     e.fuse_update = upd ? 1 : 0;
     if (upd) e.upd = *upd;
@@ -1511,17 +1508,17 @@ static int step_epilogue_impl(const char* who, const float* partials, int nparts
 
 }  // namespace vaa
 
-extern "C" int vaa_step_epilogue(const float* partials, int nparts, int n, int part_layout, const void* rowmap, int R, int B, int L, int V, int mode,
+extern "C" int vaa_step_epilogue(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
                                  const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
                                  int32_t* pred_full_tokens, float* msg, void* stream) {
-    return vaa::step_epilogue_impl("vaa_step_epilogue", partials, nparts, n, part_layout, rowmap, R, B, L, V, mode, params, loss_ws, loss_ws_bytes, scalars, pred_tokens,
+    return vaa::step_epilogue_impl("vaa_step_epilogue", partials, nparts, n, rowmap, R, B, L, V, mode, params, loss_ws, loss_ws_bytes, scalars, pred_tokens,
                                    pred_full_tokens, msg, nullptr, nullptr, stream);
 }
 
 // The single-GPU step has no exchange between the gradient and the update: K4 (vaa_patch_update without L1 clip, grad_scale = 1) is applied by
 // the epilogue on every gradient element as it is produced — same per-element arithmetic, same bits in patch / m / v. The logged statistics come
 // back as per-block partial sums stat_part [ceil(n/64)][2] = {sum |g|, sum g} (fp64) for the caller to add.
-extern "C" int vaa_step_epilogue_update(const float* partials, int nparts, int n, int part_layout, const void* rowmap, int R, int B, int L, int V, int mode,
+extern "C" int vaa_step_epilogue_update(const float* partials, int nparts, int n, const void* rowmap, int R, int B, int L, int V, int mode,
                                         const float* params, const void* loss_ws, size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens,
                                         int32_t* pred_full_tokens, float* msg, float* patch, float* m, float* v, int opt_mode, float lr, float beta1,
                                         float beta2, float eps, int step, double* stat_part, void* stream) {
@@ -1542,6 +1539,6 @@ extern "C" int vaa_step_epilogue_update(const float* partials, int nparts, int n
     u.one_m_b1 = (float)(1.0 - b1);
     u.one_m_b2 = (float)(1.0 - b2);
     u.step_size = (opt_mode == VAA_OPT_ADAMW_HF) ? (float)((double)lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step))) : 0.0f;
-    return step_epilogue_impl(who, partials, nparts, n, part_layout, rowmap, R, B, L, V, mode, params, loss_ws, loss_ws_bytes, scalars, pred_tokens,
+    return step_epilogue_impl(who, partials, nparts, n, rowmap, R, B, L, V, mode, params, loss_ws, loss_ws_bytes, scalars, pred_tokens,
                               pred_full_tokens, msg, &u, stat_part, stream);
 }

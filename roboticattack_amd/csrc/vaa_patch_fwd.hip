@@ -344,7 +344,6 @@ struct TileOut {
     uint16_t* out1;
     uint16_t* keep_t;
     uint32_t* flags;  // byte w of word t: wave w of the footprint workgroup saw a kept pixel in its rows of tile t
-    uint4* rec;       // experiment: [B,256,196] per-pixel records {x0 | y0 << 9 | kept << 18, w, n, 0} of the footprint tiles (nullptr: none)
 };
 
 constexpr int kTS = 14, kTPS = 16, kTElems = 3 * kTS * kTS;  // tile side, tiles per side, elements per tile and tower (588)
@@ -508,10 +507,6 @@ __global__ __launch_bounds__(kFwdThreads) void patch_apply_tiles_kernel(const Fw
                 o.out0[e + c * 196] = (uint16_t)(L[c] & 0xffffu);
                 o.out1[e + c * 196] = (uint16_t)(L[c] >> 16);
             }
-            if (o.rec)
-                o.rec[((size_t)b * 256 + t) * (kTS * kTS) + y * kTS + x] =
-                    make_uint4((uint32_t)rx0 | ((uint32_t)ry0 << 9) | ((kept[0] ? 1u : 0u) | (kept[1] ? 2u : 0u) | (kept[2] ? 4u : 0u)) << 18,
-                               __float_as_uint(rwf), __float_as_uint(rnf), 0u);
         }
         unsigned long long many = 0ull;
 #pragma unroll
@@ -594,7 +589,7 @@ extern "C" int vaa_patch_apply_fwd_multi(const uint8_t* img_u8, const float* pac
 namespace vaa {
 static int patch_apply_tiles_impl(const char* who, const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta,
                                   int B, int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6, uint16_t* out0,
-                                  uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, uint4* records, void* stream) {
+                                  uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* stream) {
     if (B == 0) return VAA_OK;
     if (!img_u8 || !patch || !xy || !out0 || !out1 || !mean6 || !std6 || (geometry && !theta)) {
         set_error("%s: null pointer argument", who);
@@ -617,7 +612,7 @@ static int patch_apply_tiles_impl(const char* who, const uint8_t* img_u8, const 
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) { a.nrm.mean[q] = mean6[q]; a.nrm.stdv[q] = std6[q]; }
     TileOut o;
-    o.out0 = out0; o.out1 = out1; o.keep_t = keep_tiles; o.flags = tile_flags; o.rec = records;
+    o.out0 = out0; o.out1 = out1; o.keep_t = keep_tiles; o.flags = tile_flags;
     // footprint workgroups per image: each pays a ~2 us prologue (LUT, 224 row spans, tile list) before its first tile, so FEWER, longer-lived
     // workgroups win here — measured at bs=64 with 1024 / 512 / 256 / 128 in total: 18.7 / 16.2 / 18.6 / 25.8 us (a 50x50 footprint meets ~45
     // tiles: ~6 per workgroup at 8 per image); small batches keep 16 per image
@@ -633,13 +628,5 @@ extern "C" int vaa_patch_apply_fwd_tiles(const uint8_t* img_u8, const float* pat
                                          int B, int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
                                          uint16_t* out0, uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* stream) {
     return vaa::patch_apply_tiles_impl("vaa_patch_apply_fwd_tiles", img_u8, patch, pdesc, xy, theta, B, ph, pw, geometry, mask_mode, mean6, std6, out0, out1,
-                                       keep_tiles, tile_flags, nullptr, stream);
-}
-
-// EXPERIMENT: also emits per-pixel records for the footprint tiles, records dev [B,256,196] x 16 B.
-extern "C" int vaa_patch_apply_fwd_tiles_rec(const uint8_t* img_u8, const float* patch, const int32_t* pdesc, const int32_t* xy, const float* theta,
-                                             int B, int ph, int pw, int geometry, int mask_mode, const float* mean6, const float* std6,
-                                             uint16_t* out0, uint16_t* out1, uint16_t* keep_tiles, uint32_t* tile_flags, void* records, void* stream) {
-    return vaa::patch_apply_tiles_impl("vaa_patch_apply_fwd_tiles_rec", img_u8, patch, pdesc, xy, theta, B, ph, pw, geometry, mask_mode, mean6, std6, out0,
-                                       out1, keep_tiles, tile_flags, reinterpret_cast<uint4*>(records), stream);
+                                       keep_tiles, tile_flags, stream);
 }

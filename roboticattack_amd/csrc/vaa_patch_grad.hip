@@ -51,10 +51,6 @@ struct GradArgs {
     const float* geff;
     const float* geff2;      // non-null: the tile kernel ran one tower per workgroup and `geff` holds {tower 0, tower 1} PAIRS per element: the gather adds the two
     const uint16_t* keep_t;  // TILED only: K1's tile-major keep words [B,3,256,14] (vaa_patch_apply_fwd_tiles) instead of `keep`
-    // REC (experiment): K1's per-pixel records [B,256,196] {x0 | y0 << 9 | kept << 18, w, n, 0} + its tile flag words [B,256]: the footprint is
-    // walked tile by tile from the flags and the exact sample position comes from the record instead of the row tables + coordinate chain
-    const uint4* rec;
-    const uint32_t* tflags;
 };
 
 constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTilePx;  // ViT patch-embed tiling of the 224x224 frame
@@ -86,14 +82,13 @@ __device__ __forceinline__ int round_half_up(float x) {
 // segments starting at an even column; one half-wave owns one (row, segment) slot at a time and a lane owns TWO adjacent
 // pixels of it (one 4-byte load per gradient plane, one keep byte), so a lane needs ONE LDS read (packed {jlo,len} of its
 // row) to know its pixels. Slots are dealt round-robin to the half-waves of the workgroup-row.
-template <int NCH, bool TILED, bool MULTI, bool HASK, int THREADS, int K, bool REC = false>
+template <int NCH, bool TILED, bool MULTI, bool HASK, int THREADS, int K>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void patch_grad_scatter_kernel(GradArgs a, int gx) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned long long* tile = reinterpret_cast<unsigned long long*>(smem_raw);  // [band_rows*pw][NCH] (channels interleaved)
     __shared__ float bgrid[VAA_IMG];
     __shared__ uint32_t row_word[kImgsPerPass][VAA_IMG];  // (jlo << 16) | len, jlo even
     __shared__ int row_min[kImgsPerPass], row_max[kImgsPerPass], len_max[kImgsPerPass];
-    __shared__ int tile_cnt[kImgsPerPass][4];  // REC: flagged tiles per (image, wave of 64 tiles)
     __shared__ uint32_t round_max[3];  // max |G| bits of a round, three slots in rotation (see the reset below)
     __shared__ int nonfinite;
     constexpr int HWS = THREADS / 32;  // half-waves per workgroup
@@ -171,27 +166,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
         __syncthreads();  // previous pass done with the tables (also orders the initial zero-fill)
         if (tid < kImgsPerPass) { row_min[tid] = VAA_IMG; row_max[tid] = -1; len_max[tid] = 0; }
         __syncthreads();
-        if constexpr (REC) {
-            // ---- tile list of each image from K1's flag words: row_word[q][slot] = tile id, len_max[q] = count ----
-            for (int r0 = 0; r0 < nimg * 256; r0 += THREADS) {
-                const int r = r0 + tid;
-                const int q = r >> 8, t = r & 255;
-                const bool flag = q < nimg && a.tflags[(size_t)(b0 + q * gx) * 256 + t] != 0u;
-                const unsigned long long m = __ballot(flag);
-                if ((tid & 63) == 0 && q < nimg) tile_cnt[q][t >> 6] = __popcll(m);
-                __syncthreads();
-                if (q < nimg) {
-                    int base = 0, tot = 0;
-                    for (int w = 0; w < 4; ++w) { if (w < (t >> 6)) base += tile_cnt[q][w]; tot += tile_cnt[q][w]; }
-                    if (flag) {
-                        const int slot = base + __popcll(m & ((1ull << (tid & 63)) - 1ull));
-                        if (slot < VAA_IMG) row_word[q][slot] = (uint32_t)t;
-                    }
-                    if (t == 0) { len_max[q] = min(tot, VAA_IMG); row_min[q] = 0; row_max[q] = tot > 0 ? 0 : -1; }
-                }
-                __syncthreads();
-            }
-        } else {
+        {
         // ---- per-row column bounds of each footprint (conservative) ----
             // threads cover images x 256 row slots (rows 224..255 idle), so a wave never straddles two images and the extent
             // reduction is one shuffle tree + 3 LDS atomics per wave instead of 3 same-address atomics per row
@@ -251,9 +226,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
             const int plane = ph * pw;
             const int v_hi = min(ph, v_lo + a.band_rows);
             if (nrows > 0 && v_lo < ph) {
-                const int nseg = REC ? 4 : (len_max[q] + 63) >> 6;          // <= 4 (REC: four 4-row groups per tile)
+                const int nseg = (len_max[q] + 63) >> 6;                   // <= 4
                 const uint32_t inv_nseg = (65536u + nseg - 1) / nseg;      // exact floor(s/nseg) for s < 9362
-                const int nslots = REC ? len_max[q] * 4 : nrows * nseg;
+                const int nslots = nrows * nseg;
                 const int px = a.xy[2 * b], py = a.xy[2 * b + 1];          // workgroup-uniform -> scalar loads
                 float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
                 if (a.geometry) {
@@ -291,36 +266,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                         const int r = (int)(((uint32_t)sc * inv_nseg) >> 16);
                         const int ks = sc - r * nseg;
                         int i, j0, off, len;
-                        uint4 rc2[2];
-                        if constexpr (REC) {  // slot = (tile r of the list, 4-row group ks): a half-wave's first 28 lanes = 4 rows x 7 pixel pairs
-                            const int tl = (int)row_word[q][r];
-                            const int yy = 4 * ks + hl / 7, xp = hl - (hl / 7) * 7;
-                            const bool ok = hl < 28 && yy < kTilePx;
-                            i = (tl >> 4) * kTilePx + (ok ? yy : 0);
-                            j0 = (tl & 15) * kTilePx + (ok ? 2 * xp : 0);
-                            off = 0; len = ok ? 2 : 0;
-                            const uint4* rp = a.rec + ((size_t)b * 256 + tl) * (kTilePx * kTilePx) + (i - (tl >> 4) * kTilePx) * kTilePx + (j0 - (tl & 15) * kTilePx);
-                            rc2[0] = rp[0]; rc2[1] = rp[1];
-                        } else {
-                            i = rmin + r;
-                            const uint32_t w = row_word[q][i];
-                            off = (ks << 6) + 2 * hl; len = (int)(w & 0xffffu);
-                            j0 = min((int)(w >> 16) + off, VAA_IMG - 2);  // even
-                        }
+                        i = rmin + r;
+                        const uint32_t w = row_word[q][i];
+                        off = (ks << 6) + 2 * hl; len = (int)(w & 0xffffu);
+                        j0 = min((int)(w >> 16) + off, VAA_IMG - 2);  // even
                         const bool lane_in = sidx < nslots && off < len;
                         const int pix0 = i * VAA_IMG + j0;
-                        uint32_t f = (ktiled || REC) ? 0u : (uint32_t)(pix0 & 7) << 16;  // tile-major keep words are shifted to bit 0 when they are loaded
-                        uint32_t reckept = 0u;
+                        uint32_t f = ktiled ? 0u : (uint32_t)(pix0 & 7) << 16;  // tile-major keep words are shifted to bit 0 when they are loaded
 #pragma unroll
                         for (int p = 0; p < 2; ++p) {
                             const int j = j0 + p;
                             int x0 = j, y0 = i;
                             float wf = 0.0f, nf = 0.0f;
-                            if constexpr (REC) {  // K1's own sample position of this pixel: no coordinate chain here
-                                x0 = (int)(rc2[p].x & 511u); y0 = (int)((rc2[p].x >> 9) & 511u);
-                                wf = __uint_as_float(rc2[p].y); nf = __uint_as_float(rc2[p].z);
-                                reckept |= ((rc2[p].x >> 18) & 7u) << (4 * p);
-                            } else if (a.geometry) sample_pos_frac(bgrid[j], bgrid[i], th, x0, y0, wf, nf);
+                            if (a.geometry) sample_pos_frac(bgrid[j], bgrid[i], th, x0, y0, wf, nf);
                             fw[k][p] = wf; fn[k][p] = nf;
                             const int u0 = x0 - px, v0 = y0 - py;
                             // corners off the patch, off this workgroup's row band or off the frame get weight 0; a pixel without a live corner is skipped
@@ -368,9 +326,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             for (int cc = 0; cc < NCH; ++cc) {
                                 const int c = c_base + cc;
 #ifndef VAA_K2_ABLATE_NO_LOADS
-                                if (REC) {
-                                    kb[k][cc] = ((reckept >> c) & 1u) | (((reckept >> (4 + c)) & 1u) << 1);  // the records carry the kept bits
-                                } else if (HASK) {
+                                if (HASK) {
                                     if (ktiled) {  // word (c, tile, y), bit x: a lane's pixel pair never straddles a tile (14 is even)
                                         const int ty = i / kTilePx, tx = j0 / kTilePx;
                                         kb[k][cc] = (uint32_t)ktimg[((size_t)c * 256 + ty * kTilesPerSide + tx) * kTilePx + (i - ty * kTilePx)] >> (j0 - tx * kTilePx);
@@ -514,15 +470,6 @@ int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts
     return check_launch(who);
 }
 
-// gpatch[e] = sum over the channel planes the fused tile kernel left (plane_reduce_block, vaa_common.h), fixed order
-__global__ __launch_bounds__(256) void patch_grad_reduce_planes_kernel(const float* __restrict__ planes, float* __restrict__ gpatch, int plane, int nparts,
-                                                                        int nch) {
-    __shared__ double sl[16][16][4];
-    int oe;
-    float ov;
-    (void)plane_reduce_block(planes, gpatch, plane, nparts, nch, blockIdx.x, sl, oe, ov);
-}
-
 struct GradSched {
     int gx, bands;
 };
@@ -573,8 +520,7 @@ static int launch_scatter_reduce(const GradArgs& a0, float* gpatch, hipStream_t 
         a.band_rows = (ph + gs.bands - 1) / gs.bands;
         const int nb = (ph + a.band_rows - 1) / a.band_rows;
         const size_t lds = 3 * (size_t)a.band_rows * pw * sizeof(long long);
-        if (TILED && a.rec) VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, true, 512, 3, TILED>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
-        else if (a.keep) VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, true, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
+        if (a.keep) VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, true, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
         else VAA_LAUNCH((patch_grad_scatter_kernel<3, TILED, false, false, 512, 3>), dim3(G, 1, nb), dim3(512), lds, st, a, gs.gx);
     } else {  // one channel per workgroup (grid.y), row bands (grid.z) when even one plane exceeds the LDS (> 135x135)
         a.band_rows = band_rows_for(ph, pw, 3 * G);
@@ -665,7 +611,7 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode; a.band_rows = ph;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr; a.rec = nullptr; a.tflags = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
     return launch_scatter_reduce<false>(a, gpatch, st, "vaa_patch_grad_gather");
 }
 
@@ -696,7 +642,7 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.g = gout_bf16; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr; a.rec = nullptr; a.tflags = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
     return launch_scatter_multi<false>(a, max_h, max_w, (hipStream_t)stream, "vaa_patch_grad_gather_multi");
 }
 
@@ -957,25 +903,10 @@ __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const ui
 constexpr int kEmbedFastThreads = VAA_EMBED_WAVES * 64;
 constexpr int kEmbedStageMax = ((64 * 1160 / 8 + kEmbedFastThreads - 1) / kEmbedFastThreads + 1) / 2 * 2;  // 16-byte chunks a thread stages per tower (even)
 
-// FUSE (with SPLIT): the gather runs HERE, from the registers the k-loop leaves — no tile-gradient buffer, no second launch. The gather is linear
-// in the two towers, so a workgroup scatters its own tower's scaled contribution of its own columns: kept bit from K1's keep words (staged in
-// LDS), the exact sample position recomputed per (pixel, channel), fl(G * w) rounded to the integer quantum of the workgroup's exponent and
-// added into a patch-shaped int64 accumulator in LDS (aliases the staging buffer once the k-loop is over). A column range of <= 19 blocks
-// covers at most two channels: the accumulator and the output are two channel PLANES per workgroup,
-//   planes[((b * 2 + tower) * nch + ch) * 2 + slot][ph * pw],  slot = channel - cbase(ch),  cbase(ch) = first column of the range / 196,
-// which vaa_step_epilogue (part_layout = nch) / patch_grad_reduce_planes_kernel add per channel in a fixed order.
-struct FuseArgs {
-    const int32_t* xy;
-    const float* theta;
-    const uint16_t* keep_t;  // [B,3,256,14]
-    float* planes;
-    int ph, pw, geometry;
-};
-
 // SPLIT: one tower per workgroup (blockIdx.z), its tile gradients into geff / geff2 (the gather adds the two); else both towers, summed.
 // NB: most column blocks a wave owns (ceil(ceil(37 / nch) / 8)).
-template <bool SPLIT, int NB, bool FUSE = false>
-__global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kernel(EmbedArgs a, int nch, FuseArgs fz) {
+template <bool SPLIT, int NB>
+__global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kernel(EmbedArgs a, int nch) {
     extern __shared__ __align__(16) unsigned char embed_smem[];
     uint16_t* sA = reinterpret_cast<uint16_t*>(embed_smem);
     __shared__ int16_t tiles[256];
@@ -1001,15 +932,6 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     __syncthreads();
 
     K2_STAMP(0)
-    if constexpr (FUSE) {
-        if (M == 0 || M > 64) {  // nothing kept in this image: zero planes; a tile list beyond one row group cannot be fused (the host's bound keeps it away): NaN, never silent
-            const int plane = fz.ph * fz.pw;
-            float* outp = fz.planes + ((((size_t)b * 2 + (int)blockIdx.z) * nch + ch) * 2) * plane;
-            const float fill = M == 0 ? 0.0f : __uint_as_float(0x7fc00000u);
-            for (int e = tid; e < plane * 2; e += kEmbedFastThreads) outp[e] = fill;
-            return;
-        }
-    }
     // this wave's column blocks: [nb0, nb0 + nbw) of the workgroup's range [ch * per, min(37, (ch + 1) * per))
     const int per = (kNBlocks + nch - 1) / nch;
     const int wg_lo = ch * per, wg_n = max(0, min(kNBlocks, wg_lo + per) - wg_lo);
@@ -1048,7 +970,7 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                 wp[j] = wt + packed_frag_offset(min(nb0 + min(j, max(nbw - 1, 0)), kNBlocks - 1), D >> 6, 0, 0, lane);
             // the k-loop's first weight group is requested right behind the staging loads — one memory round trip for both instead of two
             // (B=24: 11.6 -> 10.6 us warm, 14.7 -> 12.7 us with cold caches, profiles/r03_cold_probe.txt)
-            constexpr bool kEarly = SPLIT && !FUSE;
+            constexpr bool kEarly = SPLIT;
             // weight fragments requested together per k-loop group: two 64-wide chunks where a wave owns <= 2 column blocks; ONE with three
             // blocks (the second chunk's 24 VGPRs per register set are what spilled: B=64 18.1 -> 16.9 us warm, 21.7 -> 19.7 us cold)
             constexpr int GRP = (SPLIT && NB >= 3) ? 1 : kEmbedGroup;
@@ -1139,107 +1061,6 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                     }
             K2_STAMP(2 + 2 * tower)
         }
-        if constexpr (FUSE) {
-            // ================= the gather, from registers (mg == 0: the host only fuses while a tile list fits one row group) =================
-            __shared__ float bgrid[VAA_IMG];
-            __shared__ uint32_t fmax_bits;
-            __shared__ int fbad;
-            const int ph = fz.ph, pw = fz.pw, plane = ph * pw;
-            const int cbase = (wg_lo * 16) / (kTilePx * kTilePx);  // first channel of this workgroup's column range
-            __syncthreads();                                        // every wave is done with the staged rows: the LDS is free
-            unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(embed_smem);       // [plane][2 slots], channel slots interleaved
-            uint16_t* keepw = reinterpret_cast<uint16_t*>(embed_smem + (size_t)plane * 2 * 8);    // [3][M][14] keep words of the listed tiles
-            for (int e = tid; e < plane * 2; e += kEmbedFastThreads) acc64[e] = 0ull;
-            for (int e = tid; e < 3 * M * kTilePx; e += kEmbedFastThreads) {
-                const int c3 = e / (M * kTilePx), rem = e - c3 * (M * kTilePx), sl = rem / kTilePx, y = rem - sl * kTilePx;
-                keepw[e] = fz.keep_t[(((size_t)b * 3 + c3) * 256 + tiles[sl]) * kTilePx + y];
-            }
-            if (tid < VAA_IMG) bgrid[tid] = base_coord(tid);
-            if (tid == 0) { fmax_bits = 0u; fbad = 0; }
-            __syncthreads();
-            const int px = fz.xy[2 * b], py = fz.xy[2 * b + 1];
-            float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
-            if (fz.geometry) {
-#pragma unroll
-                for (int z = 0; z < 6; ++z) th[z] = fz.theta[6 * b + z];
-            }
-            // ---- pass A: kept bits and the largest kept |G| of the workgroup (fixes the accumulator's exponent) ----
-            uint32_t keptm[NB];  // bit q*4 + r
-            float lmax = 0.0f;
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                keptm[j] = 0u;
-                if (!nv[j]) continue;
-                const int c3 = n[j] / (kTilePx * kTilePx), rem = n[j] - c3 * (kTilePx * kTilePx), y = rem / kTilePx, x = rem - y * kTilePx;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int sl = q * 16 + g * 4 + r;
-                        if (sl >= M) continue;
-                        if ((keepw[(c3 * M + sl) * kTilePx + y] >> x) & 1u) {
-                            const float G = res[j][q][r];
-                            if ((__float_as_uint(G) & 0x7fffffffu) >= 0x7f800000u) bad = true;
-                            else { keptm[j] |= 1u << (q * 4 + r); lmax = fmaxf(lmax, fabsf(G)); }
-                        }
-                    }
-            }
-            lmax = wave_max(lmax);
-            if (lane == 0 && lmax > 0.0f) atomicMax(&fmax_bits, __float_as_uint(lmax));
-            if (bad) fbad = 1;
-            __syncthreads();
-            const uint32_t mbits = fmax_bits;
-            const int E = max((int)(mbits >> 23) - 127, -96);
-            const float gscale = __uint_as_float((uint32_t)(kCBits - 1 - E + 127) << 23);
-            // ---- pass B: exact sample position per kept (pixel, channel), four integer contributions each ----
-            if (mbits != 0u) {
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if (keptm[j] == 0u) continue;
-                    const int c3 = n[j] / (kTilePx * kTilePx), rem = n[j] - c3 * (kTilePx * kTilePx), y = rem / kTilePx, x = rem - y * kTilePx;
-                    const int slot = c3 - cbase;  // 0 or 1
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (!((keptm[j] >> (q * 4 + r)) & 1u)) continue;
-                            const int tl = tiles[q * 16 + g * 4 + r];
-                            const int i = (tl >> 4) * kTilePx + y, jx = (tl & 15) * kTilePx + x;
-                            int x0 = jx, y0 = i;
-                            float wf = 0.0f, nf = 0.0f;
-                            if (fz.geometry) sample_pos_frac(bgrid[jx], bgrid[i], th, x0, y0, wf, nf);
-                            const int u0 = x0 - px, v0 = y0 - py;
-                            const bool uin0 = (unsigned)u0 < (unsigned)pw, uin1 = ((unsigned)(u0 + 1) < (unsigned)pw) && (x0 + 1 < VAA_IMG);
-                            const bool vin0 = (unsigned)v0 < (unsigned)ph, vin1 = ((unsigned)(v0 + 1) < (unsigned)ph) && (y0 + 1 < VAA_IMG);
-                            if (!((uin0 || uin1) && (vin0 || vin1))) continue;
-                            const float ee = 1.0f - wf, so = 1.0f - nf;
-                            const float wx0 = uin0 ? ee : 0.0f, wx1 = uin1 ? wf : 0.0f, wy0 = vin0 ? so : 0.0f, wy1 = vin1 ? nf : 0.0f;
-                            const float wt[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};  // the fp32 weights grid_sample's backward uses
-                            const int u0c = min(max(u0, 0), pw - 1), u1c = min(max(u0 + 1, 0), pw - 1);
-                            const int v0c = min(max(v0, 0), ph - 1) * pw, v1c = min(max(v0 + 1, 0), ph - 1) * pw;
-                            const int offs[4] = {v0c + u0c, v0c + u1c, v1c + u0c, v1c + u1c};
-                            const float Gs = res[j][q][r] * gscale;
-#pragma unroll
-                            for (int cn = 0; cn < 4; ++cn) {
-                                const int ci = round_half_up(Gs * wt[cn]);
-                                if (ci != 0) atomicAdd(acc64 + offs[cn] * 2 + slot, (unsigned long long)(long long)ci);
-                            }
-                        }
-                }
-            }
-            __syncthreads();
-            // ---- drain: the two channel planes of this workgroup ----
-            const double quantum = (mbits == 0u) ? 0.0 : __longlong_as_double((long long)(E + 1 - kCBits + 1023) << 52);
-            const bool poison = fbad != 0;
-            float* outp = fz.planes + ((((size_t)b * 2 + t_lo) * nch + ch) * 2) * plane;
-            for (int e = tid; e < plane * 2; e += kEmbedFastThreads) {
-                const int slot = e / plane, t = e - slot * plane;
-                const unsigned long long raw = acc64[t * 2 + slot];
-                const double d = __builtin_fma((double)(int)(raw >> 32), 4294967296.0, (double)(unsigned)raw);
-                outp[e] = poison ? __uint_as_float(0x7fc00000u) : (float)(d * quantum);
-            }
-        } else {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (!nv[j]) continue;
@@ -1254,7 +1075,6 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                         else a.geff[el] = res[j][q][r];
                     }
                 }
-        }
         }
         K2_STAMP(5)
     }
@@ -1298,10 +1118,10 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
             return VAA_E_LAUNCH;
         }
         const dim3 grid((unsigned)Bpad * nch, ny, e.tower_split ? 2 : 1), blk(kEmbedFastThreads);
-        if (!e.tower_split) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<false, 2>), grid, blk, lds_fast, st, e, nch, FuseArgs{});
-        else if (nbmax == 1) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 1>), grid, blk, lds_fast, st, e, nch, FuseArgs{});
-        else if (nbmax == 2) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 2>), grid, blk, lds_fast, st, e, nch, FuseArgs{});
-        else VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 3>), grid, blk, lds_fast, st, e, nch, FuseArgs{});
+        if (!e.tower_split) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<false, 2>), grid, blk, lds_fast, st, e, nch);
+        else if (nbmax == 1) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 1>), grid, blk, lds_fast, st, e, nch);
+        else if (nbmax == 2) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 2>), grid, blk, lds_fast, st, e, nch);
+        else VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 3>), grid, blk, lds_fast, st, e, nch);
     } else {  // wide towers: fragments straight from global memory
         const int nch = (kNBlocks + 3) / 4;  // 10 workgroups per image
         VAA_LAUNCH(embed_dgrad_tiles_kernel, dim3((unsigned)((B + 7) / 8 * 8) * nch, ny), dim3(kEmbedThreads), 0, st, e, nch);
@@ -1342,7 +1162,7 @@ namespace vaa {
 // fixed-order sum of the partial tiles (ws[0 .. parts*3*ph*pw), parts = vaa_patch_grad_partials(B)) to the caller's vaa_step_epilogue.
 static int embed_grad_gather_impl(const char* who, const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
                                   const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, const uint16_t* keep_tiles,
-                                  const uint32_t* tile_flags, const uint4* records, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
+                                  const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
                                   int round_bf16, float* gpatch, bool defer_reduce, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 && gpatch && ph > 0 && pw > 0) {
@@ -1388,10 +1208,6 @@ static int embed_grad_gather_impl(const char* who, const uint16_t* dy0, int D0, 
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
     a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles;
-    // experiment: per-pixel records of K1 (only while a tile list fits the row-table storage: patches up to ~100 px)
-    const int tiles_bound = ((3 * ph / 2 + 13) / 14 + 2) * ((3 * pw / 2 + 13) / 14 + 2);
-    a.rec = (records && tiles_bound <= 128) ? records : nullptr;
-    a.tflags = tile_flags;
     if (keep_tiles) a.keep = reinterpret_cast<const uint8_t*>(keep_tiles);  // non-null selects the stored-mask instantiation
     return launch_scatter_reduce<true>(a, defer_reduce ? nullptr : gpatch, st, who);
 }
@@ -1402,7 +1218,7 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
                                            const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph,
                                            int pw, int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws,
                                            size_t ws_bytes, void* stream) {
-    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, keep_bits, nullptr, nullptr, nullptr, B, ph,
+    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, keep_bits, nullptr, nullptr, B, ph,
                                        pw, geometry, mask_mode, std6, round_bf16, gpatch, false, ws, ws_bytes, stream);
 }
 
@@ -1413,99 +1229,12 @@ extern "C" int vaa_patch_embed_grad_gather_tiles(const uint16_t* dy0, int D0, co
                                                  const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
                                                  int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream) {
     return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather_tiles", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, nullptr, keep_tiles, tile_flags,
-                                       nullptr, B, ph, pw, geometry, mask_mode, std6, round_bf16, gpatch, gpatch == nullptr, ws, ws_bytes, stream);
-}
-
-// EXPERIMENT: the same with K1's per-pixel records (vaa_patch_apply_fwd_tiles_rec) — the gather walks the flagged
-// tiles and takes every pixel's exact sample position from its record instead of rebuilding row tables and the coordinate chain.
-extern "C" int vaa_patch_embed_grad_gather_tiles_rec(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
-                                                     const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
-                                                     const uint32_t* tile_flags, const void* records, int B, int ph, int pw, int geometry, int mask_mode,
-                                                     const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream) {
-    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather_tiles_rec", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, nullptr, keep_tiles, tile_flags,
-                                       reinterpret_cast<const uint4*>(records), B, ph, pw, geometry, mask_mode, std6, round_bf16, gpatch, gpatch == nullptr, ws,
-                                       ws_bytes, stream);
+                                       B, ph, pw, geometry, mask_mode, std6, round_bf16, gpatch, gpatch == nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" size_t vaa_patch_embed_grad_multi_ws_bytes(int B) {
     if (B <= 0) return 0;
     return 2 * (size_t)B * 256 * vaa::kTileElems * sizeof(float) + 256;
-}
-
-// K2' with one patch per image (resize_patch=True): the tile gradients do not depend on the patches, the gather runs in MULTI mode.
-namespace vaa {
-
-// workgroups per image and tower of the fused form (0: not applicable — the caller takes vaa_patch_embed_grad_gather_tiles)
-static int fused_nch(int B, int ph, int pw, int D0, int D1) {
-    const int Dmax = D0 > D1 ? D0 : D1;
-    const int tiles_bound = ((3 * ph / 2 + 13) / 14 + 2) * ((3 * pw / 2 + 13) / 14 + 2);
-    const long Bpad = (B + 7) / 8 * 8;
-    const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
-    const size_t lds_acc = (size_t)ph * pw * 2 * sizeof(long long) + 3 * 64 * kTilePx * sizeof(uint16_t) + 64;
-    if (B <= 0 || tiles_bound > 64 || Bpad > 64 || lds_fast > 150 * 1024 || lds_acc > 150 * 1024 ||
-        (size_t)64 * (Dmax / 8) > (size_t)kEmbedStageMax * kEmbedFastThreads)
-        return 0;
-    return Bpad <= 24 ? 5 : (Bpad <= 40 ? 3 : 2);
-}
-
-}  // namespace vaa
-
-extern "C" int vaa_patch_embed_grad_fused_layout(int B, int ph, int pw, int D0, int D1) { return vaa::fused_nch(B, ph, pw, D0, D1); }
-
-// K2' in ONE launch: tile GEMM + gather from its registers (embed_dgrad_tiles_lds_kernel<true, NB, true>). Output: the channel planes
-// [B*2][nch][2][ph*pw] f32 at the start of ws (nch = vaa_patch_embed_grad_fused_layout(...) > 0 required); gpatch != NULL adds them here
-// (second launch), NULL leaves that to vaa_step_epilogue(part_layout = nch).
-extern "C" int vaa_patch_embed_grad_fused(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
-                                          const int32_t* xy, const float* theta, const uint16_t* keep_tiles, const uint32_t* tile_flags, int B, int ph,
-                                          int pw, int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws,
-                                          size_t ws_bytes, void* stream) {
-    using namespace vaa;
-    const char* who = "vaa_patch_embed_grad_fused";
-    hipStream_t st = (hipStream_t)stream;
-    if (!dy0 || !dy1 || !wt0 || !wt1 || !xy || !std6 || !keep_tiles || !tile_flags || (geometry && !theta)) {
-        set_error("%s: null pointer argument", who);
-        return VAA_E_INVALID;
-    }
-    if (B <= 0 || ph <= 0 || pw <= 0 || D0 <= 0 || D1 <= 0 || (D0 % 64) != 0 || (D1 % 64) != 0 ||
-        (mask_mode != VAA_MASK_LT_M20 && mask_mode != VAA_MASK_NE_M100) || (geometry && mask_mode == VAA_MASK_NE_M100)) {
-        set_error("%s: bad sizes/mode (B=%d ph=%d pw=%d D0=%d D1=%d mask_mode=%d)", who, B, ph, pw, D0, D1, mask_mode);
-        return VAA_E_INVALID;
-    }
-    const int nch = fused_nch(B, ph, pw, D0, D1);
-    if (nch == 0) {
-        set_error("%s: the fused form does not cover B=%d, patch %dx%d, towers %d/%d (vaa_patch_embed_grad_fused_layout == 0)", who, B, ph, pw, D0, D1);
-        return VAA_E_UNSUPPORTED;
-    }
-    const size_t plane = (size_t)ph * pw, need = (size_t)B * 2 * nch * 2 * plane * sizeof(float);
-    if (!ws || ws_bytes < need) {
-        set_error("%s: workspace %zu B < required %zu B", who, ws_bytes, need);
-        return VAA_E_WORKSPACE;
-    }
-    EmbedArgs e = {};
-    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wt0; e.wt1 = wt1; e.keep = nullptr; e.flags = tile_flags; e.geff = nullptr; e.geff2 = nullptr;
-    e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0; e.tower_split = 1;
-    for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
-    FuseArgs fz;
-    fz.xy = xy; fz.theta = theta; fz.keep_t = keep_tiles; fz.planes = (float*)ws; fz.ph = ph; fz.pw = pw; fz.geometry = geometry ? 1 : 0;
-    const int Dmax = D0 > D1 ? D0 : D1;
-    const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
-    const size_t lds_acc = plane * 2 * sizeof(long long) + 3 * 64 * kTilePx * sizeof(uint16_t) + 64;
-    const size_t lds = lds_fast > lds_acc ? lds_fast : lds_acc;
-    const int nbmax = ((kNBlocks + nch - 1) / nch + VAA_EMBED_WAVES - 1) / VAA_EMBED_WAVES;
-    const void* fn = nbmax == 1 ? (const void*)embed_dgrad_tiles_lds_kernel<true, 1, true>
-                                : (nbmax == 2 ? (const void*)embed_dgrad_tiles_lds_kernel<true, 2, true> : (const void*)embed_dgrad_tiles_lds_kernel<true, 3, true>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        set_error("%s: hipFuncSetAttribute failed", who);
-        return VAA_E_LAUNCH;
-    }
-    const dim3 grid((unsigned)((B + 7) / 8 * 8) * nch, 1, 2), blk(kEmbedFastThreads);
-    if (nbmax == 1) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 1, true>), grid, blk, lds, st, e, nch, fz);
-    else if (nbmax == 2) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 2, true>), grid, blk, lds, st, e, nch, fz);
-    else VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 3, true>), grid, blk, lds, st, e, nch, fz);
-    int rc = check_launch(who);
-    if (rc != VAA_OK || !gpatch) return rc;
-    VAA_LAUNCH(patch_grad_reduce_planes_kernel, dim3((unsigned)((3 * plane + 63) / 64)), dim3(256), 0, st, (const float*)ws, gpatch, (int)plane, B * 2, nch);
-    return check_launch(who);
 }
 
 namespace vaa {
@@ -1550,7 +1279,7 @@ static int embed_grad_gather_multi_impl(const char* who, const uint16_t* dy0, in
     a.g = nullptr; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles; a.rec = nullptr; a.tflags = nullptr;
+    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles;
     if (keep_tiles) a.keep = reinterpret_cast<const uint8_t*>(keep_tiles);  // non-null selects the stored-mask instantiation
     return launch_scatter_multi<true>(a, max_h, max_w, st, who);
 }

@@ -289,42 +289,6 @@ def patch_embed_grad_gather_multi(dy0, dy1, wp0, wp1, packed, pdesc, max_hw, xy,
     return gpacked
 
 
-def patch_embed_grad_fused(dy0, dy1, wp0, wp1, patch_shape, xy, theta, keep_tiles, tile_flags, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None,
-                           round_bf16: bool = True, defer_reduce: bool = True):
-    """K2' in ONE launch (vaa_patch_embed_grad_fused: the gather runs inside the tile kernel). Returns (planes [2B, nch*2*ph*pw] view of the
-    workspace, nch) with defer_reduce (for ops.step_epilogue(part_layout=nch)), else (gpatch [3,ph,pw], nch). None when the form does not apply
-    (vaa_patch_embed_grad_fused_layout == 0)."""
-    B = dy0.shape[0]
-    D0, D1 = int(dy0.shape[2]), int(dy1.shape[2])
-    ph, pw = int(patch_shape[-2]), int(patch_shape[-1])
-    L = _lib.lib()
-    nch = L.vaa_patch_embed_grad_fused_layout(B, ph, pw, D0, D1)
-    if nch == 0:
-        return None
-    _need(dy0, torch.bfloat16, "dy0", (B, 256, D0))
-    _need(dy1, torch.bfloat16, "dy1", (B, 256, D1))
-    _need(wp0, torch.bfloat16, "wp0", (592 * D0,))
-    _need(wp1, torch.bfloat16, "wp1", (592 * D1,))
-    _need(xy, torch.int32, "xy", (B, 2))
-    if geometry:
-        _need(theta, torch.float32, "theta", (B, 6))
-    _need(keep_tiles, torch.int16, "keep_tiles", (B, 3, 256, 14))
-    _need(tile_flags, torch.int32, "tile_flags", (B, 256))
-    nbytes = 2 * B * nch * 2 * ph * pw * 4
-    ws = _workspace(dy0.device, nbytes, "k2f")
-    gpatch = None if defer_reduce else torch.empty((3, ph, pw), dtype=torch.float32, device=dy0.device)
-    std_c = _STD if std6 is None else _lib.f32x(std6)
-    with _timed("K2_patch_embed_grad_fused", B=B, ph=ph, pw=pw):
-        rc = L.vaa_patch_embed_grad_fused(dy0.data_ptr(), D0, dy1.data_ptr(), D1, wp0.data_ptr(), wp1.data_ptr(), xy.data_ptr(),
-                                          theta.data_ptr() if geometry else None, keep_tiles.data_ptr(), tile_flags.data_ptr(), B, ph, pw,
-                                          int(bool(geometry)), int(mask_mode), std_c, int(bool(round_bf16)),
-                                          gpatch.data_ptr() if gpatch is not None else None, ws.data_ptr(), ws.numel(), _stream())
-    _lib.check(rc, "vaa_patch_embed_grad_fused")
-    if defer_reduce:
-        return ws[:nbytes].view(torch.float32).view(2 * B, nch * 2 * ph * pw), nch
-    return gpatch, nch
-
-
 def patch_embed_grad_gather_multi_tiles(dy0, dy1, wp0, wp1, packed, pdesc, max_hw, xy, theta, keep_tiles, tile_flags, geometry: bool,
                                         mask_mode: int = MASK_LT_M20, std6=None, round_bf16: bool = True):
     """K2' with one patch per image, fed by the tile-major mask of patch_apply_fwd_tiles(pdesc=...)."""
@@ -372,7 +336,7 @@ class PatchApply(torch.autograd.Function):
         g = patch_grad_gather(gout.to(torch.bfloat16).contiguous(), patch, xy, theta if ctx.geometry else None, keep,
                               ctx.geometry, ctx.mask_mode, std6=ctx.std6, defer_reduce=ctx.sink is not None)
         if ctx.sink is not None:
-            ctx.sink["partials"], ctx.sink["part_layout"] = g, 0
+            ctx.sink["partials"] = g
             g = None
         return g, None, None, None, None, None, None, None, None
 
@@ -525,17 +489,10 @@ class PatchApplyEmbed(torch.autograd.Function):
     def backward(ctx, d0, d1):
         patch, xy, theta, keep_t, flags, wp0, wp1 = ctx.saved_tensors
         d0, d1 = d0.to(torch.bfloat16).contiguous(), d1.to(torch.bfloat16).contiguous()
-        fused = None
-        if ctx.sink is not None and _fuse_k2e():  # the final sum belongs to the caller's epilogue: K2' as ONE launch where the form applies
-            fused = patch_embed_grad_fused(d0, d1, wp0, wp1, patch.shape, xy, theta if ctx.geometry else None, keep_t, flags, ctx.geometry,
-                                           ctx.mask_mode, std6=ctx.std6)
-        if fused is not None:
-            ctx.sink["partials"], ctx.sink["part_layout"] = fused
-            return (None,) * 15
         g = patch_embed_grad_gather_tiles(d0, d1, wp0, wp1, patch, xy, theta if ctx.geometry else None, keep_t, flags, ctx.geometry,
                                           ctx.mask_mode, std6=ctx.std6, defer_reduce=ctx.sink is not None)
         if ctx.sink is not None:
-            ctx.sink["partials"], ctx.sink["part_layout"] = g, 0
+            ctx.sink["partials"] = g
             g = None
         return (g,) + (None,) * 14
 
@@ -638,12 +595,6 @@ ACTION_LO, N_ACTION = 31744, 256
 import os as _os
 
 
-def _fuse_k2e() -> bool:
-    """EXPERIMENT, off by default (VAA_FUSED_K2E=1): K2' as ONE launch — the gather inside the tile kernel, per tower, from the k-loop's registers.
-    Measured (tools/k2f_bench.py, profiles/r03_k2_fused.txt): 18.1 vs 21.0 us at B=24, 26.0 vs 26.5 at B=40, 41.3 vs 31.4 at B=64 (the three-block
-    instantiation spills), and the epilogue then adds 2.7x the partial bytes (+3.6 us in the step): the per-(pixel, channel, tower) coordinate
-    chain is 6x the work of the per-pixel gather. Tile GEMM + gather stay the product path."""
-    return _os.environ.get("VAA_FUSED_K2E", "0") == "1"
 SLICE_MODES = (LOSS_UADA_DDP, LOSS_UPA)  # gradient confined to the 256 action columns
 
 
@@ -709,15 +660,13 @@ def loss_rows_stats(logits, rowmap: LossRowMap, mode: int, w: float = 5.0, alpha
 
 
 def step_epilogue(partials, msg, scalars, rowmap: LossRowMap = None, R: int = 0, V: int = 32064, mode: int = LOSS_UADA_DDP, w: float = 5.0,
-                  alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0, loss_ws=None, want_pred: bool = True, update=None, part_layout: int = 0):
+                  alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0, loss_ws=None, want_pred: bool = True, update=None):
     """vaa_step_epilogue: msg[0..n) = fixed-order sum of K2's partial tiles [parts, n]; with `rowmap` (+ the workspace loss_rows_stats left)
     K3's statistics are folded into `scalars` (f32[8], output) and the prediction maps; msg[n..n+4) = {CE, w^2*MSE, UAD, total}.
     update = dict(patch=, m=, v=, mode=, lr=, step=, beta1=, beta2=, eps=, stat_part= f64 [ceil(n/64), 2]) fuses K4 (single-GPU step:
     vaa_step_epilogue_update). Returns (pred_slice, pred_full) or (None, None)."""
     _need(partials, torch.float32, "partials")
     parts, n = int(partials.shape[0]), int(partials.shape[1])
-    if part_layout:  # the fused K2''s channel planes [2B, nch*2*plane]: the gradient has 3*plane elements
-        n = n // (2 * int(part_layout)) * 3
     _need(msg, torch.float32, "msg")
     _need(scalars, torch.float32, "scalars", (8,))
     if msg.numel() < n + 4:
@@ -726,7 +675,7 @@ def step_epilogue(partials, msg, scalars, rowmap: LossRowMap = None, R: int = 0,
     if rowmap is not None and want_pred:
         pred = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=msg.device)
         pred_full = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=msg.device)
-    common = (partials.data_ptr(), parts, n, int(part_layout), rowmap.buf.data_ptr() if rowmap is not None else None, int(R), rowmap.B if rowmap is not None else 0,
+    common = (partials.data_ptr(), parts, n, rowmap.buf.data_ptr() if rowmap is not None else None, int(R), rowmap.B if rowmap is not None else 0,
               rowmap.L if rowmap is not None else 0, int(V), int(mode), _lib.f32x([w, alpha, beta, scale]),
               loss_ws.data_ptr() if loss_ws is not None else None, loss_ws.numel() if loss_ws is not None else 0, scalars.data_ptr(),
               pred.data_ptr() if pred is not None else None, pred_full.data_ptr() if pred_full is not None else None, msg.data_ptr())

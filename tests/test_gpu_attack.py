@@ -652,7 +652,6 @@ def test_fused_epilogue_step_equals_separate_launches(monkeypatch):
     batch = synthetic.synth_batch(3, B, "noise", as_pil=False)
     ids, attn = batch["input_ids"].to(DEV), batch["attention_mask"].to(DEV)
     labels = mask_labels(batch["labels"].clone(), [0]).to(DEV)
-    monkeypatch.setenv("VAA_FUSED_K2E", "0")  # K2' as tile GEMM + gather here: the one-launch K2' differs by fp32 rounding (its own test below)
     runs = []
     for fused in (True, False, "with_update"):
         monkeypatch.setenv("VAA_FUSED_EPILOGUE", "1" if fused else "0")
@@ -691,24 +690,6 @@ def test_fused_epilogue_step_equals_separate_launches(monkeypatch):
         # the update applied inside the epilogue: same bits in the patch (and so in every later step), the logged statistics to fp32 rounding
         assert torch.equal(p1, p3) and torch.equal(s1, s3) and torch.equal(b1, b3) and torch.allclose(st1, st3, rtol=1e-6, atol=0)
     assert float((runs[0][-1][0] - runs[0][0][0]).abs().max()) > 0 and bool(torch.isfinite(runs[0][-1][1]).all())
-    # the opt-in experiment VAA_FUSED_K2E=1: K2' as ONE launch (the gather inside the tile kernel). Same step within the rounding of fl(t0 s0 w) + fl(t1 s1 w) against
-    # fl((t0 s0 + t1 s1) w): first-step gradient <= 1e-6 of its scale, patches after three AdamW steps <= 1e-5
-    monkeypatch.setenv("VAA_FUSED_K2E", "1")
-    monkeypatch.setenv("VAA_FUSED_EPILOGUE", "1")
-    att = AttackBase(m, None, "", "adamW", False)
-    img = att.randomPatchTransform.stage_images(torch.from_numpy(batch["pixel_values"]))
-    random.seed(5); np.random.seed(5)
-    patch = torch.rand(3, 50, 50, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
-    opt = PatchOptimizer(patch, 2e-3, "adamW")
-    sync = vdist.PatchGradSync(patch.numel(), 4, torch.device(DEV))
-    scal = torch.zeros(8, device=DEV)
-    for k in range(3):
-        att.fused_ddp_step(img, patch, ids, attn, labels, True, 5.0, sync.buf, scal, optimizer=opt)
-        ref_p, ref_s, ref_b, _ = runs[0][k]
-        if k == 0:
-            gref = ref_b[:7500]
-            assert float((sync.buf[:7500] - gref).abs().max()) <= 1e-6 * float(gref.abs().max()) and float(gref.abs().max()) > 0
-        assert torch.equal(scal, ref_s) and float((patch.detach() - ref_p).abs().max()) <= 1e-5
 
 
 @pytest.mark.parametrize("which,opt", [("uada", "adamW"), ("tma", "adamW"), ("tma", "pgd")])
@@ -723,7 +704,6 @@ def test_single_gpu_loops_fused_update_equals_separate_launches(tmp_path, monkey
     cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, False, True), siglip=VitCfg(192, 3, 2, 384, 0, False, False),
                      llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
     m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=9)
-    monkeypatch.setenv("VAA_FUSED_K2E", "0")  # bitwise comparison: K2' as tile GEMM + gather on both sides
     if which == "uada":
         from roboticattack_amd.attack.uada import OpenVLAAttacker
     else:
@@ -771,7 +751,6 @@ def test_single_gpu_loops_fused_update_equals_separate_launches(tmp_path, monkey
             att.patchattack_unconstrained(train, val, target_action=0.3 * np.ones(7), alpha=0.02, **kw)
             logs = (list(att.train_CE_loss), att.last_train_log["TRAIN_patch_gradient"])
         monkeypatch.undo()
-        monkeypatch.setenv("VAA_FUSED_K2E", "0")
         assert (hits["fused"] > 0 and hits["step"] == 0) if fused == "1" else (hits["fused"] == 0 and hits["step"] > 0), hits
         runs.append((snaps, torch.load(os.path.join(str(out), "last", "patch.pt")).numpy(), logs))
     (s1, p1, l1), (s0, p0, l0) = runs

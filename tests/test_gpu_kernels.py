@@ -1274,50 +1274,6 @@ def test_step_epilogue_equals_separate_launches(ops, B, dtype):
         ops.loss_rows_stats(logits, rm, ops.LOSS_UPA, grad=gsl)
 
 
-def test_records_experiment_entry_points_match_product(ops):
-    """The records experiment (vaa_patch_apply_fwd_tiles_rec / vaa_patch_embed_grad_gather_tiles_rec; measured and NOT adopted, DESIGN.md
-    section 4): same K1 outputs bit for bit, records = K1's own sample positions, gradient equal to the product path within the integer
-    accumulator's quantum (the slot order differs)."""
-    from roboticattack_amd import _lib, benchmarks
-
-    B = 6
-    L = _lib.lib()
-    st = torch.cuda.current_stream().cuda_stream
-    g = torch.Generator(device=DEV).manual_seed(3)
-    img = torch.from_numpy(synthetic.synth_images(5, B, "noise")).to(DEV)
-    patch = torch.rand(3, 50, 50, device=DEV, generator=g)
-    xy_n, th_n = benchmarks.random_params(B, 50, 50, 11)
-    xy, th = torch.from_numpy(xy_n).to(DEV), torch.from_numpy(th_n).to(DEV)
-    t0, t1, keep_t, flags = ops.patch_apply_fwd_tiles(img, patch, xy, th, True)
-    r0, r1 = torch.empty_like(t0), torch.empty_like(t1)
-    rk, rf = torch.empty_like(keep_t), torch.empty_like(flags)
-    rec = torch.zeros((B, 256, 196, 4), dtype=torch.int32, device=DEV)
-    _lib.check(L.vaa_patch_apply_fwd_tiles_rec(img.data_ptr(), patch.data_ptr(), None, xy.data_ptr(), th.data_ptr(), B, 50, 50, 1, 0, ops._MEAN, ops._STD,
-                                               r0.data_ptr(), r1.data_ptr(), rk.data_ptr(), rf.data_ptr(), rec.data_ptr(), st), "tiles_rec")
-    assert torch.equal(t0.view(torch.int16), r0.view(torch.int16)) and torch.equal(t1.view(torch.int16), r1.view(torch.int16))
-    assert torch.equal(keep_t, rk) and torch.equal(flags != 0, rf != 0)
-    # kept bits of the records == the keep words
-    rc = rec.cpu().numpy().astype(np.uint32)
-    kt = keep_t.cpu().numpy().view(np.uint16)
-    flagged = (flags.cpu().numpy() != 0)
-    kept_rec = ((rc[..., 0] >> 18) & 7).reshape(B, 256, 14, 14)
-    for c in range(3):
-        bits = (kt[:, c, :, :, None] >> np.arange(14)) & 1  # [B,256,14(y),14(x)]
-        assert np.array_equal(((kept_rec >> c) & 1)[flagged], bits[flagged])
-    D0, D1 = 64, 128
-    dy0 = (torch.randn(B, 256, D0, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
-    dy1 = (torch.randn(B, 256, D1, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
-    wp0 = ops.pack_embed_weights((torch.randn(588, D0, device=DEV, generator=g) * 0.05).to(torch.bfloat16))
-    wp1 = ops.pack_embed_weights((torch.randn(588, D1, device=DEV, generator=g) * 0.05).to(torch.bfloat16))
-    want = ops.patch_embed_grad_gather_tiles(dy0, dy1, wp0, wp1, patch, xy, th, keep_t, flags, True)
-    got = torch.empty_like(patch)
-    ws = torch.empty(L.vaa_patch_embed_grad_ws_bytes(B, 50, 50), dtype=torch.uint8, device=DEV)
-    _lib.check(L.vaa_patch_embed_grad_gather_tiles_rec(dy0.data_ptr(), D0, dy1.data_ptr(), D1, wp0.data_ptr(), wp1.data_ptr(), patch.data_ptr(), xy.data_ptr(),
-                                                       th.data_ptr(), keep_t.data_ptr(), flags.data_ptr(), rec.data_ptr(), B, 50, 50, 1, 0, ops._STD, 1,
-                                                       got.data_ptr(), ws.data_ptr(), ws.numel(), st), "gather_rec")
-    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) and float(want.abs().max()) > 0
-
-
 def test_patch_embed_grad_gather_multi_tiles_equals_planar_mask_form(ops):
     """K2' with one patch per image (resize_patch=True) fed by the tile-major mask == the planar-mask form, bitwise."""
     rs = np.random.RandomState(4)
@@ -1369,13 +1325,11 @@ def test_round3_entry_points_error_paths_and_empty_batches(ops):
     assert L.vaa_loss_rows_stats(p, 1, p, 8, 4, 10, 32064, ops.LOSS_UPA, prm, p, 1, p, 1 << 20, st) == -1 and b"VAA_LOSS_UADA_DDP" in L.vaa_last_error()
     assert L.vaa_loss_rows_stats(p, 1, p, 8, 4, 10, 32064, ops.LOSS_UADA_DDP, prm, p, 1, p, 16, st) == -4
     assert L.vaa_loss_rows_stats(p, 1, p, 100, 4, 10, 32064, ops.LOSS_UADA_DDP, prm, p, 1, p, 1 << 20, st) == -1             # R > B*(L-1)
-    assert L.vaa_step_epilogue(None, 4, 7500, 0, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, st) == -1
-    assert L.vaa_step_epilogue(p, 0, 7500, 0, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, st) == -1
-    assert L.vaa_step_epilogue(p, 4, 7501, 2, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, st) == -1                      # plane layout needs n % 3 == 0
-    assert L.vaa_patch_embed_grad_fused(p, 64, p, 64, p, p, p, p, p, p, 128, 50, 50, 1, 0, f6, 1, None, p, 1 << 30, st) == -2     # beyond the fused form
-    assert L.vaa_step_epilogue_update(p, 4, 100, 0, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, None, p, p, 0, 1e-3, 0.9, 0.999, 1e-6, 1, None, st) == -1
-    assert L.vaa_step_epilogue_update(p, 4, 100, 0, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, p, p, p, 0, 1e-3, 0.9, 0.999, 1e-6, 0, None, st) == -1  # AdamW step 0
-    assert L.vaa_step_epilogue_update(p, 4, 100, 0, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, p, p, p, 7, 1e-3, 0.9, 0.999, 1e-6, 1, None, st) == -1  # unknown mode
+    assert L.vaa_step_epilogue(None, 4, 7500, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, st) == -1
+    assert L.vaa_step_epilogue(p, 0, 7500, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, st) == -1
+    assert L.vaa_step_epilogue_update(p, 4, 100, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, None, p, p, 0, 1e-3, 0.9, 0.999, 1e-6, 1, None, st) == -1
+    assert L.vaa_step_epilogue_update(p, 4, 100, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, p, p, p, 0, 1e-3, 0.9, 0.999, 1e-6, 0, None, st) == -1  # AdamW step 0
+    assert L.vaa_step_epilogue_update(p, 4, 100, None, 0, 0, 0, 0, 0, prm, None, 0, p, None, None, p, p, p, p, 7, 1e-3, 0.9, 0.999, 1e-6, 1, None, st) == -1  # unknown mode
     # per-dispatch timer: records exactly the launches made while armed, capacity respected, names are the kernels'
     patch = torch.rand(3, 8, 8, device=DEV)
     g = torch.rand_like(patch)
@@ -1390,53 +1344,6 @@ def test_round3_entry_points_error_paths_and_empty_batches(ops):
     ops.prof_start(0)
     assert ops.prof_collect() == []
     torch.cuda.synchronize()
-
-
-@pytest.mark.parametrize("B,ph,pw,geo,D0,D1", [(64, 50, 50, 1, 1024, 1152), (40, 50, 50, 1, 128, 64), (6, 50, 50, 1, 64, 192), (3, 22, 31, 0, 64, 64),
-                                              (9, 60, 44, 1, 192, 128)])
-def test_patch_embed_grad_fused_one_launch(ops, B, ph, pw, geo, D0, D1):
-    """K2' in ONE launch (vaa_patch_embed_grad_fused: the gather runs inside the tile kernel, per tower, from the k-loop's registers) against the
-    two-launch form (tile GEMM -> tile-gradient buffer -> gather): <= 1e-6 of the gradient scale (the towers' contributions are rounded to the
-    integer quantum separately), bitwise repeatable, through its own plane sum and through the step epilogue (part_layout = nch), and against
-    the oracle (fp32 host matmul + plain-C gather) at the op-level bound of K2'."""
-    from roboticattack_amd import _lib, benchmarks
-
-    g = torch.Generator(device=DEV).manual_seed(B * 13 + ph)
-    img = torch.from_numpy(synthetic.synth_images(71, B, "noise")).to(DEV)
-    patch = torch.rand(3, ph, pw, device=DEV, generator=g)
-    xy_n, th_n = benchmarks.random_params(B, ph, pw, 6)
-    xy, th = torch.from_numpy(xy_n).to(DEV), torch.from_numpy(th_n).to(DEV)
-    _, _, keep_t, flags = ops.patch_apply_fwd_tiles(img, patch, xy, th if geo else None, bool(geo), ops.MASK_LT_M20)
-    dy0 = (torch.randn(B, 256, D0, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
-    dy1 = (torch.randn(B, 256, D1, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
-    w0 = (torch.randn(D0, 588, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
-    w1 = (torch.randn(D1, 588, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
-    wp0, wp1 = ops.pack_embed_weights(w0.t().contiguous()), ops.pack_embed_weights(w1.t().contiguous())
-    nch = _lib.lib().vaa_patch_embed_grad_fused_layout(B, ph, pw, D0, D1)
-    assert nch == (5 if B <= 24 else (3 if B <= 40 else 2))
-    ref = ops.patch_embed_grad_gather_tiles(dy0, dy1, wp0, wp1, patch, xy, th if geo else None, keep_t, flags, bool(geo))
-    got, n1 = ops.patch_embed_grad_fused(dy0, dy1, wp0, wp1, patch.shape, xy, th if geo else None, keep_t, flags, bool(geo), defer_reduce=False)
-    got = got.clone()
-    again, _ = ops.patch_embed_grad_fused(dy0, dy1, wp0, wp1, patch.shape, xy, th if geo else None, keep_t, flags, bool(geo), defer_reduce=False)
-    scale = float(ref.abs().max())
-    assert n1 == nch and scale > 0 and torch.equal(got, again)
-    assert float((got - ref).abs().max()) <= 1e-6 * scale
-    planes, n2 = ops.patch_embed_grad_fused(dy0, dy1, wp0, wp1, patch.shape, xy, th if geo else None, keep_t, flags, bool(geo))
-    n = 3 * ph * pw
-    msg, scal = torch.zeros(n + 4, device=DEV), torch.arange(8, dtype=torch.float32, device=DEV)
-    ops.step_epilogue(planes, msg, scal, part_layout=n2)
-    assert torch.equal(msg[:n].view_as(got), got) and torch.equal(msg[n:], scal[[1, 2, 7, 0]])
-
-    def fold_cpu(dy, w):
-        t = (dy.float().cpu() @ w.float().cpu()).to(torch.bfloat16)
-        return t.view(B, 16, 16, 3, 14, 14).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 224, 224)
-
-    gout_cpu = torch.cat([fold_cpu(dy0, w0), fold_cpu(dy1, w1)], dim=1).contiguous()
-    theta_o = th_n.reshape(B, 2, 3) if geo else np.tile(np.eye(3, dtype=np.float32)[:2], (B, 1, 1))
-    og = c_oracle.patch_grad(_bits(gout_cpu), patch.cpu().numpy(), xy_n, theta_o, int(geo), 0)
-    assert np.abs(got.cpu().numpy() - og).max() <= 2e-3 * np.abs(og).max() + 1e-7
-    # beyond the form's reach the layout query says so and the entry point refuses
-    assert _lib.lib().vaa_patch_embed_grad_fused_layout(128, 50, 50, D0, D1) == 0 and _lib.lib().vaa_patch_embed_grad_fused_layout(4, 100, 100, D0, D1) == 0
 
 
 @pytest.mark.gpu

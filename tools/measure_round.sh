@@ -30,5 +30,4 @@ timeout 1200 python bench.py > "${out}/bench.json" 2> "${out}/bench.err"
 # two ranks on the one GPU over gloo: the N > 1 code path at full size (functional evidence, not a scaling number)
 timeout 900 python bench.py --gpus 2 --steps 4 --warmup 1 --no-kernel-suite > "${out}/bench_2ranks_one_gpu.json" 2> "${out}/bench_2ranks_one_gpu.err"
 timeout 200 python tools/k3_onepass_check.py > "${out}/k3_onepass.txt" 2>&1
-timeout 200 python tools/k2_records_check.py 64 8 256 > "${out}/k2_records.txt" 2>&1
 ls -la "${out}"
