@@ -10,11 +10,16 @@ One step = one inner-loop iteration of UADA_wrapper_ddp (UADA_ddp.py:189-209):
     (HIP; plain K2 on the pixel gradient with VAA_FUSED_EMBED_GRAD=0) -> [RCCL all-reduce, 30 KB] -> K4 AdamW+clamp (HIP)
 Workload: bs=64 PER RANK (reference semantics, UADA_ddp.py:158 -> weak scaling), 3x50x50 patch, geometry=True, maskidx=[0],
 synthetic BridgeData-shaped frames resident in HBM as u8, random-init weights of the OpenVLA-7B architecture.
-Prints ONE JSON line on rank 0. `roofline` is the dominant hand-written kernel of the path — K1's `patch_apply_fwd_kernel`, which
-moves 70 % of the path's algorithmic bytes (48.2 of 69 MB) —
-timed inside the timed region (HIP events on the launch stream, minus an empty event bracket measured in the same steps: the in-step
-duration; the back-to-back figure is reported next to it as standalone_*); `roofline_kernels`/`k2_sweep` carry every op and the K2 batch sweep; `cpu_baseline` is the reference's
-PyTorch-CPU op sequence for the same replaced ops (oracle/ref_port.py) timed on this box's host cores.
+Prints ONE JSON line on rank 0. The timed region (`value`) runs UN-profiled; a short second pass of the same steps then runs with the
+library's per-dispatch timer armed (vaa_prof_*: every hand-written kernel launched through hipExtLaunchKernel with its own start/stop event
+pair = that dispatch's begin/end timestamps, no marker brackets, no subtraction) and gives `roofline` — the dominant hand-written kernel of
+the path, K1's `patch_apply_tiles_kernel`, which moves 70 % of the path's algorithmic bytes (48.2 of 69 MB), IN-STEP; the back-to-back
+figure is reported next to it as standalone_* — plus `roofline_kernels` / `hot_path_ops`. `k2_sweep` carries the K2 batch sweep; `cpu_baseline`
+is the reference's PyTorch-CPU op sequence for the same replaced ops (oracle/ref_port.py) timed on this box's host cores.
+N > 1 (one rank per GPU, RCCL): both timed regions — weak (`value`, bs per rank) and `strong_scaling` (the same global batch split over the
+ranks) — carry the collective's in-step cost (`allreduce_us_per_step`, `comm_frac`, measured with events on the launch stream around the
+30 KB all-reduce) and `config.env` records the NCCL_* / RCCL_* / HSA_* / VAA_* environment of the run. `--regions weak|strong|both` selects the
+regions (a full-size 8-rank functional run on ONE GPU fits with `--regions strong`).
 """
 from __future__ import annotations
 
@@ -44,6 +49,10 @@ def parse():
     ap.add_argument("--no-kernel-suite", action="store_true")
     ap.add_argument("--no-per-rank", action="store_true", help="skip the bs=8 / bs=4 per-rank step block of the N=1 record")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host CPU work for cpu_baseline")
+    ap.add_argument("--regions", type=str, default="both", choices=["weak", "strong", "both"],
+                    help="N > 1: which timed regions run (weak = bs per rank, the headline; strong = the global batch split over the ranks). "
+                         "`strong` alone is a functional / diagnostic run: `value` is then null")
+    ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the separate per-dispatch-profiled pass (-1: min(steps, 10); 0: none)")
     return ap.parse_args()
 
 
@@ -226,8 +235,54 @@ class StepRunner:
         self.opt.step(grad=g_sum.view_as(self.patch), grad_scale=self.inv_world)  # K4
 
 
-def timed_steps(runner, steps, warmup, world, dev, profile=False):
-    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; returns the max over ranks (s) and host costs."""
+def comm_summary(recs, world, steps, dt, dev):
+    """In-step cost of the gradient exchange from the per-call event brackets of PatchGradSync (one all-reduce per step): rank 0's own figures
+    plus min / max over ranks of the per-rank means — the rank that reaches the collective LAST sees the exchange alone, the others also wait
+    for it (skew), so min ~ hand-off + exchange latency and max - min ~ rank skew."""
+    import torch.distributed as dist
+
+    if world == 1 or not recs:
+        return None
+    ev = np.asarray([r[0] for r in recs], dtype=np.float64)
+    host = np.asarray([r[1] for r in recs], dtype=np.float64)
+    t = torch.tensor([ev.mean(), -ev.mean(), ev.max()], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    mean_max, mean_min, single_max = float(t[0]), -float(t[1]), float(t[2])
+    step_us = dt / steps * 1e6
+    return {"calls_per_step": len(recs) / steps, "mean_us_rank0": float(ev.mean()), "median_us_rank0": float(np.median(ev)), "max_us_rank0": float(ev.max()),
+            "host_us_rank0": float(host.mean()), "mean_us_min_over_ranks": mean_min, "mean_us_max_over_ranks": mean_max, "max_us_any_rank": single_max,
+            "comm_frac": mean_min / step_us, "comm_plus_skew_frac": mean_max / step_us,
+            "note": "events on the launch stream around dist.all_reduce of the [grad | 4 scalars] message (30,016 B at 50x50), every timed step; "
+                    "comm_frac = min-over-ranks mean / step time (the exchange itself on the critical path), comm_plus_skew_frac = max-over-ranks mean / step time "
+                    "(adds the wait for the slowest rank's message)"}
+
+
+def allreduce_back_to_back(sync, world, n=50):
+    """The collective alone: n all-reduces of the step's message back to back between two events (no compute in between, ranks aligned by
+    the collectives themselves) -> mean us per call."""
+    import torch.distributed as dist
+
+    if world == 1:
+        return None
+    for _ in range(5):
+        dist.all_reduce(sync.buf, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n):
+        dist.all_reduce(sync.buf, op=dist.ReduceOp.SUM)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n * 1e6
+    sync.buf.zero_()  # n sums of a non-zero message can overflow to inf; the next step rewrites the buffer anyway
+    return {"calls": n, "event_us_per_call": e0.elapsed_time(e1) * 1e3 / n, "wall_us_per_call": wall, "bytes": int(sync.buf.numel() * 4)}
+
+
+def timed_steps(runner, steps, warmup, world, dev, profile=False, comm=False):
+    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; returns the max over ranks (s), host costs, the
+    per-dispatch records (profile=True) and the per-call all-reduce brackets (comm=True)."""
     import torch.distributed as dist
 
     def barrier():
@@ -240,6 +295,8 @@ def timed_steps(runner, steps, warmup, world, dev, profile=False):
     barrier()
     if profile:
         runner.ops.prof_start(64 * steps)  # per-dispatch start/stop events on every hand-written kernel of the timed region
+    if comm and world > 1:
+        runner.sync.timing_start()
     t0 = time.perf_counter()
     host_enqueue, cpu0 = 0.0, time.thread_time()
     for _ in range(steps):
@@ -250,10 +307,11 @@ def timed_steps(runner, steps, warmup, world, dev, profile=False):
     barrier()
     dt = time.perf_counter() - t0
     recs = runner.ops.prof_collect() if profile else []
+    crecs = runner.sync.timing_collect() if (comm and world > 1) else []
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    return float(tmax.item()), host_enqueue / steps, host_cpu / steps, recs
+    return float(tmax.item()), host_enqueue / steps, host_cpu / steps, recs, crecs
 
 
 # kernel name (substring of the launch site's name) -> operator of the hot path
@@ -325,25 +383,55 @@ def main():
     torch.cuda.synchronize()
     stage_ms = (time.perf_counter() - t_stage) * 1e3
 
-    # ---- the timed region: weak scaling, bs = args.bs PER RANK (reference semantics, UADA_ddp.py:158) ----
+    run_weak = world == 1 or args.regions in ("weak", "both")
+    run_strong = world > 1 and args.regions in ("strong", "both")
+    psteps = min(args.steps, 10) if args.profile_steps < 0 else args.profile_steps
+
+    # ---- the timed region: weak scaling, bs = args.bs PER RANK (reference semantics, UADA_ddp.py:158). UN-profiled, like the strong region ----
     t_setup = time.perf_counter() - t_main
-    dt, host_enqueue, host_cpu, recs = timed_steps(runner, args.steps, args.warmup, world, dev, profile=True)
+    dt = host_enqueue = host_cpu = None
+    recs, comm_w, finite = [], None, True
+    if run_weak:
+        dt, host_enqueue, host_cpu, _, crecs = timed_steps(runner, args.steps, args.warmup, world, dev, comm=True)
+        comm_w = comm_summary(crecs, world, args.steps, dt, dev)
+        finite = bool(torch.isfinite(runner.scal).all())
+        # ---- the same steps once more, SEPARATELY, with the library's per-dispatch timer armed: the in-step kernel durations ----
+        if psteps > 0:
+            _, _, _, recs, _ = timed_steps(runner, psteps, 1, world, dev, profile=True)
     t_region = time.perf_counter() - t_main - t_setup
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
-    finite = bool(torch.isfinite(runner.scal).all())
+    b2b = allreduce_back_to_back(runner.sync, world) if world > 1 else None
 
     # ---- strong scaling (BASELINE config 3: "bs=64 over N GPUs"): the same global batch split over the ranks ----
     strong = None
-    if world > 1:
+    if run_strong:
         bs_s = max(1, B // world)
         torch.cuda.empty_cache()  # the weak region's cached activation blocks are not needed any more (ranks that share a GPU in test mode are near its capacity)
         r_s = StepRunner(model, dev, bs_s, patch_shape, rank, world)
-        dt_s, enq_s, cpu_s, _ = timed_steps(r_s, args.steps, args.warmup, world, dev)
+        dt_s, enq_s, cpu_s, _, crecs_s = timed_steps(r_s, args.steps, args.warmup, world, dev, comm=True)
+        comm_s = comm_summary(crecs_s, world, args.steps, dt_s, dev)
+        fin_s = torch.tensor([1.0 if bool(torch.isfinite(r_s.scal).all()) else 0.0], device=dev)
+        dist.all_reduce(fin_s, op=dist.ReduceOp.MIN)
+        mem_s = torch.tensor([torch.cuda.max_memory_allocated(dev) / 2**30], dtype=torch.float64, device=dev)
+        dist.all_reduce(mem_s, op=dist.ReduceOp.MAX)
         strong = {"per_rank_bs": bs_s, "global_batch": bs_s * world, "ms_per_step": dt_s / args.steps * 1e3, "steps_per_s": args.steps / dt_s,
-                  "images_per_s": bs_s * world * args.steps / dt_s, "host_cpu_ms_per_step": cpu_s * 1e3,
+                  "images_per_s": bs_s * world * args.steps / dt_s, "host_cpu_ms_per_step": cpu_s * 1e3, "host_enqueue_ms_per_step": enq_s * 1e3,
+                  "loss_finite_all_ranks": bool(fin_s.item() > 0.5), "peak_mem_GiB_max_over_ranks": float(mem_s.item()),
+                  "allreduce_us_per_step": comm_s, "comm_frac": comm_s["comm_frac"] if comm_s else None,
                   "note": "global batch fixed at the N=1 workload's bs, split evenly over the ranks (BASELINE config 3); timed like the weak region: "
-                          "W warm-up steps, K steps between barrier + synchronize, max over ranks"}
+                          "W warm-up steps, K steps between barrier + synchronize, max over ranks; un-profiled"}
+        if run_weak:
+            strong["speedup_vs_one_rank_weak_step"] = (bs_s * world * args.steps / dt_s) / (B * args.steps / dt)
+            strong["speedup_note"] = ("images/s of the split global batch over ALL ranks / images/s of ONE rank's bs=%d step in this same run (the weak region's "
+                                      "per-rank rate): the strong-scaling speedup 1 -> %d ranks measured inside one job" % (B, world))
         del r_s
+    # every rank's hipBLASLt / rocBLAS selections (a rank that lost them runs ~6 % slower and drags the synchronous step): min over ranks
+    tun = _tunable_entries()
+    tun_min = tun
+    if world > 1:
+        tt = torch.tensor([float(tun)], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        tun_min = int(tt.item())
 
     # ---- the per-rank step of the strong-scaling configs on ONE GPU (N=1 only): what each of 8 ranks runs in configs 3/4 (bs=8) and 5 (bs=4) ----
     per_rank = None
@@ -354,11 +442,13 @@ def main():
             torch.cuda.empty_cache()
             rb = StepRunner(model, dev, b, patch_shape, rank, world)
             n_b = max(args.steps, 10) if b <= 8 else max(args.steps // 2, 6)
-            dt_b, enq_b, cpu_b, recs_b = timed_steps(rb, n_b, 3, world, dev, profile=True)
+            dt_b, enq_b, cpu_b, _, _ = timed_steps(rb, n_b, 3, world, dev)  # un-profiled, like the headline it is compared with
+            n_p = min(n_b, 5)
+            _, _, _, recs_b, _ = timed_steps(rb, n_p, 0, world, dev, profile=True)
             hot_b = {}
             for name, us in recs_b:  # the hand-written launches of the step at this batch, per dispatch (vaa_prof_*)
                 op = next((o for sub, o in KERNEL_OPS if sub in name), "other")
-                hot_b[op] = hot_b.get(op, 0.0) + us / n_b
+                hot_b[op] = hot_b.get(op, 0.0) + us / n_p
             per_rank[f"bs{b}"] = {"ms_per_step": dt_b / n_b * 1e3, "images_per_s": b * n_b / dt_b, "images_per_s_vs_bs%d" % B: (b * n_b / dt_b) / ips64,
                                   "projected_speedup_%d_ranks_before_comm" % (B // b): (B // b) * (b * n_b / dt_b) / ips64,
                                   "host_cpu_ms_per_step": cpu_b * 1e3, "host_enqueue_ms_per_step": enq_b * 1e3, "labelled_rows": rb.R,
@@ -385,9 +475,9 @@ def main():
     for name, ts in per.items():
         op = next((o for sub, o in KERNEL_OPS if sub in name), "other")
         t = np.asarray(ts)
-        kern[name] = {"op": op, "launches": len(ts), "launches_per_step": len(ts) / args.steps, "mean_us": float(t.mean()), "median_us": float(np.median(t)),
+        kern[name] = {"op": op, "launches": len(ts), "launches_per_step": len(ts) / psteps, "mean_us": float(t.mean()), "median_us": float(np.median(t)),
                       "min_us": float(t.min()), "max_us": float(t.max())}
-        op_us[op] = op_us.get(op, 0.0) + float(t.sum()) / args.steps
+        op_us[op] = op_us.get(op, 0.0) + float(t.sum()) / psteps
     fused = tr.embed_with is not None
     if fused and "K2" in op_us:  # the TILED scatter + reduce belong to K2'
         op_us["K2e"] = op_us.get("K2e", 0.0) + op_us.pop("K2")
@@ -397,7 +487,7 @@ def main():
     hot_ops = {o: {"us_per_step": u, "algo_bytes": op_bytes.get(o), "achieved_GBs": (op_bytes[o] / u / 1e3 if o in op_bytes else None),
                    "frac": (op_bytes[o] / u / 1e3 / HBM_PEAK_GBS if o in op_bytes else None)} for o, u in op_us.items()}
     k1name = next((n for n in kern if "patch_apply_tiles_kernel" in n or "patch_apply_fwd_kernel" in n), None)
-    tfile = next((f for f in ("profiles/traffic_r03.json", "profiles/traffic_r02.json") if os.path.exists(os.path.join(ROOT, f))), None)
+    tfile = next((f for f in ("profiles/traffic_r04.json", "profiles/traffic_r03.json", "profiles/traffic_r02.json") if os.path.exists(os.path.join(ROOT, f))), None)
     tr_ops = json.load(open(os.path.join(ROOT, tfile))).get("ops", {}) if tfile else {}
     roofline = None
     if k1name:
@@ -407,28 +497,28 @@ def main():
                     "frac": nb / k1["mean_us"] / 1e3 / HBM_PEAK_GBS, "mean_us": k1["mean_us"], "min_us": k1["min_us"], "samples": k1["launches"],
                     "algo_bytes": nb, "traffic": tr_ops.get("K1t_patch_apply_fwd_tiles" if "tiles" in k1name else "K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch"),
                     "traffic_source": (tfile or "none") + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",
-                    "timing": "IN-STEP, per dispatch: every K1 launch of the timed region goes through hipExtLaunchKernel with its own start/stop event pair, "
-                              "which the runtime binds to that dispatch's begin/end timestamps — the quantity rocprofv3 --kernel-trace reports "
-                              "(profiles/r03_bench_kernel_stats.csv is the rocprofv3 summary of the same command); mean over all launches of the timed steps, "
-                              "no marker brackets, no subtraction",
+                    "timing": "IN-STEP, per dispatch: after the (un-profiled) timed region the same steps run once more with the library's per-dispatch timer armed — "
+                              "every K1 launch goes through hipExtLaunchKernel with its own start/stop event pair, which the runtime binds to that dispatch's "
+                              "begin/end timestamps, the quantity rocprofv3 --kernel-trace reports (profiles/r04_bench_kernel_stats.csv is the rocprofv3 summary of "
+                              "the same command); mean over all launches of that pass, no marker brackets, no subtraction",
                     "note": "dominant = the kernel of the hot path with the most algorithmic bytes (48.2 of ~69 MB per step); every hand-written kernel of the "
                             "timed region is listed in roofline_kernels, per-operator sums in hot_path_ops"}
         # builder-side cross reference (NOT measured by this run): rocprofv3's average for the same kernel in the committed summary of the same command
-        ref = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
+        ref = os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv")
         if os.path.exists(ref):
             import csv
 
             for row in csv.DictReader(open(ref)):
                 if k1name.split("(")[0] in row["Name"]:
                     us = float(row["AverageNs"]) * 1e-3
-                    roofline["rocprofv3_reference"] = {"file": "profiles/r03_bench_kernel_stats.csv", "calls": int(row["Calls"]), "mean_us": us,
+                    roofline["rocprofv3_reference"] = {"file": "profiles/r04_bench_kernel_stats.csv", "calls": int(row["Calls"]), "mean_us": us,
                                                        "frac": nb / us / 1e3 / HBM_PEAK_GBS,
                                                        "note": "committed rocprofv3 --kernel-trace --stats summary of `bench.py --steps 20 --warmup 3 --no-cpu-baseline "
                                                                "--no-kernel-suite --no-per-rank`; the per-dispatch events of an un-profiled run read 0.3-1.8 us above it "
                                                                "(they include the dispatch's start-up after the preceding command), so the line's frac is the lower one"}
                     break
 
-    extra = {"host_enqueue_ms_per_step": host_enqueue * 1e3, "host_cpu_ms_per_step": host_cpu * 1e3,
+    extra = {"host_enqueue_ms_per_step": host_enqueue * 1e3 if run_weak else None, "host_cpu_ms_per_step": host_cpu * 1e3 if run_weak else None,
              "host_overhead_note": "host_cpu = CPU time of the launching thread per step (python + HIP launches): what N ranks on one host need N times in parallel; "
                                    "host_enqueue = wall time inside step() without an explicit sync (it also contains waits on a full launch queue / staged H2D copies, "
                                    "so it scales with the GPU work); the step is GPU-bound while ms_per_step exceeds host_cpu",
@@ -448,7 +538,7 @@ def main():
         extra["rank_shapes"] = rank_shapes(device=str(dev))
         ks = extra["roofline_kernels_standalone"]
         used_k2 = "K2e_patch_embed_grad_gather" if fused else "K2_patch_grad_gather"
-        gpu_ops_s = sum(v["mean_us"] for k, v in ks.items() if (not k.startswith("K2") or k == used_k2) and k not in ("K3_full_rows_fwd_bwd", "K3_full_two_launches")) * 1e-6
+        gpu_ops_s = sum(v["mean_us"] for k, v in ks.items() if (not k.startswith("K2") or k == used_k2) and k not in ("K3_full_rows_fwd_bwd", "K3_full_one_launch_optin")) * 1e-6
         extra["gpu_patch_path_steps_per_s"] = 1.0 / gpu_ops_s
         if roofline:
             # the same kernel launched back to back (hipGraph replays of 10 launches between two events, same process) next to the in-step figure
@@ -460,21 +550,53 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # host-CPU leg only at N=1 (rank 0), as the bench contract asks
         cpu = cpu_baseline(B, patch_shape, args.cpu_budget)
 
+    env_rec = {k: v for k, v in sorted(os.environ.items())
+               if k.startswith(("NCCL_", "RCCL_", "HSA_", "VAA_", "TORCH_NCCL", "PYTORCH_TUNABLEOP", "HIP_VISIBLE", "ROCR_VISIBLE", "CUDA_VISIBLE", "GPU_MAX_HW_QUEUES"))}
+    config = {"workload": f"UADA_wrapper_ddp inner step: bs={B} per rank (global {B * world}), patch {args.patch}, geometry=True, maskidx=[0], "
+                          f"{model_desc}; frames resident in HBM as u8",
+              "global_batch": B * world, "images_per_s": (B * world * args.steps / dt) if run_weak else None, "parallelism": f"dp{world}",
+              "regions": ("weak" if world == 1 else args.regions),
+              "backend": (os.environ.get("VAA_DIST_BACKEND") or "nccl (RCCL)") if world > 1 else None,
+              "visible_gpus": torch.cuda.device_count(),
+              "labelled_rows_per_rank": R, "tunableop_entries_loaded": tun, "tunableop_entries_loaded_min_over_ranks": tun_min,
+              "lm_head": "labelled rows only" if use_rows else "full logits",
+              "h2d_stage_ms_per_outer_iteration": stage_ms,
+              "pcie_inclusive_value_if_restaged_every_step": (world * args.steps / (dt + args.steps * stage_ms * 1e-3)) if run_weak else None,
+              "env": env_rec}
+    if world > 1:  # the collective, where `parsed.config` keeps it
+        config["allreduce_us_per_step"] = comm_w["mean_us_min_over_ranks"] if comm_w else None
+        config["allreduce_us_per_step_max_over_ranks"] = comm_w["mean_us_max_over_ranks"] if comm_w else None
+        config["comm_frac"] = comm_w["comm_frac"] if comm_w else None
+        config["allreduce_back_to_back_us"] = b2b["event_us_per_call"] if b2b else None
+        if strong:
+            config["strong_images_per_s"] = strong["images_per_s"]
+            config["strong_ms_per_step"] = strong["ms_per_step"]
+            config["strong_comm_frac"] = strong["comm_frac"]
+            config["strong_speedup_vs_one_rank_weak_step"] = strong.get("speedup_vs_one_rank_weak_step")
+    if per_rank:  # N=1: the per-rank ratios of the strong-scaling configs, where `parsed.config` keeps them
+        for b in (32, 16, 8, 4):
+            pr = per_rank.get(f"bs{b}")
+            if pr:
+                config[f"bs{b}_images_per_s_vs_bs{B}"] = pr["images_per_s_vs_bs%d" % B]
+                config[f"bs{b}_ms_per_step"] = pr["ms_per_step"]
+        for n_r in (2, 4, 8):
+            pr = per_rank.get(f"bs{B // n_r}")
+            if pr:
+                config[f"projected_strong_speedup_{n_r}_before_comm"] = pr["projected_speedup_%d_ranks_before_comm" % n_r]
     line = {
-        "metric": "attack-steps/sec (bs=64, 3x50x50 patch, OpenVLA-7B)", "value": world * args.steps / dt,
+        "metric": "attack-steps/sec (bs=64, 3x50x50 patch, OpenVLA-7B)", "value": (world * args.steps / dt) if run_weak else None,
         "unit": "attack-steps/s (one unit = one bs-64 inner step on one rank; whole job = ranks x synchronous steps)",
-        "sync_steps_per_s": args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "sync_steps_per_s": (args.steps / dt) if run_weak else None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": (dt / args.steps * 1e3) if run_weak else None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"UADA_wrapper_ddp inner step: bs={B} per rank (global {B * world}), patch {args.patch}, geometry=True, maskidx=[0], "
-                               f"{model_desc}; frames resident in HBM as u8",
-                   "global_batch": B * world, "images_per_s": B * world * args.steps / dt, "parallelism": f"dp{world}",
-                   "backend": (os.environ.get("VAA_DIST_BACKEND") or "nccl (RCCL)") if world > 1 else None,
-                   "labelled_rows_per_rank": R, "tunableop_entries_loaded": _tunable_entries(), "lm_head": "labelled rows only" if use_rows else "full logits",
-                   "h2d_stage_ms_per_outer_iteration": stage_ms,
-                   "pcie_inclusive_value_if_restaged_every_step": world * args.steps / (dt + args.steps * stage_ms * 1e-3)},
-        "roofline": roofline, "strong_scaling": strong, "per_rank_step": per_rank, "hot_path_ops": hot_ops, "roofline_kernels": kern, "cpu_baseline": cpu,
-        "peak_mem_GiB": peak_mem, "loss_finite": finite,
+        "config": config,
+        "roofline": roofline, "strong_scaling": strong, "allreduce_us_per_step": comm_w, "comm_frac": comm_w["comm_frac"] if comm_w else None,
+        "allreduce_back_to_back": b2b, "per_rank_step": per_rank, "hot_path_ops": hot_ops, "roofline_kernels": kern, "cpu_baseline": cpu,
+        "peak_mem_GiB": peak_mem, "loss_finite": finite and (strong is None or strong["loss_finite_all_ranks"]),
+        "profiled_pass_steps": psteps if run_weak else 0,
     }
+    if not run_weak:
+        line["note"] = "--regions strong: a functional / diagnostic run of the strong-scaling region only; `value` (the weak-scaling headline) was not measured"
     line.update(extra)
     # where this process's wall time went (imports excluded): model + batch set-up, warm-up + timed region, everything reported beside it
     line["wall_s"] = {"setup": t_setup, "warmup_and_timed_region": t_region, "total": time.perf_counter() - t_main}

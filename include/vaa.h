@@ -64,6 +64,14 @@ extern "C" {
 
 const char* vaa_last_error(void);
 int vaa_version(void);
+/*
+ * Device-side failures surface here and NEVER as a silent NaN: a kernel that has to give up (today only the opt-in one-launch K3, when its
+ * grid-wide hand-over runs out of polls) NaN-poisons its outputs AND sets a bit in a pinned host word; every later library call on any
+ * stream of the process returns VAA_E_LAUNCH (with the reason in vaa_last_error()) once for it. vaa_async_error() is the explicit poll —
+ * the attack loops call it behind their once-per-outer-iteration read-back, before anything is written to disk (UADA.py:257-275).
+ * Returns VAA_OK or VAA_E_LAUNCH; reporting clears the word.
+ */
+int vaa_async_error(void);
 /* VAA_OK when a gfx950 device is visible to the HIP runtime, else VAA_E_NODEVICE. */
 int vaa_device_check(void);
 
@@ -198,10 +206,12 @@ int vaa_loss_fwd_bwd_ex(const void* logits, int dtype, int layout, const int64_t
  *                              confined to the action columns: the LM-head backward then contracts over 256 columns, not 32,064)
  *             ws >= vaa_loss_rows_ws_bytes(R). Rows are split over 2-4 workgroups so that 128 rows fill the 256 CUs; in UADA_DDP
  *             mode the gradient is written by the same pass that reads the logits. Full-row gradients whose scale needs the folded
- *             scalars (UADA's 1/CE^2 term, UADA.py:145-148; CE, TMA.py:148) are ONE launch too — statistics, grid-wide hand-over,
- *             gradient from the registers, every row read once — when the grid takes at most half of the device's resident slots,
- *             the stream is not being captured and no other stream of the process has such a launch in flight; else (and with
- *             VAA_K3_ONE_PASS=0 in the environment) two launches with the same bits in every output.
+ *             scalars (UADA's 1/CE^2 term, UADA.py:145-148; CE, TMA.py:148) can be ONE launch too — statistics, grid-wide hand-over,
+ *             gradient from the registers, every row read once — ONLY with VAA_K3_ONE_PASS=1 in the environment (opt-in since
+ *             round 4: 2.8 us per call against a residency assumption no launch API guarantees) and when the grid takes at most half
+ *             of the device's resident slots, the stream is not being captured and no other stream of the process has such a launch
+ *             in flight; else two launches with the same bits in every output. A hand-over that times out NaN-poisons the gradient AND
+ *             raises vaa_async_error() (every later library call fails once with VAA_E_LAUNCH).
  */
 size_t vaa_loss_rowmap_bytes(int B, int L);
 int vaa_loss_rowmap_build(const int64_t* labels, int B, int L, void* rowmap, size_t rowmap_bytes, void* stream);

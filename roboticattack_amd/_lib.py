@@ -56,6 +56,7 @@ EXPORTS = (
     "vaa_loss_rows_stats",
     "vaa_step_epilogue",
     "vaa_step_epilogue_update",
+    "vaa_async_error",
     "vaa_prof_start",
     "vaa_prof_stop",
     "vaa_prof_get",
@@ -188,6 +189,8 @@ def lib() -> C.CDLL:
     L.vaa_step_epilogue_update.restype = i32
     L.vaa_step_epilogue_update.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32,
                                            i32, vp, vp]
+    L.vaa_async_error.restype = i32
+    L.vaa_async_error.argtypes = []
     L.vaa_prof_start.restype = i32
     L.vaa_prof_start.argtypes = [i32]
     L.vaa_prof_stop.restype = i32

@@ -24,6 +24,11 @@ except Exception:  # pragma: no cover
     wandb = None
 
 
+class NonFiniteAttackState(RuntimeError):
+    """The attack state (loss scalars, optimiser moments, patch) stopped being finite, or a kernel reported a device-side failure: raised
+    before anything is written to disk. The reference would silently keep optimising and save the patch (UADA.py:257-275)."""
+
+
 def wandb_enabled(args) -> bool:
     return wandb is not None and args is not None and getattr(args, "wandb_project", "false") != "false"
 
@@ -154,6 +159,23 @@ class AttackBase:
             msg = self._epi_msg = torch.zeros(n + 4, dtype=torch.float32, device=patch.device)
         ops.step_epilogue(sink["partials"], msg, scalars, update=optimizer.fused_update_args())
 
+    # ---- fail loud, never NaN: once per outer iteration, behind the read-back that synchronises anyway ----
+    def assert_finite_state(self, patch, optimizer, host_scalars, where: str):
+        """`host_scalars`: the loss scalars of the outer iteration's inner steps, already on the host (their read-back was the sync).
+        AdamW's m / v are the sticky witnesses of any non-finite gradient of ANY inner step (a NaN that entered them never leaves, while the
+        clamp turns the patch itself into a finite 0), the library's failure word covers kernels that had to give up (vaa_async_error)."""
+        ops.async_error_check()
+        ok_dev = torch.isfinite(patch.detach()).all()
+        if getattr(optimizer, "m", None) is not None:
+            ok_dev = ok_dev & torch.isfinite(optimizer.m).all() & torch.isfinite(optimizer.v).all()
+        stats = getattr(optimizer, "last_stats", None)
+        if stats is not None:
+            ok_dev = ok_dev & torch.isfinite(stats).all()
+        ok_host = bool(np.isfinite(np.asarray(host_scalars, dtype=np.float64)).all())
+        if not (ok_host and bool(ok_dev)):
+            raise NonFiniteAttackState(f"{where}: non-finite attack state (loss scalars finite: {ok_host}; patch / moments / gradient statistics "
+                                       f"finite: {bool(ok_dev)}) — nothing was saved for this iteration")
+
     # ---- metrics (host, once per outer iteration) ----
     def decode_pred_gt(self, pred: torch.Tensor, labels: torch.Tensor):
         """Continuous predicted / ground-truth actions of the action rows, (b,k) order (UADA.py:165-175)."""
@@ -199,8 +221,11 @@ class AttackBase:
     def save_patch(self, patch: torch.Tensor, sub: str) -> str:
         """`torch.save(patch.detach().cpu(), <save_dir>/<sub>/patch.pt)` — plain fp32 [3,ph,pw] CPU tensor (UADA.py:257-275)."""
         d = os.path.join(self.save_dir, sub)
+        host = patch.detach().float().cpu().contiguous().clone()
+        if not bool(torch.isfinite(host).all()):  # belt and braces behind assert_finite_state
+            raise NonFiniteAttackState(f"save_patch({sub!r}): the patch holds non-finite values")
         os.makedirs(d, exist_ok=True)
-        torch.save(patch.detach().float().cpu().contiguous().clone(), os.path.join(d, "patch.pt"))
+        torch.save(host, os.path.join(d, "patch.pt"))
         return d
 
     def save_val_images(self, modified_images: torch.Tensor, d: str):

@@ -103,6 +103,7 @@ class OpenVLAAttacker(AttackBase):
             if fused_row is not None:
                 scal[fused_row, 8:10] = optimizer.last_stats
             host = scal[:innerLoop].cpu().numpy()
+            self.assert_finite_state(patch, optimizer, host[:, :8], f"TMA outer iteration {i}")
             inner_avg_loss = float(host[:, 0].mean())
             inner_rel = 0.0
             for p in rel:  # TMA.py:153-162

@@ -85,6 +85,7 @@ class OpenVLAAttacker(AttackBase):
                 scal[self._stats_row, 8:10] = optimizer.last_stats
             # one read-back per outer iteration (the reference syncs 4-5 times per inner step)
             host = scal[:innerLoop].cpu().numpy()
+            self.assert_finite_state(patch, optimizer, host[:, :8], f"UADA outer iteration {i}")
             self.train_CE_loss.extend(host[:, 1].tolist())
             self.train_MSE_distance_loss.extend(host[:, 0].tolist())
             self.train_UAD.extend(host[:, 7].tolist())

@@ -88,6 +88,7 @@ class OpenVLAAttacker(AttackBase):
             if scheduler is not None and do_step:
                 scheduler.step()
             host = scal[:innerLoop].cpu().numpy()
+            self.assert_finite_state(patch, optimizer, host[:, :8], f"UPA outer iteration {i}")
             loss, angle_loss, distance_loss = float(host[-1, 0]), float(host[-1, 3]), float(host[-1, 4])
             print(f"loss: {loss}, " if reverse_direction else f"target_loss: {loss}")
             self.last_train_log = {"TRAIN_attack_loss(CE)": loss, "TRAIN_patch_gradient": float(host[-1, 9]),

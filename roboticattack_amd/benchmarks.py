@@ -167,28 +167,27 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
         lambda: ops.loss_rows_fwd_bwd(logits, rowmap, ops.LOSS_UADA_DDP, w=5.0, grad_kind=ops.GRAD_SLICE, grad=gslice),
         algo_bytes("K3_slice", B, rows=R, esize=logits.element_size()), rows=R,
         note="the bench step's mode (UADA_DDP): row map prebuilt, gradient = the 256 action columns; 16.4 MB figure of SURVEY 8d = full-row storage, see K3_full")
-    rec("K3_full_rows_fwd_bwd", "K3",
-        lambda: ops.loss_rows_fwd_bwd(logits, rowmap, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=glog),
-        algo_bytes("K3", B, rows=R, esize=logits.element_size()), in_stream=True, rows=R,
-        note="UADA (1/CE term): full-row gradient, SURVEY 8d's 2*R'*V*e; ONE launch (statistics, grid-wide hand-over, gradient from the registers), "
-             "timed as back-to-back calls in a stream (the form is not graph-capturable)")
-
-    def k3_two_launches():
+    def k3_full(one_pass: str):
         import os
 
-        old = os.environ.get("VAA_K3_ONE_PASS")
-        os.environ["VAA_K3_ONE_PASS"] = "0"
-        try:
-            ops.loss_rows_fwd_bwd(logits, rowmap, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=glog)
-        finally:
-            if old is None:
-                del os.environ["VAA_K3_ONE_PASS"]
-            else:
-                os.environ["VAA_K3_ONE_PASS"] = old
+        def run():
+            old = os.environ.get("VAA_K3_ONE_PASS")
+            os.environ["VAA_K3_ONE_PASS"] = one_pass
+            try:
+                ops.loss_rows_fwd_bwd(logits, rowmap, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=glog)
+            finally:
+                if old is None:
+                    del os.environ["VAA_K3_ONE_PASS"]
+                else:
+                    os.environ["VAA_K3_ONE_PASS"] = old
+        return run
 
-    rec("K3_full_two_launches", "K3", k3_two_launches, algo_bytes("K3", B, rows=R, esize=logits.element_size()), in_stream=True, rows=R,
-        note="the same with VAA_K3_ONE_PASS=0 (statistics launch + finishing launch that reads every row again): what stream capture and grids beyond "
-             "half the device's residency take")
+    rec("K3_full_rows_fwd_bwd", "K3", k3_full("0"), algo_bytes("K3", B, rows=R, esize=logits.element_size()), in_stream=True, rows=R,
+        note="UADA (1/CE term): full-row gradient, SURVEY 8d's 2*R'*V*e; the DEFAULT form since round 4: statistics launch + finishing launch that reads "
+             "every row again; timed as back-to-back calls in a stream")
+    rec("K3_full_one_launch_optin", "K3", k3_full("1"), algo_bytes("K3", B, rows=R, esize=logits.element_size()), in_stream=True, rows=R,
+        note="the same with VAA_K3_ONE_PASS=1 (opt-in: statistics, grid-wide hand-over, gradient from the registers — every row read once; relies on the "
+             "whole grid being resident, fails loudly through vaa_async_error when the hand-over times out)")
     parts = ops.patch_embed_grad_gather_tiles(dy0, dy1, wt0, wt1, patch, xy, th, keep_t, tflags, True, defer_reduce=True)
     msg, scal8 = torch.zeros(3 * ph * pw + 4, device=dev), torch.zeros(8, device=dev)
     ws3 = ops.loss_rows_stats(logits, rowmap, ops.LOSS_UADA_DDP, w=5.0, grad=gslice)

@@ -20,13 +20,47 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- asynchronous device-side failures (vaa_async_error) ----
+// One word of pinned, device-mapped host memory per process: a kernel that has to give up (today: the one-launch K3's grid-wide hand-over
+// running out of polls) ORs a bit into it through its device alias; the host reads it without synchronising — in every check_launch() and in
+// vaa_async_error() — so the failure surfaces as VAA_E_LAUNCH on the next library call after the kernel ran, never as a silent NaN.
+static std::atomic<unsigned*> g_async_word{nullptr};
+static std::mutex g_async_mu;
+
+unsigned* async_error_word() {
+    unsigned* w = g_async_word.load(std::memory_order_acquire);
+    if (w) return w;
+    std::lock_guard<std::mutex> lk(g_async_mu);
+    w = g_async_word.load(std::memory_order_acquire);
+    if (w) return w;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    memset(p, 0, 64);
+    g_async_word.store(reinterpret_cast<unsigned*>(p), std::memory_order_release);
+    return reinterpret_cast<unsigned*>(p);
+}
+
+// VAA_OK, or VAA_E_LAUNCH (+ message) once per recorded failure: the word is cleared by the call that reports it
+int async_error_poll(const char* what) {
+    unsigned* w = g_async_word.load(std::memory_order_acquire);
+    if (!w) return VAA_OK;
+    const unsigned bits = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);
+    if (bits == 0u) return VAA_OK;
+    set_error("%s: an earlier kernel of this process reported a device-side failure (bits 0x%x%s): its outputs are NaN-poisoned", what, bits,
+              (bits & VAA_ASYNC_K3_HANDOVER_TIMEOUT) ? ": the one-launch K3 hand-over timed out — unset VAA_K3_ONE_PASS" : "");
+    return VAA_E_LAUNCH;
+}
+
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("%s: %s", what, hipGetErrorString(e));
         return VAA_E_LAUNCH;
     }
-    return VAA_OK;
+    return async_error_poll(what);
 }
 
 // ---- per-dispatch profiler (vaa_prof_*) ----
@@ -97,6 +131,8 @@ int vaa_prof_get(int i, const char** name, float* usec) {
 }
 
 const char* vaa_last_error(void) { return vaa::g_err; }
+
+int vaa_async_error(void) { return vaa::async_error_poll("vaa_async_error"); }
 
 int vaa_version(void) { return 100; /* 0.1.0 */ }
 

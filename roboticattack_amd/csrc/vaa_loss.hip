@@ -619,7 +619,7 @@ __device__ __forceinline__ void stat_store(S* p, const S& v) {
 // registers across a grid-wide barrier, folds the statistics and writes the gradient from them — the logits are read ONCE (the two-launch
 // form reads every row again in its finishing launch). bar: two zeroed words owned by this launch's stream, left zero.
 template <typename T, int kRowsT, bool ONEPASS>
-__global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a, unsigned* bar, unsigned gen) {
+__global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a, unsigned* bar, unsigned gen, unsigned* err_word, int max_polls) {
     constexpr int N = Vec<T>::N;
     constexpr int MAXV = 32 / N;  // 32 logits per thread in registers: covers V/split <= 16384
     const int r = blockIdx.x / a.split, h = blockIdx.x - r * a.split;
@@ -769,7 +769,11 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a, unsigned
     __shared__ int bar_ok, am_last;
     __shared__ double shf[kRowsT / 64][7];
     __shared__ unsigned hand[16];  // 0: kce, 1: nact | Rn << 16; 8..11: the row's {alse, E, pred, log-sum-exp}
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's statistics stores (agent-scope atomic stores above) have completed
+    // this thread's statistics stores (agent-scope atomic stores above) must have COMPLETED before the arrival below is counted: a
+    // workgroup-scope release fence only waits for LDS / scalar traffic (lgkmcnt) in non-tgsplit mode, so the vector-memory counter is
+    // drained explicitly (round 3 shipped without it: the folding workgroup could read a stale PartStat / SliceStat — ADVICE r3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     unsigned long long* pub = reinterpret_cast<unsigned long long*>(bar + 32 * 9);
     if (tid == 0) {
@@ -796,11 +800,17 @@ __global__ __launch_bounds__(kRowsT) void rows_stats_kernel(RowsArgs a, unsigned
         for (;;) {  // (the folding workgroup finds its own words at once)
             if (lane < 2) w = __hip_atomic_load(&pub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool ok = lane >= 2 || (unsigned)(w >> 32) == gen;
-            if (__all(ok) || ++it >= (1 << 22)) break;  // wave-uniform
+            if (__all(ok)) break;                         // wave-uniform
+            if (++it > max_polls) { it = -1; break; }    // gave up
             __builtin_amdgcn_s_sleep(4);
         }
         if (lane < 2) hand[lane] = (unsigned)w;
-        if (lane == 0) bar_ok = it < (1 << 22);  // a launch that never became fully resident gives up instead of hanging (the host admits resident grids only): NaN gradient
+        // a launch that never became fully resident gives up instead of hanging (the host admits resident grids only): NaN gradient AND the
+        // process-wide failure word (pinned host memory): the next library call returns VAA_E_LAUNCH (vaa_async_error)
+        if (lane == 0) {
+            bar_ok = it >= 0;
+            if (it < 0 && err_word) __hip_atomic_store(err_word, VAA_ASYNC_K3_HANDOVER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // a plain store: no PCIe atomics needed
+        }
         if (lane >= 8 && lane < 12) hand[lane] = __hip_atomic_load(reinterpret_cast<const unsigned*>(&a.slice[r]) + (lane - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -950,7 +960,8 @@ __device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, do
     else if (a.mode == VAA_LOSS_UADA_DDP) { f.total = f.MSE; }                                           // UADA_ddp.py:203-206
     else { f.total = (double)a.scale * f.CE; f.dce = (double)a.scale; }                                 // TMA.py:148
     if (handing) {  // the waiting workgroups need {kce, nact, Rn}: hand over now, publish afterwards
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's log-sum-exp words (issued a reduction ago) have completed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's log-sum-exp words have COMPLETED before the publication below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         if (tid == 0) {
             const float kce = f.nrow > 0 ? (float)(f.dce / f.nrow) : 0.0f;
@@ -1369,7 +1380,7 @@ static bool rows_one_pass_stream_ok(hipStream_t st) {
     return true;
 }
 
-constexpr bool kOnePassDefault = true;
+constexpr bool kOnePassDefault = false;  // opt-in since round 4 (VAA_K3_ONE_PASS=1): 2.8 us per call do not pay for a residency assumption
 static bool rows_one_pass_wanted() {  // VAA_K3_ONE_PASS=1 / 0 overrides the default
     const char* ev = getenv("VAA_K3_ONE_PASS");
     return ev && *ev ? (ev[0] != '0') : kOnePassDefault;
@@ -1385,23 +1396,29 @@ static bool rows_one_pass_fits(const RowsArgs& a, int dtype) {
 }
 
 static int launch_rows_stats(const RowsArgs& a, int dtype, hipStream_t st, const char* who, unsigned* bar = nullptr, unsigned gen = 0u) {
+    unsigned* err = bar ? async_error_word() : nullptr;
+    int polls = 1 << 22;
+    if (bar) {  // test hook: VAA_K3_HANDOVER_POLLS=0 makes every waiting workgroup give up at once (the failure path's test)
+        const char* ev = getenv("VAA_K3_HANDOVER_POLLS");
+        if (ev && *ev) polls = atoi(ev);
+    }
     const int nt = rows_threads(a.V);
     const dim3 gs((unsigned)(a.R * a.split));
     unsigned* nobar = nullptr;
     if (bar) {  // one pass: statistics, grid barrier, fold, full-row gradient from the registers
         if (dtype == VAA_DTYPE_F32) {
-            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, true>), gs, dim3(256), 0, st, a, bar, gen);
-            else VAA_LAUNCH((rows_stats_kernel<float, 512, true>), gs, dim3(512), 0, st, a, bar, gen);
+            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, true>), gs, dim3(256), 0, st, a, bar, gen, err, polls);
+            else VAA_LAUNCH((rows_stats_kernel<float, 512, true>), gs, dim3(512), 0, st, a, bar, gen, err, polls);
         } else {
-            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, true>), gs, dim3(256), 0, st, a, bar, gen);
-            else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, true>), gs, dim3(512), 0, st, a, bar, gen);
+            if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, true>), gs, dim3(256), 0, st, a, bar, gen, err, polls);
+            else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, true>), gs, dim3(512), 0, st, a, bar, gen, err, polls);
         }
     } else if (dtype == VAA_DTYPE_F32) {
-        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, false>), gs, dim3(256), 0, st, a, nobar, 0u);
-        else VAA_LAUNCH((rows_stats_kernel<float, 512, false>), gs, dim3(512), 0, st, a, nobar, 0u);
+        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<float, 256, false>), gs, dim3(256), 0, st, a, nobar, 0u, nobar, 0);
+        else VAA_LAUNCH((rows_stats_kernel<float, 512, false>), gs, dim3(512), 0, st, a, nobar, 0u, nobar, 0);
     } else {
-        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, false>), gs, dim3(256), 0, st, a, nobar, 0u);
-        else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, false>), gs, dim3(512), 0, st, a, nobar, 0u);
+        if (nt == 256) VAA_LAUNCH((rows_stats_kernel<uint16_t, 256, false>), gs, dim3(256), 0, st, a, nobar, 0u, nobar, 0);
+        else VAA_LAUNCH((rows_stats_kernel<uint16_t, 512, false>), gs, dim3(512), 0, st, a, nobar, 0u, nobar, 0);
     }
     return check_launch(who);
 }

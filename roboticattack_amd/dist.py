@@ -64,6 +64,38 @@ class PatchGradSync:
         self.n_grad, self.n_scalars = n_grad, n_scalars
         self.buf = torch.zeros(n_grad + n_scalars, dtype=torch.float32, device=device)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._timing = None  # measurement aid (bench.py): [(start event, stop event, host seconds)] of every all-reduce while armed
+
+    # ---- measurement aid: what the collective costs INSIDE a step (UADA_ddp.py:206: DDP's bucket all-reduce fires inside backward) ----
+    def timing_start(self):
+        """Arm: every all-reduce from here on is bracketed by two events ON THE LAUNCH STREAM (the current stream: the collective is ordered
+        behind the epilogue that wrote the message, and K4 behind the collective). The bracket therefore covers the hand-off to the backend's
+        stream, the wait for the slowest rank's message and the exchange itself — the time the step's critical path spends in the collective."""
+        self._timing = []
+
+    def timing_collect(self):
+        """Disarm; returns [(event us, host us)] per all-reduce (event us = GPU time between the two events; host us = wall time the launching
+        thread spent inside dist.all_reduce — gloo blocks the host, RCCL only enqueues)."""
+        recs, self._timing = self._timing or [], None
+        out = []
+        for e0, e1, host_s in recs:
+            e1.synchronize()
+            out.append((e0.elapsed_time(e1) * 1e3, host_s * 1e6))
+        return out
+
+    def _all_reduce(self):
+        if self._timing is None or not self.buf.is_cuda:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+            return
+        import time
+
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        t0 = time.perf_counter()
+        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+        host_s = time.perf_counter() - t0
+        e1.record()
+        self._timing.append((e0, e1, host_s))
 
     def allreduce(self, grad: torch.Tensor, scalars: torch.Tensor | None = None):
         """Returns (summed grad view [n_grad], summed scalars view [n_scalars]); divide by world for means."""
@@ -71,7 +103,7 @@ class PatchGradSync:
         if scalars is not None and self.n_scalars:
             self.buf[self.n_grad :].copy_(scalars.reshape(-1)[: self.n_scalars])
         if self.world > 1:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+            self._all_reduce()
         return self.buf[: self.n_grad], self.buf[self.n_grad :]
 
     def allreduce_step(self, grad: torch.Tensor, loss_scalars: torch.Tensor, pick: torch.Tensor):
@@ -86,7 +118,7 @@ class PatchGradSync:
     def allreduce_packed(self):
         """The message is already in `buf` ([grad | scalars], e.g. written by vaa_step_epilogue): ONE all-reduce(sum), views returned."""
         if self.world > 1:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+            self._all_reduce()
         return self.buf[: self.n_grad], self.buf[self.n_grad :]
 
 

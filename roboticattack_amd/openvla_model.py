@@ -428,6 +428,28 @@ class OpenVLAShaped(nn.Module):
         f1.record_stream(cur)
         return f0, f1
 
+    def _rope_tables(self, T: int, device, dtype):
+        """(cos, sin, (cos_half, sin_half)) of the T positions of a prompt bucket, built ONCE per (T, device, dtype): they are constants of the
+        model, and rebuilding them every step cost ~10 small launches (arange / pow / reciprocal / outer / cat / cos / sin / casts, ~55 us —
+        three quarters of the whole hand-written path). Same ops as before on first use: bitwise the per-step tables."""
+        key = (int(T), str(device), dtype)
+        cache = self.__dict__.setdefault("_rope_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            hd = self.cfg.llm_dim // self.cfg.llm_heads
+            with torch.no_grad():
+                inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, device=device, dtype=torch.float32) / hd))
+                ang = torch.outer(torch.arange(T, device=device, dtype=torch.float32), inv)
+                ang = torch.cat([ang, ang], dim=-1)
+                cos, sin = ang.cos().to(dtype)[None, None], ang.sin().to(dtype)[None, None]
+                half = ang[:, : hd // 2]
+                # fused path: HF rounds cos/sin to the activation dtype before use (modeling_llama rotary) — keep that rounding
+                tab = (half.cos().to(dtype).float().contiguous(), half.sin().to(dtype).float().contiguous())
+            if len(cache) >= 16:  # prompt buckets are few; never grow without bound
+                cache.clear()
+            hit = cache[key] = (cos, sin, tab)
+        return hit
+
     def seq_bucket(self, L: int) -> int:
         """Padded prompt length of the rows-only path (cfg.seq_floor / seq_multiple; VAA_SEQ_FLOOR overrides the floor, 0 = off)."""
         import os
@@ -453,20 +475,20 @@ class OpenVLAShaped(nn.Module):
         if rows is not None and pack is None:
             # rows-only path: right-pad the prompts to the bucket length (causal attention: the labelled rows do not see the extra pad
             # positions); `rows` from label_row_index already addresses the bucketed layout
-            Lb = self.seq_bucket(input_ids.shape[1])
+            # the padded length travels WITH the index (label_row_index tags it): the two sides cannot disagree when the environment
+            # changes between the calls; an untagged index (built by other means for the documented [B*(256+L)] layout) must address
+            # the bucketed layout of seq_bucket(L) itself
+            S_rows = getattr(rows, "vaa_S", None)
+            Lb = (int(S_rows) - N_IMG_TOKENS) if S_rows is not None else self.seq_bucket(input_ids.shape[1])
+            if Lb < input_ids.shape[1]:
+                raise ValueError(f"hidden_states: the row index was built for prompts of {Lb} tokens, input_ids has {input_ids.shape[1]}")
             if Lb != input_ids.shape[1]:
                 input_ids = F.pad(input_ids, (0, Lb - input_ids.shape[1]), value=PAD_ID)
         emb = self.embed_tokens(input_ids)
         x = torch.cat([emb[:, :1], proj.to(emb.dtype), emb[:, 1:]], dim=1)
         T = x.shape[1]
         hd = self.cfg.llm_dim // self.cfg.llm_heads
-        inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, device=x.device, dtype=torch.float32) / hd))
-        ang = torch.outer(torch.arange(T, device=x.device, dtype=torch.float32), inv)
-        ang = torch.cat([ang, ang], dim=-1)
-        cos, sin = ang.cos().to(x.dtype)[None, None], ang.sin().to(x.dtype)[None, None]
-        half = ang[:, : hd // 2]
-        # fused path: HF rounds cos/sin to the activation dtype before use (modeling_llama rotary) — keep that rounding
-        rope_tab = (half.cos().to(x.dtype).float().contiguous(), half.sin().to(x.dtype).float().contiguous())
+        cos, sin, rope_tab = self._rope_tables(T, x.device, x.dtype)
         from . import model_ops
 
         if pack is not None and model_ops.enabled(x) and model_ops.attention_enabled(x.view(x.shape[0], T, self.cfg.llm_heads, hd)) and hd in (64, 128):
@@ -499,7 +521,9 @@ class OpenVLAShaped(nn.Module):
         B, L = labels.shape
         S = N_IMG_TOKENS + self.seq_bucket(L)
         bk = (labels[:, 1:] != IGNORE_INDEX).nonzero(as_tuple=False)  # [R,2] sorted row-major
-        return bk[:, 0] * S + N_IMG_TOKENS + bk[:, 1]
+        idx = bk[:, 0] * S + N_IMG_TOKENS + bk[:, 1]
+        idx.vaa_S = S  # hidden_states pads the prompts to THIS length (the environment is not consulted a second time)
+        return idx
 
     def forward_rows(self, input_ids, pixel_values, labels, row_index=None, patch_embeds=None, pack=None):
         """Logits [R,V] of the labelled rows only, in (b,k) row-major order of labels[b,k+1] != -100 (VAA_LAYOUT_ROWS):
@@ -548,8 +572,17 @@ def build_openvla(cfg: OpenVLACfg | None = None, device="cuda", dtype=torch.bflo
     """Random-init OpenVLA-7B-shaped model created directly on `device` in `dtype` (15 GB in bf16)."""
     if torch.device(device).type == "cuda" and dtype == torch.bfloat16:
         enable_tuned_gemms()
-    with torch.device(device):
-        m = OpenVLAShaped(cfg)
+    # parameters are created in `dtype` directly (no fp32 copy of the 7.5 B parameters: 30 GB of transient HBM per process, which 8 ranks
+    # sharing one GPU in the functional multi-rank runs cannot afford); init_random overwrites every matrix, the 1-D defaults (ones / zeros)
+    # are exact in any dtype
+    prev = torch.get_default_dtype()
+    try:
+        if dtype.is_floating_point:
+            torch.set_default_dtype(dtype)
+        with torch.device(device):
+            m = OpenVLAShaped(cfg)
+    finally:
+        torch.set_default_dtype(prev)
     m = m.to(dtype)
     m.init_random(seed)
     return m.eval()

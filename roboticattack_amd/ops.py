@@ -102,6 +102,12 @@ def device_check() -> None:
     _lib.check(_lib.lib().vaa_device_check(), "vaa_device_check")
 
 
+def async_error_check() -> None:
+    """Raises VaaError when a kernel of this process recorded a device-side failure since the last poll (include/vaa.h: vaa_async_error).
+    Call it behind a synchronisation point — the word is written by the kernel that failed."""
+    _lib.check(_lib.lib().vaa_async_error(), "vaa_async_error")
+
+
 # ------------------------------------------------------------------------------------------------------
 # K1 / K2
 # ------------------------------------------------------------------------------------------------------

@@ -104,8 +104,11 @@ class RandomPatchTransform:
 
     def _to_dev(self, xy, theta):
         """(x, y) and theta of one step -> device tensors through ONE pinned staging buffer and ONE async copy (the only host->device traffic
-        of a step: 32 B per image). A ring of slots, each guarded by an event, keeps a slot's host and device memory untouched until the
-        copy that read it has completed and for the steps that may still hold its tensors."""
+        of a step: 32 B per image). The HOST side is a ring of pinned slots, each guarded by the event of the copy that last read it; the
+        DEVICE side is a fresh tensor from the caching allocator per call (no launch, no hipMalloc), so a tensor that an autograd graph saved
+        for its backward (PatchApply / PatchApplyEmbed keep xy and theta) lives exactly as long as that graph — however many later calls
+        (validation sweeps, micro-batches built before backward, retain_graph) happen in between (round 3 handed out views of a reused
+        8-slot device ring: ADVICE r3)."""
         self.last_params = (xy, theta)
         if self.device.type != "cuda":
             return torch.from_numpy(xy).to(self.device), torch.from_numpy(theta).to(self.device)
@@ -113,13 +116,12 @@ class RandomPatchTransform:
         ring = getattr(self, "_ring", None)
         if ring is None or ring["B"] != B:
             ring = self._ring = {"B": B, "i": 0, "host": [torch.empty(8 * B, dtype=torch.int32).pin_memory() for _ in range(self._RING)],
-                                 "dev": [torch.empty(8 * B, dtype=torch.int32, device=self.device) for _ in range(self._RING)],
                                  "ev": [None] * self._RING}
         k = ring["i"]
         ring["i"] = (k + 1) % self._RING
         if ring["ev"][k] is not None:
             ring["ev"][k].synchronize()  # the copy that last read this slot is done (it was enqueued _RING steps ago)
-        h, d = ring["host"][k], ring["dev"][k]
+        h, d = ring["host"][k], torch.empty(8 * B, dtype=torch.int32, device=self.device)
         hn = h.numpy()
         hn[: 2 * B] = xy.reshape(-1)
         hn[2 * B :].view(np.float32)[:] = theta.reshape(-1)

@@ -492,6 +492,18 @@ def test_bench_py_two_ranks_one_gpu(tmp_path):
     assert d["cpu_baseline"] is None and d["roofline"]["kernel"].startswith("patch_apply_")
     ss = d["strong_scaling"]  # BASELINE config 3's shape: the N=1 batch split over the ranks
     assert ss["per_rank_bs"] == 2 and ss["global_batch"] == 4 and ss["images_per_s"] > 0 and abs(ss["images_per_s"] * ss["ms_per_step"] * 1e-3 - 4) < 1e-6
+    # the collective is timed inside BOTH regions (events on the launch stream around the 30 KB all-reduce, one per step) and summarised where
+    # the driver's `parsed.config` keeps it; the back-to-back figure sits beside it
+    for comm, cfrac in ((d["allreduce_us_per_step"], d["comm_frac"]), (ss["allreduce_us_per_step"], ss["comm_frac"])):
+        assert comm["calls_per_step"] == 1 and 0 < comm["mean_us_min_over_ranks"] <= comm["mean_us_max_over_ranks"] <= comm["max_us_any_rank"] * (1 + 1e-9)
+        assert 0 < cfrac < 1 and abs(cfrac - comm["comm_frac"]) < 1e-12 and comm["comm_plus_skew_frac"] >= cfrac
+    c = d["config"]
+    assert c["regions"] == "both" and c["comm_frac"] == d["comm_frac"] and c["strong_comm_frac"] == ss["comm_frac"] and c["allreduce_back_to_back_us"] > 0
+    assert c["allreduce_us_per_step"] == d["allreduce_us_per_step"]["mean_us_min_over_ranks"] and c["strong_images_per_s"] == ss["images_per_s"]
+    assert c["tunableop_entries_loaded_min_over_ranks"] <= c["tunableop_entries_loaded"] and c["env"]["VAA_DIST_BACKEND"] == "gloo"
+    assert ss["loss_finite_all_ranks"] and ss["speedup_vs_one_rank_weak_step"] > 0 and d["allreduce_back_to_back"]["bytes"] == 4 * (3 * 50 * 50 + 4)
+    # the headline region is un-profiled; the per-dispatch records come from the separate pass
+    assert d["profiled_pass_steps"] == 3 and d["roofline"]["samples"] == 3
 
 
 def test_bench_py_self_launches_its_ranks():
@@ -513,6 +525,17 @@ def test_bench_py_self_launches_its_ranks():
     assert d["n_gpus"] == 2 and d["loss_finite"] and d["config"]["global_batch"] == 8 and d["strong_scaling"]["per_rank_bs"] == 2
     if torch.cuda.device_count() < 2:
         assert d["config"]["backend"] == "gloo"
+    # --regions strong: the strong-scaling region alone (what a full-size 8-rank functional run on ONE GPU uses); `value` is then null
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--model", "tiny", "--bs", "8",
+                          "--no-cpu-baseline", "--no-kernel-suite", "--regions", "strong"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    ss = d["strong_scaling"]
+    assert d["n_gpus"] == 4 and d["value"] is None and d["config"]["regions"] == "strong" and d["roofline"] is None and "note" in d
+    assert ss["per_rank_bs"] == 2 and ss["global_batch"] == 8 and ss["loss_finite_all_ranks"] and d["loss_finite"] and 0 < ss["comm_frac"] < 1
+    assert d["config"]["strong_comm_frac"] == ss["comm_frac"] and d["config"]["visible_gpus"] == torch.cuda.device_count()
 
 
 @pytest.mark.parametrize("resize", [False, True])
@@ -757,3 +780,59 @@ def test_single_gpu_loops_fused_update_equals_separate_launches(tmp_path, monkey
     assert np.array_equal(p1, p0) and len(s1) == len(s0) and all(np.array_equal(a, b) for a, b in zip(s1, s0))
     assert l1[0] == l0[0] and np.allclose(np.asarray(l1[-1], np.float64), np.asarray(l0[-1], np.float64), rtol=1e-5, atol=1e-12)
     assert float(np.abs(p1 - 0.5).max()) <= 0.5 + 1e-6
+
+
+@pytest.mark.parametrize("which", ["uada", "tma", "upa"])
+def test_attack_loops_fail_loudly_on_non_finite_state(tmp_path, which):
+    """Fail loud, never NaN: an inf upstream gradient in ONE inner step of the second outer iteration — the loss scalars
+    stay finite, K2 turns the gradient into NaN rows by design, AdamW's m / v keep the NaN while the clamp turns the patch into a finite 0 —
+    raises NonFiniteAttackState at that iteration's read-back, BEFORE anything of it is written: `last/patch.pt` still holds the finite
+    patch the validation of outer iteration 0 saved. The reference would keep optimising and save the degenerate patch (UADA.py:257-275)."""
+    import types
+
+    from roboticattack_amd.attack.engine import NonFiniteAttackState
+    from roboticattack_amd.surrogate import SurrogateVLA
+
+    vla = SurrogateVLA(seed=5).to(DEV)
+    args = types.SimpleNamespace(wandb_project="false")
+    _seed()
+    train, val = _Fresh([7000] * 4, 4), _Fresh([7100], 2)
+    if which == "uada":
+        from roboticattack_amd.attack.uada import OpenVLAAttacker
+
+        att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="adamW")
+        run = lambda: att.patchattack_unconstrained(train, val, num_iter=4, patch_size=[3, 50, 50], lr=0.03, accumulate_steps=1, maskidx=[0], warmup=1,  # noqa: E731
+                                                    geometry=True, innerLoop=3, args=args)
+    elif which == "tma":
+        from roboticattack_amd.attack.tma import OpenVLAAttacker
+
+        att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="adamW")
+        run = lambda: att.patchattack_unconstrained(train, val, num_iter=4, target_action=np.zeros(7), patch_size=[3, 50, 50], alpha=0.03,  # noqa: E731
+                                                    accumulate_steps=1, maskidx=[0, 1], warmup=1, geometry=True, innerLoop=3, args=args)
+    else:
+        from roboticattack_amd.attack.upa import OpenVLAAttacker
+
+        att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="adamW", alpha=0.8, belta=0.2)
+        run = lambda: att.patchattack_unconstrained(train, val, num_iter=4, patch_size=[3, 50, 50], lr=0.03, accumulate_steps=1, maskidx=[0, 1, 2],  # noqa: E731
+                                                    warmup=1, geometry=True, innerLoop=3, reverse_direction=True, args=args)
+    att.val_batches = 1
+    calls = {"n": 0}
+    orig = att.model_loss
+
+    def poisoned(*a, **k):
+        total, scalars, pred = orig(*a, **k)
+        if total is not None:
+            calls["n"] += 1
+            if calls["n"] == 5:  # outer iteration 1, inner step 1
+                total = total * float("inf")
+        return total, scalars, pred
+
+    att.model_loss = poisoned
+    with pytest.raises(NonFiniteAttackState, match="outer iteration 1"):
+        run()
+    saved = torch.load(os.path.join(str(tmp_path), "last", "patch.pt"))
+    assert bool(torch.isfinite(saved).all()) and float(saved.min()) >= 0.0 and float(saved.max()) <= 1.0
+    # save_patch itself refuses a non-finite patch (belt and braces)
+    with pytest.raises(NonFiniteAttackState):
+        att.save_patch(torch.full((3, 4, 4), float("nan")), "never")
+    assert not os.path.exists(os.path.join(str(tmp_path), "never", "patch.pt"))

@@ -1441,3 +1441,45 @@ def test_k3_full_rows_under_capture_and_beyond_half_residency(ops):
     ce = torch.nn.functional.cross_entropy(z2.double(), tgt, reduction="mean")
     assert abs(float(sc2[1]) - float(ce)) <= 3e-5 * max(1.0, abs(float(ce)))
     assert torch.isfinite(g2).all()
+
+
+@pytest.mark.gpu
+def test_k3_one_pass_handover_timeout_fails_loudly(ops, monkeypatch):
+    """Fail loud, never NaN: the opt-in one-launch K3 whose grid-wide hand-over runs out of polls (forced here with
+    VAA_K3_HANDOVER_POLLS=0: every waiting workgroup gives up at once) NaN-poisons the gradient AND raises the library's failure word — the NEXT
+    library call of the process returns VAA_E_LAUNCH with the reason, once; vaa_async_error() is the explicit poll. The default form (two launches)
+    has no hand-over and is unaffected."""
+    from roboticattack_amd import _lib
+    from roboticattack_amd.labels import mask_labels
+
+    _, labels, _ = synthetic.synth_text_batch(11, 64)
+    labels = mask_labels(labels, [0]).to(DEV)
+    R = int((labels[:, 1:] != -100).sum())
+    logits = (torch.randn(R, 32064, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 2).to(torch.bfloat16)
+    rm = ops.LossRowMap(labels)
+    ops.async_error_check()  # clean before
+    monkeypatch.delenv("VAA_K3_ONE_PASS", raising=False)
+    ops.prof_start(8)
+    _, _, _, g_ref = ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL)
+    torch.cuda.synchronize()
+    assert len(ops.prof_collect()) == 2 and torch.isfinite(g_ref.float()).all()  # two launches by default
+    monkeypatch.setenv("VAA_K3_ONE_PASS", "1")
+    monkeypatch.setenv("VAA_K3_HANDOVER_POLLS", "0")
+    g = torch.zeros_like(logits)
+    ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=g)
+    torch.cuda.synchronize()
+    assert torch.isnan(g.float()).any()  # poisoned, never stale or silently partial
+    patch = torch.rand(3, 8, 8, device=DEV)
+    with pytest.raises(_lib.VaaError, match="hand-over timed out"):  # the next library call, whatever it is, reports the failure ...
+        ops.patch_update(patch, torch.rand_like(patch), torch.zeros_like(patch), torch.zeros_like(patch), ops.OPT_ADAMW_HF, 1e-3, 1)
+    ops.async_error_check()                                           # ... once: the word is cleared by the report
+    ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=g)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.VaaError, match="vaa_async_error"):       # the explicit poll
+        ops.async_error_check()
+    monkeypatch.delenv("VAA_K3_HANDOVER_POLLS")
+    g2 = torch.zeros_like(logits)
+    ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=g2)  # un-forced: the one-launch form works and agrees
+    torch.cuda.synchronize()
+    ops.async_error_check()
+    assert torch.equal(g2.view(torch.int16), g_ref.view(torch.int16))

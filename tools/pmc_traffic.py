@@ -80,8 +80,8 @@ def main():
            "K2et_deferred_reduce": ("embed_dgrad_tiles", "patch_grad_scatter_kernel<3, true, false"),             # tile GEMM + gather; the final sum is the epilogue's
            "K3_loss_rows_fwd_bwd": ("rows_stats_kernel<unsigned short, 256, false>", "rows_finish_kernel<unsigned short, 256>|256"),        # UADA_DDP: gradient slice, one finishing workgroup
            "K3s_loss_rows_stats": ("rows_stats_kernel<unsigned short, 256, false>",),
-           "K3_full_rows_fwd_bwd": ("rows_stats_kernel<unsigned short, 256, true>",),                              # UADA: full-row gradient in ONE launch (rows read once)
-           "K3_full_two_launches": ("rows_stats_kernel<unsigned short, 256, false>", "rows_finish_kernel<unsigned short, 256>|131072"),  # VAA_K3_ONE_PASS=0 / under capture
+           "K3_full_one_launch_optin": ("rows_stats_kernel<unsigned short, 256, true>",),                          # UADA: full-row gradient in ONE launch (VAA_K3_ONE_PASS=1, rows read once)
+           "K3_full_rows_fwd_bwd": ("rows_stats_kernel<unsigned short, 256, false>", "rows_finish_kernel<unsigned short, 256>|131072"),  # the default since round 4: two launches
            "EPI_step_epilogue": ("step_epilogue_kernel",),
            "K4_patch_update": ("patch_update_kernel",)}
     # a kernel that belongs to two ops (reduce: K2 and K2'; stats: both K3 modes) ran once per op call, so its per-launch mean is counted once in each
