@@ -267,20 +267,12 @@ int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const uint16_t* dy1
                                 int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes,
                                 void* stream);
 /* the same fed by the tile-major mask of vaa_patch_apply_fwd_tiles (keep_tiles, tile_flags: both required). gpatch == NULL leaves the final
- * fixed-order sum to the caller: the vaa_patch_grad_partials(B) partial tiles [parts][3*ph*pw] f32 then sit at the start of ws.
- *   tile_rows dev int32 [vaa_tile_rows_bytes(B) / 4] or NULL: the compact row list of the flagged tiles, built by vaa_tile_rows_build right
- *             behind vaa_patch_apply_fwd_tiles (one small launch in the forward). With it — and where vaa_patch_embed_grad_wants_rows(...) == 1:
- *             batches whose flagged tiles alone fill the chip, round_bf16 != 0, towers of up to 1152 columns — the patch-embed backward runs as
- *             ONE cross-image contraction [all flagged tiles, D] x [D, 588] per tower (64-row items, pipelined staging) instead of one workgroup
- *             chain per image; the result is bit for bit the per-image form's. */
+ * fixed-order sum to the caller: the vaa_patch_grad_partials(B) partial tiles [parts][3*ph*pw] f32 then sit at the start of ws. */
 int vaa_patch_grad_partials(int B);
-size_t vaa_tile_rows_bytes(int B);
-int vaa_tile_rows_build(const uint32_t* tile_flags, int B, int32_t* tile_rows, void* stream);
-int vaa_patch_embed_grad_wants_rows(int B, int ph, int pw, int D0, int D1);
 int vaa_patch_embed_grad_gather_tiles(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wp0, const uint16_t* wp1,
                                       const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
-                                      const uint32_t* tile_flags, const int32_t* tile_rows, int B, int ph, int pw, int geometry, int mask_mode,
-                                      const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream);
+                                      const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
+                                      int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream);
 /* the same with one patch per image (resize_patch=True; packed / pdesc / gpacked as in vaa_patch_grad_gather_multi):
  * ws >= vaa_patch_embed_grad_multi_ws_bytes(B); the resize adjoint then folds gpacked into the base patch's gradient */
 size_t vaa_patch_embed_grad_multi_ws_bytes(int B);

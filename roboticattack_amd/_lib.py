@@ -53,9 +53,6 @@ EXPORTS = (
     "vaa_patch_grad_partials",
     "vaa_patch_embed_grad_gather_multi_tiles",
     "vaa_patch_embed_grad_gather_tiles",
-    "vaa_tile_rows_bytes",
-    "vaa_tile_rows_build",
-    "vaa_patch_embed_grad_wants_rows",
     "vaa_loss_rows_stats",
     "vaa_step_epilogue",
     "vaa_step_epilogue_update",
@@ -184,13 +181,7 @@ def lib() -> C.CDLL:
     L.vaa_patch_grad_partials.restype = i32
     L.vaa_patch_grad_partials.argtypes = [i32]
     L.vaa_patch_embed_grad_gather_tiles.restype = i32
-    L.vaa_patch_embed_grad_gather_tiles.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
-    L.vaa_tile_rows_bytes.restype = sz
-    L.vaa_tile_rows_bytes.argtypes = [i32]
-    L.vaa_tile_rows_build.restype = i32
-    L.vaa_tile_rows_build.argtypes = [vp, i32, vp, vp]
-    L.vaa_patch_embed_grad_wants_rows.restype = i32
-    L.vaa_patch_embed_grad_wants_rows.argtypes = [i32, i32, i32, i32, i32]
+    L.vaa_patch_embed_grad_gather_tiles.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
     L.vaa_loss_rows_stats.restype = i32
     L.vaa_loss_rows_stats.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, i32, vp, sz, vp]
     L.vaa_step_epilogue.restype = i32

@@ -51,10 +51,6 @@ struct GradArgs {
     const float* geff;
     const float* geff2;      // non-null: the tile kernel ran one tower per workgroup and `geff` holds {tower 0, tower 1} PAIRS per element: the gather adds the two
     const uint16_t* keep_t;  // TILED only: K1's tile-major keep words [B,3,256,14] (vaa_patch_apply_fwd_tiles) instead of `keep`
-    // TILED, bf16 planes (embed_dgrad_rows_kernel): the two towers' tile gradients as the bf16 values the model's backward hands over,
-    // gt0 / gt1 [B,256,588]; the gather forms bf16 * (1/std) per tower and adds them — the fp32 operations of the pair form, bit for bit
-    const uint16_t* gt0;
-    const uint16_t* gt1;
 };
 
 constexpr int kTilePx = 14, kTilesPerSide = 16, kTileElems = 3 * kTilePx * kTilePx;  // ViT patch-embed tiling of the 224x224 frame
@@ -313,13 +309,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
                             for (int cc = 0; cc < NCH; ++cc) {
                                 const size_t ge = gel + (c_base + cc) * (kTilePx * kTilePx);  // even
-                                if (a.gt0) {  // one 4-byte load per tower = the lane's two pixels
-                                    const uint32_t p0 = *reinterpret_cast<const uint32_t*>(a.gt0 + ge);
-                                    const uint32_t p1 = *reinterpret_cast<const uint32_t*>(a.gt1 + ge);
-                                    const float s0 = a.istd6[c_base + cc], s1 = a.istd6[c_base + cc + 3];
-                                    gt[k][0][cc] = __uint_as_float(p0 << 16) * s0 + __uint_as_float(p1 << 16) * s1;
-                                    gt[k][1][cc] = __uint_as_float(p0 & 0xffff0000u) * s0 + __uint_as_float(p1 & 0xffff0000u) * s1;
-                                } else if (a.geff2) {  // {tower 0, tower 1} pairs, added here — the tile kernel's own fp32 sum
+                                if (a.geff2) {  // {tower 0, tower 1} pairs, added here — the tile kernel's own fp32 sum
                                     const float4 v4 = *reinterpret_cast<const float4*>(a.geff + 2 * ge);
                                     gt[k][0][cc] = v4.x + v4.y;
                                     gt[k][1][cc] = v4.z + v4.w;
@@ -621,7 +611,7 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode; a.band_rows = ph;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr; a.gt0 = nullptr; a.gt1 = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
     return launch_scatter_reduce<false>(a, gpatch, st, "vaa_patch_grad_gather");
 }
 
@@ -652,7 +642,7 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.g = gout_bf16; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr; a.gt0 = nullptr; a.gt1 = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
     return launch_scatter_multi<false>(a, max_h, max_w, (hipStream_t)stream, "vaa_patch_grad_gather_multi");
 }
 
@@ -672,12 +662,10 @@ struct EmbedArgs {
     const uint16_t *wt0, *wt1;  // conv weights of the two towers in the PACKED fragment order of embed_pack_weights_kernel
     const uint8_t* keep;        // [B,3,224*224/8] keep bits from K1
     const uint32_t* flags;      // [B,256] tile flag words from K1's tile-major form (else nullptr: derived from `keep`)
-    const int32_t* tile_rows;   // compact row list of the flagged tiles (vaa_tile_rows_build) or nullptr: enables the cross-image kernel
     float* geff;                // [B,256,588], indexed by tile (ty*16 + tx); only the flagged tiles are written
     float* geff2;               // non-null: room for the pair layout of tower_split ({tower 0, tower 1} per element, in geff)
     int B, D0, D1, round_bf16;
     int tower_split;            // one tower per workgroup (grid.z = 2): halves the per-workgroup chain while the launch is far from filling the chip
-    int bf16_planes;            // set by launch_embed_tiles: the cross-image kernel ran and left bf16 planes {tower 0, tower 1} [B,256,588] at geff
     float istd6[6];
 };
 
@@ -835,15 +823,13 @@ constexpr int kEmbedGroup = VAA_EMBED_GROUP;  // 64-wide k-chunks whose weight f
 //   * the A fragments of chunk u+1 are read from LDS before the MFMAs of chunk u (one ds_read per row block and k-half, all issued
 //     together), so the LDS latency is covered by twelve MFMAs instead of being paid in front of every pair.
 //   * MFMA order: all row blocks against the first k-half, then the second: consecutive MFMAs never share an accumulator.
-template <int NQ, int NB, int G = kEmbedGroup, bool ZERO = true>
+template <int NQ, int NB, int G = kEmbedGroup>
 __device__ __forceinline__ void embed_kloop(const uint16_t* ap, int SA, const uint16_t* const (&wp)[NB], int nchunk, v4f_e (&acc)[NB][4],
                                             const v8s_e (*pre)[NB][2] = nullptr) {
-    if constexpr (ZERO) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[j][q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
-    }
+        for (int q = 0; q < 4; ++q) acc[j][q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
     auto load_group = [&](v8s_e (&bf)[G][NB][2], int k0) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
@@ -1098,237 +1084,9 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
 #endif
 }
 
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// K2' tile GEMM as ONE cross-image contraction (round 4). The flagged tiles of ALL images form one compact row list (vaa_tile_rows_build: a
-// one-workgroup prefix over K1's tile flags, launched right behind K1 in the forward — hundreds of milliseconds before the backward needs
-// it), cut into row groups of 64; a work item is (row group, column range, tower):
-//     T[group rows, range] = dY_tower[rows, :] @ W_tower[:, range]
-// — 64 gathered dY rows staged in LDS, every wave owns ONE 16-column block of the range and streams its packed weight fragments from L2.
-// Against the per-image kernel above (one workgroup per image, tower and column range):
-//   * no M padding and no per-image imbalance: every item has 64 rows (a 50x50 footprint flags 12..30 tiles of an image: 1-2 row blocks
-//     of 16, padded, and the launch lasts as long as its slowest image);
-//   * the weights a workgroup streams drop from 19 to <= 8 column blocks: ~390 KB instead of ~700 KB of L2 -> CU operand traffic per
-//     workgroup, which is what the per-image k-loop waits for (L2 delivers ~55 B/clk to a CU when all CUs pull);
-//   * pipelined staging: ALL dY rows of the item are requested at once (one memory round trip), but written to LDS and consumed in pieces of
-//     6 k-chunks — the MFMAs of piece p run while the later pieces are still arriving; the weight fragments are prefetched across the piece
-//     boundaries (one continuous ping-pong of two register sets of 3 chunks), one barrier per piece;
-//   * XCD-aware item map: XCD x = (tower, row groups g % 4) — a tower's weights are fetched by 4 of the 8 L2s instead of 8, a row group's
-//     dY rows by one;
-//   * the result leaves as the bf16 values the model's own backward would hand over (the rounding the unfused path performs), one bf16 plane
-//     per tower: half the bytes of the fp32 {tower 0, tower 1} pairs; the gather multiplies by 1/std and adds the towers — the very fp32
-//     operations the pair form performed, bit for bit.
-// Persistent launch: gridDim.x workgroups (the CU count, a multiple of 8) loop over their XCD's items (one each at the BASELINE shapes).
-struct RowsGemmArgs {
-    const uint16_t *dy0, *dy1;  // [B,256,D0], [B,256,D1] bf16
-    const uint16_t *wt0, *wt1;  // packed weights (embed_pack_weights_kernel)
-    const int32_t* tile_rows;   // {total, 0, 0, 0} + the compact list of flagged global tile ids b * 256 + tile (vaa_tile_rows_build)
-    uint16_t *t0, *t1;          // out: bf16 tile gradients per tower [B,256,588] (only flagged tiles are written)
-    int B, D0, D1, nch;         // nch: column ranges (ceil(37 / nch) <= 8 16-column blocks each)
-};
-
-constexpr int kRowsPerGroup = 64;
-constexpr int kRowsG = 3;                 // k-chunks per weight register set
-constexpr int kRowsPiece = 2 * kRowsG;    // k-chunks per staged piece = one ping-pong round of the k-loop
-constexpr int kRowsMaxD = 1152;           // towers of up to 18 k-chunks = 3 pieces
-constexpr int kRowsPieces = kRowsMaxD / 64 / kRowsPiece;
-
-// compact row list of the flagged tiles: ONE workgroup, run t of thread t = tile ids [t * per, (t + 1) * per)
-__global__ __launch_bounds__(1024) void tile_rows_compact_kernel(const uint32_t* __restrict__ flags, int N, int32_t* __restrict__ out) {
-    __shared__ int wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int per = (((N + 1023) / 1024) + 3) & ~3;
-    const int f_lo = min(N, tid * per), f_hi = min(N, f_lo + per);
-    int cnt = 0;
-    for (int f = f_lo; f < f_hi; f += 4) {  // N is a multiple of 256, per of 4: whole uint4s
-        const uint4 w = *reinterpret_cast<const uint4*>(flags + f);
-        cnt += (w.x != 0u) + (w.y != 0u) + (w.z != 0u) + (w.w != 0u);
-    }
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    int base = incl - cnt, total = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        if (q < wv) base += wave_tot[q];
-        total += wave_tot[q];
-    }
-    if (tid == 0) { out[0] = total; out[1] = 0; out[2] = 0; out[3] = 0; }
-    if (cnt > 0) {
-        int r = base;
-        for (int f = f_lo; f < f_hi; f += 4) {
-            const uint4 w = *reinterpret_cast<const uint4*>(flags + f);
-            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int z = 0; z < 4; ++z)
-                if (ww[z] != 0u) out[4 + r++] = f + z;
-        }
-    }
-}
-
-__global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_rows_kernel(RowsGemmArgs a) {
-    extern __shared__ __align__(16) unsigned char embed_smem[];
-    uint16_t* sA = reinterpret_cast<uint16_t*>(embed_smem);
-    __shared__ int32_t rows[kRowsPerGroup];  // this item's rows: global tile ids b * 256 + tile
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
-    constexpr int G = kRowsG;
-
-    // ---- this workgroup's items: XCD x = blockIdx % 8 = (tower, row groups g % 4); item j of the XCD = (row group gm + 4 (j / nch), range j % nch) ----
-    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    const int tower = xcd & 1, gm = xcd >> 1;
-    const int D = tower ? a.D1 : a.D0, SA = D + 8, nchunk = D >> 6;  // 64-wide k-chunks
-    const uint16_t* dy = tower ? a.dy1 : a.dy0;
-    const uint16_t* wt = tower ? a.wt1 : a.wt0;
-    uint16_t* outp = tower ? a.t1 : a.t0;
-    const int per_cb = (kNBlocks + a.nch - 1) / a.nch;  // <= 8: one block per wave
-    auto wave_block = [&](int ch) {  // this wave's column block of range ch, or -1
-        const int nb = ch * per_cb + wv;
-        return (wv < per_cb && nb < kNBlocks) ? nb : -1;
-    };
-    auto load_group = [&](v8s_e (&bf)[G][2], const uint16_t* wp, int k0) {  // unconditional (tail groups re-request the last chunk): the compiler counts them
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const int kc = min(k0 + u, nchunk - 1);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) bf[u][h] = *reinterpret_cast<const v8s_e*>(wp + (size_t)kc * 1024 + h * 512);
-        }
-    };
-#ifdef VAA_K2_TIMING  // tools/scratch/k2xtiming.py
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = wall_clock64();
-#endif
-    const int total = a.tile_rows[0];
-    const int n_groups = (total + kRowsPerGroup - 1) / kRowsPerGroup;
-    const int ngx = n_groups > gm ? (n_groups - gm + 3) >> 2 : 0;
-    const int srow = tid >> 3, ssub = tid & 7;  // staging: 8 threads per row, 16 bytes each = one 64-wide k-chunk of the row per load instruction
-
-    for (int j = slot0; j < ngx * a.nch; j += nslots) {
-        const int grp = gm + 4 * (j / a.nch), ch = j - (j / a.nch) * a.nch;
-        const int r_lo = grp * kRowsPerGroup;
-        const int M = min(kRowsPerGroup, total - r_lo), nq = (M + 15) >> 4;  // workgroup-uniform
-        const int nb = wave_block(ch);
-        const uint16_t* wp = wt + packed_frag_offset(max(nb, 0), nchunk, 0, 0, lane);  // a wave without a block streams block 0 and stores nothing
-        v8s_e bfa[G][2], bfb[G][2];
-        load_group(bfa, wp, 0);  // the first weight group does not depend on the rows: requested first
-        __syncthreads();         // the previous item is done with rows[] and the staged tile
-        if (tid < kRowsPerGroup) rows[tid] = tid < M ? a.tile_rows[4 + r_lo + tid] : 0;
-        __syncthreads();
-        K2_STAMP(0)
-        // ---- request ALL dY rows of the item (whole K), piece-major: load `it` of piece p = k-chunk 6 p + it of row srow ----
-        const uint16_t* src = dy + (size_t)rows[srow] * D + ssub * 8;
-        uint4 st[kRowsPieces][kRowsPiece];
-#pragma unroll
-        for (int p = 0; p < kRowsPieces; ++p)
-#pragma unroll
-            for (int it = 0; it < kRowsPiece; ++it) {
-                const int kc = p * kRowsPiece + it;
-                st[p][it] = make_uint4(0, 0, 0, 0);
-                if (srow < M && kc < nchunk) st[p][it] = *reinterpret_cast<const uint4*>(src + kc * 64);
-            }
-        v4f_e acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = (v4f_e){0.f, 0.f, 0.f, 0.f};
-        const uint16_t* ap = &sA[c * SA + g * 16];
-        K2_STAMP(1)
-        auto compute_group = [&](const v8s_e (&bf)[G][2], int k0, auto nqtag) {
-            constexpr int NQ = decltype(nqtag)::value;
-            if (k0 >= nchunk) return;  // wave-uniform
-            v8s_e af[2][NQ][2];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) af[0][q][h] = *reinterpret_cast<const v8s_e*>(ap + q * 16 * SA + k0 * 64 + h * 8);
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                const int kc = k0 + u;
-                if (kc < nchunk) {  // wave-uniform
-                    if (u + 1 < G) {
-                        const int kn = min(kc + 1, nchunk - 1);
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) af[(u + 1) & 1][q][h] = *reinterpret_cast<const v8s_e*>(ap + q * 16 * SA + kn * 64 + h * 8);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);  // the next chunk's LDS reads are issued before this chunk's MFMAs
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][q][h], bf[u][h], acc[q], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        };
-        auto pieces = [&](auto nqtag) {
-#pragma unroll
-            for (int p = 0; p < kRowsPieces; ++p) {
-                const int k0 = p * kRowsPiece;
-                if (k0 >= nchunk) break;  // workgroup-uniform
-                load_group(bfb, wp, k0 + G);
-                // piece p: registers -> LDS (rows M .. 16 nq - 1 are zeros), barrier, its two weight groups
-                if (srow < nq * 16) {
-#pragma unroll
-                    for (int it = 0; it < kRowsPiece; ++it)
-                        if (k0 + it < nchunk) *reinterpret_cast<uint4*>(&sA[srow * SA + (k0 + it) * 64 + ssub * 8]) = st[p][it];
-                }
-                __syncthreads();
-                if (p == 0) { K2_STAMP(2) }
-                if (nb >= 0) {
-                    compute_group(bfa, k0, nqtag);
-                    load_group(bfa, wp, k0 + 2 * G);
-                    compute_group(bfb, k0 + G, nqtag);
-                }
-                K2_STAMP(3 + p)
-            }
-        };
-        switch (nq) {  // workgroup-uniform
-            case 1: pieces(std::integral_constant<int, 1>{}); break;
-            case 2: pieces(std::integral_constant<int, 2>{}); break;
-            case 3: pieces(std::integral_constant<int, 3>{}); break;
-            default: pieces(std::integral_constant<int, 4>{}); break;
-        }
-        // ---- store: bf16 (the rounding point of the model's own backward), C/D layout: column = lane & 15, row = 4 * (lane >> 4) + r ----
-        const int n = nb * 16 + c;
-        if (nb >= 0 && n < kTileElems) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int sl = q * 16 + g * 4 + r;
-                    if (sl < M) outp[(size_t)rows[sl] * kTileElems + n] = (uint16_t)f32_to_bf16_bits(acc[q][r]);
-                }
-        }
-        K2_STAMP(6)
-    }
-#ifdef VAA_K2_TIMING
-    if (lane == 0 && vaa_k2_dbg)
-        for (int z = 0; z < 8; ++z) vaa_k2_dbg[((size_t)blockIdx.x * 16 + wv) * 8 + z] = tacc[z];
-#endif
-}
-
 }  // namespace vaa
 
 namespace vaa {
-
-// flagged tiles of a batch: a footprint of area ph x pw meets about (sqrt(ph pw) / 14 + 1)^2 tiles (20.5 per image measured at 50x50, rotation <= 30 deg)
-static long est_flagged_rows(int B, int ph, int pw) {
-    const double side = sqrt((double)ph * pw) / 14.0 + 1.0;
-    return (long)((double)B * side * side);
-}
-
-// does the cross-image tile GEMM take this shape? (host-side rule shared by vaa_patch_embed_grad_wants_rows and the launch)
-static bool rows_form_applies(int B, int ph, int pw, int D0, int D1) {
-    const char* ev = getenv("VAA_K2E_ROWS");
-    if (ev && ev[0] == '0') return false;
-    const int Dmax = D0 > D1 ? D0 : D1;
-    if (B <= 0 || Dmax > kRowsMaxD || (D0 % 64) || (D1 % 64) || (long)B * 256 > (1l << 22)) return false;
-    if (ev && *ev) return true;  // forced on
-    return est_flagged_rows(B, ph, pw) > 24 * 21;  // below ~24 images of 50x50 the per-image kernel (5 x 2 workgroups per image) is the shorter chain
-}
 
 // tile gradients of every image (both towers) into e.geff; the LDS-resident variant while a tower's 64 gathered rows fit
 static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, const char* who) {
@@ -1339,37 +1097,7 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
     const unsigned ny = (unsigned)(tiles_bound <= 64 ? 1 : (tiles_bound <= 128 ? 2 : 4));
     const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
     e.tower_split = 0;
-    e.bf16_planes = 0;
-    const bool lds_ok = lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads;
-    // ONE cross-image contraction (embed_dgrad_rows_kernel) once the batch alone can fill the chip with 64-row items: needs the compact row
-    // list built behind K1 (vaa_tile_rows_build), the bf16 rounding point (round_bf16) and towers that fit the LDS-resident staging.
-    // VAA_K2E_ROWS=0 forces the per-image kernel (measurement aid).
-    if (e.tile_rows && rows_form_applies(B, ph, pw, e.D0, e.D1) && e.round_bf16 && e.geff2) {
-        static int cus[16];
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); dev = 0; }
-        if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus[dev] = 256; }
-        const int grid = cus[dev] / 8 * 8 > 0 ? cus[dev] / 8 * 8 : 8;
-        // column ranges: an XCD = (tower, groups g % 4) holds grid / 8 workgroups; ceil(groups / 4) x nch items should fit them, one item per
-        // workgroup (one group of margin: the row count is data; beyond that the persistent loop takes a second round). 5 .. 9 ranges = 8 .. 5
-        // column blocks per item, one per wave
-        const long groups = (est_flagged_rows(B, ph, pw) + kRowsPerGroup - 1) / kRowsPerGroup;
-        int nch = (int)((grid / 8) / ((groups + 1 + 3) / 4));
-        nch = nch < 5 ? 5 : (nch > 9 ? 9 : nch);
-        RowsGemmArgs r;
-        r.dy0 = e.dy0; r.dy1 = e.dy1; r.wt0 = e.wt0; r.wt1 = e.wt1; r.tile_rows = e.tile_rows;
-        r.t0 = reinterpret_cast<uint16_t*>(e.geff);
-        r.t1 = r.t0 + (size_t)B * 256 * kTileElems;
-        r.B = B; r.D0 = e.D0; r.D1 = e.D1; r.nch = nch;
-        if (hipFuncSetAttribute((const void*)embed_dgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast) != hipSuccess) {
-            set_error("%s: hipFuncSetAttribute failed", who);
-            return VAA_E_LAUNCH;
-        }
-        VAA_LAUNCH(embed_dgrad_rows_kernel, dim3((unsigned)grid), dim3(kEmbedFastThreads), lds_fast, st, r);
-        e.bf16_planes = 1;
-        return VAA_OK;
-    }
-    if (lds_ok) {
+    if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
         // Workgroups per image. A workgroup's time is a chain — tile list, staging of a tower's rows, k-loop, (second tower), store —, so while
         // the launch fits ONE residency wave of the 256 CUs a workgroup takes ONE tower (grid.z = 2: its chain halves; the gather adds the two
         // towers' tile gradients — the very fp32 add the unsplit kernel does) and as few column blocks as that leaves room for:
@@ -1434,7 +1162,7 @@ namespace vaa {
 // fixed-order sum of the partial tiles (ws[0 .. parts*3*ph*pw), parts = vaa_patch_grad_partials(B)) to the caller's vaa_step_epilogue.
 static int embed_grad_gather_impl(const char* who, const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
                                   const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, const uint16_t* keep_tiles,
-                                  const uint32_t* tile_flags, const int32_t* tile_rows, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
+                                  const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
                                   int round_bf16, float* gpatch, bool defer_reduce, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 && gpatch && ph > 0 && pw > 0) {
@@ -1467,7 +1195,7 @@ static int embed_grad_gather_impl(const char* who, const uint16_t* dy0, int D0, 
     char* wsb = reinterpret_cast<char*>(ws);
     const size_t part_bytes = (vaa_patch_grad_ws_bytes(B, ph, pw) + 255) / 256 * 256;
     EmbedArgs e;
-    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wt0; e.wt1 = wt1; e.keep = keep_bits; e.flags = tile_flags; e.tile_rows = tile_rows;
+    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wt0; e.wt1 = wt1; e.keep = keep_bits; e.flags = tile_flags;
     e.geff = reinterpret_cast<float*>(wsb + part_bytes);
     e.geff2 = e.geff + (size_t)B * 256 * kTileElems;
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
@@ -1480,8 +1208,6 @@ static int embed_grad_gather_impl(const char* who, const uint16_t* dy0, int D0, 
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
     a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles;
-    a.gt0 = e.bf16_planes ? reinterpret_cast<const uint16_t*>(e.geff) : nullptr;
-    a.gt1 = e.bf16_planes ? a.gt0 + (size_t)B * 256 * kTileElems : nullptr;
     if (keep_tiles) a.keep = reinterpret_cast<const uint8_t*>(keep_tiles);  // non-null selects the stored-mask instantiation
     return launch_scatter_reduce<true>(a, defer_reduce ? nullptr : gpatch, st, who);
 }
@@ -1492,38 +1218,18 @@ extern "C" int vaa_patch_embed_grad_gather(const uint16_t* dy0, int D0, const ui
                                            const float* patch, const int32_t* xy, const float* theta, const uint8_t* keep_bits, int B, int ph,
                                            int pw, int geometry, int mask_mode, const float* std6, int round_bf16, float* gpatch, void* ws,
                                            size_t ws_bytes, void* stream) {
-    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, keep_bits, nullptr, nullptr, nullptr, B, ph,
+    return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, keep_bits, nullptr, nullptr, B, ph,
                                        pw, geometry, mask_mode, std6, round_bf16, gpatch, false, ws, ws_bytes, stream);
 }
 
 extern "C" int vaa_patch_grad_partials(int B) { return B > 0 ? vaa::grad_sched(B).gx : 0; }
 
-// Compact row list of the flagged tiles of a batch, the row index of the cross-image K2' tile GEMM: tile_rows = int32 {total, 0, 0, 0} followed
-// by the global tile ids b * 256 + tile of the tiles whose flag word is non-zero, in increasing order. One small launch, meant to sit right
-// behind vaa_patch_apply_fwd_tiles in the forward (the backward that reads it is the whole model away).
-extern "C" size_t vaa_tile_rows_bytes(int B) { return B > 0 ? ((size_t)B * 256 + 4) * sizeof(int32_t) : 0; }
-
-extern "C" int vaa_tile_rows_build(const uint32_t* tile_flags, int B, int32_t* tile_rows, void* stream) {
-    using namespace vaa;
-    if (B == 0) return VAA_OK;
-    if (!tile_flags || !tile_rows || B < 0 || (long)B * 256 > (1l << 22)) {
-        set_error("vaa_tile_rows_build: bad arguments (B=%d)", B);
-        return VAA_E_INVALID;
-    }
-    VAA_LAUNCH(tile_rows_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tile_flags, B * 256, tile_rows);
-    return check_launch("vaa_tile_rows_build");
-}
-
-// 1 when vaa_patch_embed_grad_gather_tiles would run the cross-image tile GEMM for this shape if it is given a row list (so that callers only
-// pay for vaa_tile_rows_build where it is used), else 0
-extern "C" int vaa_patch_embed_grad_wants_rows(int B, int ph, int pw, int D0, int D1) { return vaa::rows_form_applies(B, ph, pw, D0, D1) ? 1 : 0; }
-
 extern "C" int vaa_patch_embed_grad_gather_tiles(const uint16_t* dy0, int D0, const uint16_t* dy1, int D1, const uint16_t* wt0, const uint16_t* wt1,
                                                  const float* patch, const int32_t* xy, const float* theta, const uint16_t* keep_tiles,
-                                                 const uint32_t* tile_flags, const int32_t* tile_rows, int B, int ph, int pw, int geometry, int mask_mode,
-                                                 const float* std6, int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream) {
+                                                 const uint32_t* tile_flags, int B, int ph, int pw, int geometry, int mask_mode, const float* std6,
+                                                 int round_bf16, float* gpatch, void* ws, size_t ws_bytes, void* stream) {
     return vaa::embed_grad_gather_impl("vaa_patch_embed_grad_gather_tiles", dy0, D0, dy1, D1, wt0, wt1, patch, xy, theta, nullptr, keep_tiles, tile_flags,
-                                       tile_rows, B, ph, pw, geometry, mask_mode, std6, round_bf16, gpatch, gpatch == nullptr, ws, ws_bytes, stream);
+                                       B, ph, pw, geometry, mask_mode, std6, round_bf16, gpatch, gpatch == nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" size_t vaa_patch_embed_grad_multi_ws_bytes(int B) {
@@ -1562,7 +1268,7 @@ static int embed_grad_gather_multi_impl(const char* who, const uint16_t* dy0, in
         return VAA_E_WORKSPACE;
     }
     EmbedArgs e;
-    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wp0; e.wt1 = wp1; e.keep = keep_bits; e.flags = tile_flags; e.tile_rows = nullptr; e.geff = reinterpret_cast<float*>(ws);
+    e.dy0 = dy0; e.dy1 = dy1; e.wt0 = wp0; e.wt1 = wp1; e.keep = keep_bits; e.flags = tile_flags; e.geff = reinterpret_cast<float*>(ws);
     e.geff2 = e.geff + (size_t)B * 256 * kTileElems;
     e.B = B; e.D0 = D0; e.D1 = D1; e.round_bf16 = round_bf16 ? 1 : 0;
     for (int q = 0; q < 6; ++q) e.istd6[q] = (float)(1.0 / (double)std6[q]);
@@ -1574,8 +1280,6 @@ static int embed_grad_gather_multi_impl(const char* who, const uint16_t* dy0, in
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
     a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles;
-    a.gt0 = e.bf16_planes ? reinterpret_cast<const uint16_t*>(e.geff) : nullptr;
-    a.gt1 = e.bf16_planes ? a.gt0 + (size_t)B * 256 * kTileElems : nullptr;
     if (keep_tiles) a.keep = reinterpret_cast<const uint8_t*>(keep_tiles);  // non-null selects the stored-mask instantiation
     return launch_scatter_multi<true>(a, max_h, max_w, st, who);
 }

@@ -162,23 +162,6 @@ def patch_apply_fwd_tiles(img_u8, patch, xy, theta, geometry: bool, mask_mode: i
     return out0, out1, keep_t, flags
 
 
-def tile_rows_build(tile_flags: torch.Tensor) -> torch.Tensor:
-    """vaa_tile_rows_build: the compact row list of the flagged tiles (int32 {total, 0, 0, 0} + global tile ids), the row index of the
-    cross-image K2' tile GEMM. One small launch, issued right behind K1 in the forward."""
-    B = tile_flags.shape[0]
-    _need(tile_flags, torch.int32, "tile_flags", (B, 256))
-    L = _lib.lib()
-    rows = torch.empty(L.vaa_tile_rows_bytes(B) // 4, dtype=torch.int32, device=tile_flags.device)
-    with _timed("K1_tile_rows_build", B=B):
-        rc = L.vaa_tile_rows_build(tile_flags.data_ptr(), B, rows.data_ptr(), _stream())
-    _lib.check(rc, "vaa_tile_rows_build")
-    return rows
-
-
-def embed_grad_wants_rows(B: int, ph: int, pw: int, D0: int, D1: int) -> bool:
-    return bool(_lib.lib().vaa_patch_embed_grad_wants_rows(int(B), int(ph), int(pw), int(D0), int(D1)))
-
-
 def patch_grad_gather(gout_bf16, patch, xy, theta, keep_bits, geometry: bool, mask_mode: int = MASK_LT_M20, std6=None, defer_reduce: bool = False):
     """K2. gout_bf16 [B,6,224,224] bf16 -> dL/d patch [3,ph,pw] f32 (sum over the batch). defer_reduce=True returns the partial tiles
     [parts, 3*ph*pw] (a view of the workspace) for ops.step_epilogue to add."""
@@ -252,10 +235,9 @@ def patch_embed_grad_gather(dy0, dy1, wp0, wp1, patch, xy, theta, keep_bits, geo
 
 
 def patch_embed_grad_gather_tiles(dy0, dy1, wp0, wp1, patch, xy, theta, keep_tiles, tile_flags, geometry: bool, mask_mode: int = MASK_LT_M20,
-                                  std6=None, round_bf16: bool = True, defer_reduce: bool = False, tile_rows=None):
+                                  std6=None, round_bf16: bool = True, defer_reduce: bool = False):
     """K2' fed by the tile-major mask of patch_apply_fwd_tiles. defer_reduce=True returns (partials view [parts, 3*ph*pw] of the workspace):
-    the fixed-order sum is then left to ops.step_epilogue. tile_rows (tile_rows_build(tile_flags)): the patch-embed backward runs as one
-    cross-image contraction where embed_grad_wants_rows(...) says so (same bits)."""
+    the fixed-order sum is then left to ops.step_epilogue."""
     B = dy0.shape[0]
     D0, D1 = int(dy0.shape[2]), int(dy1.shape[2])
     _need(dy0, torch.bfloat16, "dy0", (B, 256, D0))
@@ -268,8 +250,6 @@ def patch_embed_grad_gather_tiles(dy0, dy1, wp0, wp1, patch, xy, theta, keep_til
         _need(theta, torch.float32, "theta", (B, 6))
     _need(keep_tiles, torch.int16, "keep_tiles", (B, 3, 256, 14))
     _need(tile_flags, torch.int32, "tile_flags", (B, 256))
-    if tile_rows is not None:
-        _need(tile_rows, torch.int32, "tile_rows", (B * 256 + 4,))
     ph, pw = int(patch.shape[1]), int(patch.shape[2])
     L = _lib.lib()
     ws = _workspace(patch.device, L.vaa_patch_embed_grad_ws_bytes(B, ph, pw), "k2e")
@@ -277,8 +257,7 @@ def patch_embed_grad_gather_tiles(dy0, dy1, wp0, wp1, patch, xy, theta, keep_til
     std_c = _STD if std6 is None else _lib.f32x(std6)
     with _timed("K2_patch_embed_grad_gather_tiles", B=B, ph=ph, pw=pw):
         rc = L.vaa_patch_embed_grad_gather_tiles(dy0.data_ptr(), D0, dy1.data_ptr(), D1, wp0.data_ptr(), wp1.data_ptr(), patch.data_ptr(), xy.data_ptr(),
-                                                 theta.data_ptr() if geometry else None, keep_tiles.data_ptr(), tile_flags.data_ptr(),
-                                                 tile_rows.data_ptr() if tile_rows is not None else None, B, ph, pw,
+                                                 theta.data_ptr() if geometry else None, keep_tiles.data_ptr(), tile_flags.data_ptr(), B, ph, pw,
                                                  int(bool(geometry)), int(mask_mode), std_c, int(bool(round_bf16)),
                                                  gpatch.data_ptr() if gpatch is not None else None, ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "vaa_patch_embed_grad_gather_tiles")
@@ -506,24 +485,18 @@ class PatchApplyEmbed(torch.autograd.Function):
         p = patch.detach().contiguous()
         # K1 writes the two GEMM operands directly (tile-major): no [B,6,224,224] tensor, no im2col copies
         t0, t1, keep_t, flags = patch_apply_fwd_tiles(img_u8, p, xy, theta, geometry, mask_mode, mean6=mean6, std6=std6)
-        # the backward's row index (cross-image tile GEMM), built here — the whole model away from its reader — where the shape takes that form
-        rows = None
-        if patch.requires_grad and embed_grad_wants_rows(t0.shape[0], p.shape[1], p.shape[2], w0.shape[0], w1.shape[0]):
-            rows = tile_rows_build(flags)
         e0 = torch.nn.functional.linear(t0, w0, b0)
         e1 = torch.nn.functional.linear(t1, w1, b1)
-        ctx.has_rows = rows is not None
-        ctx.save_for_backward(p, xy, theta if geometry else xy, keep_t, flags, wp0, wp1, *((rows,) if rows is not None else ()))
+        ctx.save_for_backward(p, xy, theta if geometry else xy, keep_t, flags, wp0, wp1)
         ctx.geometry, ctx.mask_mode, ctx.std6 = bool(geometry), int(mask_mode), std6
         return e0, e1
 
     @staticmethod
     def backward(ctx, d0, d1):
-        patch, xy, theta, keep_t, flags, wp0, wp1 = ctx.saved_tensors[:7]
-        rows = ctx.saved_tensors[7] if ctx.has_rows else None
+        patch, xy, theta, keep_t, flags, wp0, wp1 = ctx.saved_tensors
         d0, d1 = d0.to(torch.bfloat16).contiguous(), d1.to(torch.bfloat16).contiguous()
         g = patch_embed_grad_gather_tiles(d0, d1, wp0, wp1, patch, xy, theta if ctx.geometry else None, keep_t, flags, ctx.geometry,
-                                          ctx.mask_mode, std6=ctx.std6, defer_reduce=ctx.sink is not None, tile_rows=rows)
+                                          ctx.mask_mode, std6=ctx.std6, defer_reduce=ctx.sink is not None)
         if ctx.sink is not None:
             ctx.sink["partials"] = g
             g = None

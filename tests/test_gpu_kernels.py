@@ -1316,9 +1316,9 @@ def test_round3_entry_points_error_paths_and_empty_batches(ops):
     assert L.vaa_patch_apply_fwd_tiles(p, p, None, p, p, 2, 50, 50, 1, 1, f6, f6, p, p, p, p, st) == -2 and b"geometry=0" in L.vaa_last_error()
     # K2' tile-major: keep words without flags, widths, workspace
     a = (p, 64, p, 64, p, p, p, p, p)
-    assert L.vaa_patch_embed_grad_gather_tiles(*a, p, None, None, 2, 50, 50, 1, 0, f6, 1, p, p, 1 << 30, st) == -1
-    assert L.vaa_patch_embed_grad_gather_tiles(p, 96, p, 64, p, p, p, p, p, p, p, None, 2, 50, 50, 1, 0, f6, 1, p, p, 1 << 30, st) == -1
-    assert L.vaa_patch_embed_grad_gather_tiles(*a, p, p, None, 2, 50, 50, 1, 0, f6, 1, p, p, 1024, st) == -4 and b"workspace" in L.vaa_last_error()
+    assert L.vaa_patch_embed_grad_gather_tiles(*a, p, None, 2, 50, 50, 1, 0, f6, 1, p, p, 1 << 30, st) == -1
+    assert L.vaa_patch_embed_grad_gather_tiles(p, 96, p, 64, p, p, p, p, p, p, p, 2, 50, 50, 1, 0, f6, 1, p, p, 1 << 30, st) == -1
+    assert L.vaa_patch_embed_grad_gather_tiles(*a, p, p, 2, 50, 50, 1, 0, f6, 1, p, p, 1024, st) == -4 and b"workspace" in L.vaa_last_error()
     assert L.vaa_patch_grad_partials(0) == 0 and L.vaa_patch_grad_partials(64) == 64 and L.vaa_patch_grad_partials(5000) == 512
     # split K3 form + epilogue
     prm = _lib.f32x([5.0, 0.8, 0.2, 1.0])
