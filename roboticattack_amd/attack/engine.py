@@ -131,11 +131,12 @@ class AttackBase:
         pe = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std, geometry=geometry, grad_sink=sink)
         h = self.vla.hidden_rows(input_ids, None, self._row_index, patch_embeds=pe, pack=pack)
         W = self.vla.lm_head.weight
+        R = int(h.shape[0])
         logits = torch.nn.functional.linear(h.detach(), W)  # [R,V]: the LM head on the labelled rows
-        gsl = torch.empty((logits.shape[0], ops.N_ACTION), dtype=logits.dtype, device=logits.device)
+        gsl = torch.empty((R, ops.N_ACTION), dtype=logits.dtype, device=logits.device)
         ws = ops.loss_rows_stats(logits, self._row_map, ops.LOSS_UADA_DDP, w, grad=gsl)      # K3: statistics + d loss / d action logits
         h.backward(gsl @ W[ops.ACTION_LO : ops.ACTION_LO + ops.N_ACTION])                     # head backward over 256 columns, model backward, K2'
-        _, pred_full = ops.step_epilogue(sink["partials"], msg, scalars, rowmap=self._row_map, R=int(logits.shape[0]), V=int(W.shape[0]),
+        _, pred_full = ops.step_epilogue(sink["partials"], msg, scalars, rowmap=self._row_map, R=R, V=int(W.shape[0]),
                                          mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws,
                                          update=optimizer.fused_update_args() if optimizer is not None else None)
         return pred_full

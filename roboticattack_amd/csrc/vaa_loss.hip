@@ -17,11 +17,10 @@
 #include <mutex>
 
 #include "vaa_common.h"
+#include "vaa_rows.h"
 
 namespace vaa {
 
-constexpr int kA0 = 31744;   // first action token (UADA.py:384)
-constexpr int kNA = 256;     // action bins
 constexpr int kRowThreads = 1024;
 
 struct RowStat {  // one per LABELLED row, stored compactly at its row-major rank `rowidx` among labelled positions
@@ -492,19 +491,7 @@ __global__ __launch_bounds__(kGradT) void loss_grad_kernel(LossArgs a, int J) {
 //   Gradient storage: VAA_GRAD_FULL [R,V] or VAA_GRAD_SLICE [R,256] (UADA_DDP / UPA: the gradient is zero outside the action
 //   columns, so the LM-head backward contracts over 256 columns instead of 32,064).
 // =====================================================================================================================
-struct RowMap {
-    int b, k, lab, ord;
-};
-struct PartStat {  // one per (row, part)
-    float m, s;    // max and sum exp(z - m) over the part
-    float zlab;    // logit of the label if it lies in this part, else -inf
-    int amax;      // argmax over the part (global column index), lowest index on ties
-};
-struct SliceStat {  // one per row
-    float alse, E;
-    int pred;
-    int pad;
-};
+// RowMap / PartStat / SliceStat: vaa_rows.h (shared with the fused LM head of vaa_head.hip)
 
 // threads per workgroup of the row kernels: 256 while a row fits 4 parts x 256 threads x 32 logits (V <= 32,768: fewer waves per barrier,
 // 512 workgroups at R' = 128 — 15.9 -> 14.6 us), else 512
@@ -1158,7 +1145,7 @@ __global__ __launch_bounds__(256) void step_epilogue_kernel(EpiArgs e, RowsArgs 
     }
 }
 
-static int rows_split(int R, int V) {  // parts per row so that >= 256 workgroups are resident; a part must fit threads x 32 logits
+int rows_split(int R, int V) {  // parts per row so that >= 256 workgroups are resident; a part must fit threads x 32 logits
     const int nt = rows_threads(V);
     int s = 1;
     while (s < 4 && R * s < 256) s <<= 1;
