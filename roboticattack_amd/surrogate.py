@@ -66,3 +66,82 @@ class SurrogateVLA(nn.Module):
         logits = h2 @ self.head
         loss = hf_causal_ce(logits, labels) if labels is not None else None
         return types.SimpleNamespace(loss=loss, logits=logits)
+
+
+class SurrogateEmbedVLA(nn.Module):
+    """SurrogateVLA whose 256 image tokens come from TWO bf16 patch-embed towers — timm's PatchEmbed (Conv2d(3, D, 14, stride 14),
+    modeling_prismatic.py:120-123) evaluated as a GEMM over 14x14 tiles — followed by an fp32 projector: the smallest model on which the
+    production backward K2' (patch-embed backward on the tiles under the patch + gather) runs, so that K2' and the fused
+    update can be put on a REFERENCE-LOOP trajectory (tools/gen_golden.py:gen_trajectory_k2e drives the reference's own UADA loop over this
+    very module on the CPU; tests/test_gpu_attack.py replays it through K1 tile-major -> K2' -> epilogue + K4).
+
+    It offers both boundaries: `forward(pixel_values=...)` (what the reference calls; bf16 pixel_values as UADA.py:142 casts them) and the
+    rows / patch-embed interface of OpenVLAShaped (`patch_embed_params`, `label_row_index`, `forward_rows(..., patch_embeds=)`)."""
+
+    def __init__(self, d: int = 48, D0: int = 64, D1: int = 128, vocab: int = MODEL_VOCAB, seed: int = 0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        bf = torch.bfloat16
+        self.w0 = nn.Parameter((torch.randn(D0, 588, generator=g) * 0.02).to(bf), requires_grad=False)
+        self.b0 = nn.Parameter((torch.randn(D0, generator=g) * 0.01).to(bf), requires_grad=False)
+        self.w1 = nn.Parameter((torch.randn(D1, 588, generator=g) * 0.02).to(bf), requires_grad=False)
+        self.b1 = nn.Parameter((torch.randn(D1, generator=g) * 0.01).to(bf), requires_grad=False)
+        self.proj = nn.Parameter(torch.randn(D0 + D1, d, generator=g) / math.sqrt(D0 + D1), requires_grad=False)
+        self.tok = nn.Parameter(torch.randn(vocab, d, generator=g) * 0.5, requires_grad=False)
+        self.mix = nn.Parameter(torch.randn(d, d, generator=g) / math.sqrt(d), requires_grad=False)
+        self.head = nn.Parameter(torch.randn(d, vocab, generator=g) * 0.3, requires_grad=False)
+        self.vision_backbone = types.SimpleNamespace(
+            featurizer=types.SimpleNamespace(patch_embed=types.SimpleNamespace(num_patches=N_IMG_TOKENS))
+        )
+        self._packed = None
+
+    @property
+    def device(self) -> torch.device:
+        return self.tok.device
+
+    @staticmethod
+    def _tiles(x3: torch.Tensor) -> torch.Tensor:  # [B,3,224,224] -> [B,256,588], columns (c, y, x): timm PatchEmbed's im2col
+        B = x3.shape[0]
+        return x3.reshape(B, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(B, 256, 588)
+
+    def embeds(self, pixel_values: torch.Tensor):
+        x = pixel_values.to(torch.bfloat16)
+        return F.linear(self._tiles(x[:, :3]), self.w0, self.b0), F.linear(self._tiles(x[:, 3:]), self.w1, self.b1)
+
+    def _logits(self, input_ids, e0, e1):
+        x = torch.cat([e0, e1], dim=2).float() @ self.proj  # [B,256,d] fp32 from here on
+        te = self.tok[input_ids]
+        h = torch.cat([te[:, :1], x, te[:, 1:]], dim=1)
+        S = h.shape[1]
+        denom = torch.arange(1, S + 1, device=h.device, dtype=h.dtype)[None, :, None]
+        c = torch.cumsum(h, dim=1) / denom
+        h2 = torch.tanh(c @ self.mix) + 0.25 * h
+        return h2 @ self.head
+
+    def forward(self, input_ids, attention_mask=None, pixel_values=None, labels=None, **_):
+        logits = self._logits(input_ids, *self.embeds(pixel_values))
+        loss = hf_causal_ce(logits, labels) if labels is not None else None
+        return types.SimpleNamespace(loss=loss, logits=logits)
+
+    # ---- the rows / patch-embed interface of OpenVLAShaped ----
+    def patch_embed_params(self):
+        if not self.w0.is_cuda:
+            return None
+        if self._packed is None or self._packed[0].device != self.w0.device:
+            from . import ops
+
+            self._packed = (ops.pack_embed_weights(self.w0.t().contiguous()), ops.pack_embed_weights(self.w1.t().contiguous()))
+        return (self.w0, self.b0, self._packed[0], self.w1, self.b1, self._packed[1])
+
+    def label_row_index(self, labels):
+        B, L = labels.shape
+        S = N_IMG_TOKENS + L
+        bk = (labels[:, 1:] != IGNORE_INDEX).nonzero(as_tuple=False)
+        return bk[:, 0] * S + N_IMG_TOKENS + bk[:, 1]
+
+    def forward_rows(self, input_ids, pixel_values, labels, row_index=None, patch_embeds=None, pack=None):
+        e0, e1 = (patch_embeds[0], patch_embeds[1]) if patch_embeds is not None else self.embeds(pixel_values)
+        logits = self._logits(input_ids, e0, e1)
+        if row_index is None:
+            row_index = self.label_row_index(labels)
+        return logits.reshape(-1, logits.shape[-1]).index_select(0, row_index)

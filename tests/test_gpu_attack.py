@@ -836,3 +836,69 @@ def test_attack_loops_fail_loudly_on_non_finite_state(tmp_path, which):
     with pytest.raises(NonFiniteAttackState):
         att.save_patch(torch.full((3, 4, 4), float("nan")), "never")
     assert not os.path.exists(os.path.join(str(tmp_path), "never", "patch.pt"))
+
+
+def test_uada_trajectory_k2e_vs_reference_loop(tmp_path, monkeypatch):
+    """The PRODUCTION backward on a reference-loop trajectory: tools/gen_golden.py:gen_trajectory_k2e drove the reference's
+    own `UADA.patchattack_unconstrained` over SurrogateEmbedVLA (two bf16 patch-embed towers + fp32 body) on the CPU — bf16 pixel_values, the
+    dense bf16 pixel gradient, torch's autograd through paste / warp — and recorded the patch after every inner step. Here the same module sits
+    on the GPU and exposes its patch-embed weights, so every training step runs K1 tile-major -> K2' (tile GEMM on the flagged tiles + gather)
+    -> step epilogue with the AdamW update inside: the patch after EVERY inner step, `last/patch.pt` and the logged losses must agree within
+    the north-star tolerance 1e-4."""
+    import types
+
+    from roboticattack_amd import ops
+    from roboticattack_amd.attack.uada import OpenVLAAttacker
+    from roboticattack_amd.surrogate import SurrogateEmbedVLA
+
+    d = np.load(os.path.join(GOLDEN, "traj_uada_k2e.npz"))
+    num_iter, inner, bs, warm = int(d["num_iter"]), int(d["inner"]), int(d["bs"]), int(d["warmup"])
+    vla = SurrogateEmbedVLA(seed=int(d["model_seed"])).to(DEV)
+    att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="adamW", resize_patch=False)
+    assert att.randomPatchTransform.embed_with is vla and att.use_rows
+    att.val_batches = int(d["val_batches"])
+    calls = {"k2e": 0, "epi_update": 0, "k2": 0}
+    o_k2e, o_epi, o_k2 = ops.patch_embed_grad_gather_tiles, ops.step_epilogue, ops.patch_grad_gather
+
+    def c_k2e(*a, **k):
+        calls["k2e"] += 1
+        return o_k2e(*a, **k)
+
+    def c_epi(*a, **k):
+        calls["epi_update"] += 1 if k.get("update") is not None else 0
+        return o_epi(*a, **k)
+
+    def c_k2(*a, **k):
+        calls["k2"] += 1
+        return o_k2(*a, **k)
+
+    monkeypatch.setattr(ops, "patch_embed_grad_gather_tiles", c_k2e)
+    monkeypatch.setattr(ops, "step_epilogue", c_epi)
+    monkeypatch.setattr(ops, "patch_grad_gather", c_k2)
+    snaps = []
+    orig = att.inner_step
+
+    def rec(patch, *a, **k):
+        r = orig(patch, *a, **k)
+        snaps.append(patch.detach().cpu().numpy().copy())
+        return r
+
+    att.inner_step = rec
+    _seed()
+    train = _Fresh([int(d["train_seed0"]) + i for i in range(num_iter)], bs)
+    val = _Fresh([int(d["val_seed"])], 1)
+    att.patchattack_unconstrained(train, val, num_iter=num_iter, target_action=np.zeros(7), patch_size=[3, 50, 50], lr=float(d["lr"]),
+                                  accumulate_steps=1, maskidx=list(d["maskidx"]), warmup=warm, filterGripTrainTo1=False, geometry=True,
+                                  innerLoop=inner, args=types.SimpleNamespace(wandb_project="false"))
+    # every training step went through K2' and the update fused into the epilogue; plain K2 never ran
+    assert calls["k2e"] == num_iter * inner and calls["epi_update"] == num_iter * inner and calls["k2"] == 0, calls
+    ref = d["patches"]
+    assert len(snaps) == len(ref) == num_iter * inner
+    err = [float(np.abs(s - r).max()) for s, r in zip(snaps, ref)]
+    assert max(err) <= 1e-4, err
+    assert np.abs(ref[-1] - ref[0]).max() > 5e-3 and np.array_equal(snaps[0], snaps[inner - 1])  # it moves; lr = 0 during outer iteration 0
+    last = torch.load(os.path.join(str(tmp_path), "last", "patch.pt"))
+    assert np.abs(last.numpy() - d["last_saved"]).max() <= 1e-4
+    np.testing.assert_allclose(att.train_CE_loss, d["train_ce"], rtol=2e-4)
+    np.testing.assert_allclose(att.train_MSE_distance_loss, d["train_mse"], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(att.train_UAD, d["train_uad"], atol=1e-4)

@@ -532,6 +532,63 @@ def gen_trajectory():
 
 
 # ------------------------------------------------------------------------------------------------
+# UADA trajectory of the reference's own loop over SurrogateEmbedVLA — the tiny model with two bf16 patch-embed towers on which the
+# production backward K2' (+ the update fused into the step epilogue) runs: puts K2' on a reference-loop trajectory
+# ------------------------------------------------------------------------------------------------
+def gen_trajectory_k2e():
+    import transformers
+
+    from oracle.ref_port import HFAdamW
+    from roboticattack_amd.surrogate import SurrogateEmbedVLA
+
+    UADA = ref.UADA
+    transformers.AdamW = HFAdamW
+    UADA.transformers.AdamW = HFAdamW
+    num_iter, inner, bs, warm, lr = 4, 3, 3, 1, 2e-3
+    vla = SurrogateEmbedVLA(seed=6)
+    processor = types.SimpleNamespace(tokenizer=ref_import.FakeTokenizer(), image_processor=types.SimpleNamespace(apply_transform=None))
+    save_dir = "/tmp/vaa_golden_traj_k2e"
+    shutil.rmtree(save_dir, ignore_errors=True)
+    os.makedirs(save_dir)
+
+    class _Fresh:
+        def __init__(self, seeds, b):
+            self.seeds, self.b = seeds, b
+
+        def __iter__(self):
+            for s_ in self.seeds:
+                yield synthetic.synth_batch(s_, self.b, "smooth")
+
+    train, val = _Fresh([9000 + i for i in range(num_iter)], bs), _Fresh([9100], 1)
+    snapshots = []
+    att = UADA.OpenVLAAttacker(vla, processor, save_dir, optimizer="adamW", resize_patch=False)
+    orig_step = HFAdamW.step
+
+    def rec_step(self, closure=None):
+        orig_step(self)
+        snapshots.append(self.param_groups[0]["params"][0].detach().clone().clamp(0, 1).numpy())
+
+    HFAdamW.step = rec_step
+    UADA.tqdm = lambda x, *a, **k: x
+    UADA.range = lambda *a: __builtins__.range(2) if a == (1000,) else __builtins__.range(*a)
+    random.seed(42)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    try:
+        att.patchattack_unconstrained(train, val, num_iter=num_iter, target_action=np.zeros(7), patch_size=[3, 50, 50], lr=lr,
+                                      accumulate_steps=1, maskidx=[0, 1], warmup=warm, filterGripTrainTo1=False, geometry=True,
+                                      innerLoop=inner, args=types.SimpleNamespace(wandb_project="false"))
+    finally:
+        HFAdamW.step = orig_step
+    final = torch.load(os.path.join(save_dir, "last", "patch.pt"))
+    np.savez_compressed(os.path.join(GOLD, "traj_uada_k2e.npz"), num_iter=num_iter, inner=inner, bs=bs, warmup=warm, lr=lr,
+                        maskidx=np.array([0, 1]), model_seed=6, train_seed0=9000, val_seed=9100, val_batches=2,
+                        patches=np.stack(snapshots).astype(np.float32), last_saved=final.numpy(),
+                        train_ce=np.array(att.train_CE_loss), train_mse=np.array(att.train_MSE_distance_loss), train_uad=np.array(att.train_UAD))
+    print("traj_k2e: steps", len(snapshots), "delta", np.abs(snapshots[-1] - snapshots[0]).max(), "ce", att.train_CE_loss[:3])
+
+
+# ------------------------------------------------------------------------------------------------
 # TMA / UPA trajectories through the reference's own loops (tiny surrogate model)
 # ------------------------------------------------------------------------------------------------
 class _TokWithText(ref_import.FakeTokenizer):
@@ -638,8 +695,8 @@ def gen_sim():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1k2", "resize", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "sim"]
+    which = sys.argv[1:] or ["k1k2", "resize", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "trajk2e", "sim"]
     fns = dict(k1k2=gen_k1k2, resize=gen_resize, rng=gen_rng_stream, labels=gen_labels_tokenizer, k3=gen_k3, sched=gen_sched, fmt=gen_patch_format,
-               traj=gen_trajectory, traj2=gen_trajectory_tma_upa, sim=gen_sim)
+               traj=gen_trajectory, traj2=gen_trajectory_tma_upa, trajk2e=gen_trajectory_k2e, sim=gen_sim)
     for w in which:
         fns[w]()
