@@ -316,7 +316,7 @@ def timed_steps(runner, steps, warmup, world, dev, profile=False, comm=False):
 
 # kernel name (substring of the launch site's name) -> operator of the hot path
 KERNEL_OPS = (("patch_apply_fwd_kernel", "K1"), ("patch_apply_tiles_kernel", "K1"), ("embed_dgrad_tiles", "K2e"), ("patch_grad_scatter_kernel", "K2"), ("patch_grad_reduce_kernel", "K2"),
-              ("rows_stats_kernel", "K3"), ("rows_finish_kernel", "K3"), ("loss_stats_kernel", "K3"), ("loss_grad_kernel", "K3"), ("step_epilogue_kernel", "EPI"), ("patch_update_kernel", "K4"),
+              ("head_stats_kernel", "K3h"), ("head_finish_kernel", "K3h"), ("rows_stats_kernel", "K3"), ("rows_finish_kernel", "K3"), ("loss_stats_kernel", "K3"), ("loss_grad_kernel", "K3"), ("step_epilogue_kernel", "EPI"), ("patch_update_kernel", "K4"),
               ("patch_resize", "K0"))
 
 
@@ -437,6 +437,7 @@ def main():
     per_rank = None
     if world == 1 and not args.no_per_rank and args.model == "openvla-7b":
         per_rank = {}
+        cfg_m = getattr(model, "cfg", None)
         ips64 = B * args.steps / dt
         for b in (32, 16, 8, 4):
             torch.cuda.empty_cache()
@@ -449,10 +450,15 @@ def main():
             for name, us in recs_b:  # the hand-written launches of the step at this batch, per dispatch (vaa_prof_*)
                 op = next((o for sub, o in KERNEL_OPS if sub in name), "other")
                 hot_b[op] = hot_b.get(op, 0.0) + us / n_p
+            head_us = [us for name, us in recs_b if "head_stats_kernel" in name]
             per_rank[f"bs{b}"] = {"ms_per_step": dt_b / n_b * 1e3, "images_per_s": b * n_b / dt_b, "images_per_s_vs_bs%d" % B: (b * n_b / dt_b) / ips64,
                                   "projected_speedup_%d_ranks_before_comm" % (B // b): (B // b) * (b * n_b / dt_b) / ips64,
                                   "host_cpu_ms_per_step": cpu_b * 1e3, "host_enqueue_ms_per_step": enq_b * 1e3, "labelled_rows": rb.R,
                                   "hot_path_us_per_step": sum(hot_b.values()), "hot_path_ops_us": hot_b}
+            if head_us and cfg_m is not None:  # the fused LM head (a 263 MB weight stream at the 7B shape): in-step duration and HBM rate
+                hb = 2 * 32064 * cfg_m.llm_dim
+                per_rank[f"bs{b}"]["fused_head"] = {"kernel": "head_stats_kernel", "mean_us": float(np.mean(head_us)), "algo_bytes": hb,
+                                                    "achieved_GBs": hb / float(np.mean(head_us)) / 1e3, "frac": hb / float(np.mean(head_us)) / 1e3 / HBM_PEAK_GBS}
             del rb
         per_rank["note"] = ("full-model step (same code path as the timed region) at the per-rank batches of the strong-scaling runs — global 64 over 2 / 4 / 8 "
                             "ranks -> bs = 32 / 16 / 8 (BASELINE config 3; config 4: 32 over 4 -> 8), config 5: 32 over 8 -> bs=4 — on this one GPU; projected "
@@ -484,6 +490,8 @@ def main():
     op_bytes = {"K1": algo_bytes("K1", B, patch_shape[1], patch_shape[2]), "K2": algo_bytes("K2", B, patch_shape[1], patch_shape[2]),
                 "K2e": algo_bytes("K2e", B, patch_shape[1], patch_shape[2], embed_width=embed_width),
                 "K3": algo_bytes("K3_slice" if use_rows else "K3", B, rows=R, esize=esz), "K4": algo_bytes("K4", B, patch_shape[1], patch_shape[2])}
+    if "K3h" in op_us and cfg is not None and hasattr(cfg, "llm_dim"):  # LM head fused with K3's statistics: the head weight streamed once + the hidden rows
+        op_bytes["K3h"] = 2 * 32064 * cfg.llm_dim + 2 * R * cfg.llm_dim
     hot_ops = {o: {"us_per_step": u, "algo_bytes": op_bytes.get(o), "achieved_GBs": (op_bytes[o] / u / 1e3 if o in op_bytes else None),
                    "frac": (op_bytes[o] / u / 1e3 / HBM_PEAK_GBS if o in op_bytes else None)} for o, u in op_us.items()}
     k1name = next((n for n in kern if "patch_apply_tiles_kernel" in n or "patch_apply_fwd_kernel" in n), None)

@@ -248,6 +248,26 @@ int vaa_step_epilogue_update(const float* partials, int nparts, int n, const voi
                              float beta2, float eps, int step, double* stat_part, void* stream);
 
 /*
+ * LM head FUSED with K3's statistics (SURVEY.md section 8f-2 as the survey wrote it; for callers that own the LM-head weight) — replaces
+ * `logits = lm_head(hidden)` on the labelled rows (modeling_prismatic.py:404-415 -> HF Llama's bf16 lm_head) followed by vaa_loss_rows_stats:
+ * the [R,V] logits are never written. The head weight is streamed from HBM once (full 128-byte lines through LDS into MFMA fragments), every
+ * workgroup reduces its 128 vocabulary columns to per-row {max, sum exp, argmax, label logit}; a second small launch folds them per row,
+ * computes the action-slice statistics (UADA.py:384-389) and — VAA_LOSS_UADA_DDP — writes the gradient slice.
+ *   hidden   dev bf16 [R,D]: final-norm hidden states of the labelled rows, in the row map's order;  w_head dev bf16 [V,D]
+ *   rowmap, R, B, L, V, mode, params: as vaa_loss_rows_stats;  grad_slice dev bf16 [R,256] or NULL (only VAA_LOSS_UADA_DDP)
+ *   loss_ws  dev >= vaa_loss_rows_ws_bytes(R): left exactly as vaa_loss_rows_stats leaves it — vaa_step_epilogue[_update] folds it unchanged
+ *   head_ws  dev >= vaa_head_loss_ws_bytes(R, V) scratch;  logits_dbg dev bf16 [R,V] or NULL (tests: the bf16 logits the statistics were made of)
+ * Covers vaa_head_loss_rows_applies(R, D, V) == 1: R <= 128 rows (one pass over the weight), D a multiple of 64; else VAA_E_UNSUPPORTED and the
+ * caller keeps its GEMM + vaa_loss_rows_stats. Logits are the fp32 MFMA sums rounded to bf16 (the reference's bf16 head); for the same bf16
+ * logits the slice statistics and the gradient slice are bit for bit those of vaa_loss_rows_stats, CE agrees to fp32 summation order.
+ */
+size_t vaa_head_loss_ws_bytes(int R, int V);
+int vaa_head_loss_rows_applies(int R, int D, int V);
+int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* w_head, int D, const void* rowmap, int R, int B, int L, int V, int mode,
+                             const float* params, void* grad_slice, void* loss_ws, size_t loss_ws_bytes, void* head_ws, size_t head_ws_bytes,
+                             uint16_t* logits_dbg, void* stream);
+
+/*
  * K2' (for callers that own the model's patch-embed weights) — K2 fed by the gradient of the ViT patch-embed OUTPUTS instead of the pixel gradient: the
  * patch-embed backward (modeling_prismatic.py:120-123 -> timm PatchEmbed, Conv2d(3, D, 14, stride 14) == a GEMM over 588-pixel
  * tiles) is evaluated by MFMA only for the 14x14 tiles that carry kept patch pixels and consumed in place by the gather.

@@ -54,6 +54,9 @@ EXPORTS = (
     "vaa_patch_embed_grad_gather_multi_tiles",
     "vaa_patch_embed_grad_gather_tiles",
     "vaa_loss_rows_stats",
+    "vaa_head_loss_ws_bytes",
+    "vaa_head_loss_rows_applies",
+    "vaa_head_loss_rows_stats",
     "vaa_step_epilogue",
     "vaa_step_epilogue_update",
     "vaa_async_error",
@@ -184,6 +187,12 @@ def lib() -> C.CDLL:
     L.vaa_patch_embed_grad_gather_tiles.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(f32), i32, vp, vp, sz, vp]
     L.vaa_loss_rows_stats.restype = i32
     L.vaa_loss_rows_stats.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, i32, vp, sz, vp]
+    L.vaa_head_loss_ws_bytes.restype = sz
+    L.vaa_head_loss_ws_bytes.argtypes = [i32, i32]
+    L.vaa_head_loss_rows_applies.restype = i32
+    L.vaa_head_loss_rows_applies.argtypes = [i32, i32, i32]
+    L.vaa_head_loss_rows_stats.restype = i32
+    L.vaa_head_loss_rows_stats.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, sz, vp, sz, vp, vp]
     L.vaa_step_epilogue.restype = i32
     L.vaa_step_epilogue.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp]
     L.vaa_step_epilogue_update.restype = i32

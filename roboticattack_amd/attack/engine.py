@@ -117,6 +117,17 @@ class AttackBase:
         return (os.environ.get("VAA_FUSED_EPILOGUE", "1") != "0" and self.use_rows and hasattr(self.vla, "hidden_rows")
                 and t.embed_with is not None and not t.resize_patch)
 
+    @staticmethod
+    def _fused_head(R, h, W) -> bool:
+        """LM head fused with K3's statistics (vaa_head_loss_rows_stats) for this shape? Up to 64 labelled rows — the per-rank shapes of the
+        multi-GPU configs: bs = 8 -> 16 rows — the fused kernel streams the 263 MB head weight at 5.6 TB/s in the step (47 us + 9 us for the
+        fold against 67 + 11 us for the hipBLASLt GEMM + K3 statistics); at 128 rows (bs = 64) its on-chip work per k-chunk makes it 7 us
+        SLOWER than the GEMM path (profiles/r04_head_fused.txt), which stays. VAA_FUSED_HEAD=1 / 0 forces it on / off."""
+        mode = os.environ.get("VAA_FUSED_HEAD", "auto")
+        if mode == "0" or h.dtype != torch.bfloat16 or W.dtype != torch.bfloat16 or not ops.head_loss_rows_applies(R, int(h.shape[1]), int(W.shape[0])):
+            return False
+        return mode == "1" or R <= 64
+
     def fused_ddp_step(self, pixel_values, patch, input_ids, attention_mask, labels, geometry, w, msg, scalars, optimizer=None):
         """The UADA_ddp inner step (UADA_ddp.py:189-206) up to the gradient exchange, six hand-written launches around the model:
         K1 -> [ViTs, Llama, LM head on the labelled rows] -> K3 statistics + gradient slice -> [head / model backward] -> K2' tile GEMM ->
@@ -132,9 +143,13 @@ class AttackBase:
         h = self.vla.hidden_rows(input_ids, None, self._row_index, patch_embeds=pe, pack=pack)
         W = self.vla.lm_head.weight
         R = int(h.shape[0])
-        logits = torch.nn.functional.linear(h.detach(), W)  # [R,V]: the LM head on the labelled rows
-        gsl = torch.empty((R, ops.N_ACTION), dtype=logits.dtype, device=logits.device)
-        ws = ops.loss_rows_stats(logits, self._row_map, ops.LOSS_UADA_DDP, w, grad=gsl)      # K3: statistics + d loss / d action logits
+        gsl = torch.empty((R, ops.N_ACTION), dtype=h.dtype, device=h.device)
+        if self._fused_head(R, h, W):
+            # SURVEY.md 8f-2 as the survey wrote it: LM head + K3 statistics in ONE weight-streaming kernel — the [R,V] logits are never written
+            ws = ops.head_loss_rows_stats(h.detach().contiguous(), W, self._row_map, ops.LOSS_UADA_DDP, w, grad=gsl)
+        else:
+            logits = torch.nn.functional.linear(h.detach(), W)  # [R,V]: the LM head on the labelled rows through hipBLASLt
+            ws = ops.loss_rows_stats(logits, self._row_map, ops.LOSS_UADA_DDP, w, grad=gsl)  # K3: statistics + d loss / d action logits
         h.backward(gsl @ W[ops.ACTION_LO : ops.ACTION_LO + ops.N_ACTION])                     # head backward over 256 columns, model backward, K2'
         _, pred_full = ops.step_epilogue(sink["partials"], msg, scalars, rowmap=self._row_map, R=R, V=int(W.shape[0]),
                                          mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws,

@@ -71,12 +71,13 @@ struct ProfRec {
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;   // pool of event pairs; the first g_prof_used are recorded
 static int g_prof_used = 0;
+static int g_prof_cap = 0;             // the capacity of the CURRENT arming (the pool itself only grows)
 static std::atomic<bool> g_prof_armed{false};  // read without the lock on every launch
 
 bool prof_next(const char* name, hipEvent_t* start, hipEvent_t* stop) {
     if (!g_prof_armed.load(std::memory_order_acquire)) return false;  // fast path of every un-profiled launch
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_armed || g_prof_used >= (int)g_prof.size()) return false;  // pool exhausted: later dispatches run unprofiled
+    if (!g_prof_armed || g_prof_used >= g_prof_cap) return false;  // capacity reached: later dispatches run unprofiled
     ProfRec& r = g_prof[g_prof_used++];
     r.name = name;
     *start = r.start;
@@ -103,6 +104,7 @@ int vaa_prof_start(int capacity) {
         g_prof.push_back(r);
     }
     g_prof_used = 0;
+    g_prof_cap = capacity;
     g_prof_armed = capacity > 0;
     return VAA_OK;
 }

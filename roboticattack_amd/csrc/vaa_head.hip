@@ -1,18 +1,19 @@
-// head_fused_probe.hip — PROBE (round 4; measured, NOT adopted: profiles/r04_head_fused.txt): SURVEY.md section 8f-2 as the
-// survey wrote it, the LM head on the labelled rows FUSED with K3's statistics. Not part of libvaa_hip.so; tools/head_bench.py builds it into a
-// variant library (tools/scratch/build_variant.sh HEAD tools/probe/head_fused_probe.hip) and binds its three entry points itself.
+// vaa_head.hip — SURVEY.md section 8f-2 as the survey wrote it: the LM head on the labelled rows FUSED with K3's statistics.
 //
 // Replaces `logits = lm_head(hidden_rows)` (modeling_prismatic.py:404-415 -> HF Llama's lm_head, bf16) + the statistics pass of K3
 // (vaa_loss_rows_stats: HF's CE terms and weighted_loss's soft-argmax, UADA_ddp.py:99-124) for the data-parallel UADA step, whose gradient
 // lives in the 256 action columns: the [R',V] logits are never written to memory.
 //
-//   head_stats_kernel<NQ>   grid = ceil(V / 128) workgroups of 8 waves; workgroup w owns the 128 vocabulary columns [128 w, 128 w + 128):
-//       * the 128 weight rows W[n, :] (8 KB each, contiguous in K) are streamed from HBM exactly once, straight into MFMA B fragments
-//         (lane = (column n, k-group): 16 bytes per lane, a row's four lanes cover 64 contiguous bytes), three 128-wide k-chunks ahead
-//         of their use — 263 MB at V = 32,064, D = 4,096: the kernel is a weight stream, its floor is 263 MB / HBM bandwidth;
-//       * the hidden rows H [R' <= 128, D] (1 MB, L2-resident, read by every workgroup) go through a double-buffered LDS image in full
-//         256-byte row pieces, one barrier per 128-wide k-chunk; every wave multiplies all R' rows against its own 16 columns
-//         (mfma_f32_16x16x32_bf16; 32 % of the matrix pipe suffices to keep up with the stream);
+//   head_stats_kernel<NRB>  grid = ceil(V / 128) workgroups of 8 waves; workgroup w owns the 128 vocabulary columns [128 w, 128 w + 128):
+//       * the kernel is a WEIGHT STREAM — 263 MB at V = 32,064, D = 4,096, read from HBM exactly once with nontemporal loads; its floor is
+//         263 MB / HBM bandwidth. Both operands are staged through LDS in FULL 128-byte lines (8 consecutive threads = one row's line of a
+//         64-wide k-chunk): 64-byte fragment-shaped loads straight into MFMA operands streamed at 3.0-4.5 TB/s whatever the prefetch depth,
+//         full lines reach 6.1 TB/s (profiles/r04_head_fused.txt). Chunks are requested four steps ahead into four register sets and written
+//         to a double-buffered LDS image one step before their use (requests complete in order: waiting for chunk ch + 1 leaves chunks
+//         ch + 2 .. ch + 4 in flight); one barrier per chunk. Workgroup w walks K starting at chunk 5 w mod 64: all workgroups reading the same
+//         k offset of weight rows 8 KB apart at once put the chip's requests on a few memory channels (58 -> 43 us at R' = 16);
+//       * the hidden rows H [R' <= 128, D] (1 MB, L2-resident) are read by every workgroup the same way; mfma_f32_16x16x32_bf16, a wave
+//         multiplies all rows against its 16 columns (R' <= 64) or half the rows against 32 columns (R' = 128: 6 fragment reads per 8 MFMAs);
 //       * epilogue: the accumulators are rounded to bf16 (what the reference's bf16 head hands to `.float()`), laid out as a [R', 128] tile
 //         in LDS and reduced per row to {max, sum exp, argmax, label logit} = one PartStat per (row, workgroup); the two workgroups that
 //         own the action columns 31744..31999 also leave those logits in a [R', 256] fp32 buffer.
@@ -27,26 +28,28 @@ namespace vaa {
 typedef short v8s_h __attribute__((ext_vector_type(8)));
 typedef float v4f_h __attribute__((ext_vector_type(4)));
 
-constexpr int kHT = 256;             // threads per workgroup: 4 waves, ONE per SIMD (up to 512 VGPRs each: the weight stream lives in registers)
-constexpr int kHCols = 128;          // vocabulary columns per workgroup: 32 per wave
-constexpr int kHK = 128;             // k-chunk
-constexpr int kHSA = kHK + 8;        // padded LDS row of the H image (bf16 elements): 272 B, conflict-free 16-byte fragment reads
+#ifndef VAA_HEAD_WAVES
+#define VAA_HEAD_WAVES 8
+#endif
+constexpr int kHT = VAA_HEAD_WAVES * 64;  // threads per workgroup: 8 waves (two per SIMD: one wave's fragment reads hide behind the other's MFMAs)
+constexpr int kHCols = 128;          // vocabulary columns per workgroup
+constexpr int kHCB = kHCols / 16 / VAA_HEAD_WAVES;  // 16-column blocks per wave
+#ifndef VAA_HEAD_K
+#define VAA_HEAD_K 64
+#endif
+constexpr int kHK = VAA_HEAD_K;      // k-chunk: one (64) or two (128) 128-byte lines of every weight row and of every hidden row
+constexpr int kHSA = kHK + 8;        // padded LDS row (bf16 elements): 144 B, conflict-free 16-byte fragment reads
 constexpr int kHTileS = kHCols + 4;  // padded row of the fp32 logits tile
 constexpr int kHRowsMax = 128;
-constexpr int kHRing = 4;            // LDS ring of H chunks
+#ifndef VAA_HEAD_SETS
+#define VAA_HEAD_SETS 4
+#endif
+constexpr int kHSets = VAA_HEAD_SETS;  // register sets: chunks ch + 1 .. ch + SETS are in registers / in flight while chunk ch is multiplied
 #ifdef VAA_HEAD_PLAIN_LOADS
 #define VAA_HEAD_LOAD(p) (*(p))
 #else
 #define VAA_HEAD_LOAD(p) __builtin_nontemporal_load(p)
 #endif
-#ifndef VAA_HEAD_SETS1
-#define VAA_HEAD_SETS1 8
-#endif
-#ifndef VAA_HEAD_SETS4
-#define VAA_HEAD_SETS4 4
-#endif
-// weight register sets (32 VGPRs each; SETS - 1 k-chunks are in flight ahead of the one being multiplied), by the hidden rows' register needs
-template <int NRB> struct HeadSets { static constexpr int value = NRB >= 4 ? VAA_HEAD_SETS4 : VAA_HEAD_SETS1; };
 
 struct HeadArgs {
     const uint16_t* h;      // [R, D] bf16 hidden rows (final norm applied)
@@ -58,152 +61,138 @@ struct HeadArgs {
     int R, D, V, nwg;
 };
 
-// NRB = 32-row blocks of hidden rows (R' <= 32 NRB). A wave owns TWO 16-column blocks and all rows: mfma_f32_16x16x32_bf16 with the weight
-// rows as B fragments straight from global memory (lane = (column, k-group): 16 bytes per lane, the four lanes of a column cover 64 contiguous
-// bytes — the widest piece of one row a single load instruction can hand to MFMA operands; a per-lane-row layout, 64 lines per instruction,
-// measured 2.4x slower) and the hidden rows as A fragments from LDS, each read feeding two MFMAs.
+// v4: BOTH operands are staged through LDS in full 128-byte lines (8 consecutive threads = one row's line of a k-chunk; a wave instruction =
+// 8 whole lines) — the 64-byte fragment-shaped register loads of v1..v3 streamed at 3.0-4.5 TB/s whatever the prefetch depth. Chunks are
+// requested four steps ahead into four register sets, written to a double-buffered LDS image one step before their use (requests complete
+// in order: waiting for chunk ch + 1 leaves chunks ch + 2 .. ch + 4 in flight), one barrier per 64-wide chunk. A wave multiplies all hidden
+// rows against its 32 columns (mfma_f32_16x16x32_bf16, every A fragment read feeds two MFMAs).
 template <int NRB>
 __global__ __launch_bounds__(kHT) void head_stats_kernel(HeadArgs a) {
     extern __shared__ __align__(16) unsigned char head_smem[];
-    uint16_t* hb = reinterpret_cast<uint16_t*>(head_smem);  // [kHRing][ROWS][kHSA]
-    float* tile = reinterpret_cast<float*>(head_smem);      // epilogue: [ROWS][kHTileS]
-    constexpr int ROWS = NRB * 32, NQ = NRB * 2;            // NQ: 16-row blocks
-    constexpr int HL = ROWS * (kHK / 8) / kHT;  // 16-byte loads per thread and H chunk: 2 NRB
+    constexpr int ROWS = NRB * 32, NQ = NRB * 2;
+    // waves = (column group, row half): with 128 rows a wave takes HALF the rows against TWO column blocks — 6 fragment reads per 8 MFMAs instead
+    // of 9 (the LDS read traffic is what bounds the 128-row form)
+    constexpr int RH = (NRB >= 4 && kHCB == 1) ? 2 : 1, CBW = kHCB * RH, NQW = NQ / RH;
+    uint16_t* hb = reinterpret_cast<uint16_t*>(head_smem);   // [2][ROWS][kHSA]
+    uint16_t* wb = hb + 2 * ROWS * kHSA;                      // [2][kHCols][kHSA]
+    float* tile = reinterpret_cast<float*>(head_smem);       // epilogue: [ROWS][kHTileS]
+    constexpr int HL = (ROWS * (kHK / 8) + kHT - 1) / kHT;  // 16-byte loads per thread and H chunk
+    constexpr int WL = kHCols * (kHK / 8) / kHT;  // ... and W chunk: 4
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * kHCols;
     const int nchunks = a.D / kHK;
 #ifndef VAA_HEAD_STAGGER
 #define VAA_HEAD_STAGGER 5
 #endif
-    // k-chunk order: workgroup w starts at chunk (5 w) mod nchunks and wraps around. Without the stagger every workgroup reads the SAME k offset of
-    // its 128 weight rows (8 KB apart) at the same time: the requests of the whole chip fall on a few memory channels.
+    // k-chunk order: workgroup w starts at chunk (5 w) mod nchunks and wraps around (all workgroups reading the same k offset of weight rows 8 KB
+    // apart at the same time puts the requests of the whole chip on a few memory channels)
     const int kstart = (int)((blockIdx.x * (unsigned)VAA_HEAD_STAGGER) % (unsigned)nchunks);
     auto kchunk = [&](int ch) { const int cc = min(ch, nchunks - 1) + kstart; return cc >= nchunks ? cc - nchunks : cc; };
-    // this lane's two weight rows: columns n0 + 32 wv + 16 cb + c (columns beyond V re-read the last row; their results are never used)
-    const uint16_t* wrow[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) wrow[cb] = a.w + (size_t)min(n0 + wv * 32 + cb * 16 + c, a.V - 1) * a.D + g * 16;
-    constexpr int SETS = HeadSets<NRB>::value, DEPTH = SETS - 1;
-    static_assert(SETS >= 4 && SETS % 2 == 0, "the rotation pairs the weight sets with the two H register sets");
-    // k-slices: within a 128-wide chunk (two 128-byte lines of a weight row) k-group g owns the 32-byte slot g of each line; MFMA 2 L + p takes
-    // the p-th 16 bytes of its slot in line L. The two load instructions of a line touch the SAME 16 lines (one per column) instead of two
-    // different half-lines each (any assignment of k to lanes is valid as long as the A and the B fragments agree)
-    auto kofs = [](int jj) { return (jj >> 1) * 64 + (jj & 1) * 8; };
-    v8s_h wreg[SETS][8];  // [set][cb * 4 + j]
-    auto load_w = [&](v8s_h (&dst)[8], int ch) {  // unconditional (the tail re-requests the last chunk): the compiler counts the requests
-        const size_t off = (size_t)kchunk(ch) * kHK;
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)  // streamed once: nontemporal, kept out of the L2 the H rows live in
-                dst[cb * 4 + jj] = VAA_HEAD_LOAD(reinterpret_cast<const v8s_h*>(wrow[cb] + off + kofs(jj)));
-    };
-    uint4 hreg[2][HL];
-    auto load_h = [&](uint4 (&dst)[HL], int ch) {
-        const int chc = kchunk(ch);
+    constexpr int PPR = kHK / 8;                               // 16-byte pieces per row of a chunk
+    const int srow = tid / PPR, spiece = tid % PPR;            // staging: PPR consecutive threads per row (full 128-byte lines)
+    constexpr int SR = kHT / PPR;                              // rows per staging pass
+    uint4 hreg[kHSets][HL], wreg[kHSets][WL];
+    auto load_chunk = [&](uint4 (&hd)[HL], uint4 (&wd)[WL], int ch) {  // unconditional addresses (the tail re-requests the last chunk)
+        const size_t koff = (size_t)kchunk(ch) * kHK + spiece * 8;
 #pragma unroll
         for (int it = 0; it < HL; ++it) {
-            const int idx = tid + it * kHT, row = idx >> 4, piece = idx & 15;
-            dst[it] = make_uint4(0, 0, 0, 0);
-            if (row < a.R) dst[it] = *reinterpret_cast<const uint4*>(a.h + (size_t)row * a.D + chc * kHK + piece * 8);
+            const int row = srow + it * SR;
+            hd[it] = make_uint4(0, 0, 0, 0);
+            if (row < a.R) hd[it] = *reinterpret_cast<const uint4*>(a.h + (size_t)row * a.D + koff);
+        }
+#pragma unroll
+        for (int it = 0; it < WL; ++it) {
+            const int col = min(n0 + srow + it * SR, a.V - 1);  // columns beyond V re-read the last row; their results are never used
+            typedef unsigned u32x4_h __attribute__((ext_vector_type(4)));
+            const u32x4_h v = VAA_HEAD_LOAD(reinterpret_cast<const u32x4_h*>(a.w + (size_t)col * a.D + koff));  // streamed once: nontemporal
+            wd[it] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
-    auto store_h = [&](const uint4 (&src)[HL], int buf) {
+    auto store_chunk = [&](const uint4 (&hs)[HL], const uint4 (&ws)[WL], int buf) {
 #pragma unroll
-        for (int it = 0; it < HL; ++it) {
-            const int idx = tid + it * kHT, row = idx >> 4, piece = idx & 15;
-            *reinterpret_cast<uint4*>(&hb[(buf * ROWS + row) * kHSA + piece * 8]) = src[it];
-        }
+        for (int it = 0; it < HL; ++it)
+            if (srow + it * SR < ROWS) *reinterpret_cast<uint4*>(&hb[(buf * ROWS + srow + it * SR) * kHSA + spiece * 8]) = hs[it];
+#pragma unroll
+        for (int it = 0; it < WL; ++it) *reinterpret_cast<uint4*>(&wb[(buf * kHCols + srow + it * SR) * kHSA + spiece * 8]) = ws[it];
     };
-    v4f_h acc[2][NQ];
+    const int cg = wv / RH, rh = wv % RH;
+    v4f_h acc[CBW][NQW];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[cb][q] = (v4f_h){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NQW; ++q) acc[cb][q] = (v4f_h){0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: H chunks 0..2 into the ring, weight chunks 0..2 in flight, H chunk 3 requested ----
-    // Request ORDER is the design: loads complete in order, so waiting for an H chunk drains every weight request issued before it. H chunk
-    // x is therefore requested a full step before weight chunk x - 1: the wait for it (end of step x - 3) leaves two weight chunks in flight.
-    load_h(hreg[0], 0);
-    store_h(hreg[0], 0);
-    load_h(hreg[0], 1);
-    load_h(hreg[1], 2);
+    // ---- prologue: chunks 0..3 requested, chunk 0 into the LDS image ----
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s) load_w(wreg[s], s);
-    store_h(hreg[0], 1);
-    store_h(hreg[1], 2);
-    load_h(hreg[1], 3);
+    for (int s = 0; s < kHSets; ++s) load_chunk(hreg[s], wreg[s], s);
+    store_chunk(hreg[0], wreg[0], 0);
     __syncthreads();
 
-    auto step = [&](int ch, const v8s_h (&wcur)[8], v8s_h (&wnext)[8], uint4 (&hnew)[HL], const uint4 (&hold)[HL]) {
-        load_h(hnew, ch + 4);
-        load_w(wnext, ch + DEPTH);
-        const uint16_t* ap = &hb[((ch & (kHRing - 1)) * ROWS + c) * kHSA + g * 16];
-        v8s_h af[2][NQ];
+    auto step = [&](int ch, uint4 (&hnew)[HL], uint4 (&wnew)[WL], const uint4 (&hnext)[HL], const uint4 (&wnext)[WL]) {
+        load_chunk(hnew, wnew, ch + kHSets);  // into the set chunk ch left when it was written to LDS a step ago
+        const uint16_t* ap = &hb[((ch & 1) * ROWS + rh * (ROWS / RH) + c) * kHSA + g * 8];
+        const uint16_t* bp = &wb[((ch & 1) * kHCols + cg * (16 * CBW) + c) * kHSA + g * 8];
+        if (ch < nchunks) {  // workgroup-uniform (false only in the padded steps behind the last chunk)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) af[0][q] = *reinterpret_cast<const v8s_h*>(ap + q * 16 * kHSA + kofs(0));
+            for (int jj = 0; jj < kHK / 32; ++jj) {
+                v8s_h af[NQW], bf[CBW];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            if (jj + 1 < 4) {
+                for (int cb = 0; cb < CBW; ++cb) bf[cb] = *reinterpret_cast<const v8s_h*>(bp + cb * 16 * kHSA + jj * 32);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) af[(jj + 1) & 1][q] = *reinterpret_cast<const v8s_h*>(ap + q * 16 * kHSA + kofs(jj + 1));
+                for (int q = 0; q < NQW; ++q) af[q] = *reinterpret_cast<const v8s_h*>(ap + q * 16 * kHSA + jj * 32);
+#pragma unroll
+                for (int q = 0; q < NQW; ++q)
+#pragma unroll
+                    for (int cb = 0; cb < CBW; ++cb) acc[cb][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q], bf[cb], acc[cb][q], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);  // the next k-step's LDS reads are issued before this step's MFMAs
-            if (ch < nchunks) {  // workgroup-uniform (false only in the padded steps behind the last chunk)
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) acc[cb][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jj & 1][q], wcur[cb * 4 + jj], acc[cb][q], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
-        store_h(hold, (ch + 3) & (kHRing - 1));  // H chunk ch + 3 (requested a step ago): its slot was last read in step ch - 1
+        store_chunk(hnext, wnext, (ch + 1) & 1);  // chunk ch + 1 (requested three steps ago): its buffer was last read in step ch - 1
         __syncthreads();
     };
-    static_assert(kHRing == 4, "H chunk x is requested in step x - 4 and stored in step x - 3");
-    // SETS steps per iteration, fully unrolled: register sets are indexed statically and the request counts stay static. Steps beyond the last
-    // chunk (D / 128 not a multiple of SETS) only re-request the last chunk (unconditional loads) and skip the MFMAs.
-    for (int ch0 = 0; ch0 < nchunks; ch0 += SETS) {
+    // kHSets steps per iteration, fully unrolled: register sets are indexed statically and the request counts stay static
+    for (int ch0 = 0; ch0 < nchunks; ch0 += kHSets) {
 #pragma unroll
-        for (int u = 0; u < SETS; ++u) step(ch0 + u, wreg[u], wreg[(u + DEPTH) % SETS], hreg[u & 1], hreg[(u + 1) & 1]);
+        for (int u = 0; u < kHSets; ++u) step(ch0 + u, hreg[u], wreg[u], hreg[(u + 1) % kHSets], wreg[(u + 1) % kHSets]);
     }
-    // (the loop's last barrier: every wave is done with the H ring — the LDS becomes the logits tile)
+    // (the loop's last barrier: every wave is done with the LDS images — the LDS becomes the logits tile)
 
-    // ---- epilogue: bf16-rounded logits -> LDS tile [ROWS][128] ----
-    // C/D layout: column = lane & 15, row = 4 (lane >> 4) + r
+    // ---- epilogue: bf16-rounded logits -> LDS tile [ROWS][128]; C/D layout: column = lane & 15, row = 4 (lane >> 4) + r ----
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < NQW; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                tile[(q * 16 + g * 4 + r) * kHTileS + wv * 32 + cb * 16 + c] = bf16_bits_to_f32(f32_to_bf16_bits(acc[cb][q][r]));
+                tile[(rh * (ROWS / RH) + q * 16 + g * 4 + r) * kHTileS + cg * (16 * CBW) + cb * 16 + c] = bf16_bits_to_f32(f32_to_bf16_bits(acc[cb][q][r]));
     __syncthreads();
     const int ncols = min(kHCols, a.V - n0);
     // per-row statistics: 2 threads per row, thread `part` takes the columns part, part + 2, ...
     {
-        const int row = tid >> 1, part = tid & 1;
+        constexpr int TPR = kHT / kHRowsMax;  // threads per row
+        const int row = tid / TPR, part = tid % TPR;
         const bool live = row < ROWS && row < a.R;
         float m = -INFINITY;
         int mi = 0x7fffffff;
         if (live) {
             const float* tr = tile + row * kHTileS;
-            for (int cl = part; cl < ncols; cl += 2) {  // increasing columns: the first maximum wins
+            for (int cl = part; cl < ncols; cl += TPR) {  // increasing columns: the first maximum wins
                 const float v = tr[cl];
                 if (v > m) { m = v; mi = n0 + cl; }
             }
         }
-        {
-            const float om = __shfl_xor(m, 1, 64);
-            const int oi = __shfl_xor(mi, 1, 64);
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) {
+            const float om = __shfl_xor(m, o, 64);
+            const int oi = __shfl_xor(mi, o, 64);
             if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
         }
         float s = 0.0f;
         if (live) {
             const float* tr = tile + row * kHTileS;
-            for (int cl = part; cl < ncols; cl += 2) s += expf(tr[cl] - m);
+            for (int cl = part; cl < ncols; cl += TPR) s += expf(tr[cl] - m);
         }
-        s += __shfl_xor(s, 1, 64);
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, 64);
         if (live && part == 0) {
             PartStat ps;
             ps.m = m;
@@ -400,7 +389,7 @@ extern "C" int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* 
     a.logits_dbg = logits_dbg;
     a.R = R; a.D = D; a.V = V;
     const int nrb = R <= 32 ? 1 : (R <= 64 ? 2 : 4);
-    const size_t lds_h = (size_t)kHRing * nrb * 32 * kHSA * sizeof(uint16_t), lds_t = (size_t)nrb * 32 * kHTileS * sizeof(float);
+    const size_t lds_h = (size_t)2 * (nrb * 32 + kHCols) * kHSA * sizeof(uint16_t), lds_t = (size_t)nrb * 32 * kHTileS * sizeof(float);
     const size_t lds = lds_h > lds_t ? lds_h : lds_t;
     const void* fn = nrb == 1 ? (const void*)head_stats_kernel<1> : (nrb == 2 ? (const void*)head_stats_kernel<2> : (const void*)head_stats_kernel<4>);
     if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

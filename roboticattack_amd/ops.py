@@ -665,6 +665,33 @@ def loss_rows_stats(logits, rowmap: LossRowMap, mode: int, w: float = 5.0, alpha
     return ws
 
 
+def head_loss_rows_applies(R: int, D: int, V: int) -> bool:
+    return bool(_lib.lib().vaa_head_loss_rows_applies(int(R), int(D), int(V)))
+
+
+def head_loss_rows_stats(hidden, w_head, rowmap: "LossRowMap", mode: int = LOSS_UADA_DDP, w: float = 5.0, alpha: float = 0.8, beta: float = 0.2,
+                         scale: float = 1.0, grad=None, want_logits: bool = False):
+    """vaa_head_loss_rows_stats: LM head on the labelled rows fused with K3's statistics — `hidden` [R,D] bf16, `w_head` [V,D]
+    bf16; the [R,V] logits are never written. Returns the K3 workspace for ops.step_epilogue(loss_ws=...) exactly like loss_rows_stats
+    (and the bf16 logits [R,V] the statistics were made of when want_logits: tests)."""
+    R, D = int(hidden.shape[0]), int(hidden.shape[1])
+    V = int(w_head.shape[0])
+    _need(hidden, torch.bfloat16, "hidden", (R, D))
+    _need(w_head, torch.bfloat16, "w_head", (V, D))
+    if grad is not None:
+        _need(grad, torch.bfloat16, "grad", (R, N_ACTION))
+    L = _lib.lib()
+    ws = _workspace(hidden.device, L.vaa_loss_rows_ws_bytes(R), "k3")
+    hws = _workspace(hidden.device, L.vaa_head_loss_ws_bytes(R, V), "k3h")
+    dbg = torch.empty((R, V), dtype=torch.bfloat16, device=hidden.device) if want_logits else None
+    with _timed("K3_head_loss_rows_stats", rows=R, V=V, D=D):
+        rc = L.vaa_head_loss_rows_stats(hidden.data_ptr(), w_head.data_ptr(), D, rowmap.buf.data_ptr(), R, rowmap.B, rowmap.L, V, int(mode),
+                                        _lib.f32x([w, alpha, beta, scale]), grad.data_ptr() if grad is not None else None, ws.data_ptr(), ws.numel(),
+                                        hws.data_ptr(), hws.numel(), dbg.data_ptr() if dbg is not None else None, _stream())
+    _lib.check(rc, "vaa_head_loss_rows_stats")
+    return (ws, dbg) if want_logits else ws
+
+
 def step_epilogue(partials, msg, scalars, rowmap: LossRowMap = None, R: int = 0, V: int = 32064, mode: int = LOSS_UADA_DDP, w: float = 5.0,
                   alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0, loss_ws=None, want_pred: bool = True, update=None):
     """vaa_step_epilogue: msg[0..n) = fixed-order sum of K2's partial tiles [parts, n]; with `rowmap` (+ the workspace loss_rows_stats left)

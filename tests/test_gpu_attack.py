@@ -609,7 +609,8 @@ def test_bench_contract_line_tiny(model, extra_env):
     assert abs(d["roofline"]["achieved"] - d["roofline"]["algo_bytes"] / k1["mean_us"] / 1e3) < 1e-6 * d["roofline"]["achieved"]
     fused = model == "tiny" and not extra_env  # K1 tile-major, K3 statistics, K2' tile GEMM + gather, epilogue incl. K4: 5 launches per step at N=1
     if fused:
-        assert set(d["hot_path_ops"]) >= {"K1", "K3", "K2e", "EPI"} and "K4" not in d["hot_path_ops"] and d["hot_path_launches_per_step"] == 5
+        # (at bs = 8 the LM head runs fused with K3's statistics: two launches, head_stats + head_finish, instead of GEMM + statistics -> 6)
+        assert set(d["hot_path_ops"]) >= {"K1", "K3h", "K2e", "EPI"} and "K4" not in d["hot_path_ops"] and d["hot_path_launches_per_step"] == 6
     else:
         k4 = next(v for n, v in k.items() if "patch_update_kernel" in n)
         assert k4["launches"] == 2 and set(d["hot_path_ops"]) >= {"K1", "K3", "K4"}
@@ -675,6 +676,7 @@ def test_fused_epilogue_step_equals_separate_launches(monkeypatch):
     batch = synthetic.synth_batch(3, B, "noise", as_pil=False)
     ids, attn = batch["input_ids"].to(DEV), batch["attention_mask"].to(DEV)
     labels = mask_labels(batch["labels"].clone(), [0]).to(DEV)
+    monkeypatch.setenv("VAA_FUSED_HEAD", "0")  # bitwise comparison: the LM head through the GEMM on both sides (the fused head has its own test below)
     runs = []
     for fused in (True, False, "with_update"):
         monkeypatch.setenv("VAA_FUSED_EPILOGUE", "1" if fused else "0")
@@ -902,3 +904,53 @@ def test_uada_trajectory_k2e_vs_reference_loop(tmp_path, monkeypatch):
     np.testing.assert_allclose(att.train_CE_loss, d["train_ce"], rtol=2e-4)
     np.testing.assert_allclose(att.train_MSE_distance_loss, d["train_mse"], rtol=2e-3, atol=1e-5)
     np.testing.assert_allclose(att.train_UAD, d["train_uad"], atol=1e-4)
+
+
+def test_fused_head_step_vs_gemm_head_step(monkeypatch):
+    """The data-parallel UADA step with the LM head FUSED into K3's statistics (vaa_head_loss_rows_stats: what `fused_ddp_step` runs up to 64
+    labelled rows, i.e. at the per-rank batches of the multi-GPU configs) against the same step with the head as a hipBLASLt GEMM +
+    vaa_loss_rows_stats: the two heads round the same fp32 sums to bf16 in different summation orders, so single logits may differ by one
+    bf16 rounding — loss scalars within 2e-3 relative, predictions equal, patches after three AdamW steps within 2e-5; and the fused kernels
+    really are the ones that ran (two launches instead of GEMM + statistics)."""
+    import random
+
+    from roboticattack_amd import dist as vdist
+    from roboticattack_amd import ops, synthetic
+    from roboticattack_amd.attack.engine import AttackBase
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+    from roboticattack_amd.optim import PatchOptimizer
+
+    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, False, True), siglip=VitCfg(192, 3, 2, 384, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=9)
+    B = 6
+    batch = synthetic.synth_batch(3, B, "noise", as_pil=False)
+    ids, attn = batch["input_ids"].to(DEV), batch["attention_mask"].to(DEV)
+    labels = mask_labels(batch["labels"].clone(), [0]).to(DEV)
+    runs = {}
+    for mode in ("0", "auto"):
+        monkeypatch.setenv("VAA_FUSED_HEAD", mode)
+        att = AttackBase(m, None, "", "adamW", False)
+        assert att.fused_ddp_available()
+        img = att.randomPatchTransform.stage_images(torch.from_numpy(batch["pixel_values"]))
+        random.seed(5); np.random.seed(5)
+        patch = torch.rand(3, 50, 50, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
+        opt = PatchOptimizer(patch, 2e-3, "adamW")
+        sync = vdist.PatchGradSync(patch.numel(), 4, torch.device(DEV))
+        scal = torch.zeros(8, device=DEV)
+        snaps = []
+        ops.prof_start(256)
+        for _ in range(3):
+            pf = att.fused_ddp_step(img, patch, ids, attn, labels, True, 5.0, sync.buf, scal, optimizer=opt)
+            snaps.append((patch.detach().clone(), scal.clone(), pf.clone()))
+        names = [n for n, _ in ops.prof_collect()]
+        runs[mode] = (snaps, names)
+    n_head = sum("head_stats_kernel" in n for n in runs["auto"][1]), sum("head_finish_kernel" in n for n in runs["auto"][1])
+    assert n_head == (3, 3) and not any("rows_stats_kernel" in n for n in runs["auto"][1])
+    assert sum("rows_stats_kernel" in n for n in runs["0"][1]) == 3 and not any("head_stats_kernel" in n for n in runs["0"][1])
+    for (p0, s0, f0), (p1, s1, f1) in zip(runs["0"][0], runs["auto"][0]):
+        assert torch.allclose(s0, s1, rtol=2e-3, atol=1e-5), (s0, s1)
+        assert float((f0 != f1).float().mean()) <= 0.1  # an argmax can flip only where two logits tie to one bf16 rounding
+        assert float((p0 - p1).abs().max()) <= 2e-5
+    assert float((runs["0"][0][-1][0] - runs["0"][0][0][0]).abs().max()) > 0

@@ -1483,3 +1483,92 @@ def test_k3_one_pass_handover_timeout_fails_loudly(ops, monkeypatch):
     torch.cuda.synchronize()
     ops.async_error_check()
     assert torch.equal(g2.view(torch.int16), g_ref.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,maskidx,D", [(8, [0], 4096), (32, [0], 4096), (64, [0], 4096), (5, [0, 3], 192), (13, [0, 1, 2], 320), (3, [6], 64)])
+def test_head_loss_rows_stats_vs_oracle_and_gemm_path(ops, B, maskidx, D):
+    """SURVEY.md 8f-2 as written: LM head FUSED with K3's statistics (vaa_head_loss_rows_stats; the attack step uses it up to 64 labelled rows —
+    the per-rank shapes of the multi-GPU configs). Checked three ways on the same hidden rows and head weight:
+      * its bf16 logits (test-only dump) == the hipBLASLt head's bf16 logits up to single bf16 roundings (fp32 summation order) on < 1 % of them;
+      * the C ORACLE fed with those very logits: loss scalars <= 3e-5, gradient slice <= 1e-2 of its scale (bf16 storage), both argmax maps exact;
+      * vaa_loss_rows_stats fed with those very logits: gradient slice and slice statistics BIT FOR BIT, CE to fp32 summation order.
+    Shapes: OpenVLA's head (D = 4096) at bs = 8 / 32 / 64 and small towers incl. D not a multiple of 256 (padded k-steps) and ragged row counts."""
+    from roboticattack_amd.labels import mask_labels
+
+    V = 32064
+    rs = np.random.RandomState(B * 11 + D)
+    _, labels, _ = synthetic.synth_text_batch(500 + B, B)
+    labels = mask_labels(labels, maskidx)
+    L = labels.shape[1]
+    rows = _rows(labels.numpy())
+    R = len(rows)
+    rb, rp = np.array([r[0] for r in rows]), np.array([r[1] for r in rows])
+    g = torch.Generator(device=DEV).manual_seed(B + D)
+    W = (torch.randn(V, D, device=DEV, generator=g) * (1.3 / np.sqrt(D))).to(torch.bfloat16)
+    W[31744:32000] *= 2.0  # spread the action logits
+    h = torch.randn(R, D, device=DEV, generator=g).to(torch.bfloat16)
+    rm = ops.LossRowMap(labels.to(DEV))
+    assert ops.head_loss_rows_applies(R, D, V)
+    gs = torch.full((R, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ws, lg = ops.head_loss_rows_stats(h, W, rm, ops.LOSS_UADA_DDP, 5.0, grad=gs, want_logits=True)
+    n = 7500
+    parts, msg = torch.zeros((4, n), device=DEV), torch.zeros(n + 4, device=DEV)
+    sc = torch.zeros(8, device=DEV)
+    pred, pred_full = ops.step_epilogue(parts, msg, sc, rowmap=rm, R=R, V=V, mode=ops.LOSS_UADA_DDP, w=5.0, loss_ws=ws)
+    torch.cuda.synchronize()
+    # (1) the logits are the head's
+    ref_lg = torch.nn.functional.linear(h, W)
+    dl = (lg.float() - ref_lg.float()).abs()
+    ulp = ref_lg.float().abs().clamp_min(1e-3) * 2.0 ** -7
+    assert float((dl > 0).float().mean()) < 0.01 and bool((dl <= 1.01 * ulp).all())
+    # (2) the oracle on the kernel's own logits
+    full = torch.zeros((B, 256 + L, V), dtype=torch.float32)
+    full[torch.from_numpy(rb), torch.from_numpy(rp)] = lg.float().cpu()
+    so, go = c_oracle.loss(full.numpy(), labels.numpy(), c_oracle.MODE_UADA_DDP, w=5.0)
+    gor = go[rb, rp][:, 31744:32000]
+    assert np.allclose(sc.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5), (sc.cpu().numpy(), so)
+    assert float(sc[5]) == R  # (UAD, scalars[7], is checked through the product's statistics kernel below: the oracle reports it elsewhere)
+    assert np.abs(gs.float().cpu().numpy() - gor).max() <= 1e-2 * max(np.abs(gor).max(), 1e-30) and np.abs(gor).max() > 0
+    zf = lg.float().cpu().numpy()
+    pf, ps = pred_full.cpu().numpy().reshape(B, L - 1), pred.cpu().numpy().reshape(B, L - 1)
+    for i, (b, p) in enumerate(rows):
+        k = p - 256
+        assert pf[b, k] == int(zf[i].argmax())
+        if labels[b, k + 1] > 2:
+            assert ps[b, k] == 31744 + int(zf[i, 31744:32000].argmax())
+    assert int((pf >= 0).sum()) == R
+    # (3) the product's statistics kernel on the same logits: same bits where the arithmetic is the same
+    gs2 = torch.empty_like(gs)
+    sc2 = torch.zeros(8, device=DEV)
+    ws2 = ops.loss_rows_stats(lg, rm, ops.LOSS_UADA_DDP, 5.0, grad=gs2)
+    pred2, pred_full2 = ops.step_epilogue(parts, msg, sc2, rowmap=rm, R=R, V=V, mode=ops.LOSS_UADA_DDP, w=5.0, loss_ws=ws2)
+    assert torch.equal(gs2.view(torch.int16), gs.view(torch.int16)) and torch.equal(pred2, pred) and torch.equal(pred_full2, pred_full)
+    assert torch.equal(sc2[[2, 6, 7]], sc[[2, 6, 7]]) and abs(float(sc2[1]) - float(sc[1])) <= 2e-6 * abs(float(sc2[1]))
+    # bitwise repeatable
+    gs3 = torch.empty_like(gs)
+    ops.head_loss_rows_stats(h, W, rm, ops.LOSS_UADA_DDP, 5.0, grad=gs3)
+    sc3 = torch.zeros(8, device=DEV)
+    ops.step_epilogue(parts, msg, sc3, rowmap=rm, R=R, V=V, mode=ops.LOSS_UADA_DDP, w=5.0, loss_ws=ws)
+    assert torch.equal(gs3.view(torch.int16), gs.view(torch.int16)) and torch.equal(sc3, sc)
+
+
+@pytest.mark.gpu
+def test_head_loss_rows_stats_argument_checks(ops):
+    import ctypes as C
+
+    from roboticattack_amd import _lib
+
+    L = _lib.lib()
+    p, st = C.c_void_p(0x1000), None
+    prm = _lib.f32x([5.0, 0.8, 0.2, 1.0])
+    assert L.vaa_head_loss_rows_applies(128, 4096, 32064) == 1 and L.vaa_head_loss_rows_applies(129, 4096, 32064) == 0
+    assert L.vaa_head_loss_rows_applies(16, 4100, 32064) == 0 and L.vaa_head_loss_rows_applies(16, 4096, 30000) == 0
+    assert L.vaa_head_loss_ws_bytes(0, 32064) == 0 and L.vaa_head_loss_ws_bytes(16, 32064) >= 16 * 251 * 16 + 16 * 256 * 4
+    a = (p, p, 4096, p, 16, 8, 30, 32064)
+    assert L.vaa_head_loss_rows_stats(None, p, 4096, p, 16, 8, 30, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -1
+    assert L.vaa_head_loss_rows_stats(p, p, 4096, p, 200, 100, 30, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -2 and b"GEMM" in L.vaa_last_error()
+    assert L.vaa_head_loss_rows_stats(*a, ops.LOSS_UPA, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -1 and b"UADA_DDP" in L.vaa_last_error()
+    assert L.vaa_head_loss_rows_stats(*a, ops.LOSS_UADA_DDP, prm, p, p, 16, p, 1 << 24, None, st) == -4
+    assert L.vaa_head_loss_rows_stats(*a, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 16, None, st) == -4 and b"workspace" in L.vaa_last_error()
+    assert L.vaa_head_loss_rows_stats(p, p, 4096, p, 100, 8, 10, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -2  # R > B*(L-1)

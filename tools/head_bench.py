@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""PROBE: LM head fused with K3's statistics (tools/probe/head_fused_probe.hip) against the LM-head GEMM (hipBLASLt) + vaa_loss_rows_stats:
-agreement, per-dispatch / in-stream / cold-cache times. Needs the variant library:
-    tools/scratch/build_variant.sh HEAD tools/probe/head_fused_probe.hip  &&  python tools/head_bench.py [R ...]
+"""LM head fused with K3's statistics (vaa_head_loss_rows_stats, csrc/vaa_head.hip) against the LM-head GEMM (hipBLASLt) + vaa_loss_rows_stats:
+agreement, per-dispatch / in-stream / cold-cache times.   python tools/head_bench.py [R ...]
 (R = labelled rows: 128 at bs=64 with maskidx=[0], 16 at bs=8)"""
 import os
 import sys
@@ -12,35 +11,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["VAA_LIB_PATH"] = os.path.join(ROOT, "tools", "scratch", "libvaa_HEAD.so")
-import ctypes as C  # noqa: E402
-
-from roboticattack_amd import _lib, ops, synthetic  # noqa: E402
+from roboticattack_amd import ops, synthetic  # noqa: E402
 from roboticattack_amd.labels import mask_labels  # noqa: E402
 
-
-def _bind():
-    L = _lib.lib()
-    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
-    L.vaa_head_loss_ws_bytes.restype = sz
-    L.vaa_head_loss_ws_bytes.argtypes = [i32, i32]
-    L.vaa_head_loss_rows_stats.restype = i32
-    L.vaa_head_loss_rows_stats.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp, vp, sz, vp, sz, vp, vp]
-    return L
-
-
-def head_loss_rows_stats(hidden, w_head, rowmap, mode, w, grad=None, want_logits=False):
-    """the probe's entry point, bound here (it is not part of the product ABI)"""
-    L = _bind()
-    R, D, V = int(hidden.shape[0]), int(hidden.shape[1]), int(w_head.shape[0])
-    ws = ops._workspace(hidden.device, L.vaa_loss_rows_ws_bytes(R), "k3")
-    hws = ops._workspace(hidden.device, L.vaa_head_loss_ws_bytes(R, V), "k3h")
-    dbg = torch.empty((R, V), dtype=torch.bfloat16, device=hidden.device) if want_logits else None
-    rc = L.vaa_head_loss_rows_stats(hidden.data_ptr(), w_head.data_ptr(), D, rowmap.buf.data_ptr(), R, rowmap.B, rowmap.L, V, int(mode),
-                                    _lib.f32x([w, 0.8, 0.2, 1.0]), grad.data_ptr() if grad is not None else None, ws.data_ptr(), ws.numel(),
-                                    hws.data_ptr(), hws.numel(), dbg.data_ptr() if dbg is not None else None, ops._stream())
-    _lib.check(rc, "vaa_head_loss_rows_stats")
-    return (ws, dbg) if want_logits else ws
+head_loss_rows_stats = ops.head_loss_rows_stats
 
 DEV = "cuda:0"
 D, V = 4096, 32064

@@ -27,7 +27,10 @@ timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-
 
 timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "${out}/bench_no_cpu.json" 2> "${out}/bench_no_cpu.err"
 timeout 1200 python bench.py > "${out}/bench.json" 2> "${out}/bench.err"
-# two ranks on the one GPU over gloo: the N > 1 code path at full size (functional evidence, not a scaling number)
+# two ranks on the one GPU over gloo: the N > 1 code path at full size, both timed regions (functional evidence, not a scaling number)
 timeout 900 python bench.py --gpus 2 --steps 4 --warmup 1 --no-kernel-suite > "${out}/bench_2ranks_one_gpu.json" 2> "${out}/bench_2ranks_one_gpu.err"
+# eight ranks on the one GPU, the strong-scaling region alone (bs = 8 per rank, BASELINE config 3's split): the full-size 8-rank functional run.
+# VAA_NO_TN_DGRAD=1 drops the 12.9 GB of resident transposed weights per rank so that eight copies of the model fit the 288 GB
+VAA_NO_TN_DGRAD=1 timeout 1500 python bench.py --gpus 8 --steps 3 --warmup 1 --regions strong --no-cpu-baseline --no-kernel-suite > "${out}/bench_8ranks_one_gpu.json" 2> "${out}/bench_8ranks_one_gpu.err"
 timeout 200 python tools/k3_onepass_check.py > "${out}/k3_onepass.txt" 2>&1
 ls -la "${out}"
