@@ -546,7 +546,7 @@ def main():
         extra["rank_shapes"] = rank_shapes(device=str(dev))
         ks = extra["roofline_kernels_standalone"]
         used_k2 = "K2e_patch_embed_grad_gather" if fused else "K2_patch_grad_gather"
-        gpu_ops_s = sum(v["mean_us"] for k, v in ks.items() if (not k.startswith("K2") or k == used_k2) and k not in ("K3_full_rows_fwd_bwd", "K3_full_one_launch_optin")) * 1e-6
+        gpu_ops_s = sum(v["mean_us"] for k, v in ks.items() if (not k.startswith("K2") or k == used_k2) and k not in ("K3_full_rows_fwd_bwd", "K3_full_one_launch_optin", "K3h_head_loss_rows_stats", "K3h_gemm_path_for_comparison")) * 1e-6
         extra["gpu_patch_path_steps_per_s"] = 1.0 / gpu_ops_s
         if roofline:
             # the same kernel launched back to back (hipGraph replays of 10 launches between two events, same process) next to the in-step figure

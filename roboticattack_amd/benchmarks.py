@@ -196,6 +196,20 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
     rec("EPI_step_epilogue", "K2", lambda: ops.step_epilogue(parts, msg, scal8, rowmap=rowmap, R=R, V=32064, mode=ops.LOSS_UADA_DDP, w=5.0, loss_ws=ws3),
         parts.numel() * 4 + 4 * 3 * ph * pw, note="K2's final fixed-order sum + K3's fold + the DDP message in one launch")
     rec("K4_patch_update", "K4", lambda: ops.patch_update(patch, gp, m, v, ops.OPT_ADAMW_HF, 1e-3, 1), algo_bytes("K4", B, ph, pw))
+    # SURVEY 8f-2 as written: LM head (OpenVLA-7B: [32064, 4096] bf16 = 263 MB) fused with K3's statistics — what the attack step runs up to 64
+    # labelled rows (the per-rank shapes of the multi-GPU configs); a weight stream: algorithmic bytes = the head weight + the hidden rows, once
+    Dh = 4096
+    if ops.head_loss_rows_applies(R, Dh, 32064):
+        gh = torch.Generator(device=dev).manual_seed(3)
+        w_head = (torch.randn(32064, Dh, device=dev, generator=gh) * 0.02).to(torch.bfloat16)
+        hid = torch.randn(R, Dh, device=dev, generator=gh).to(torch.bfloat16)
+        nb = 2 * 32064 * Dh + 2 * R * Dh
+        rec("K3h_head_loss_rows_stats", "K3h", lambda: ops.head_loss_rows_stats(hid, w_head, rowmap, ops.LOSS_UADA_DDP, 5.0, grad=gslice), nb, in_stream=True,
+            rows=R, note="LM head + K3 statistics + gradient slice in two launches (head_stats_kernel + head_finish_kernel), back-to-back calls in a stream: "
+                         "the 263 MB of weights partly stay in the 256 MB Infinity Cache between calls — the in-step figure is in per_rank_step.*.fused_head")
+        rec("K3h_gemm_path_for_comparison", "K3h", lambda: ops.loss_rows_stats(torch.nn.functional.linear(hid, w_head), rowmap, ops.LOSS_UADA_DDP, 5.0, grad=gslice),
+            nb, in_stream=True, rows=R, note="the same through the hipBLASLt LM-head GEMM + vaa_loss_rows_stats (what the step runs above 64 rows)")
+        del w_head, hid
     return res
 
 

@@ -33,4 +33,8 @@ timeout 900 python bench.py --gpus 2 --steps 4 --warmup 1 --no-kernel-suite > "$
 # VAA_NO_TN_DGRAD=1 drops the 12.9 GB of resident transposed weights per rank so that eight copies of the model fit the 288 GB
 VAA_NO_TN_DGRAD=1 timeout 1500 python bench.py --gpus 8 --steps 3 --warmup 1 --regions strong --no-cpu-baseline --no-kernel-suite > "${out}/bench_8ranks_one_gpu.json" 2> "${out}/bench_8ranks_one_gpu.err"
 timeout 200 python tools/k3_onepass_check.py > "${out}/k3_onepass.txt" 2>&1
+timeout 300 python tools/head_bench.py 128 64 16 > "${out}/head_bench.txt" 2>&1
+# the per-rank step of BASELINE config 3 (bs = 8: the LM head runs fused with K3's statistics) under rocprofv3
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b8 -o b8 -- python bench.py --bs 8 --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank > "${out}/bench_bs8_under_rocprof.json" 2> "${out}/bench_bs8_under_rocprof.err"
+cp "$(stats_csv /tmp/prof_b8)" "${out}/bench_bs8_kernel_stats.csv" 2>/dev/null
 ls -la "${out}"
