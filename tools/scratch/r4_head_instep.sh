@@ -3,7 +3,7 @@
 root="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$root"
 out=$root/gpurun_out/r4h; mkdir -p $out
 export TMPDIR=/tmp
-for bs in 64 8; do
+for bs in 64; do
 for v in 0 1; do
   VAA_FUSED_HEAD=$v timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_h${bs}_$v -o h -- python bench.py --bs $bs --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank --profile-steps 0 > $out/bench_bs${bs}_$v.json 2> $out/bench_bs${bs}_$v.err
   f=$(find /tmp/prof_h${bs}_$v -name '*kernel_stats.csv' | head -1)
