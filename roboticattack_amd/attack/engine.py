@@ -53,7 +53,7 @@ class AttackBase:
         self.randomPatchTransform = RandomPatchTransform(self.device, resize_patch)
         if os.environ.get("VAA_FUSED_EMBED_GRAD", "1") != "0" and hasattr(vla, "forward_rows") and hasattr(vla, "patch_embed_params"):
             # a model that exposes its patch-embed parameters is handed patch-embed OUTPUTS in training steps and K2' never
-            # builds the dense pixel gradient (the embed backward runs on the ~36 tiles under the patch only; per-image patches of
+            # builds the dense pixel gradient (the embed backward runs on the ~20 flagged tiles under the patch only; per-image patches of
             # resize_patch=True included). A black-box model (no patch_embed_params) and VAA_FUSED_EMBED_GRAD=0 keep the pixel_values
             # boundary of the reference.
             self.randomPatchTransform.embed_with = vla
