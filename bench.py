@@ -13,7 +13,8 @@ synthetic BridgeData-shaped frames resident in HBM as u8, random-init weights of
 Prints ONE JSON line on rank 0. The timed region (`value`) runs UN-profiled; a short second pass of the same steps then runs with the
 library's per-dispatch timer armed (vaa_prof_*: every hand-written kernel launched through hipExtLaunchKernel with its own start/stop event
 pair = that dispatch's begin/end timestamps, no marker brackets, no subtraction) and gives `roofline` — the dominant hand-written kernel of
-the path, K1's `patch_apply_tiles_kernel`, which moves 70 % of the path's algorithmic bytes (48.2 of 69 MB), IN-STEP; the back-to-back
+the path IN-STEP: `head_stats_kernel`, the LM head fused with K3's statistics, ONE pass over the 263 MB head weight (264.8 of ~334 MB of the
+path's algorithmic bytes per step, and its longest kernel); K1's `patch_apply_tiles_kernel` (48.2 MB) is `roofline_k1`; the back-to-back
 figure is reported next to it as standalone_* — plus `roofline_kernels` / `hot_path_ops`. `k2_sweep` carries the K2 batch sweep; `cpu_baseline`
 is the reference's PyTorch-CPU op sequence for the same replaced ops (oracle/ref_port.py) timed on this box's host cores.
 N > 1 (one rank per GPU, RCCL): both timed regions — weak (`value`, bs per rank) and `strong_scaling` (the same global batch split over the
@@ -495,36 +496,55 @@ def main():
     hot_ops = {o: {"us_per_step": u, "algo_bytes": op_bytes.get(o), "achieved_GBs": (op_bytes[o] / u / 1e3 if o in op_bytes else None),
                    "frac": (op_bytes[o] / u / 1e3 / HBM_PEAK_GBS if o in op_bytes else None)} for o, u in op_us.items()}
     k1name = next((n for n in kern if "patch_apply_tiles_kernel" in n or "patch_apply_fwd_kernel" in n), None)
+    hname = next((n for n in kern if "head_stats_kernel" in n), None)
     tfile = next((f for f in ("profiles/traffic_r04.json", "profiles/traffic_r03.json", "profiles/traffic_r02.json") if os.path.exists(os.path.join(ROOT, f))), None)
-    tr_ops = json.load(open(os.path.join(ROOT, tfile))).get("ops", {}) if tfile else {}
-    roofline = None
-    if k1name:
-        k1 = kern[k1name]
-        nb = op_bytes["K1"]
-        roofline = {"kernel": k1name + " (K1)", "bound": "hbm", "achieved": nb / k1["mean_us"] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": nb / k1["mean_us"] / 1e3 / HBM_PEAK_GBS, "mean_us": k1["mean_us"], "min_us": k1["min_us"], "samples": k1["launches"],
-                    "algo_bytes": nb, "traffic": tr_ops.get("K1t_patch_apply_fwd_tiles" if "tiles" in k1name else "K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch"),
-                    "traffic_source": (tfile or "none") + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",
-                    "timing": "IN-STEP, per dispatch: after the (un-profiled) timed region the same steps run once more with the library's per-dispatch timer armed — "
-                              "every K1 launch goes through hipExtLaunchKernel with its own start/stop event pair, which the runtime binds to that dispatch's "
-                              "begin/end timestamps, the quantity rocprofv3 --kernel-trace reports (profiles/r04_bench_kernel_stats.csv is the rocprofv3 summary of "
-                              "the same command); mean over all launches of that pass, no marker brackets, no subtraction",
-                    "note": "dominant = the kernel of the hot path with the most algorithmic bytes (48.2 of ~69 MB per step); every hand-written kernel of the "
-                            "timed region is listed in roofline_kernels, per-operator sums in hot_path_ops"}
+    tr_all = json.load(open(os.path.join(ROOT, tfile))) if tfile else {}
+    tr_ops = tr_all.get("ops", {})
+
+    def roofline_of(kname, label, nb, traffic):
+        """the contract's roofline object for ONE hand-written kernel of the timed region (HBM-bound byte work)"""
+        k = kern[kname]
+        r = {"kernel": f"{kname} ({label})", "bound": "hbm", "achieved": nb / k["mean_us"] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": nb / k["mean_us"] / 1e3 / HBM_PEAK_GBS, "mean_us": k["mean_us"], "min_us": k["min_us"], "samples": k["launches"],
+             "algo_bytes": nb, "traffic": traffic,
+             "traffic_source": (tfile or "none") + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",
+             "timing": "IN-STEP, per dispatch: after the (un-profiled) timed region the same steps run once more with the library's per-dispatch timer armed — "
+                       "every launch of the library goes through hipExtLaunchKernel with its own start/stop event pair, which the runtime binds to that dispatch's "
+                       "begin/end timestamps, the quantity rocprofv3 --kernel-trace reports (profiles/r04_bench_kernel_stats.csv is the rocprofv3 summary of "
+                       "the same command); mean over all launches of that pass, no marker brackets, no subtraction"}
         # builder-side cross reference (NOT measured by this run): rocprofv3's average for the same kernel in the committed summary of the same command
         ref = os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv")
         if os.path.exists(ref):
             import csv
 
             for row in csv.DictReader(open(ref)):
-                if k1name.split("(")[0] in row["Name"]:
+                if kname.strip("() ").split("(")[0] in row["Name"]:  # ("(head_stats_kernel<4>)" / "patch_apply_tiles_kernel": the launch site's spelling)
                     us = float(row["AverageNs"]) * 1e-3
-                    roofline["rocprofv3_reference"] = {"file": "profiles/r04_bench_kernel_stats.csv", "calls": int(row["Calls"]), "mean_us": us,
-                                                       "frac": nb / us / 1e3 / HBM_PEAK_GBS,
-                                                       "note": "committed rocprofv3 --kernel-trace --stats summary of `bench.py --steps 20 --warmup 3 --no-cpu-baseline "
-                                                               "--no-kernel-suite --no-per-rank`; the per-dispatch events of an un-profiled run read 0.3-1.8 us above it "
-                                                               "(they include the dispatch's start-up after the preceding command), so the line's frac is the lower one"}
+                    r["rocprofv3_reference"] = {"file": "profiles/r04_bench_kernel_stats.csv", "calls": int(row["Calls"]), "mean_us": us,
+                                                "frac": nb / us / 1e3 / HBM_PEAK_GBS,
+                                                "note": "committed rocprofv3 --kernel-trace --stats summary of `bench.py --steps 20 --warmup 3 --no-cpu-baseline "
+                                                        "--no-kernel-suite --no-per-rank`; the per-dispatch events of an un-profiled run read 0.3-1.8 us above it "
+                                                        "(they include the dispatch's start-up after the preceding command), so the line's frac is the lower one"}
                     break
+        return r
+
+    # the dominant kernel = the hand-written kernel of the timed region with the most algorithmic bytes (and, at the 7B shape, the longest): the
+    # LM head fused with K3's statistics when the step runs it (263 MB weight stream), else K1; the other one is reported beside it
+    roofline = roofline_k1 = roofline_head = None
+    if k1name:
+        roofline_k1 = roofline_of(k1name, "K1", op_bytes["K1"],
+                                  tr_ops.get("K1t_patch_apply_fwd_tiles" if "tiles" in k1name else "K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch"))
+    if hname and "K3h" in op_bytes:
+        t_head = next((v.get("hbm_bytes_per_launch") for kk, v in tr_all.items() if "head_stats_kernel" in kk and isinstance(v, dict)), None)
+        if R != 128 or args.model != "openvla-7b":
+            t_head = None  # the committed PMC passes ran the 7B head at 128 rows
+        roofline_head = roofline_of(hname, "K3h: LM head + K3 statistics, one pass over the head weight", op_bytes["K3h"], t_head)
+    roofline = max((r for r in (roofline_k1, roofline_head) if r), key=lambda r: r["algo_bytes"], default=None)
+    if roofline:
+        by = {o: b for o, b in op_bytes.items() if o in op_us and b}
+        roofline["note"] = ("dominant = the hand-written kernel of the timed region with the most algorithmic bytes (%.1f of ~%.0f MB per step); every hand-written "
+                            "kernel of the timed region is listed in roofline_kernels, per-operator sums in hot_path_ops, K1 in roofline_k1"
+                            % (roofline["algo_bytes"] / 1e6, sum(by.values()) / 1e6))
 
     extra = {"host_enqueue_ms_per_step": host_enqueue * 1e3 if run_weak else None, "host_cpu_ms_per_step": host_cpu * 1e3 if run_weak else None,
              "host_overhead_note": "host_cpu = CPU time of the launching thread per step (python + HIP launches): what N ranks on one host need N times in parallel; "
@@ -548,12 +568,13 @@ def main():
         used_k2 = "K2e_patch_embed_grad_gather" if fused else "K2_patch_grad_gather"
         gpu_ops_s = sum(v["mean_us"] for k, v in ks.items() if (not k.startswith("K2") or k == used_k2) and k not in ("K3_full_rows_fwd_bwd", "K3_full_one_launch_optin", "K3h_head_loss_rows_stats", "K3h_gemm_path_for_comparison")) * 1e-6
         extra["gpu_patch_path_steps_per_s"] = 1.0 / gpu_ops_s
-        if roofline:
-            # the same kernel launched back to back (hipGraph replays of 10 launches between two events, same process) next to the in-step figure
-            k = ks["K1_patch_apply_fwd"]
-            roofline.update({"measured_device_copy_GBs": copy_bw, "standalone_mean_us": k["mean_us"], "standalone_achieved": k["achieved_GBs"],
-                             "standalone_frac": k["achieved_GBs"] / HBM_PEAK_GBS, "frac_of_measured_copy_bw": roofline["achieved"] / copy_bw,
-                             "standalone_frac_of_measured_copy_bw": k["achieved_GBs"] / copy_bw})
+        # the same kernels launched back to back (hipGraph replays of 10 launches between two events, same process) next to the in-step figures
+        for r, key in ((roofline_k1, "K1_patch_apply_fwd"), (roofline_head, "K3h_head_loss_rows_stats")):
+            if r and key in ks:
+                k = ks[key]
+                r.update({"measured_device_copy_GBs": copy_bw, "standalone_mean_us": k["mean_us"], "standalone_achieved": k["achieved_GBs"],
+                          "standalone_frac": k["achieved_GBs"] / HBM_PEAK_GBS, "frac_of_measured_copy_bw": r["achieved"] / copy_bw,
+                          "standalone_frac_of_measured_copy_bw": k["achieved_GBs"] / copy_bw})
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # host-CPU leg only at N=1 (rank 0), as the bench contract asks
         cpu = cpu_baseline(B, patch_shape, args.cpu_budget)
@@ -598,7 +619,7 @@ def main():
         "ms_per_step": (dt / args.steps * 1e3) if run_weak else None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": config,
-        "roofline": roofline, "strong_scaling": strong, "allreduce_us_per_step": comm_w, "comm_frac": comm_w["comm_frac"] if comm_w else None,
+        "roofline": roofline, "roofline_k1": roofline_k1 if roofline is not roofline_k1 else None, "strong_scaling": strong, "allreduce_us_per_step": comm_w, "comm_frac": comm_w["comm_frac"] if comm_w else None,
         "allreduce_back_to_back": b2b, "per_rank_step": per_rank, "hot_path_ops": hot_ops, "roofline_kernels": kern, "cpu_baseline": cpu,
         "peak_mem_GiB": peak_mem, "loss_finite": finite and (strong is None or strong["loss_finite_all_ranks"]),
         "profiled_pass_steps": psteps if run_weak else 0,

@@ -250,7 +250,7 @@ int vaa_step_epilogue_update(const float* partials, int nparts, int n, const voi
 /*
  * LM head FUSED with K3's statistics (SURVEY.md section 8f-2 as the survey wrote it; for callers that own the LM-head weight) — replaces
  * `logits = lm_head(hidden)` on the labelled rows (modeling_prismatic.py:404-415 -> HF Llama's bf16 lm_head) followed by vaa_loss_rows_stats:
- * the [R,V] logits are never written. The head weight is streamed from HBM once (full 128-byte lines through LDS into MFMA fragments), every
+ * the [R,V] logits are never written. The head weight is streamed from HBM once (full 128-byte lines, global -> LDS by LDS-DMA, into MFMA fragments), every
  * workgroup reduces its 128 vocabulary columns to per-row {max, sum exp, argmax, label logit}; a second small launch folds them per row,
  * computes the action-slice statistics (UADA.py:384-389) and — VAA_LOSS_UADA_DDP — writes the gradient slice.
  *   hidden   dev bf16 [R,D]: final-norm hidden states of the labelled rows, in the row map's order;  w_head dev bf16 [V,D]

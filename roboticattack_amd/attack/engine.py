@@ -119,14 +119,15 @@ class AttackBase:
 
     @staticmethod
     def _fused_head(R, h, W) -> bool:
-        """LM head fused with K3's statistics (vaa_head_loss_rows_stats) for this shape? Up to 64 labelled rows — the per-rank shapes of the
-        multi-GPU configs: bs = 8 -> 16 rows — the fused kernel streams the 263 MB head weight at 5.6 TB/s in the step (47 us + 9 us for the
-        fold against 67 + 11 us for the hipBLASLt GEMM + K3 statistics); at 128 rows (bs = 64) its on-chip work per k-chunk makes it 7 us
-        SLOWER than the GEMM path (profiles/r04_head_fused.txt), which stays. VAA_FUSED_HEAD=1 / 0 forces it on / off."""
+        """LM head fused with K3's statistics (vaa_head_loss_rows_stats) for this shape? Whenever the kernel covers it (bf16, up to 128 labelled
+        rows = bs 64 with maskidx=[0]): one pass over the 263 MB head weight, the [R,V] logits are never written. In the step, same box:
+        bs = 8 (16 rows) 45 us (5.8 TB/s) + 7 us fold against 64 + 10 us for the hipBLASLt GEMM + K3 statistics; bs = 32: 47 + 8 against
+        62 + 10; bs = 64 (128 rows, where a CU's line rate, not HBM, bounds the kernel): 54 + 8 against 55-57 + 11
+        (profiles/r04_head_fused.txt). VAA_FUSED_HEAD=0 restores the GEMM path."""
         mode = os.environ.get("VAA_FUSED_HEAD", "auto")
         if mode == "0" or h.dtype != torch.bfloat16 or W.dtype != torch.bfloat16 or not ops.head_loss_rows_applies(R, int(h.shape[1]), int(W.shape[0])):
             return False
-        return mode == "1" or R <= 64
+        return True
 
     def fused_ddp_step(self, pixel_values, patch, input_ids, attention_mask, labels, geometry, w, msg, scalars, optimizer=None):
         """The UADA_ddp inner step (UADA_ddp.py:189-206) up to the gradient exchange, six hand-written launches around the model:

@@ -208,9 +208,9 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
         nb = 2 * 32064 * Dh + 2 * R * Dh
         rec("K3h_head_loss_rows_stats", "K3h", lambda: ops.head_loss_rows_stats(hid, w_head, rowmap, ops.LOSS_UADA_DDP, 5.0, grad=gslice), nb, in_stream=True,
             rows=R, note="LM head + K3 statistics + gradient slice in two launches (head_stats_kernel + head_finish_kernel), back-to-back calls in a stream: "
-                         "the 263 MB of weights partly stay in the 256 MB Infinity Cache between calls — the in-step figure is in per_rank_step.*.fused_head")
+                         "the 263 MB of weights partly stay in the 256 MB Infinity Cache between calls — the in-step figure is the bench line's `roofline`")
         rec("K3h_gemm_path_for_comparison", "K3h", lambda: ops.loss_rows_stats(torch.nn.functional.linear(hid, w_head), rowmap, ops.LOSS_UADA_DDP, 5.0, grad=gslice),
-            nb, in_stream=True, rows=R, note="the same through the hipBLASLt LM-head GEMM + vaa_loss_rows_stats (what the step runs above 64 rows)")
+            nb, in_stream=True, rows=R, note="the same through the hipBLASLt LM-head GEMM + vaa_loss_rows_stats (what the step runs with VAA_FUSED_HEAD=0)")
         del w_head, hid
     return res
 

@@ -5,18 +5,22 @@
 // lives in the 256 action columns: the [R',V] logits are never written to memory.
 //
 //   head_stats_kernel<NRB>  grid = ceil(V / 128) workgroups of 8 waves; workgroup w owns the 128 vocabulary columns [128 w, 128 w + 128):
-//       * the kernel is a WEIGHT STREAM — 263 MB at V = 32,064, D = 4,096, read from HBM exactly once with nontemporal loads; its floor is
-//         263 MB / HBM bandwidth. Both operands are staged through LDS in FULL 128-byte lines (8 consecutive threads = one row's line of a
-//         64-wide k-chunk): 64-byte fragment-shaped loads straight into MFMA operands streamed at 3.0-4.5 TB/s whatever the prefetch depth,
-//         full lines reach 6.1 TB/s (profiles/r04_head_fused.txt). Chunks are requested four steps ahead into four register sets and written
-//         to a double-buffered LDS image one step before their use (requests complete in order: waiting for chunk ch + 1 leaves chunks
-//         ch + 2 .. ch + 4 in flight); one barrier per chunk. Workgroup w walks K starting at chunk 5 w mod 64: all workgroups reading the same
-//         k offset of weight rows 8 KB apart at once put the chip's requests on a few memory channels (58 -> 43 us at R' = 16);
+//       * the kernel is a WEIGHT STREAM — 263 MB at V = 32,064, D = 4,096, read from HBM exactly once; its floor is 263 MB / HBM bandwidth.
+//         Both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) in FULL 128-byte
+//         lines: a DMA instruction moves 8 rows x 128 B of a 64-wide k-chunk (64-byte fragment-shaped loads straight into MFMA operands
+//         streamed at 3.0-4.5 TB/s whatever the prefetch depth, full lines reach 6.2 TB/s: profiles/r04_head_fused.txt). A ring of four
+//         LDS slots of [hidden rows | 128 weight rows]: chunk c + 3 is requested in step c into the slot chunk c - 1 was read from; counted
+//         vmcnt waits + ONE raw s_barrier per chunk (a __syncthreads would drain the requests in flight); weights with the nontemporal
+//         policy. Workgroup w walks K starting at chunk 5 w mod 64: all workgroups reading the same k offset of weight rows 8 KB apart at
+//         once put the chip's requests on a few memory channels (58 -> 43 us at R' = 16);
 //       * the hidden rows H [R' <= 128, D] (1 MB, L2-resident) are read by every workgroup the same way; mfma_f32_16x16x32_bf16, a wave
 //         multiplies all rows against its 16 columns (R' <= 64) or half the rows against 32 columns (R' = 128: 6 fragment reads per 8 MFMAs);
 //       * epilogue: the accumulators are rounded to bf16 (what the reference's bf16 head hands to `.float()`), laid out as a [R', 128] tile
 //         in LDS and reduced per row to {max, sum exp, argmax, label logit} = one PartStat per (row, workgroup); the two workgroups that
 //         own the action columns 31744..31999 also leave those logits in a [R', 256] fp32 buffer.
+//       Above 64 rows the kernel is bound by the LINE RATE of a CU's memory path, not by HBM: every workgroup pulls all of H next to its
+//       share of W (256 lines of 128 B per chunk at R' = 128 against 160 at R' <= 32) and a CU sustains ~300 lines/us in this mix —
+//       42 / 44 / 49 / 55 us back to back at 32 / 64 / 96 / 128 rows whatever the staging form or the prefetch depth (profiles/r04_head_fused.txt).
 //   head_finish_kernel      grid = R' workgroups: folds a row's ceil(V / 128) PartStats into ONE (stored in K3's workspace layout, the other
 //       parts neutral), computes the action-slice statistics with the arithmetic of rows_stats_kernel (same bits for the same logits) and
 //       — UADA_DDP — writes the gradient slice. vaa_step_epilogue then folds the rows exactly as it does behind vaa_loss_rows_stats.
@@ -33,7 +37,6 @@ typedef float v4f_h __attribute__((ext_vector_type(4)));
 #endif
 constexpr int kHT = VAA_HEAD_WAVES * 64;  // threads per workgroup: 8 waves (two per SIMD: one wave's fragment reads hide behind the other's MFMAs)
 constexpr int kHCols = 128;          // vocabulary columns per workgroup
-constexpr int kHCB = kHCols / 16 / VAA_HEAD_WAVES;  // 16-column blocks per wave
 constexpr int kHK = 64;              // k-chunk: one 128-byte line of every weight row and of every hidden row
 constexpr int kHSA = kHK;            // LDS row (bf16 elements): 128 B, UNPADDED — the eight 16-byte pieces of row r sit at slot (piece ^ (r & 7)).
                                      // The hardware serves a ds_read_b128 in groups of 16 lanes that mix two k-groups ({0-3, 12-15} of one with {4-11} of
@@ -41,16 +44,7 @@ constexpr int kHSA = kHK;            // LDS row (bf16 elements): 128 B, UNPADDED
                                      // = 36 % of SQ_LDS_IDX_ACTIVE); with the XOR placement the 16 lanes of a group cover the 16 slots of 256 B exactly once
 constexpr int kHTileS = kHCols + 4;  // padded row of the fp32 logits tile
 constexpr int kHRowsMax = 128;
-#ifndef VAA_HEAD_SETS
-#define VAA_HEAD_SETS 4
-#endif
-constexpr int kHSets = VAA_HEAD_SETS;  // register sets: chunks ch + 1 .. ch + SETS are in registers / in flight while chunk ch is multiplied
-#ifdef VAA_HEAD_PLAIN_LOADS
-#define VAA_HEAD_LOAD(p) (*(p))
-#else
-#define VAA_HEAD_LOAD(p) __builtin_nontemporal_load(p)
-#endif
-
+constexpr int kHRing = 4;            // LDS slots: chunks ch + 1, ch + 2 (and, once requested, ch + 3) are in flight while chunk ch is multiplied
 struct HeadArgs {
     const uint16_t* h;      // [R, D] bf16 hidden rows (final norm applied)
     const uint16_t* w;      // [V, D] bf16 LM-head weight
@@ -61,113 +55,92 @@ struct HeadArgs {
     int R, D, V, nwg;
 };
 
-// v4: BOTH operands are staged through LDS in full 128-byte lines (8 consecutive threads = one row's line of a k-chunk; a wave instruction =
-// 8 whole lines) — the 64-byte fragment-shaped register loads of v1..v3 streamed at 3.0-4.5 TB/s whatever the prefetch depth. Chunks are
-// requested four steps ahead into four register sets, written to a double-buffered LDS image one step before their use (requests complete
-// in order: waiting for chunk ch + 1 leaves chunks ch + 2 .. ch + 4 in flight), one barrier per 64-wide chunk. A wave multiplies all hidden
-// rows against its 32 columns (mfma_f32_16x16x32_bf16, every A fragment read feeds two MFMAs).
 template <int NRB>
 __global__ __launch_bounds__(kHT) void head_stats_kernel(HeadArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the kernel's stub (it does not know the LDS-DMA builtin)
     extern __shared__ __align__(16) unsigned char head_smem[];
-    constexpr int ROWS = NRB * 32, NQ = NRB * 2;
-    // waves = (column group, row half): with 128 rows a wave takes HALF the rows against TWO column blocks — 6 fragment reads per 8 MFMAs instead
-    // of 9 (the LDS read traffic is what bounds the 128-row form)
+    constexpr int ROWS = NRB * 32, NQ = NRB * 2, NW = VAA_HEAD_WAVES;
+    constexpr int kHCB = kHCols / 16 / NW;  // 16-column blocks per wave
+    // waves = (column group, row half): with 128 rows a wave takes HALF the rows against TWO column blocks — 6 fragment reads per 8 MFMAs instead of 9
     constexpr int RH = (NRB >= 4 && kHCB == 1) ? 2 : 1, CBW = kHCB * RH, NQW = NQ / RH;
-    uint16_t* hb = reinterpret_cast<uint16_t*>(head_smem);   // [2][ROWS][kHSA]
-    uint16_t* wb = hb + 2 * ROWS * kHSA;                      // [2][kHCols][kHSA]
-    float* tile = reinterpret_cast<float*>(head_smem);       // epilogue: [ROWS][kHTileS]
-    constexpr int HL = (ROWS * (kHK / 8) + kHT - 1) / kHT;  // 16-byte loads per thread and H chunk
-    constexpr int WL = kHCols * (kHK / 8) / kHT;  // ... and W chunk: 4
+    constexpr int RING = kHRing, TR = ROWS + kHCols;          // ring slots; rows per slot: [hidden rows | weight rows]
+    uint16_t* ring = reinterpret_cast<uint16_t*>(head_smem);  // [RING][TR][kHSA]
+    float* tile = reinterpret_cast<float*>(head_smem);        // epilogue: [ROWS][kHTileS]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * kHCols;
     const int nchunks = a.D / kHK;
-#ifndef VAA_HEAD_STAGGER
-#define VAA_HEAD_STAGGER 5
-#endif
     // k-chunk order: workgroup w starts at chunk (5 w) mod nchunks and wraps around (all workgroups reading the same k offset of weight rows 8 KB
     // apart at the same time puts the requests of the whole chip on a few memory channels)
-    const int kstart = (int)((blockIdx.x * (unsigned)VAA_HEAD_STAGGER) % (unsigned)nchunks);
+    const int kstart = (int)((blockIdx.x * 5u) % (unsigned)nchunks);
     auto kchunk = [&](int ch) { const int cc = min(ch, nchunks - 1) + kstart; return cc >= nchunks ? cc - nchunks : cc; };
-    constexpr int PPR = kHK / 8;                               // 16-byte pieces per row of a chunk (8)
-    auto lds_off = [](int row, int piece) { return row * kHSA + ((piece ^ (row & 7)) << 3); };  // element offset of (row, 16-byte piece) in an LDS image
-    const int srow = tid / PPR, spiece = tid % PPR;            // staging: PPR consecutive threads per row (full 128-byte lines)
-    constexpr int SR = kHT / PPR;                              // rows per staging pass
-    uint4 hreg[kHSets][HL], wreg[kHSets][WL];
-    auto load_chunk = [&](uint4 (&hd)[HL], uint4 (&wd)[WL], int ch) {  // unconditional addresses (the tail re-requests the last chunk)
-        const size_t koff = (size_t)kchunk(ch) * kHK + spiece * 8;
-#pragma unroll
-        for (int it = 0; it < HL; ++it) {
-            const int row = srow + it * SR;
-            hd[it] = make_uint4(0, 0, 0, 0);
-            if (row < a.R) hd[it] = *reinterpret_cast<const uint4*>(a.h + (size_t)row * a.D + koff);
-        }
-#pragma unroll
-        for (int it = 0; it < WL; ++it) {
-            const int col = min(n0 + srow + it * SR, a.V - 1);  // columns beyond V re-read the last row; their results are never used
-            typedef unsigned u32x4_h __attribute__((ext_vector_type(4)));
-            const u32x4_h v = VAA_HEAD_LOAD(reinterpret_cast<const u32x4_h*>(a.w + (size_t)col * a.D + koff));  // streamed once: nontemporal
-            wd[it] = make_uint4(v[0], v[1], v[2], v[3]);
-        }
-    };
-    auto store_chunk = [&](const uint4 (&hs)[HL], const uint4 (&ws)[WL], int buf) {
-#pragma unroll
-        for (int it = 0; it < HL; ++it)
-            if (srow + it * SR < ROWS) *reinterpret_cast<uint4*>(&hb[buf * ROWS * kHSA + lds_off(srow + it * SR, spiece)]) = hs[it];
-#pragma unroll
-        for (int it = 0; it < WL; ++it) *reinterpret_cast<uint4*>(&wb[buf * kHCols * kHSA + lds_off(srow + it * SR, spiece)]) = ws[it];
-    };
+    auto lds_off = [](int row, int piece) { return row * kHSA + ((piece ^ (row & 7)) << 3); };  // element offset of (row, 16-byte piece) in a slot
     const int cg = wv / RH, rh = wv % RH;
     v4f_h acc[CBW][NQW];
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
         for (int q = 0; q < NQW; ++q) acc[cb][q] = (v4f_h){0.f, 0.f, 0.f, 0.f};
+    const int arow = rh * (ROWS / RH) + c, brow = ROWS + cg * (16 * CBW) + c;  // row blocks start at multiples of 16: (row & 7) == (c & 7) for every block
 
-    // ---- prologue: chunks 0..3 requested, chunk 0 into the LDS image ----
+    // ---- LDS-DMA: instruction = 64 lanes x 16 B to (wave-uniform base) + 16 lane = 8 rows x 128 B of the UNPADDED slot image; lane l = (row l >> 3,
+    //      slot l & 7) fetches piece (l & 7) ^ (row & 7): the XOR placement on the SOURCE side ----
+    constexpr int NIH = ROWS / 8, IWH = (NIH + NW - 1) / NW, IWW = kHCols / 8 / NW, IW = IWH + IWW;  // instructions per wave and chunk: hidden + weights
+    static_assert(kHCols / 8 % NW == 0, "weight rows split evenly over the waves");
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);  // the DMA destination (M0) is per wave
+    const int lrow = lane >> 3, lpiece = (lane & 7) ^ lrow;
+    const uint16_t* src[IW];
+    int dsto[IW];  // element offset of the instruction's 8 rows inside a slot
 #pragma unroll
-    for (int s = 0; s < kHSets; ++s) load_chunk(hreg[s], wreg[s], s);
-    store_chunk(hreg[0], wreg[0], 0);
-    __syncthreads();
-
-    auto step = [&](int ch, uint4 (&hnew)[HL], uint4 (&wnew)[WL], const uint4 (&hnext)[HL], const uint4 (&wnext)[WL]) {
-        load_chunk(hnew, wnew, ch + kHSets);  // into the set chunk ch left when it was written to LDS a step ago
-        const uint16_t* hbuf = hb + (ch & 1) * ROWS * kHSA;
-        const uint16_t* wbuf = wb + (ch & 1) * kHCols * kHSA;
-        const int arow = rh * (ROWS / RH) + c, brow = cg * (16 * CBW) + c;  // row blocks start at multiples of 16: (row & 7) == (c & 7) for every block
-        if (ch < nchunks) {  // workgroup-uniform (false only in the padded steps behind the last chunk)
-            // fragments of k-step jj + 1 are read before the MFMAs of k-step jj (two register sets)
-            v8s_h af[2][NQW], bf[2][CBW];
-            auto read_frags = [&](int set, int jj) {
-#pragma unroll
-                for (int cb = 0; cb < CBW; ++cb) bf[set][cb] = *reinterpret_cast<const v8s_h*>(wbuf + lds_off(brow + cb * 16, jj * 4 + g));
-#pragma unroll
-                for (int q = 0; q < NQW; ++q) af[set][q] = *reinterpret_cast<const v8s_h*>(hbuf + lds_off(arow + q * 16, jj * 4 + g));
-            };
-            read_frags(0, 0);
-            // chunk ch + 1 (requested three steps ago) goes into the OTHER LDS buffer now — behind this step's first fragment reads, in front of its
-            // MFMAs, which cover the write latency (its buffer was last read in step ch - 1)
-            store_chunk(hnext, wnext, (ch + 1) & 1);
-#pragma unroll
-            for (int jj = 0; jj < kHK / 32; ++jj) {
-                if (jj + 1 < kHK / 32) read_frags((jj + 1) & 1, jj + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < NQW; ++q)
-#pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb) acc[cb][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jj & 1][q], bf[jj & 1][cb], acc[cb][q], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            store_chunk(hnext, wnext, (ch + 1) & 1);
-        }
-        __syncthreads();
-    };
-    // kHSets steps per iteration, fully unrolled: register sets are indexed statically and the request counts stay static
-    for (int ch0 = 0; ch0 < nchunks; ch0 += kHSets) {
-#pragma unroll
-        for (int u = 0; u < kHSets; ++u) step(ch0 + u, hreg[u], wreg[u], hreg[(u + 1) % kHSets], wreg[(u + 1) % kHSets]);
+    for (int it = 0; it < IWH; ++it) {
+        const int i = min(wvu + it * NW, NIH - 1);  // fewer instructions than waves: the spare waves repeat the last one (same bytes, same place)
+        src[it] = a.h + (size_t)min(i * 8 + lrow, a.R - 1) * a.D + lpiece * 8;  // rows beyond R' repeat the last row: never reduced
+        dsto[it] = i * 8 * kHSA;
     }
-    // (the loop's last barrier: every wave is done with the LDS images — the LDS becomes the logits tile)
+#pragma unroll
+    for (int it = 0; it < IWW; ++it) {
+        const int i = wvu + it * NW;
+        src[IWH + it] = a.w + (size_t)min(n0 + i * 8 + lrow, a.V - 1) * a.D + lpiece * 8;  // columns beyond V re-read the last row; never used
+        dsto[IWH + it] = (ROWS + i * 8) * kHSA;
+    }
+    auto request = [&](int ch) {  // the request counts are static: behind the end the last chunk is requested again (never read)
+        const int koff = kchunk(ch) * kHK;
+        uint16_t* slot = ring + (size_t)(ch & (RING - 1)) * TR * kHSA;
+#pragma unroll
+        for (int it = 0; it < IW; ++it) {
+            auto* dst = (__attribute__((address_space(3))) void*)(slot + dsto[it]);
+            if (it < IWH) __builtin_amdgcn_global_load_lds(src[it] + koff, dst, 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds(src[it] + koff, dst, 16, 0, 2);  // weights are streamed once: nontemporal
+        }
+    };
+#pragma unroll
+    for (int ch = 0; ch < RING - 1; ++ch) request(ch);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * IW) : "memory");  // this wave's share of chunk ch has landed (requests complete in order)
+        __builtin_amdgcn_s_barrier();                                           // ... and everybody else's; everybody is done reading chunk ch - 1
+        request(ch + RING - 1);                                                 // into the slot of chunk ch - 1
+        const uint16_t* sl = ring + (size_t)(ch & (RING - 1)) * TR * kHSA;
+        // fragments of k-step jj + 1 are read before the MFMAs of k-step jj (two register sets)
+        v8s_h af[2][NQW], bf[2][CBW];
+        auto read_frags = [&](int set, int jj) {
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) bf[set][cb] = *reinterpret_cast<const v8s_h*>(sl + lds_off(brow + cb * 16, jj * 4 + g));
+#pragma unroll
+            for (int q = 0; q < NQW; ++q) af[set][q] = *reinterpret_cast<const v8s_h*>(sl + lds_off(arow + q * 16, jj * 4 + g));
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int jj = 0; jj < kHK / 32; ++jj) {
+            if (jj + 1 < kHK / 32) read_frags((jj + 1) & 1, jj + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQW; ++q)
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) acc[cb][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jj & 1][q], bf[jj & 1][cb], acc[cb][q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the spare requests behind the end must land before the LDS becomes the logits tile
+    __syncthreads();
 
     // ---- epilogue: bf16-rounded logits -> LDS tile [ROWS][128]; C/D layout: column = lane & 15, row = 4 (lane >> 4) + r ----
 #pragma unroll
@@ -232,6 +205,7 @@ __global__ __launch_bounds__(kHT) void head_stats_kernel(HeadArgs a) {
             if (cl < ncols) a.logits_dbg[(size_t)r * a.V + n0 + cl] = (uint16_t)f32_to_bf16_bits(tile[r * kHTileS + cl]);
         }
     }
+#endif
 }
 
 struct HeadFinishArgs {
@@ -402,7 +376,7 @@ extern "C" int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* 
     a.logits_dbg = logits_dbg;
     a.R = R; a.D = D; a.V = V;
     const int nrb = R <= 32 ? 1 : (R <= 64 ? 2 : 4);
-    const size_t lds_h = (size_t)2 * (nrb * 32 + kHCols) * kHSA * sizeof(uint16_t), lds_t = (size_t)nrb * 32 * kHTileS * sizeof(float);
+    const size_t lds_h = (size_t)kHRing * (nrb * 32 + kHCols) * kHSA * sizeof(uint16_t), lds_t = (size_t)nrb * 32 * kHTileS * sizeof(float);
     const size_t lds = lds_h > lds_t ? lds_h : lds_t;
     const void* fn = nrb == 1 ? (const void*)head_stats_kernel<1> : (nrb == 2 ? (const void*)head_stats_kernel<2> : (const void*)head_stats_kernel<4>);
     if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -413,7 +387,8 @@ extern "C" int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* 
     if (nrb == 1) VAA_LAUNCH((head_stats_kernel<1>), grid, blk, lds, st, a);
     else if (nrb == 2) VAA_LAUNCH((head_stats_kernel<2>), grid, blk, lds, st, a);
     else VAA_LAUNCH((head_stats_kernel<4>), grid, blk, lds, st, a);
-    int rc = check_launch(who);
+    int rc;
+    rc = check_launch(who);
     if (rc != VAA_OK) return rc;
     HeadFinishArgs f;
     f.part_in = a.part; f.slice_logits = a.slice_logits; f.rowmap = a.rowmap;

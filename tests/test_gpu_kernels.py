@@ -1488,8 +1488,7 @@ def test_k3_one_pass_handover_timeout_fails_loudly(ops, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,maskidx,D", [(8, [0], 4096), (32, [0], 4096), (64, [0], 4096), (5, [0, 3], 192), (13, [0, 1, 2], 320), (3, [6], 64)])
 def test_head_loss_rows_stats_vs_oracle_and_gemm_path(ops, B, maskidx, D):
-    """SURVEY.md 8f-2 as written: LM head FUSED with K3's statistics (vaa_head_loss_rows_stats; the attack step uses it up to 64 labelled rows —
-    the per-rank shapes of the multi-GPU configs). Checked three ways on the same hidden rows and head weight:
+    """SURVEY.md 8f-2 as written: LM head FUSED with K3's statistics (vaa_head_loss_rows_stats; the attack step uses it up to 128 labelled rows). Checked three ways on the same hidden rows and head weight:
       * its bf16 logits (test-only dump) == the hipBLASLt head's bf16 logits up to single bf16 roundings (fp32 summation order) on < 1 % of them;
       * the C ORACLE fed with those very logits: loss scalars <= 3e-5, gradient slice <= 1e-2 of its scale (bf16 storage), both argmax maps exact;
       * vaa_loss_rows_stats fed with those very logits: gradient slice and slice statistics BIT FOR BIT, CE to fp32 summation order.
