@@ -7,6 +7,13 @@ Every case draws a batch, a prompt-length range, a labelling pattern (subsets of
 without any label), a mode (UADA, UADA_DDP, UPA, CE) and a logits dtype, then checks scalars (3e-5), gradients (5e-4 of the row scale
 for fp32, 1e-2 for bf16 storage), slice-vs-full storage, the action-slice and full-vocabulary argmax, for the rows route (row map) and
 the label-driven route (FULL layout).
+
+    python tools/soak_loss.py --head --seconds 300 --seed 3
+
+K3h (`vaa_head_loss_rows_stats`, LM head fused with K3's statistics): every case draws a batch (1 ... 128 labelled rows, samples without
+labels), a head width D (multiples of 64 up to 1024, or 4096), scales, ties (duplicated weight rows in different workgroups' column ranges,
+a dominant column) and checks the kernel's bf16 logits against a torch GEMM (single bf16 roundings), the ORACLE on those logits (scalars
+3e-5, gradient slice 1e-2 of its scale, both argmax maps with first-maximum-wins) and `vaa_loss_rows_stats` on those logits (bit for bit).
 """
 import argparse
 import os
@@ -100,19 +107,97 @@ def one_case(seed):
     return fails
 
 
+def one_head_case(seed):
+    from roboticattack_amd.labels import mask_labels
+
+    rs = np.random.RandomState(seed)
+    fails = []
+    V = 32064
+    B = int(rs.choice([1, 2, 3, 5, 8, 13, 21, 32, 48, 64]))
+    nmask = int(rs.choice([1, 1, 1, 2, 3, 7]))
+    if B * nmask > 128:
+        nmask = 1
+    maskidx = sorted(rs.choice(7, nmask, replace=False).tolist())
+    _, labels, _ = synthetic.synth_text_batch(seed % 9973, B, min_len=int(rs.randint(12, 30)), max_len=int(rs.randint(30, 44)))
+    labels = mask_labels(labels, maskidx)
+    lab = labels.numpy().copy()
+    for b in range(B):
+        if B > 1 and rs.rand() < 0.15:
+            lab[b] = -100  # a sample without labels
+    if not (lab[:, 1:] != -100).any():
+        return fails
+    labels = torch.from_numpy(lab)
+    L = labels.shape[1]
+    bk = np.argwhere(lab[:, 1:] != -100)
+    R = len(bk)
+    D = int(rs.choice([64, 128, 192, 320, 512, 1024, 4096], p=[.15, .15, .15, .15, .15, .15, .1]))
+    if not ops.head_loss_rows_applies(R, D, V):
+        return fails
+    g = torch.Generator(device=DEV).manual_seed(seed % (2**31))
+    W = (torch.randn(V, D, device=DEV, generator=g) * float(rs.uniform(0.3, 3.0) / np.sqrt(D))).to(torch.bfloat16)
+    W[31744:32000] *= float(rs.uniform(0.5, 4.0))
+    for _ in range(int(rs.randint(0, 4))):  # exact ties across workgroups: the lowest column must win
+        a, b = int(rs.randint(0, V)), int(rs.randint(0, V))
+        W[b] = W[a]
+    h = (torch.randn(R, D, device=DEV, generator=g) * float(rs.uniform(0.3, 2.0))).to(torch.bfloat16)
+    if rs.rand() < 0.3:  # a dominant column
+        W[int(rs.randint(0, V))] = (h[int(rs.randint(0, R))].float() * 0.5).to(torch.bfloat16)
+    w = float(rs.uniform(1, 8))
+    tag = f"seed={seed} B={B} maskidx={maskidx} R={R} D={D}"
+    rm = ops.LossRowMap(labels.to(DEV))
+    gs = torch.full((R, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ws, lg = ops.head_loss_rows_stats(h, W, rm, ops.LOSS_UADA_DDP, w, grad=gs, want_logits=True)
+    n = 64
+    parts, msg = torch.zeros((4, n), device=DEV), torch.zeros(n + 4, device=DEV)
+    sc = torch.zeros(8, device=DEV)
+    pred, pred_full = ops.step_epilogue(parts, msg, sc, rowmap=rm, R=R, V=V, mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws)
+    ref_lg = torch.nn.functional.linear(h, W)
+    dl = (lg.float() - ref_lg.float()).abs()
+    ulp = ref_lg.float().abs().clamp_min(1e-3) * 2.0 ** -7
+    if not (float((dl > 0).float().mean()) < 0.02 and bool((dl <= 1.01 * ulp).all())):
+        fails.append(f"head logits  {tag}: differing {float((dl > 0).float().mean()):.4f}, max/ulp {float((dl / ulp).max()):.2f}")
+    full = torch.zeros((B, 256 + L, V), dtype=torch.float32)
+    full[torch.from_numpy(bk[:, 0]), torch.from_numpy(bk[:, 1] + 256)] = lg.float().cpu()
+    so, go = c_oracle.loss(full.numpy(), lab, c_oracle.MODE_UADA_DDP, w=w)
+    gor = go[bk[:, 0], bk[:, 1] + 256][:, 31744:32000]
+    if not np.allclose(sc.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5):
+        fails.append(f"head scalars {tag}: {sc.cpu().numpy()[:5]} vs {so[:5]}")
+    if not (np.abs(gs.float().cpu().numpy() - gor).max() <= 1e-2 * max(np.abs(gor).max(), 1e-30)):
+        fails.append(f"head grad    {tag}: {np.abs(gs.float().cpu().numpy() - gor).max() / max(np.abs(gor).max(), 1e-30):.3e}")
+    zf = lg.float().cpu().numpy()
+    pfn, psn = pred_full.cpu().numpy().reshape(B, L - 1), pred.cpu().numpy().reshape(B, L - 1)
+    for i, (b, k) in enumerate(bk):
+        if pfn[b, k] != int(zf[i].argmax()):
+            fails.append(f"head argmax  {tag} row {i}: {pfn[b, k]} vs {int(zf[i].argmax())}")
+            break
+        if lab[b, k + 1] > 2 and psn[b, k] != 31744 + int(zf[i, 31744:32000].argmax()):
+            fails.append(f"head slice argmax {tag} row {i}")
+            break
+    if int((pfn >= 0).sum()) != R:
+        fails.append(f"head pred count {tag}")
+    gs2, sc2 = torch.empty_like(gs), torch.zeros(8, device=DEV)
+    ws2 = ops.loss_rows_stats(lg, rm, ops.LOSS_UADA_DDP, w, grad=gs2)
+    pred2, pred_full2 = ops.step_epilogue(parts, msg, sc2, rowmap=rm, R=R, V=V, mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws2)
+    if not (torch.equal(gs2.view(torch.int16), gs.view(torch.int16)) and torch.equal(pred2, pred) and torch.equal(pred_full2, pred_full)
+            and torch.equal(sc2[[2, 6, 7]], sc[[2, 6, 7]])):
+        fails.append(f"head vs K3 statistics on the same logits {tag}")
+    return fails
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--head", action="store_true", help="soak K3h (vaa_head_loss_rows_stats) instead of K3")
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     ops.device_check()
     t0, n, bad = time.time(), 0, []
     while time.time() - t0 < a.seconds:
-        bad += one_case(a.seed * 1000003 + n)
+        bad += (one_head_case if a.head else one_case)(a.seed * 1000003 + n)
         n += 1
     for b in bad:
         print("FAIL", b)
-    print(f"soak_loss: {n} cases in {time.time() - t0:.0f} s, {len(bad)} failures")
+    print(f"soak_loss{' --head' if a.head else ''}: {n} cases in {time.time() - t0:.0f} s, {len(bad)} failures")
     sys.exit(1 if bad else 0)
 
 
