@@ -1065,17 +1065,18 @@ def test_patch_embed_grad_gather_vs_unfused(ops, B, ph, pw, geo, D0, D1):
     assert np.abs(ref.cpu().numpy() - og).max() <= 2e-3 * np.abs(og).max() + 1e-7
 
 
-@pytest.mark.parametrize("tool,seconds,seed", [("soak_parity.py", 45, 101), ("soak_loss.py", 20, 102)])
+@pytest.mark.parametrize("tool,seconds,seed", [("soak_parity.py", 45, 101), ("soak_loss.py", 20, 102), ("soak_loss.py --head", 20, 103)])
 def test_randomised_soak_leg(tool, seconds, seed):
     """A fixed-seed, time-boxed leg of the randomised parity soaks (tools/soak_parity.py: K0/K1/K2/K2'/K5 against the plain-C oracle over
     random patch sizes 1..224, batches, edge-biased placements, general affines, per-image patches; tools/soak_loss.py: K3 in all modes,
-    layouts and dtypes) inside the driver's own `pytest -m gpu` run — the K1 hole at bs > 64 of round 2 was found by exactly this tool."""
+    layouts and dtypes; `--head`: K3h over row counts 1..128, head widths, ties across workgroups) inside the driver's own `pytest -m gpu` run — the K1 hole at bs > 64 of round 2 was found by exactly this tool."""
     import subprocess
     import sys
 
     from conftest import ROOT
 
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--seconds", str(seconds), "--seed", str(seed)],
+    tool, *flags = tool.split()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), *flags, "--seconds", str(seconds), "--seed", str(seed)],
                          capture_output=True, text=True, cwd=ROOT, timeout=seconds * 6 + 300)
     tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else ""
     assert out.returncode == 0 and " 0 failures" in tail, (out.stdout[-3000:], out.stderr[-2000:])
