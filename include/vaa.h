@@ -256,7 +256,7 @@ int vaa_step_epilogue_update(const float* partials, int nparts, int n, const voi
  *   hidden   dev bf16 [R,D]: final-norm hidden states of the labelled rows, in the row map's order;  w_head dev bf16 [V,D]
  *   rowmap, R, B, L, V, mode, params: as vaa_loss_rows_stats;  grad_slice dev bf16 [R,256] or NULL (only VAA_LOSS_UADA_DDP)
  *   loss_ws  dev >= vaa_loss_rows_ws_bytes(R): left exactly as vaa_loss_rows_stats leaves it — vaa_step_epilogue[_update] folds it unchanged
- *   head_ws  dev >= vaa_head_loss_ws_bytes(R, V) scratch;  logits_dbg dev bf16 [R,V] or NULL (tests: the bf16 logits the statistics were made of)
+ *   head_ws  dev >= vaa_head_loss_ws_bytes(R, V): scratch + the rows' 256 action logits (bf16) for vaa_head_loss_rows_finish;  logits_dbg dev bf16 [R,V] or NULL (tests: the bf16 logits the statistics were made of)
  * Covers vaa_head_loss_rows_applies(R, D, V) == 1: R <= 128 rows (one pass over the weight), D a multiple of 64; else VAA_E_UNSUPPORTED and the
  * caller keeps its GEMM + vaa_loss_rows_stats. Logits are the fp32 MFMA sums rounded to bf16 (the reference's bf16 head); for the same bf16
  * logits the slice statistics and the gradient slice are bit for bit those of vaa_loss_rows_stats, CE agrees to fp32 summation order.
@@ -266,6 +266,20 @@ int vaa_head_loss_rows_applies(int R, int D, int V);
 int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* w_head, int D, const void* rowmap, int R, int B, int L, int V, int mode,
                              const float* params, void* grad_slice, void* loss_ws, size_t loss_ws_bytes, void* head_ws, size_t head_ws_bytes,
                              uint16_t* logits_dbg, void* stream);
+
+/*
+ * The finishing pass behind vaa_head_loss_rows_stats for callers that do not run vaa_step_epilogue: folds the rows into scalars[8] and the
+ * prediction maps exactly like the second launch of vaa_loss_rows_fwd_bwd (same kernel), reading a row's 256 action logits from head_ws
+ * instead of [R,V] logits — and, VAA_LOSS_UPA (UPA.py:367-387: the gradient needs the batch means), writes the gradient slice.
+ * Together the two calls evaluate every mode WITHOUT logits in memory (validation passes; UADA_DDP and UPA also with their gradient);
+ * the gradients of the modes with a cross-entropy term (VAA_LOSS_UADA, VAA_LOSS_CE) need every logit: VAA_E_UNSUPPORTED, use the LM-head
+ * GEMM + vaa_loss_rows_fwd_bwd there.
+ *   rowmap, R, B, L, V, mode, params: as given to vaa_head_loss_rows_stats;  loss_ws, head_ws: as it left them
+ *   scalars dev f32[8]; pred_tokens / pred_full_tokens dev i32 [B,L-1] or NULL;  grad_slice dev bf16 [R,256] or NULL (only VAA_LOSS_UPA)
+ */
+int vaa_head_loss_rows_finish(const void* rowmap, int R, int B, int L, int V, int mode, const float* params, void* loss_ws, size_t loss_ws_bytes,
+                              const void* head_ws, size_t head_ws_bytes, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens,
+                              void* grad_slice, void* stream);
 
 /*
  * K2' (for callers that own the model's patch-embed weights) — K2 fed by the gradient of the ViT patch-embed OUTPUTS instead of the pixel gradient: the

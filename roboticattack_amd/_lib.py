@@ -57,6 +57,7 @@ EXPORTS = (
     "vaa_head_loss_ws_bytes",
     "vaa_head_loss_rows_applies",
     "vaa_head_loss_rows_stats",
+    "vaa_head_loss_rows_finish",
     "vaa_step_epilogue",
     "vaa_step_epilogue_update",
     "vaa_async_error",
@@ -193,6 +194,8 @@ def lib() -> C.CDLL:
     L.vaa_head_loss_rows_applies.argtypes = [i32, i32, i32]
     L.vaa_head_loss_rows_stats.restype = i32
     L.vaa_head_loss_rows_stats.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, sz, vp, sz, vp, vp]
+    L.vaa_head_loss_rows_finish.restype = i32
+    L.vaa_head_loss_rows_finish.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, sz, vp, vp, vp, vp, vp]
     L.vaa_step_epilogue.restype = i32
     L.vaa_step_epilogue.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp]
     L.vaa_step_epilogue_update.restype = i32

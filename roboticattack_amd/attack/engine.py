@@ -77,8 +77,22 @@ class AttackBase:
                 # LM head + loss on the labelled rows: the head's backward contracts over the 256 action
                 # columns when the loss lives there (UADA_DDP, UPA)
                 h = self.vla.hidden_rows(input_ids, None if pe is not None else pix, self._row_index, patch_embeds=pe, pack=pack)
-                total, scalars, _, pred_full = ops.HeadLossRows.apply(h, self.vla.lm_head.weight, self._row_map, mode, w, alpha, beta, scale)
+                W = self.vla.lm_head.weight
+                # ... and with the LM head FUSED into K3's statistics there (K3h: no [R,V] logits at all); UADA's 1/CE and TMA's CE gradients need
+                # every logit and keep the GEMM head
+                head = ops.HeadLossRowsFused if (mode in ops.SLICE_MODES and self._fused_head(int(h.shape[0]), h, W)) else ops.HeadLossRows
+                total, scalars, _, pred_full = head.apply(h, W, self._row_map, mode, w, alpha, beta, scale)
                 return total, scalars, pred_full
+            if not need_grad and hasattr(self.vla, "hidden_rows") and self._row_count > 0 and self._fused_head(self._row_count, None, self.vla.lm_head.weight):
+                # evaluation only (validation passes, every mode): head + statistics + fold without logits in memory when K3h covers the shape
+                h = self.vla.hidden_rows(input_ids, None if pe is not None else pix, self._row_index, patch_embeds=pe, pack=pack)
+                if h.dtype == torch.bfloat16:
+                    scalars, _, pred_full, _ = ops.head_loss_rows_fwd_bwd(h.detach().contiguous(), self.vla.lm_head.weight, self._row_map, mode, w, alpha, beta,
+                                                                          scale, want_grad=False)
+                    return None, scalars, pred_full
+                logits = self.vla.lm_head(h)
+                scalars, _, pred_full, _ = ops.loss_rows_fwd_bwd(logits.detach().contiguous(), self._row_map, mode, w, alpha, beta, scale, want_grad=False)
+                return None, scalars, pred_full
             logits = self.vla.forward_rows(input_ids, None if pe is not None else pix, labels, self._row_index, patch_embeds=pe, pack=pack)
             if need_grad:
                 total, scalars, _, pred_full = ops.DiscrepancyLossRows.apply(logits.contiguous(), self._row_map, mode, w, alpha, beta, scale)
@@ -125,9 +139,9 @@ class AttackBase:
         62 + 10; bs = 64 (128 rows, where a CU's line rate, not HBM, bounds the kernel): 54 + 8 against 55-57 + 11
         (profiles/r04_head_fused.txt). VAA_FUSED_HEAD=0 restores the GEMM path."""
         mode = os.environ.get("VAA_FUSED_HEAD", "auto")
-        if mode == "0" or h.dtype != torch.bfloat16 or W.dtype != torch.bfloat16 or not ops.head_loss_rows_applies(R, int(h.shape[1]), int(W.shape[0])):
+        if mode == "0" or (h is not None and h.dtype != torch.bfloat16) or W.dtype != torch.bfloat16 or not W.is_cuda:
             return False
-        return True
+        return ops.head_loss_rows_applies(R, int(W.shape[1]), int(W.shape[0]))
 
     def fused_ddp_step(self, pixel_values, patch, input_ids, attention_mask, labels, geometry, w, msg, scalars, optimizer=None):
         """The UADA_ddp inner step (UADA_ddp.py:189-206) up to the gradient exchange, six hand-written launches around the model:

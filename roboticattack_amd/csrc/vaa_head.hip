@@ -36,7 +36,7 @@ typedef float v4f_h __attribute__((ext_vector_type(4)));
 #define VAA_HEAD_WAVES 8
 #endif
 constexpr int kHT = VAA_HEAD_WAVES * 64;  // threads per workgroup: 8 waves (two per SIMD: one wave's fragment reads hide behind the other's MFMAs)
-constexpr int kHCols = 128;          // vocabulary columns per workgroup
+constexpr int kHCols = kHeadCols;    // vocabulary columns per workgroup (128)
 constexpr int kHK = 64;              // k-chunk: one 128-byte line of every weight row and of every hidden row
 constexpr int kHSA = kHK;            // LDS row (bf16 elements): 128 B, UNPADDED — the eight 16-byte pieces of row r sit at slot (piece ^ (r & 7)).
                                      // The hardware serves a ds_read_b128 in groups of 16 lanes that mix two k-groups ({0-3, 12-15} of one with {4-11} of
@@ -50,7 +50,7 @@ struct HeadArgs {
     const uint16_t* w;      // [V, D] bf16 LM-head weight
     const int* rowmap;      // K3's row map {R, #action rows, 0, 0} + RowMap[R]
     PartStat* part;         // [R][nwg]
-    float* slice_logits;    // [R][256] action-column logits (bf16-rounded values)
+    uint16_t* slice_logits; // [R][256] action-column logits, bf16
     uint16_t* logits_dbg;   // [R][V] bf16 or nullptr (tests)
     int R, D, V, nwg;
 };
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kHT) void head_stats_kernel(HeadArgs a) {
     if (n0 >= kA0 && n0 < kA0 + kNA) {  // the action columns (31744 is a multiple of 128: two whole workgroups)
         for (int idx = tid; idx < rows_live * kHCols; idx += kHT) {
             const int r = idx >> 7, cl = idx & 127;
-            a.slice_logits[(size_t)r * kNA + (n0 - kA0) + cl] = tile[r * kHTileS + cl];
+            a.slice_logits[(size_t)r * kNA + (n0 - kA0) + cl] = (uint16_t)f32_to_bf16_bits(tile[r * kHTileS + cl]);  // (exact: the tile holds bf16-rounded values)
         }
     }
     if (a.logits_dbg) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kHT) void head_stats_kernel(HeadArgs a) {
 
 struct HeadFinishArgs {
     const PartStat* part_in;    // [R][nwg]
-    const float* slice_logits;  // [R][256]
+    const uint16_t* slice_logits;  // [R][256] bf16
     const int* rowmap;
     PartStat* part_out;         // K3 workspace: [R][4], `split` parts per row are read by the fold
     SliceStat* slice_out;       // [R]
@@ -272,9 +272,9 @@ __global__ __launch_bounds__(256) void head_finish_kernel(HeadFinishArgs a) {
 #pragma unroll
     for (int e = 0; e < N; ++e) x[e] = -INFINITY;
     if (own) {
-        const float4 v0 = *reinterpret_cast<const float4*>(a.slice_logits + (size_t)r * kNA + lane * N);
-        const float4 v1 = *reinterpret_cast<const float4*>(a.slice_logits + (size_t)r * kNA + lane * N + 4);
-        x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+        const uint4 v = *reinterpret_cast<const uint4*>(a.slice_logits + (size_t)r * kNA + lane * N);
+        x[0] = bf16_bits_to_f32(v.x & 0xffffu); x[1] = bf16_bits_to_f32(v.x >> 16); x[2] = bf16_bits_to_f32(v.y & 0xffffu); x[3] = bf16_bits_to_f32(v.y >> 16);
+        x[4] = bf16_bits_to_f32(v.z & 0xffffu); x[5] = bf16_bits_to_f32(v.z >> 16); x[6] = bf16_bits_to_f32(v.w & 0xffffu); x[7] = bf16_bits_to_f32(v.w >> 16);
     }
     int ai = 0;
 #pragma unroll
@@ -328,7 +328,6 @@ __global__ __launch_bounds__(256) void head_finish_kernel(HeadFinishArgs a) {
     }
 }
 
-static size_t head_align(size_t n) { return (n + 255) / 256 * 256; }
 
 }  // namespace vaa
 
@@ -336,8 +335,7 @@ extern "C" size_t vaa_loss_rows_ws_bytes(int R);
 
 extern "C" size_t vaa_head_loss_ws_bytes(int R, int V) {
     if (R <= 0 || V <= 0) return 0;
-    const size_t nwg = (size_t)(V + vaa::kHCols - 1) / vaa::kHCols;
-    return vaa::head_align((size_t)R * nwg * sizeof(vaa::PartStat)) + vaa::head_align((size_t)R * vaa::kNA * sizeof(float));
+    return vaa::head_ws_slice_offset(R, V) + vaa::head_ws_align((size_t)R * vaa::kNA * sizeof(uint16_t));
 }
 
 extern "C" int vaa_head_loss_rows_applies(int R, int D, int V) {
@@ -372,7 +370,7 @@ extern "C" int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* 
     a.h = hidden; a.w = w_head; a.rowmap = (const int*)rowmap;
     a.nwg = (V + kHCols - 1) / kHCols;
     a.part = (PartStat*)head_ws;
-    a.slice_logits = (float*)((char*)head_ws + head_align((size_t)R * a.nwg * sizeof(PartStat)));
+    a.slice_logits = (uint16_t*)((char*)head_ws + head_ws_slice_offset(R, V));
     a.logits_dbg = logits_dbg;
     a.R = R; a.D = D; a.V = V;
     const int nrb = R <= 32 ? 1 : (R <= 64 ? 2 : 4);

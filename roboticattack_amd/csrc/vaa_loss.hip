@@ -551,6 +551,8 @@ struct RowsArgs {
     int32_t* pred_tokens;
     int32_t* pred_full;
     int R, B, L, V, mode, split, grad_slice;
+    int ldz, zcol0;     // logits row stride (elements) and the vocabulary column of its first element: V, 0 — or 256, kA0 when `logits` is the
+                        // action-column buffer vaa_head_loss_rows_stats left (vaa_head_loss_rows_finish: only the slice is ever read)
     float w, alpha, beta, scale;
 };
 
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
     constexpr int MAXV = 32 / N;
     const int nvec = a.V / N, pvec = (nvec + gsplit - 1) / gsplit;
     const int v_lo = h * pvec, v_hi = min(nvec, v_lo + pvec);
-    const T* z = reinterpret_cast<const T*>(a.logits) + (size_t)r * a.V;
+    const T* z = reinterpret_cast<const T*>(a.logits) + (ptrdiff_t)r * a.ldz - a.zcol0;
     float v[MAXV][N];
     if (full_grad && r < a.R) {
 #pragma unroll
@@ -1282,6 +1284,7 @@ static int rows_args(const char* who, const void* logits, int dtype, const void*
     a.logits = logits; a.rowmap = (const int*)rowmap; a.part = (PartStat*)ws; a.slice = (SliceStat*)((char*)ws + (size_t)R * 4 * sizeof(PartStat));
     a.grad = grad; a.scalars = scalars; a.pred_tokens = pred_tokens; a.pred_full = pred_full_tokens;
     a.R = R; a.B = B; a.L = L; a.V = V; a.mode = mode; a.split = rows_split(R, V); a.grad_slice = (grad_kind == VAA_GRAD_SLICE) ? 1 : 0;
+    a.ldz = V; a.zcol0 = 0;
     a.w = params[0]; a.alpha = params[1]; a.beta = params[2]; a.scale = params[3];
     return VAA_OK;
 }
@@ -1464,6 +1467,42 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
         else VAA_LAUNCH((rows_finish_kernel<uint16_t, 512>), dim3(G), dim3(512), 0, st, a, gsplit);
     }
     return check_launch("vaa_loss_rows_fwd_bwd(finish)");
+}
+
+// The finishing pass behind vaa_head_loss_rows_stats (LM head fused with K3's statistics): the fold of the rows into the scalars, the
+// prediction maps and — VAA_LOSS_UPA — the gradient slice, which needs the folded batch means (UPA.py:375-387). It is rows_finish_kernel,
+// the second launch of vaa_loss_rows_fwd_bwd, reading the 256 action logits of a row from the buffer the head kernel left instead of
+// from [R,V] logits: the same bits for the same logits.
+extern "C" int vaa_head_loss_rows_finish(const void* rowmap, int R, int B, int L, int V, int mode, const float* params, void* loss_ws,
+                                         size_t loss_ws_bytes, const void* head_ws, size_t head_ws_bytes, float* scalars, int32_t* pred_tokens,
+                                         int32_t* pred_full_tokens, void* grad_slice, void* stream) {
+    using namespace vaa;
+    const char* who = "vaa_head_loss_rows_finish";
+    if (!scalars || !head_ws) {
+        set_error("%s: null pointer argument", who);
+        return VAA_E_INVALID;
+    }
+    if (grad_slice && mode != VAA_LOSS_UPA) {
+        set_error("%s: gradient slice asked for mode %d (VAA_LOSS_UADA_DDP: vaa_head_loss_rows_stats writes it; modes with a cross-entropy term need "
+                  "the [R,V] logits: LM-head GEMM + vaa_loss_rows_fwd_bwd)", who, mode);
+        return mode == VAA_LOSS_UADA_DDP ? VAA_E_INVALID : VAA_E_UNSUPPORTED;
+    }
+    if (R > 0 && head_ws_bytes < vaa_head_loss_ws_bytes(R, V)) {
+        set_error("%s: head workspace %zu B < required %zu B", who, head_ws_bytes, vaa_head_loss_ws_bytes(R, V));
+        return VAA_E_WORKSPACE;
+    }
+    RowsArgs a;
+    const void* zs = (const char*)head_ws + head_ws_slice_offset(R, V);
+    int rc = rows_args(who, zs, VAA_DTYPE_BF16, rowmap, R, B, L, V, mode, params, scalars, pred_tokens, pred_full_tokens, grad_slice, VAA_GRAD_SLICE,
+                       loss_ws, loss_ws_bytes, a);
+    if (rc != VAA_OK) return rc;
+    a.ldz = kNA;
+    a.zcol0 = kA0;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned G = grad_slice ? (unsigned)R : 1u;  // one workgroup per row writes its slice; the scalars alone take one workgroup
+    if (rows_threads(V) == 256) VAA_LAUNCH((rows_finish_kernel<uint16_t, 256>), dim3(G), dim3(256), 0, st, a, 1);
+    else VAA_LAUNCH((rows_finish_kernel<uint16_t, 512>), dim3(G), dim3(512), 0, st, a, 1);
+    return check_launch(who);
 }
 
 // The statistics pass of vaa_loss_rows_fwd_bwd alone (UADA_DDP mode: it also writes the gradient slice, which needs nothing from other

@@ -1,5 +1,6 @@
 // vaa_rows.h — row-statistics records of K3's ROWS path, shared by vaa_loss.hip (K3) and vaa_head.hip (LM head fused with K3's statistics).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace vaa {
@@ -21,6 +22,11 @@ struct SliceStat {  // one per row
     int pad;
 };
 
-int rows_split(int R, int V);  // parts per row of the K3 workspace layout [R][4] PartStat + [R] SliceStat (vaa_loss.hip)
+int rows_split(int R, int V);
+
+// head workspace of vaa_head_loss_rows_stats: [R][ceil(V / 128)] PartStat, then (256-byte aligned) the action-column logits [R][256] bf16
+constexpr int kHeadCols = 128;  // vocabulary columns per workgroup of head_stats_kernel
+inline size_t head_ws_align(size_t n) { return (n + 255) / 256 * 256; }
+inline size_t head_ws_slice_offset(int R, int V) { return head_ws_align((size_t)R * ((V + kHeadCols - 1) / kHeadCols) * sizeof(PartStat)); }  // parts per row of the K3 workspace layout [R][4] PartStat + [R] SliceStat (vaa_loss.hip)
 
 }  // namespace vaa

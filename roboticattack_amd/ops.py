@@ -692,6 +692,33 @@ def head_loss_rows_stats(hidden, w_head, rowmap: "LossRowMap", mode: int = LOSS_
     return (ws, dbg) if want_logits else ws
 
 
+def head_loss_rows_fwd_bwd(hidden, w_head, rowmap: "LossRowMap", mode: int, w: float = 5.0, alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0,
+                           want_grad: bool = True, want_pred: bool = True, want_logits: bool = False):
+    """LM head + K3 on the labelled rows WITHOUT logits in memory: vaa_head_loss_rows_stats (weight stream + per-row fold) followed by
+    vaa_head_loss_rows_finish (scalars, prediction maps, UPA's gradient slice). Same returns as loss_rows_fwd_bwd with GRAD_SLICE:
+    (scalars f32[8], pred_slice, pred_full, grad [R,256] bf16 | None). A gradient exists for the modes whose loss lives in the action
+    columns (SLICE_MODES); the other modes are evaluated only (want_grad=False: validation passes)."""
+    if want_grad and mode not in SLICE_MODES:
+        raise _lib.VaaError(f"head_loss_rows_fwd_bwd: mode {mode} has a cross-entropy term — its gradient needs the [R,V] logits (HeadLossRows)")
+    R = int(hidden.shape[0])
+    V = int(w_head.shape[0])
+    dev = hidden.device
+    grad = torch.empty((R, N_ACTION), dtype=torch.bfloat16, device=dev) if want_grad else None
+    out = head_loss_rows_stats(hidden, w_head, rowmap, mode, w, alpha, beta, scale, grad=grad if mode == LOSS_UADA_DDP else None, want_logits=want_logits)
+    ws, lg = out if want_logits else (out, None)
+    L = _lib.lib()
+    hws = _workspace(dev, L.vaa_head_loss_ws_bytes(R, V), "k3h")
+    scalars = torch.empty(8, dtype=torch.float32, device=dev)
+    pred = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=dev) if want_pred else None
+    pred_full = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=dev) if want_pred else None
+    with _timed("K3_head_loss_rows_finish", rows=R, V=V):
+        rc = L.vaa_head_loss_rows_finish(rowmap.buf.data_ptr(), R, rowmap.B, rowmap.L, V, int(mode), _lib.f32x([w, alpha, beta, scale]), ws.data_ptr(), ws.numel(),
+                                         hws.data_ptr(), hws.numel(), scalars.data_ptr(), pred.data_ptr() if want_pred else None,
+                                         pred_full.data_ptr() if want_pred else None, grad.data_ptr() if (want_grad and mode == LOSS_UPA) else None, _stream())
+    _lib.check(rc, "vaa_head_loss_rows_finish")
+    return (scalars, pred, pred_full, grad, lg) if want_logits else (scalars, pred, pred_full, grad)
+
+
 def step_epilogue(partials, msg, scalars, rowmap: LossRowMap = None, R: int = 0, V: int = 32064, mode: int = LOSS_UADA_DDP, w: float = 5.0,
                   alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0, loss_ws=None, want_pred: bool = True, update=None):
     """vaa_step_epilogue: msg[0..n) = fixed-order sum of K2's partial tiles [parts, n]; with `rowmap` (+ the workspace loss_rows_stats left)
@@ -768,6 +795,24 @@ class HeadLossRows(torch.autograd.Function):
         g, weight = ctx.saved_tensors
         wsel = weight[ACTION_LO : ACTION_LO + N_ACTION] if ctx.sliced else weight
         dh = (g * gtotal.to(g.dtype)) @ wsel
+        return dh, None, None, None, None, None, None, None
+
+
+class HeadLossRowsFused(torch.autograd.Function):
+    """HeadLossRows for the modes whose loss lives in the 256 action columns (UADA_DDP, UPA) with the LM head FUSED into K3's statistics
+    (head_loss_rows_fwd_bwd: the [R,V] logits never reach memory); backward dh = g_slice [R,256] @ W[31744:32000] as in HeadLossRows."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, rowmap, mode, w, alpha, beta, scale):
+        scalars, pred, pred_full, g = head_loss_rows_fwd_bwd(hidden.detach().contiguous(), weight, rowmap, mode, w, alpha, beta, scale, want_grad=True)
+        ctx.save_for_backward(g, weight)
+        ctx.mark_non_differentiable(scalars, pred, pred_full)
+        return scalars[0].clone(), scalars, pred, pred_full
+
+    @staticmethod
+    def backward(ctx, gtotal, _gs, _gp, _gf):
+        g, weight = ctx.saved_tensors
+        dh = (g * gtotal.to(g.dtype)) @ weight[ACTION_LO : ACTION_LO + N_ACTION]
         return dh, None, None, None, None, None, None, None
 
 

@@ -965,3 +965,51 @@ def test_fused_head_step_vs_gemm_head_step(monkeypatch):
         assert float((f0 != f1).float().mean()) <= 0.1  # an argmax can flip only where two logits tie to one bf16 rounding
         assert float((p0 - p1).abs().max()) <= 2e-5
     assert float((runs["0"][0][-1][0] - runs["0"][0][0][0]).abs().max()) > 0
+
+
+def test_model_loss_fused_head_vs_gemm_head(monkeypatch):
+    """`AttackBase.model_loss` — what the UPA / single-GPU loops and every validation pass call — with the LM head fused into K3's statistics
+    (K3h: UPA and UADA_DDP with their gradient, UADA and CE in evaluation) against the same call with VAA_FUSED_HEAD=0 (hipBLASLt head + K3 on
+    [R,V] logits): scalars within 2e-3 relative (the two heads round the same fp32 sums to bf16 in different orders), predictions equal up to
+    ties, patch gradients within 2e-2 of their scale and aligned; and the fused kernels really ran (no rows_stats launch)."""
+    import random
+
+    from roboticattack_amd import ops, synthetic
+    from roboticattack_amd.attack.engine import AttackBase
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+
+    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, False, True), siglip=VitCfg(192, 3, 2, 384, 0, False, False),
+                     llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=11)
+    B = 5
+    batch = synthetic.synth_batch(4, B, "noise", as_pil=False)
+    ids, attn = batch["input_ids"].to(DEV), batch["attention_mask"].to(DEV)
+    labels = mask_labels(batch["labels"].clone(), [0, 1, 2]).to(DEV)
+    res = {}
+    for env in ("0", "auto"):
+        monkeypatch.setenv("VAA_FUSED_HEAD", env)
+        att = AttackBase(m, None, "", "adamW", False)
+        img = att.randomPatchTransform.stage_images(torch.from_numpy(batch["pixel_values"]))
+        out = {}
+        for mode, need_grad in ((ops.LOSS_UPA, True), (ops.LOSS_UADA_DDP, True), (ops.LOSS_UADA, False), (ops.LOSS_CE, False), (ops.LOSS_UPA, False)):
+            random.seed(5); np.random.seed(5)
+            patch = torch.rand(3, 50, 50, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(need_grad)
+            ops.prof_start(256)
+            with torch.set_grad_enabled(need_grad):
+                pix = att.randomPatchTransform.apply_random_patch_batch(img, patch, mean=att.mean, std=att.std, geometry=True)
+                total, scalars, pred = att.model_loss(ids, attn, pix, labels, mode, w=5.0, need_grad=need_grad)
+                if need_grad:
+                    total.backward()
+            names = [n for n, _ in ops.prof_collect()]
+            out[(mode, need_grad)] = (scalars.clone(), pred.clone(), patch.grad.clone() if need_grad else None, names)
+        res[env] = out
+    for key, (s1, p1, g1, n1) in res["auto"].items():
+        s0, p0, g0, n0 = res["0"][key]
+        assert any("head_stats_kernel" in n for n in n1) and any("rows_finish_kernel" in n for n in n1) and not any("rows_stats_kernel" in n for n in n1), (key, n1)
+        assert any("rows_stats_kernel" in n for n in n0) and not any("head_stats_kernel" in n for n in n0), (key, n0)
+        assert torch.allclose(s0, s1, rtol=2e-3, atol=1e-5), (key, s0, s1)
+        assert float((p0 != p1).float().mean()) <= 0.1
+        if g0 is not None:
+            assert float(g0.abs().max()) > 0 and float((g0 - g1).abs().max()) <= 2e-2 * float(g0.abs().max())
+            assert torch.nn.functional.cosine_similarity(g0.flatten(), g1.flatten(), dim=0) > 0.999

@@ -1554,6 +1554,53 @@ def test_head_loss_rows_stats_vs_oracle_and_gemm_path(ops, B, maskidx, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode_name", ["UPA", "UADA_DDP", "UADA", "CE"])
+@pytest.mark.parametrize("B,maskidx,D", [(13, [0, 1, 2], 192), (32, [0, 1, 2], 4096), (16, [0, 1, 2, 3, 4, 5, 6], 256)])
+def test_head_loss_rows_fwd_bwd_without_logits(ops, mode_name, B, maskidx, D):
+    """Every K3 mode evaluated WITHOUT logits in memory: vaa_head_loss_rows_stats + vaa_head_loss_rows_finish (UPA and UADA_DDP with their gradient
+    slice; UADA / CE evaluation only, their gradients need every logit) against
+      * vaa_loss_rows_fwd_bwd on the kernel's own bf16 logits: predictions, slice statistics, UAD and the gradient slice BIT FOR BIT (the finishing pass
+        is the same kernel reading the same 256 action logits from the head's buffer), CE / total to fp32 summation order;
+      * the C ORACLE on those logits: scalars <= 3e-5, gradient slice <= 1e-2 of its scale (bf16 storage)."""
+    from roboticattack_amd.labels import mask_labels
+
+    V = 32064
+    mode = {"UPA": ops.LOSS_UPA, "UADA_DDP": ops.LOSS_UADA_DDP, "UADA": ops.LOSS_UADA, "CE": ops.LOSS_CE}[mode_name]
+    om = {"UPA": c_oracle.MODE_UPA, "UADA_DDP": c_oracle.MODE_UADA_DDP, "UADA": c_oracle.MODE_UADA, "CE": c_oracle.MODE_CE}[mode_name]
+    _, labels, _ = synthetic.synth_text_batch(900 + B, B)
+    labels = mask_labels(labels, maskidx)
+    L = labels.shape[1]
+    rows = _rows(labels.numpy())
+    R = len(rows)
+    rb, rp = np.array([r[0] for r in rows]), np.array([r[1] for r in rows])
+    g = torch.Generator(device=DEV).manual_seed(B * 7 + D)
+    W = (torch.randn(V, D, device=DEV, generator=g) * (1.3 / np.sqrt(D))).to(torch.bfloat16)
+    W[31744:32000] *= 2.0
+    h = torch.randn(R, D, device=DEV, generator=g).to(torch.bfloat16)
+    rm = ops.LossRowMap(labels.to(DEV))
+    want_grad = mode in ops.SLICE_MODES
+    kw = dict(w=4.0, alpha=0.7, beta=0.3, scale=1.0)
+    sc, pred, pf, gs, lg = ops.head_loss_rows_fwd_bwd(h, W, rm, mode, want_grad=want_grad, want_logits=True, **kw)
+    sc2, pred2, pf2, gs2 = ops.loss_rows_fwd_bwd(lg, rm, mode, want_grad=want_grad, grad_kind=ops.GRAD_SLICE, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(pred, pred2) and torch.equal(pf, pf2)
+    assert torch.equal(sc[[2, 5, 6, 7]], sc2[[2, 5, 6, 7]]) and torch.allclose(sc, sc2, rtol=3e-6, atol=1e-7), (sc, sc2)
+    if want_grad:
+        assert torch.equal(gs.view(torch.int16), gs2.view(torch.int16)) and float(gs.float().abs().max()) > 0
+    else:
+        assert gs is None
+        with pytest.raises(Exception, match="cross-entropy"):
+            ops.head_loss_rows_fwd_bwd(h, W, rm, mode, want_grad=True, **kw)
+    full = torch.zeros((B, 256 + L, V), dtype=torch.float32)
+    full[torch.from_numpy(rb), torch.from_numpy(rp)] = lg.float().cpu()
+    so, go = c_oracle.loss(full.numpy(), labels.numpy(), om, **kw)
+    assert np.allclose(sc.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5), (sc.cpu().numpy(), so)
+    if want_grad:
+        gor = go[rb, rp][:, 31744:32000]
+        assert np.abs(gs.float().cpu().numpy() - gor).max() <= 1e-2 * max(np.abs(gor).max(), 1e-30)
+
+
+@pytest.mark.gpu
 def test_head_loss_rows_stats_argument_checks(ops):
     import ctypes as C
 
@@ -1564,7 +1611,7 @@ def test_head_loss_rows_stats_argument_checks(ops):
     prm = _lib.f32x([5.0, 0.8, 0.2, 1.0])
     assert L.vaa_head_loss_rows_applies(128, 4096, 32064) == 1 and L.vaa_head_loss_rows_applies(129, 4096, 32064) == 0
     assert L.vaa_head_loss_rows_applies(16, 4100, 32064) == 0 and L.vaa_head_loss_rows_applies(16, 4096, 30000) == 0
-    assert L.vaa_head_loss_ws_bytes(0, 32064) == 0 and L.vaa_head_loss_ws_bytes(16, 32064) >= 16 * 251 * 16 + 16 * 256 * 4
+    assert L.vaa_head_loss_ws_bytes(0, 32064) == 0 and L.vaa_head_loss_ws_bytes(16, 32064) >= 16 * 251 * 16 + 16 * 256 * 2
     a = (p, p, 4096, p, 16, 8, 30, 32064)
     assert L.vaa_head_loss_rows_stats(None, p, 4096, p, 16, 8, 30, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -1
     assert L.vaa_head_loss_rows_stats(p, p, 4096, p, 200, 100, 30, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -2 and b"GEMM" in L.vaa_last_error()
@@ -1572,3 +1619,10 @@ def test_head_loss_rows_stats_argument_checks(ops):
     assert L.vaa_head_loss_rows_stats(*a, ops.LOSS_UADA_DDP, prm, p, p, 16, p, 1 << 24, None, st) == -4
     assert L.vaa_head_loss_rows_stats(*a, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 16, None, st) == -4 and b"workspace" in L.vaa_last_error()
     assert L.vaa_head_loss_rows_stats(p, p, 4096, p, 100, 8, 10, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -2  # R > B*(L-1)
+    # the finishing pass: a gradient slice only for UPA (UADA_DDP's is written by the statistics call, CE terms need the [R,V] logits)
+    f = (p, 16, 8, 30, 32064)
+    assert L.vaa_head_loss_rows_finish(*f, ops.LOSS_UADA, prm, p, 1 << 20, p, 1 << 24, p, None, None, p, st) == -2 and b"GEMM" in L.vaa_last_error()
+    assert L.vaa_head_loss_rows_finish(*f, ops.LOSS_UADA_DDP, prm, p, 1 << 20, p, 1 << 24, p, None, None, p, st) == -1
+    assert L.vaa_head_loss_rows_finish(*f, ops.LOSS_UPA, prm, p, 1 << 20, p, 16, p, None, None, p, st) == -4
+    assert L.vaa_head_loss_rows_finish(*f, ops.LOSS_UPA, prm, p, 16, p, 1 << 24, p, None, None, p, st) == -4
+    assert L.vaa_head_loss_rows_finish(*f, ops.LOSS_UPA, prm, p, 1 << 20, p, 1 << 24, None, None, None, None, st) == -1
