@@ -356,6 +356,10 @@ extern "C" int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* 
                   kHRowsMax, D, kHK, V, B, L);
         return VAA_E_UNSUPPORTED;
     }
+    if ((((uintptr_t)hidden) | ((uintptr_t)w_head)) & 15u) {  // the rows are fetched in 16-byte pieces (global -> LDS)
+        set_error("%s: hidden and w_head must be 16-byte aligned", who);
+        return VAA_E_INVALID;
+    }
     if (grad_slice && mode != VAA_LOSS_UADA_DDP) {
         set_error("%s: only VAA_LOSS_UADA_DDP has a gradient that does not depend on the folded scalars (mode %d)", who, mode);
         return VAA_E_INVALID;

@@ -1616,6 +1616,7 @@ def test_head_loss_rows_stats_argument_checks(ops):
     assert L.vaa_head_loss_rows_stats(None, p, 4096, p, 16, 8, 30, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -1
     assert L.vaa_head_loss_rows_stats(p, p, 4096, p, 200, 100, 30, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -2 and b"GEMM" in L.vaa_last_error()
     assert L.vaa_head_loss_rows_stats(*a, ops.LOSS_UPA, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -1 and b"UADA_DDP" in L.vaa_last_error()
+    assert L.vaa_head_loss_rows_stats(C.c_void_p(0x1008), p, 4096, p, 16, 8, 30, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -1 and b"aligned" in L.vaa_last_error()
     assert L.vaa_head_loss_rows_stats(*a, ops.LOSS_UADA_DDP, prm, p, p, 16, p, 1 << 24, None, st) == -4
     assert L.vaa_head_loss_rows_stats(*a, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 16, None, st) == -4 and b"workspace" in L.vaa_last_error()
     assert L.vaa_head_loss_rows_stats(p, p, 4096, p, 100, 8, 10, 32064, ops.LOSS_UADA_DDP, prm, p, p, 1 << 20, p, 1 << 24, None, st) == -2  # R > B*(L-1)

@@ -151,19 +151,31 @@ def one_head_case(seed):
     parts, msg = torch.zeros((4, n), device=DEV), torch.zeros(n + 4, device=DEV)
     sc = torch.zeros(8, device=DEV)
     pred, pred_full = ops.step_epilogue(parts, msg, sc, rowmap=rm, R=R, V=V, mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws)
-    ref_lg = torch.nn.functional.linear(h, W)
-    dl = (lg.float() - ref_lg.float()).abs()
-    ulp = ref_lg.float().abs().clamp_min(1e-3) * 2.0 ** -7
-    if not (float((dl > 0).float().mean()) < 0.02 and bool((dl <= 1.01 * ulp).all())):
-        fails.append(f"head logits  {tag}: differing {float((dl > 0).float().mean()):.4f}, max/ulp {float((dl / ulp).max()):.2f}")
+    # the logits against the exact products (fp64): half a bf16 step at the value + the error an fp32 accumulation of D terms may carry
+    # (2e-6 of the sum of the terms' magnitudes: near-zero logits are sums of large cancelling terms — seed 63000294)
+    ref64 = h.double() @ W.double().t()
+    mag = h.double().abs() @ W.double().abs().t()
+    dl = (lg.double() - ref64).abs()
+    bound = 0.5 * torch.maximum(ref64.abs(), lg.double().abs()) * 2.0 ** -7 + 2e-6 * mag + 1e-30
+    if not bool((dl <= bound).all()):
+        i = int((dl / bound).argmax())
+        fails.append(f"head logits  {tag}: worst |d|/bound {float((dl / bound).max()):.2f} at row {i // V} col {i % V}: {float(lg.flatten()[i]):.6g} vs {float(ref64.flatten()[i]):.6g}, sum|terms| {float(mag.flatten()[i]):.4g}")
     full = torch.zeros((B, 256 + L, V), dtype=torch.float32)
     full[torch.from_numpy(bk[:, 0]), torch.from_numpy(bk[:, 1] + 256)] = lg.float().cpu()
     so, go = c_oracle.loss(full.numpy(), lab, c_oracle.MODE_UADA_DDP, w=w)
     gor = go[bk[:, 0], bk[:, 1] + 256][:, 31744:32000]
     if not np.allclose(sc.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5):
         fails.append(f"head scalars {tag}: {sc.cpu().numpy()[:5]} vs {so[:5]}")
-    if not (np.abs(gs.float().cpu().numpy() - gor).max() <= 1e-2 * max(np.abs(gor).max(), 1e-30)):
-        fails.append(f"head grad    {tag}: {np.abs(gs.float().cpu().numpy() - gor).max() / max(np.abs(gor).max(), 1e-30):.3e}")
+    # bf16 storage: 1e-2 of the gradient's scale — except where every labelled row's action slice is saturated (one bin holds nearly all of the
+    # probability): p_i (i - E) is then a difference of fp32 numbers of size ~100 scaled by ~eps and the whole gradient is that small (the same
+    # case the K3 leg documents; seed 63000857: 2.3e-2 of a gradient of 1e-6 with max p = 0.999996 in the one action row — bit for bit the GEMM route's result below)
+    zs = lg.float().cpu().numpy()[:, 31744:32000].astype(np.float64)
+    act = lab[bk[:, 0], bk[:, 1] + 1] > 2  # rows that carry a gradient (action tokens)
+    pr = np.exp(zs - zs.max(1, keepdims=True))
+    pmax = float((pr / pr.sum(1, keepdims=True)).max(1)[act].min()) if act.any() else 0.0
+    gerr = np.abs(gs.float().cpu().numpy() - gor).max() / max(np.abs(gor).max(), 1e-30)
+    if not (gerr <= (1e-2 if pmax < 0.9999 else 1e-1)):
+        fails.append(f"head grad    {tag}: {gerr:.3e} (min over the action rows of max p = {pmax:.8f})")
     zf = lg.float().cpu().numpy()
     pfn, psn = pred_full.cpu().numpy().reshape(B, L - 1), pred.cpu().numpy().reshape(B, L - 1)
     for i, (b, k) in enumerate(bk):
@@ -187,10 +199,15 @@ def one_head_case(seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--head", action="store_true", help="soak K3h (vaa_head_loss_rows_stats) instead of K3")
+    ap.add_argument("--case", type=int, default=None, help="run ONE case with this full case seed (as printed in a FAIL line) and exit")
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     ops.device_check()
+    if a.case is not None:
+        bad = (one_head_case if a.head else one_case)(a.case)
+        print("\n".join("FAIL " + b for b in bad) or f"case {a.case}: ok")
+        sys.exit(1 if bad else 0)
     t0, n, bad = time.time(), 0, []
     while time.time() - t0 < a.seconds:
         bad += (one_head_case if a.head else one_case)(a.seed * 1000003 + n)
