@@ -1490,7 +1490,8 @@ def test_k3_one_pass_handover_timeout_fails_loudly(ops, monkeypatch):
 @pytest.mark.parametrize("B,maskidx,D", [(8, [0], 4096), (32, [0], 4096), (64, [0], 4096), (5, [0, 3], 192), (13, [0, 1, 2], 320), (3, [6], 64)])
 def test_head_loss_rows_stats_vs_oracle_and_gemm_path(ops, B, maskidx, D):
     """SURVEY.md 8f-2 as written: LM head FUSED with K3's statistics (vaa_head_loss_rows_stats; the attack step uses it up to 128 labelled rows). Checked three ways on the same hidden rows and head weight:
-      * its bf16 logits (test-only dump) == the hipBLASLt head's bf16 logits up to single bf16 roundings (fp32 summation order) on < 1 % of them;
+      * its bf16 logits (test-only dump) == the hipBLASLt head's bf16 logits on > 99 % of them, and within half a bf16 step + the fp32 accumulation
+        error of the exact (fp64) products everywhere;
       * the C ORACLE fed with those very logits: loss scalars <= 3e-5, gradient slice <= 1e-2 of its scale (bf16 storage), both argmax maps exact;
       * vaa_loss_rows_stats fed with those very logits: gradient slice and slice statistics BIT FOR BIT, CE to fp32 summation order.
     Shapes: OpenVLA's head (D = 4096) at bs = 8 / 32 / 64 and small towers incl. D not a multiple of 256 (padded k-steps) and ragged row counts."""
@@ -1519,9 +1520,12 @@ def test_head_loss_rows_stats_vs_oracle_and_gemm_path(ops, B, maskidx, D):
     torch.cuda.synchronize()
     # (1) the logits are the head's
     ref_lg = torch.nn.functional.linear(h, W)
-    dl = (lg.float() - ref_lg.float()).abs()
-    ulp = ref_lg.float().abs().clamp_min(1e-3) * 2.0 ** -7
-    assert float((dl > 0).float().mean()) < 0.01 and bool((dl <= 1.01 * ulp).all())
+    assert float((lg != ref_lg).float().mean()) < 0.01
+    # ... and against the exact products: half a bf16 step at the value + what an fp32 accumulation of D terms may carry (2e-6 of the sum of
+    # the terms' magnitudes — a near-zero logit is a sum of large cancelling terms, and the GEMM library's own summation order is not fixed)
+    ref64, mag = h.double() @ W.double().t(), h.double().abs() @ W.double().abs().t()
+    assert bool(((lg.double() - ref64).abs() <= 0.5 * torch.maximum(ref64.abs(), lg.double().abs()) * 2.0 ** -7 + 2e-6 * mag + 1e-30).all())
+    del ref64, mag
     # (2) the oracle on the kernel's own logits
     full = torch.zeros((B, 256 + L, V), dtype=torch.float32)
     full[torch.from_numpy(rb), torch.from_numpy(rp)] = lg.float().cpu()
