@@ -389,8 +389,7 @@ extern "C" int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* 
     if (nrb == 1) VAA_LAUNCH((head_stats_kernel<1>), grid, blk, lds, st, a);
     else if (nrb == 2) VAA_LAUNCH((head_stats_kernel<2>), grid, blk, lds, st, a);
     else VAA_LAUNCH((head_stats_kernel<4>), grid, blk, lds, st, a);
-    int rc;
-    rc = check_launch(who);
+    int rc = check_launch(who);
     if (rc != VAA_OK) return rc;
     HeadFinishArgs f;
     f.part_in = a.part; f.slice_logits = a.slice_logits; f.rowmap = a.rowmap;
