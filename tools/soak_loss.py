@@ -166,16 +166,15 @@ def one_head_case(seed):
     gor = go[bk[:, 0], bk[:, 1] + 256][:, 31744:32000]
     if not np.allclose(sc.cpu().numpy()[:5], so[:5], rtol=3e-5, atol=3e-5):
         fails.append(f"head scalars {tag}: {sc.cpu().numpy()[:5]} vs {so[:5]}")
-    # bf16 storage: 1e-2 of the gradient's scale — except where every labelled row's action slice is saturated (one bin holds nearly all of the
-    # probability): p_i (i - E) is then a difference of fp32 numbers of size ~100 scaled by ~eps and the whole gradient is that small (the same
-    # case the K3 leg documents; seed 63000857: 2.3e-2 of a gradient of 1e-6 with max p = 0.999996 in the one action row — bit for bit the GEMM route's result below)
-    zs = lg.float().cpu().numpy()[:, 31744:32000].astype(np.float64)
-    act = lab[bk[:, 0], bk[:, 1] + 1] > 2  # rows that carry a gradient (action tokens)
-    pr = np.exp(zs - zs.max(1, keepdims=True))
-    pmax = float((pr / pr.sum(1, keepdims=True)).max(1)[act].min()) if act.any() else 0.0
-    gerr = np.abs(gs.float().cpu().numpy() - gor).max() / max(np.abs(gor).max(), 1e-30)
-    if not (gerr <= (1e-2 if pmax < 0.9999 else 1e-1)):
-        fails.append(f"head grad    {tag}: {gerr:.3e} (min over the action rows of max p = {pmax:.8f})")
+    # bf16 storage: 1e-2 of the gradient's scale + what the fp32 soft-argmax carries: g_i = kE p_i (i - E) with |kE| <= 2 w^2 / (nact 256) and E (a sum of 256
+    # terms up to 256) good to ~6e-5 absolute in fp32. In a saturated slice (one bin holds nearly all of the probability) i - E is that small and the whole
+    # gradient with it — seeds 63000857 (2.3e-2 of a gradient of 1e-6, max p = 0.999996) and 73002355 (kernel 0, oracle 1e-9, max p = 1 - 2.7e-7), both bit for
+    # bit the GEMM route's result below
+    nact = int((lab[bk[:, 0], bk[:, 1] + 1] > 2).sum())
+    gerr = np.abs(gs.float().cpu().numpy() - gor).max()
+    gtol = 1e-2 * np.abs(gor).max() + (2.0 * w * w / (max(nact, 1) * 256.0)) * 6e-5
+    if not (gerr <= gtol):
+        fails.append(f"head grad    {tag}: |d| {gerr:.3e} > {gtol:.3e} (max|g| {np.abs(gor).max():.3e})")
     zf = lg.float().cpu().numpy()
     pfn, psn = pred_full.cpu().numpy().reshape(B, L - 1), pred.cpu().numpy().reshape(B, L - 1)
     for i, (b, k) in enumerate(bk):

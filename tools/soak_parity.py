@@ -187,9 +187,13 @@ def one_case(seed):
             fold = lambda d, ww: (d.float().cpu() @ ww.float().cpu()).to(torch.bfloat16).view(B, 16, 16, 3, 14, 14).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 224, 224)
             gcat = torch.cat([fold(dy[0], w[0]), fold(dy[1], w[1])], dim=1).contiguous()
             om = c_oracle.patch_grad_multi(bits(gcat), o_packed, pdesc_n, xy2, theta, geo, 0)
+            # the same gather of the MAGNITUDES of the pixel gradients: what one bf16 rounding step (2^-8) of every contribution can add up to. A per-image
+            # gradient is the sum of two towers' contributions that may cancel; 5e-3 of the image's largest element covers one step of that element only
+            # (seed 71004666: 5.6e-3 on one 98x181 image)
+            omag = c_oracle.patch_grad_multi(bits(gcat.abs()), o_packed, pdesc_n, xy2, theta, geo, 0)
             for (h, w_, off, _z) in pdesc_n:
                 a, b = fm[off : off + 3 * h * w_], om[off : off + 3 * h * w_]
-                if not (np.abs(a - b).max() <= 5e-3 * max(np.abs(b).max(), 1e-30) + 1e-30):
+                if not (np.abs(a - b) <= 5e-3 * max(np.abs(b).max(), 1e-30) + 2.0 ** -8 * np.abs(omag[off : off + 3 * h * w_]) + 1e-30).all():
                     fails.append(f"K2' multi {tag} image {h}x{w_} D={D0}+{D1}: rel err {np.abs(a - b).max() / max(np.abs(b).max(), 1e-30):.3e}")
         gb = ops.patch_resize_bwd(t(o_gp), t(pdesc_n), bh, bw).cpu().numpy()
         o_gb = c_oracle.patch_resize_bwd(o_gp, pdesc_n, bh, bw)
@@ -208,8 +212,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--case", type=int, default=None, help="run ONE case with this full case seed (as printed in a FAIL line) and exit")
     a = ap.parse_args()
     ops.device_check()
+    if a.case is not None:
+        bad = one_case(a.case)
+        print("\n".join("FAIL " + b for b in bad) or f"case {a.case}: ok")
+        sys.exit(1 if bad else 0)
     t0, n, bad = time.time(), 0, []
     while time.time() - t0 < a.seconds:
         bad += one_case(a.seed * 1000003 + n)
