@@ -136,12 +136,12 @@ int main() {
     const int total_instr = 2048;  // per workgroup: 2 MB = K3h's 128-row case (1 MB of weights + 1 MB of hidden rows)
     printf("per workgroup %d KB, %d workgroups; B/clk at 2.4 GHz\n", total_instr, kWG);
     printf("%-9s %-10s %-8s %-6s %-8s %-4s %9s %9s\n", "dest", "pattern", "source", "waves", "barrier", "k", "us", "B/clk/CU");
-    for (int dma = 1; dma >= 1; --dma)
-        for (int pattern = 2; pattern < 4; ++pattern)
+    for (int dma = 1; dma >= 0; --dma)
+        for (int pattern = 0; pattern < 4; ++pattern)
             for (int src = 0; src < 2; ++src)        // 0: the same 2 MB for everybody (L2 hits), 1: own 1 MB slab (HBM stream); pattern 2 = both
                 for (int stag = 0; stag < 2; ++stag)
                     for (int waves = 8; waves >= 2; waves >>= 1)
-                        for (int bar = 0; bar < 2; ++bar) {
+                        for (int bar = 0; bar < 4; ++bar) {
                             if ((waves != 8 && (bar || stag == 0)) || (pattern >= 2 && src == 0)) continue;
                             Args a;
                             a.src = buf;
@@ -149,14 +149,14 @@ int main() {
                             a.instr_per_wave = ((src == 1 && pattern < 2) ? total_instr / 2 : total_instr) / waves;
                             a.pattern = pattern;
                             a.active_waves = waves;
-                            a.barrier_every = bar ? 4 : 0;
+                            a.barrier_every = bar ? (2 << bar) : 0;  // one s_barrier per 4 / 8 / 16 instructions per wave (K3h: 4 = one k-chunk)
                             a.stagger = stag;
                             a.asym = 0;
                             a.sink = sink;
                             const size_t bytes = (size_t)a.instr_per_wave * waves * 1024;
                             const float us = run(dma, a);
                             printf("%-9s %-10s %-8s %-6d %-8s %-4s %9.1f %9.1f\n", dma ? "LDS-DMA" : "registers", pattern == 3 ? "K3h split" : (pattern == 2 ? "K3h mix" : (pattern ? "contig" : "rows8x128")),
-                                   pattern >= 2 ? "HBM+L2" : (src == 0 ? "L2" : "HBM"), waves, bar ? "per 4" : "-", stag ? "stag" : "-", us, (double)bytes / (us * 2400.0));
+                                   pattern >= 2 ? "HBM+L2" : (src == 0 ? "L2" : "HBM"), waves, bar == 0 ? "-" : (bar == 1 ? "per 4" : (bar == 2 ? "per 8" : "per 16")), stag ? "stag" : "-", us, (double)bytes / (us * 2400.0));
                         }
     for (int bar = 0; bar < 2; ++bar) {
         Args a;
