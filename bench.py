@@ -6,26 +6,38 @@
 
 One step = one inner-loop iteration of UADA_wrapper_ddp (UADA_ddp.py:189-209):
     host RNG draws -> K1 paste/warp (HIP) -> OpenVLA-7B-shaped bf16 forward + activation backward (PyTorch-ROCm)
-    -> K3 loss fwd+bwd on the labelled rows (HIP) -> K2' patch-embed backward on the tiles under the patch (MFMA) + patch-grad gather
-    (HIP; plain K2 on the pixel gradient with VAA_FUSED_EMBED_GRAD=0) -> [RCCL all-reduce, 30 KB] -> K4 AdamW+clamp (HIP)
-Workload: bs=64 PER RANK (reference semantics, UADA_ddp.py:158 -> weak scaling), 3x50x50 patch, geometry=True, maskidx=[0],
-synthetic BridgeData-shaped frames resident in HBM as u8, random-init weights of the OpenVLA-7B architecture.
-Prints ONE JSON line on rank 0. The timed region (`value`) runs UN-profiled; a short second pass of the same steps then runs with the
-library's per-dispatch timer armed (vaa_prof_*: every hand-written kernel launched through hipExtLaunchKernel with its own start/stop event
-pair = that dispatch's begin/end timestamps, no marker brackets, no subtraction) and gives `roofline` — the dominant hand-written kernel of
-the path IN-STEP: `head_stats_kernel`, the LM head fused with K3's statistics, ONE pass over the 263 MB head weight (264.8 of ~334 MB of the
-path's algorithmic bytes per step, and its longest kernel); K1's `patch_apply_tiles_kernel` (48.2 MB) is `roofline_k1`; the back-to-back
-figure is reported next to it as standalone_* — plus `roofline_kernels` / `hot_path_ops`. `k2_sweep` carries the K2 batch sweep; `cpu_baseline`
-is the reference's PyTorch-CPU op sequence for the same replaced ops (oracle/ref_port.py) timed on this box's host cores.
-N > 1 (one rank per GPU, RCCL): both timed regions — weak (`value`, bs per rank) and `strong_scaling` (the same global batch split over the
-ranks) — carry the collective's in-step cost (`allreduce_us_per_step`, `comm_frac`, measured with events on the launch stream around the
-30 KB all-reduce) and `config.env` records the NCCL_* / RCCL_* / HSA_* / VAA_* environment of the run. `--regions weak|strong|both` selects the
-regions (a full-size 8-rank functional run on ONE GPU fits with `--regions strong`).
+    -> LM head + K3 loss statistics on the labelled rows (HIP) -> K2' patch-embed backward on the tiles under the patch (MFMA) +
+    patch-grad gather (HIP) -> [RCCL all-reduce, 30 KB] -> K4 AdamW + clamp (HIP, inside the step epilogue at N=1)
+Workload: bs=64 PER RANK (reference semantics, UADA_ddp.py:158 -> weak scaling), 3x50x50 patch, geometry=True, maskidx=[0], synthetic
+BridgeData-shaped frames resident in HBM as u8, random-init weights of the OpenVLA-7B architecture.
+
+OUTPUT. stdout carries exactly ONE line: a COMPACT JSON record (< 4 KB, pure ASCII, strict JSON — non-finite floats become null, no
+free-text notes) with the contract's keys: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling /
+vs_baseline / dtype / data / config{...} / roofline{...} / roofline_k1{...} / cpu_baseline{...} / hot_path_* / loss_finite / peak_mem_GiB /
+wall_s. Everything else (per-kernel tables, the standalone kernel suite, the K1 / K2 batch sweeps, rank_shapes, per-leg CPU tables, the
+per-rank and per-config step blocks in full, the environment) goes to the FULL record, a JSON file (`--full-out`, default
+gpurun_out/bench_full.json); its path is in the compact line (`full_record`).
+
+What is measured:
+  * `value`: W warm-up steps, then exactly K steps between barrier + synchronize, max over ranks; UN-profiled.
+  * `roofline` / `roofline_k1`: a short second pass of the same steps with the library's per-dispatch timer armed (vaa_prof_*: every
+    hand-written kernel launched through hipExtLaunchKernel with its own start/stop event pair = that dispatch's begin/end timestamps). The
+    dominant hand-written kernel IN-STEP is the one with the most algorithmic bytes that the step actually ran (the fused LM head
+    `head_stats_kernel` when the step dispatches it, else K1's `patch_apply_tiles_kernel`).
+  * N=1 only: the per-rank steps of the strong-scaling configs (bs = 32 / 16 / 8 / 4), the inner steps of BASELINE configs 2 / 4 / 5
+    (`config.cfg{2,4,5}_*`: single-GPU UADA with 1/CE at bs=16 geometry off; TMA's CE gradient at bs=8; UPA with resize_patch 3x100x100 at
+    bs=4 — the product loops' own `inner_step`), the standalone kernel suite + sweeps (full record; `config.k2_sweep_frac` in the line) and
+    `cpu_baseline` (oracle/ref_port.py on the host cores, bounded sample).
+  * N>1 (one rank per GPU, RCCL): only the two timed regions — weak (`value`) and strong (the same global batch split over the ranks,
+    `config.strong_*`) — with the collective's in-step cost (`config.allreduce_us_per_step`, `config.comm_frac`); the process group is
+    destroyed right after them. `--regions weak|strong|both`.
+`--attack uada|tma|upa` (N=1) makes the main timed region one of the other product loops (for rocprofv3 summaries of configs 2 / 4 / 5).
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import random
 import sys
@@ -37,6 +49,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+LINE_LIMIT = 4096  # bytes of the stdout record
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -46,15 +60,74 @@ def parse():
     ap.add_argument("--bs", type=int, default=64, help="per-rank batch (UADA_ddp.py:158)")
     ap.add_argument("--patch", type=str, default="3,50,50")
     ap.add_argument("--model", type=str, default="openvla-7b", choices=["openvla-7b", "tiny", "surrogate"])
+    ap.add_argument("--attack", type=str, default="uada_ddp", choices=["uada_ddp", "uada", "tma", "upa"],
+                    help="the product loop whose inner step the main timed region runs (default: the headline, UADA_ddp.py:189-209); the others are N=1 diagnostics")
+    ap.add_argument("--geometry", type=str, default="true", choices=["true", "false"])
+    ap.add_argument("--maskidx", type=str, default="", help="comma list; default: 0 (uada*), 0..6 (tma), unused by upa's reverse-direction loss")
+    ap.add_argument("--resize-patch", action="store_true", help="upa: per-image patch scale s~U(0.61,1.39) (appply_random_transform.py:113-118)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-suite", action="store_true")
-    ap.add_argument("--no-per-rank", action="store_true", help="skip the bs=8 / bs=4 per-rank step block of the N=1 record")
+    ap.add_argument("--no-per-rank", action="store_true", help="skip the bs = 32 / 16 / 8 / 4 per-rank step block of the N=1 record")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE config 2 / 4 / 5 step block of the N=1 record")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host CPU work for cpu_baseline")
     ap.add_argument("--regions", type=str, default="both", choices=["weak", "strong", "both"],
                     help="N > 1: which timed regions run (weak = bs per rank, the headline; strong = the global batch split over the ranks). "
                          "`strong` alone is a functional / diagnostic run: `value` is then null")
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the separate per-dispatch-profiled pass (-1: min(steps, 10); 0: none)")
+    ap.add_argument("--full-out", type=str, default=os.path.join("gpurun_out", "bench_full.json"), help="where the FULL record goes (relative to the repo root)")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the stdout record: compact, strict JSON
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _clean(o, sig=6):
+    """Strict-JSON view of a record: floats rounded to `sig` significant digits, non-finite floats -> None, numpy scalars -> python."""
+    if isinstance(o, dict):
+        return {str(k): _clean(v, sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_clean(v, sig) for v in o]
+    if isinstance(o, (bool, type(None), str)):
+        return o
+    if isinstance(o, (int, np.integer)):
+        return int(o)
+    if isinstance(o, (float, np.floating)):
+        f = float(o)
+        if not math.isfinite(f):
+            return None
+        if f == 0.0:
+            return 0.0
+        return float(f"{f:.{sig}g}")
+    return str(o)
+
+
+def _refuse_constant(name):
+    raise ValueError(f"non-finite JSON constant {name!r}")
+
+
+def encode_line(rec, optional=()):
+    """The ONE stdout line: ASCII, < LINE_LIMIT bytes, no NaN / Infinity (as tokens or inside strings); keys named in `optional`
+    (dotted paths, least important first) are dropped one by one if the record would not fit."""
+    rec = _clean(rec)
+    optional = list(optional)
+    while True:
+        line = json.dumps(rec, allow_nan=False, ensure_ascii=True, separators=(",", ":"))
+        if len(line) < LINE_LIMIT or not optional:
+            break
+        path = optional.pop(0).split(".")
+        d = rec
+        for k in path[:-1]:
+            d = d.get(k) if isinstance(d, dict) else None
+            if d is None:
+                break
+        if isinstance(d, dict):
+            d.pop(path[-1], None)
+    if len(line) >= LINE_LIMIT:
+        raise RuntimeError(f"bench record is {len(line)} bytes (limit {LINE_LIMIT})")
+    if not line.isascii() or "NaN" in line or "Infinity" in line or "\n" in line:
+        raise RuntimeError("bench record is not a strict single-line ASCII JSON object")
+    json.loads(line, parse_constant=_refuse_constant)
+    return line
 
 
 def _tunable_entries() -> int:
@@ -72,7 +145,7 @@ def build_model(kind, dev):
     from roboticattack_amd.openvla_model import build_openvla, openvla_7b_cfg, tiny_cfg
 
     if kind == "openvla-7b":
-        return build_openvla(openvla_7b_cfg(), device=dev, dtype=torch.bfloat16, seed=0), "OpenVLA-7B shape (DINOv2-L/14 + SigLIP-so400m/14 + Llama-2-7B), random init"
+        return build_openvla(openvla_7b_cfg(), device=dev, dtype=torch.bfloat16, seed=0), "OpenVLA-7B shape, random init"
     if kind == "tiny":
         return build_openvla(tiny_cfg(), device=dev, dtype=torch.bfloat16, seed=0), "tiny topology-equal model (bf16)"
     from roboticattack_amd.surrogate import SurrogateVLA
@@ -80,6 +153,9 @@ def build_model(kind, dev):
     return SurrogateVLA(seed=0).to(dev), "fp32 surrogate"
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# cpu_baseline: the reference's CPU op sequence (oracle/ref_port.py) on the host cores — the ONLY place bench.py touches oracle/
+# ------------------------------------------------------------------------------------------------------------------------------------
 def _cpu_leg(threads, bs, patch_shape, budget_s, conn):
     """One leg of the CPU baseline in its own process (so that a thread count that thrashes can be stopped by the parent)."""
     import numpy as _np
@@ -139,13 +215,13 @@ def _cpu_leg(threads, bs, patch_shape, budget_s, conn):
 def cpu_baseline(bs, patch_shape, budget_s=25.0):
     """The reference's CPU path for the replaced ops (oracle/ref_port.py: per-image PyTorch op chain + autograd for K1/K2, HF-style CE +
     weighted_loss on fp32 logits [B,S,32064] + backward for K3, HF AdamW + clamp for K4), timed on this box's host cores with ONE thread
-    and with ALL logical cores: 2 warm-ups, then 5 timed iterations, min and median reported.
+    and with ALL logical cores: 2 warm-ups, then 5 timed iterations, min and median.
 
     Bounded: every leg times a slice of the per-rank batch whose size a 2-image probe picks so that 2 + 5 iterations fit the leg's
-    budget (one K3 iteration at bs=64 on one thread takes ~30 s) and scales linearly to bs; every leg runs in its own process under a
-    wall-clock guard, because torch.set_num_threads(256) thrashes on the reference's many tiny per-image ops (a single-image iteration
-    was seen to take seconds): a leg that exceeds its guard is reported as timed out. Hosts with more than 32 logical cores also get a
-    32-thread leg (the setting the CPU path ran best at in round 1)."""
+    budget and scales linearly to bs; every leg runs in its own process under a wall-clock guard, because torch.set_num_threads(256)
+    thrashes on the reference's many tiny per-image ops: a leg that exceeds its guard is reported as timed out. Hosts with more than 32
+    logical cores also get a 32-thread leg (the setting the CPU path ran best at in round 1).
+    Returns (compact object for the stdout line, full object with every leg)."""
     import multiprocessing as mp
 
     ncores = os.cpu_count() or 1
@@ -172,30 +248,33 @@ def cpu_baseline(bs, patch_shape, budget_s=25.0):
             p.join(5)
     ok = {k: v for k, v in legs.items() if "steps_per_s_min_time" in v}
     best = max(ok, key=lambda k: ok[k]["steps_per_s_min_time"]) if ok else None
-    S = ok[best]["logits_S"] if best else 0
-    return {
-        "value": ok[best]["steps_per_s_min_time"] if best else None, "unit": "patch-path steps/s on host CPU (K1+K2+K3+K4 only, model excluded)",
-        "cores": ok[best]["threads"] if best else 0, "kind": "port",
-        "sample": f"oracle/ref_port.py (PyTorch-CPU restatement of the reference op sequence), patch {patch_shape}, geometry=True, fp32 logits "
-                  f"[bs,{S},32064]; legs: 1 thread, all {ncores} logical cores" + (", 32 threads" if ncores > 32 else "") + "; per leg 2 warm-ups "
-                  f"then 5 timed iterations, min and median, on a slice of the bs={bs} batch sized by a 2-image probe (sample_bs_* in `legs`), "
-                  f"scaled linearly to bs={bs}; each leg in its own process under a wall-clock guard; value = the fastest leg's min",
-        "legs": legs, "host_logical_cores": ncores,
-    }
+    bl = ok[best] if best else {}
+    compact = {"value": bl.get("steps_per_s_min_time"), "unit": "patch-path steps/s (K1+K2+K3+K4 on host CPU, model excluded)",
+               "cores": bl.get("threads", 0), "kind": "port",
+               "sample": f"oracle/ref_port.py, slice of the bs={bs} batch sized by a 2-image probe (K1K2K4 {bl.get('sample_bs_K1_K2_K4')} img, "
+                         f"K3 {bl.get('sample_bs_K3')} img), scaled linearly to bs={bs}; best of {len(plan)} thread counts, min of 5",
+               "host_logical_cores": ncores, "ms_K1_K2_K4": bl.get("ms_K1_K2_K4_min"), "ms_K3": bl.get("ms_K3_min")}
+    full = dict(compact, legs=legs)
+    return compact, full
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# step runners: the product loops' own inner steps on synthetic frames resident in HBM
+# ------------------------------------------------------------------------------------------------------------------------------------
 class StepRunner:
     """One rank's attack-loop state for a per-rank batch of B images: the inner step of attack/uada_ddp.py — the SAME code
     (AttackBase.fused_ddp_step / model_loss) — on synthetic frames resident in HBM."""
 
-    def __init__(self, model, dev, B, patch_shape, rank, world):
+    name = "uada_ddp"
+
+    def __init__(self, model, dev, B, patch_shape, rank, world, geometry=True, maskidx=(0,)):
         from roboticattack_amd import dist as vdist
         from roboticattack_amd import ops, synthetic
         from roboticattack_amd.attack.engine import AttackBase
         from roboticattack_amd.labels import mask_labels
         from roboticattack_amd.optim import PatchOptimizer
 
-        self.ops, self.model, self.dev, self.B, self.world = ops, model, dev, B, world
+        self.ops, self.model, self.dev, self.B, self.world, self.geometry = ops, model, dev, B, world, bool(geometry)
         self.att = AttackBase(model, None, "", "adamW", False)  # K2' (SURVEY.md 8f-3) when the model exposes its patch-embed weights; VAA_FUSED_EMBED_GRAD=0: plain K2
         self.use_rows = self.att.use_rows
         self.tr = self.att.randomPatchTransform
@@ -204,7 +283,7 @@ class StepRunner:
         self.img = self.tr.stage_images(torch.from_numpy(self.batch["pixel_values"]))
         self.input_ids = self.batch["input_ids"].to(dev)
         self.attn = self.batch["attention_mask"].to(dev)
-        self.labels = mask_labels(self.batch["labels"].clone(), [0]).to(dev)
+        self.labels = mask_labels(self.batch["labels"].clone(), list(maskidx)).to(dev)
         torch.manual_seed(42)  # UADA_wrapper_ddp.py:53: every rank seeds 42
         patch = torch.rand(patch_shape).to(dev) if rank == 0 else torch.empty(patch_shape).to(dev)
         vdist.broadcast_patch(patch)
@@ -221,14 +300,14 @@ class StepRunner:
         self.opt.zero_grad()
         if self.fused and self.world == 1:
             # host draws -> K1 (tile-major) -> model -> K3 statistics -> backward -> K2' tiles + scatter -> epilogue incl. K4 (nothing to exchange)
-            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, True, 5.0, self.sync.buf, self.scal, optimizer=self.opt)
+            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, self.geometry, 5.0, self.sync.buf, self.scal, optimizer=self.opt)
             return
         if self.fused:
             # ... -> epilogue: the message is in sync.buf -> all-reduce -> K4
-            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, True, 5.0, self.sync.buf, self.scal)
+            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, self.geometry, 5.0, self.sync.buf, self.scal)
             g_sum, _ = self.sync.allreduce_packed()  # [grad | CE, MSE, UAD, total]: one all-reduce per step
         else:
-            pix = self.tr.apply_random_patch_batch(self.img, self.patch, mean=a.mean, std=a.std, geometry=True)  # host RNG draws + K1
+            pix = self.tr.apply_random_patch_batch(self.img, self.patch, mean=a.mean, std=a.std, geometry=self.geometry)  # host RNG draws + K1
             total, scalars, _ = a.model_loss(self.input_ids, self.attn, pix, self.labels, ops.LOSS_UADA_DDP, w=5.0)  # model + LM head + K3
             total.backward()  # ... -> K2 (or K2' fed by the patch-embed output gradients)
             g_sum, _ = self.sync.allreduce_step(self.patch.grad, scalars, self.pick)
@@ -236,10 +315,82 @@ class StepRunner:
         self.opt.step(grad=g_sum.view_as(self.patch), grad_scale=self.inv_world)  # K4
 
 
+class LoopRunner:
+    """The inner step of one of the single-GPU product loops — attack/uada.py (UADA.py:133-159), attack/tma.py (TMA.py:124-175),
+    attack/upa.py (UPA.py:127-159) — called through the loop's own `inner_step`, on synthetic frames resident in HBM (N=1)."""
+
+    def __init__(self, kind, model, dev, B, patch_shape, geometry=True, maskidx=None, resize_patch=False):
+        from roboticattack_amd import ops, synthetic
+        from roboticattack_amd.labels import mask_labels, tma_target_labels, tma_target_tokens
+        from roboticattack_amd.optim import PatchOptimizer
+
+        self.name, self.ops, self.model, self.dev, self.B, self.world, self.geometry = kind, ops, model, dev, B, 1, bool(geometry)
+        batch = synthetic.synth_batch(1234, B, "noise", as_pil=False)
+        self.batch = batch
+        labels = batch["labels"].clone()
+        l1 = 0.0
+        if kind == "uada":
+            from roboticattack_amd.attack.uada import OpenVLAAttacker
+
+            self.att = OpenVLAAttacker(model, None, "", "adamW", False)
+            self.maskidx = list(maskidx) if maskidx is not None else [0]
+            labels = mask_labels(labels, self.maskidx)
+            lr = 1e-3  # UADA_wrapper.py:93
+        elif kind == "tma":
+            from roboticattack_amd.attack.tma import OpenVLAAttacker
+
+            self.att = OpenVLAAttacker(model, None, "", "adamW", False)
+            self.maskidx = list(maskidx) if maskidx is not None else list(range(7))  # BASELINE config 4: a 7-DoF target vector
+            target = tma_target_tokens(np.zeros(7), self.maskidx, self.att.action_tokenizer)  # targetAction 0 (TMA_wrapper.py:123)
+            labels = tma_target_labels(labels, target)
+            lr = 2e-3  # TMA_wrapper.py:95
+        elif kind == "upa":
+            from roboticattack_amd.attack.upa import OpenVLAAttacker
+
+            self.att = OpenVLAAttacker(model, None, "", "adamW", bool(resize_patch), 0.8, 0.2)
+            self.maskidx = list(maskidx) if maskidx is not None else [0, 1, 2]
+            self.mode, self.scale = self.att._mode(False, True)  # reverse_direction=True (UPA_wrapper.py default): labels stay unmasked
+            lr, l1 = 2e-3, 1e-3  # UPA_wrapper.py:96, UPA.py:157
+        else:
+            raise ValueError(kind)
+        self.use_rows = self.att.use_rows
+        self.tr = self.att.randomPatchTransform
+        self.img = self.tr.stage_images(torch.from_numpy(batch["pixel_values"]))
+        self.input_ids, self.attn, self.labels = batch["input_ids"].to(dev), batch["attention_mask"].to(dev), labels.to(dev)
+        torch.manual_seed(42)
+        self.patch = torch.rand(patch_shape).to(dev).requires_grad_(True)
+        self.opt = PatchOptimizer(self.patch, lr, "adamW", l1_clip=l1)
+        self.scal10 = torch.zeros((1, 10), dtype=torch.float32, device=dev)
+        self.R = int((self.labels[:, 1:] != -100).sum())
+        self.sync = None
+
+    @property
+    def scal(self):
+        return self.scal10[0, :8]
+
+    def step(self):
+        a = self.att
+        if self.name == "uada":
+            a.inner_step(self.patch, self.opt, self.img, self.input_ids, self.attn, self.labels, self.geometry, self.scal10, 0)
+        elif self.name == "tma":
+            a.inner_step(self.patch, self.opt, self.img, self.input_ids, self.attn, self.labels, self.geometry, False, self.scal10, 0)
+        else:
+            a.inner_step(self.patch, self.opt, self.img, self.input_ids, self.attn, self.labels, self.geometry, self.mode, self.scale, self.scal10, 0)
+
+
+def make_runner(kind, model, dev, B, patch_shape, rank, world, geometry=True, maskidx=None, resize_patch=False):
+    if kind == "uada_ddp":
+        return StepRunner(model, dev, B, patch_shape, rank, world, geometry=geometry, maskidx=maskidx if maskidx is not None else (0,))
+    if world != 1:
+        raise SystemExit("--attack uada / tma / upa are single-GPU loops of the reference (N=1 diagnostics); N > 1 runs the data-parallel UADA step")
+    return LoopRunner(kind, model, dev, B, patch_shape, geometry=geometry, maskidx=maskidx, resize_patch=resize_patch)
+
+
 def comm_summary(recs, world, steps, dt, dev):
-    """In-step cost of the gradient exchange from the per-call event brackets of PatchGradSync (one all-reduce per step): rank 0's own figures
-    plus min / max over ranks of the per-rank means — the rank that reaches the collective LAST sees the exchange alone, the others also wait
-    for it (skew), so min ~ hand-off + exchange latency and max - min ~ rank skew."""
+    """In-step cost of the gradient exchange from the per-call event brackets of PatchGradSync (one all-reduce per step; events on the launch
+    stream around dist.all_reduce of the [grad | 4 scalars] message, 30,016 B at 50x50): rank 0's own figures plus min / max over ranks of
+    the per-rank means — the rank that reaches the collective LAST sees the exchange alone, the others also wait for it (skew), so
+    min ~ hand-off + exchange latency (comm_frac = min / step time) and max - min ~ rank skew (comm_plus_skew_frac = max / step time)."""
     import torch.distributed as dist
 
     if world == 1 or not recs:
@@ -252,10 +403,7 @@ def comm_summary(recs, world, steps, dt, dev):
     step_us = dt / steps * 1e6
     return {"calls_per_step": len(recs) / steps, "mean_us_rank0": float(ev.mean()), "median_us_rank0": float(np.median(ev)), "max_us_rank0": float(ev.max()),
             "host_us_rank0": float(host.mean()), "mean_us_min_over_ranks": mean_min, "mean_us_max_over_ranks": mean_max, "max_us_any_rank": single_max,
-            "comm_frac": mean_min / step_us, "comm_plus_skew_frac": mean_max / step_us,
-            "note": "events on the launch stream around dist.all_reduce of the [grad | 4 scalars] message (30,016 B at 50x50), every timed step; "
-                    "comm_frac = min-over-ranks mean / step time (the exchange itself on the critical path), comm_plus_skew_frac = max-over-ranks mean / step time "
-                    "(adds the wait for the slowest rank's message)"}
+            "comm_frac": mean_min / step_us, "comm_plus_skew_frac": mean_max / step_us}
 
 
 def allreduce_back_to_back(sync, world, n=50):
@@ -277,7 +425,7 @@ def allreduce_back_to_back(sync, world, n=50):
     e1.record()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / n * 1e6
-    sync.buf.zero_()  # n sums of a non-zero message can overflow to inf; the next step rewrites the buffer anyway
+    sync.buf.zero_()  # n sums of a non-zero message can overflow; the next step rewrites the buffer anyway
     return {"calls": n, "event_us_per_call": e0.elapsed_time(e1) * 1e3 / n, "wall_us_per_call": wall, "bytes": int(sync.buf.numel() * 4)}
 
 
@@ -316,9 +464,27 @@ def timed_steps(runner, steps, warmup, world, dev, profile=False, comm=False):
 
 
 # kernel name (substring of the launch site's name) -> operator of the hot path
-KERNEL_OPS = (("patch_apply_fwd_kernel", "K1"), ("patch_apply_tiles_kernel", "K1"), ("embed_dgrad_tiles", "K2e"), ("patch_grad_scatter_kernel", "K2"), ("patch_grad_reduce_kernel", "K2"),
-              ("head_stats_kernel", "K3h"), ("head_finish_kernel", "K3h"), ("rows_stats_kernel", "K3"), ("rows_finish_kernel", "K3"), ("loss_stats_kernel", "K3"), ("loss_grad_kernel", "K3"), ("step_epilogue_kernel", "EPI"), ("patch_update_kernel", "K4"),
-              ("patch_resize", "K0"))
+KERNEL_OPS = (("patch_apply_fwd_kernel", "K1"), ("patch_apply_tiles_kernel", "K1"), ("patch_apply", "K1"), ("embed_dgrad", "K2e"), ("patch_grad_scatter", "K2"), ("patch_grad_reduce", "K2"),
+              ("patch_grad", "K2"), ("head_stats_kernel", "K3h"), ("head_finish_kernel", "K3h"), ("rows_stats_kernel", "K3"), ("rows_finish_kernel", "K3"), ("rows_", "K3"),
+              ("loss_stats_kernel", "K3"), ("loss_grad_kernel", "K3"), ("loss_", "K3"), ("step_epilogue_kernel", "EPI"), ("patch_update_kernel", "K4"), ("patch_resize", "K0"), ("resize", "K0"))
+
+
+def op_of(name):
+    return next((o for sub, o in KERNEL_OPS if sub in name), "other")
+
+
+def kernel_table(recs, psteps):
+    """per-kernel durations of a per-dispatch-profiled pass: every dispatch's own begin/end timestamps (vaa_prof_*)"""
+    per = {}
+    for name, us in recs:
+        per.setdefault(name, []).append(us)
+    kern, op_us = {}, {}
+    for name, ts in per.items():
+        t = np.asarray(ts)
+        kern[name] = {"op": op_of(name), "launches": len(ts), "launches_per_step": len(ts) / psteps, "mean_us": float(t.mean()), "median_us": float(np.median(t)),
+                      "min_us": float(t.min()), "max_us": float(t.max()), "us_per_step": float(t.sum()) / psteps}
+        op_us[kern[name]["op"]] = op_us.get(kern[name]["op"], 0.0) + float(t.sum()) / psteps
+    return kern, op_us
 
 
 def self_launch(args):
@@ -341,6 +507,128 @@ def self_launch(args):
     os.execvpe(cmd[0], cmd, env)
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# N=1 blocks beside the headline
+# ------------------------------------------------------------------------------------------------------------------------------------
+def head_bytes(cfg):
+    return 2 * 32064 * cfg.llm_dim if cfg is not None and hasattr(cfg, "llm_dim") else None
+
+
+def per_rank_block(model, dev, B, patch_shape, steps, ips_ref):
+    """The per-rank step of the strong-scaling configs on ONE GPU: what each of 2 / 4 / 8 ranks runs in config 3 (bs = 32 / 16 / 8; config 4:
+    32 over 4 -> 8) and config 5 (32 over 8 -> 4). projected speedup = ranks x images/s at that batch / images/s at bs=B, i.e. the
+    strong-scaling ceiling before the 30 KB all-reduce."""
+    from roboticattack_amd.benchmarks import HBM_PEAK_GBS
+
+    out = {}
+    hb = head_bytes(getattr(model, "cfg", None))
+    for b in (32, 16, 8, 4):
+        if b >= B:
+            continue
+        torch.cuda.empty_cache()
+        rb = StepRunner(model, dev, b, patch_shape, 0, 1)
+        n_b = max(steps, 10) if b <= 8 else max(steps // 2, 6)
+        dt_b, enq_b, cpu_b, _, _ = timed_steps(rb, n_b, 3, 1, dev)  # un-profiled, like the headline it is compared with
+        n_p = min(n_b, 5)
+        _, _, _, recs_b, _ = timed_steps(rb, n_p, 0, 1, dev, profile=True)
+        kern_b, hot_b = kernel_table(recs_b, n_p)
+        e = {"ms_per_step": dt_b / n_b * 1e3, "images_per_s": b * n_b / dt_b, "images_per_s_vs_bs%d" % B: (b * n_b / dt_b) / ips_ref,
+             "projected_speedup_%d_ranks_before_comm" % (B // b): (B // b) * (b * n_b / dt_b) / ips_ref,
+             "host_cpu_ms_per_step": cpu_b * 1e3, "host_enqueue_ms_per_step": enq_b * 1e3, "labelled_rows": rb.R,
+             "hot_path_us_per_step": sum(hot_b.values()), "hot_path_ops_us": hot_b}
+        hk = next((k for n, k in kern_b.items() if "head_stats_kernel" in n), None)
+        if hk and hb:  # the fused LM head (a 263 MB weight stream at the 7B shape): in-step duration and HBM rate
+            e["fused_head"] = {"kernel": "head_stats_kernel", "mean_us": hk["mean_us"], "algo_bytes": hb, "achieved_GBs": hb / hk["mean_us"] / 1e3,
+                               "frac": hb / hk["mean_us"] / 1e3 / HBM_PEAK_GBS}
+        out[f"bs{b}"] = e
+        del rb
+    return out
+
+
+CONFIG_STEPS = (
+    # tag, loop, per-rank batch, patch, geometry, resize_patch, what BASELINE.json calls it
+    ("cfg2", "uada", 16, [3, 50, 50], False, False, "UADA single-GPU: bs=16, geometry=False, loss = MSE + 1/CE (UADA.py:133-159)"),
+    ("cfg4", "tma", 8, [3, 50, 50], True, False, "TMA per-rank step: bs=8 (32 over 4 GPUs), 7-DoF target, CE gradient (TMA.py:124-175)"),
+    ("cfg5", "upa", 4, [3, 100, 100], True, True, "UPA per-rank step: bs=4 (32 over 8 GPUs), resize_patch 3x100x100 (UPA.py:127-159)"),
+)
+
+
+def config_block(model, dev, steps):
+    """The inner steps of BASELINE configs 2 / 4 / 5 at their per-rank shapes through the product loops' own `inner_step`: ms per step
+    (un-profiled), then the hand-written launches of the step per dispatch (per kernel and per operator) and the dominant hand-written
+    kernel (most algorithmic bytes) with its HBM fraction."""
+    out = {}
+    for tag, kind, b, pshape, geo, resize, what in CONFIG_STEPS:
+        torch.cuda.empty_cache()
+        r = LoopRunner(kind, model, dev, b, pshape, geometry=geo, resize_patch=resize)
+        n = max(steps, 10)
+        dt, enq, cpu, _, _ = timed_steps(r, n, 3, 1, dev)
+        n_p = 5
+        _, _, _, recs, _ = timed_steps(r, n_p, 0, 1, dev, profile=True)
+        kern, op_us = kernel_table(recs, n_p)
+        e = {"what": what, "loop": kind, "bs": b, "patch": pshape, "geometry": geo, "resize_patch": resize, "labelled_rows": r.R,
+             "ms_per_step": dt / n * 1e3, "steps_per_s": n / dt, "images_per_s": b * n / dt, "host_cpu_ms_per_step": cpu * 1e3,
+             "hot_path_us_per_step": sum(op_us.values()), "hot_path_launches_per_step": sum(k["launches_per_step"] for k in kern.values()),
+             "hot_path_ops_us": op_us, "kernels": kern, "loss_finite": bool(torch.isfinite(r.scal).all())}
+        e["dominant"] = dominant_kernel(kern, model, r, b, pshape)
+        out[tag] = e
+        del r
+    return out
+
+
+def kernel_bytes(name, model, runner, B, pshape):
+    """Algorithmic bytes per launch of a hand-written kernel of the step, by its launch-site name (None: a latency-bound helper)."""
+    from roboticattack_amd.benchmarks import algo_bytes
+
+    cfg = getattr(model, "cfg", None)
+    R = runner.R
+    ph, pw = pshape[1], pshape[2]
+    if getattr(runner, "tr", None) is not None and runner.tr.resize_patch and runner.tr.last_sizes is not None:
+        ph, pw = [int(v) for v in np.asarray(runner.tr.last_sizes).mean(axis=0)]  # per-image sizes: the mean footprint of the last draw
+    width = (cfg.dino.dim + cfg.siglip.dim) if cfg is not None and hasattr(cfg, "dino") else 1024 + 1152
+    if "patch_apply" in name:
+        return algo_bytes("K1", B, ph, pw)
+    if "head_stats_kernel" in name and head_bytes(cfg):
+        return head_bytes(cfg) + 2 * R * cfg.llm_dim
+    if "embed_dgrad" in name or ("patch_grad_scatter" in name and getattr(runner.tr, "embed_with", None) is not None):
+        return algo_bytes("K2e", B, ph, pw, embed_width=width)  # the op's bytes: quoted on the tile GEMM, its scatter moves the tile gradients again
+    if "patch_grad" in name:
+        return algo_bytes("K2", B, ph, pw)
+    if "rows_stats_kernel" in name or "rows_finish_kernel" in name or "loss_stats_kernel" in name or "loss_grad_kernel" in name:
+        esz = 2 if cfg is not None else 4
+        if runner.name in ("uada", "tma"):  # CE gradient over every logit of the labelled rows: the statistics pass reads them, the finish pass reads + writes
+            return algo_bytes("K3", B, rows=R, esize=esz) * (0.5 if "stats" in name else 1.0)
+        return algo_bytes("K3_slice", B, rows=R, esize=esz) if "stats" in name else None
+    return None
+
+
+def dominant_kernel(kern, model, runner, B, pshape):
+    from roboticattack_amd.benchmarks import HBM_PEAK_GBS
+
+    best = None
+    for name, k in kern.items():
+        nb = kernel_bytes(name, model, runner, B, pshape)
+        if nb and (best is None or nb > best["algo_bytes"]):
+            best = {"kernel": name.strip("() "), "op": k["op"], "mean_us": k["mean_us"], "algo_bytes": int(nb), "achieved_GBs": nb / k["mean_us"] / 1e3,
+                    "frac": nb / k["mean_us"] / 1e3 / HBM_PEAK_GBS, "launches_per_step": k["launches_per_step"]}
+    return best
+
+
+def write_full(path, full):
+    """the FULL record -> a JSON file (strict JSON too); returns the repo-relative path or None when it cannot be written"""
+    p = path if os.path.isabs(path) else os.path.join(ROOT, path)
+    try:
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            json.dump(_clean(full, sig=8), f, allow_nan=False, indent=1)
+            f.write("\n")
+        print(f"bench.py: full record -> {p}", file=sys.stderr)
+        return os.path.relpath(p, ROOT)
+    except OSError as e:
+        print(f"bench.py: could not write the full record to {p}: {e}", file=sys.stderr)
+        return None
+
+
 def main():
     t_main = time.perf_counter()
     args = parse()
@@ -351,12 +639,12 @@ def main():
     sys.stdout.flush()
     stdout_fd = os.dup(1)
     os.dup2(2, 1)
-    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     import torch.distributed as dist
 
     from roboticattack_amd import dist as vdist
     from roboticattack_amd import ops
-    from roboticattack_amd.benchmarks import HBM_PEAK_GBS, algo_bytes, k2_sweep, kernel_suite
+    from roboticattack_amd.benchmarks import HBM_PEAK_GBS, k2_sweep, kernel_suite
 
     ops.device_check()
     dev = vdist.local_device()
@@ -369,9 +657,12 @@ def main():
 
     patch_shape = [int(v) for v in args.patch.split(",")]
     B = args.bs
+    geometry = args.geometry == "true"
+    maskidx = [int(v) for v in args.maskidx.split(",")] if args.maskidx else None
     model, model_desc = build_model(args.model, dev)
-    runner = StepRunner(model, dev, B, patch_shape, rank, world)
+    runner = make_runner(args.attack, model, dev, B, patch_shape, rank, world, geometry=geometry, maskidx=maskidx, resize_patch=args.resize_patch)
     use_rows, tr, R = runner.use_rows, runner.tr, runner.R
+    headline = args.attack == "uada_ddp"
 
     # PCIe leg, outside the timed region: staging the batch's frames (host list of uint8 HWC arrays -> HBM), done once per
     # OUTER iteration by the attack loops; the reference re-does ToTensor + H2D for every image on every inner step.
@@ -408,7 +699,7 @@ def main():
     if run_strong:
         bs_s = max(1, B // world)
         torch.cuda.empty_cache()  # the weak region's cached activation blocks are not needed any more (ranks that share a GPU in test mode are near its capacity)
-        r_s = StepRunner(model, dev, bs_s, patch_shape, rank, world)
+        r_s = StepRunner(model, dev, bs_s, patch_shape, rank, world, geometry=geometry)
         dt_s, enq_s, cpu_s, _, crecs_s = timed_steps(r_s, args.steps, args.warmup, world, dev, comm=True)
         comm_s = comm_summary(crecs_s, world, args.steps, dt_s, dev)
         fin_s = torch.tensor([1.0 if bool(torch.isfinite(r_s.scal).all()) else 0.0], device=dev)
@@ -418,13 +709,9 @@ def main():
         strong = {"per_rank_bs": bs_s, "global_batch": bs_s * world, "ms_per_step": dt_s / args.steps * 1e3, "steps_per_s": args.steps / dt_s,
                   "images_per_s": bs_s * world * args.steps / dt_s, "host_cpu_ms_per_step": cpu_s * 1e3, "host_enqueue_ms_per_step": enq_s * 1e3,
                   "loss_finite_all_ranks": bool(fin_s.item() > 0.5), "peak_mem_GiB_max_over_ranks": float(mem_s.item()),
-                  "allreduce_us_per_step": comm_s, "comm_frac": comm_s["comm_frac"] if comm_s else None,
-                  "note": "global batch fixed at the N=1 workload's bs, split evenly over the ranks (BASELINE config 3); timed like the weak region: "
-                          "W warm-up steps, K steps between barrier + synchronize, max over ranks; un-profiled"}
-        if run_weak:
+                  "allreduce_us_per_step": comm_s, "comm_frac": comm_s["comm_frac"] if comm_s else None}
+        if run_weak:  # images/s of the split global batch over ALL ranks / images/s of ONE rank's bs=B step in this same run
             strong["speedup_vs_one_rank_weak_step"] = (bs_s * world * args.steps / dt_s) / (B * args.steps / dt)
-            strong["speedup_note"] = ("images/s of the split global batch over ALL ranks / images/s of ONE rank's bs=%d step in this same run (the weak region's "
-                                      "per-rank rate): the strong-scaling speedup 1 -> %d ranks measured inside one job" % (B, world))
         del r_s
     # every rank's hipBLASLt / rocBLAS selections (a rank that lost them runs ~6 % slower and drags the synchronous step): min over ranks
     tun = _tunable_entries()
@@ -433,176 +720,99 @@ def main():
         tt = torch.tensor([float(tun)], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MIN)
         tun_min = int(tt.item())
-
-    # ---- the per-rank step of the strong-scaling configs on ONE GPU (N=1 only): what each of 8 ranks runs in configs 3/4 (bs=8) and 5 (bs=4) ----
-    per_rank = None
-    if world == 1 and not args.no_per_rank and args.model == "openvla-7b":
-        per_rank = {}
-        cfg_m = getattr(model, "cfg", None)
-        ips64 = B * args.steps / dt
-        for b in (32, 16, 8, 4):
-            torch.cuda.empty_cache()
-            rb = StepRunner(model, dev, b, patch_shape, rank, world)
-            n_b = max(args.steps, 10) if b <= 8 else max(args.steps // 2, 6)
-            dt_b, enq_b, cpu_b, _, _ = timed_steps(rb, n_b, 3, world, dev)  # un-profiled, like the headline it is compared with
-            n_p = min(n_b, 5)
-            _, _, _, recs_b, _ = timed_steps(rb, n_p, 0, world, dev, profile=True)
-            hot_b = {}
-            for name, us in recs_b:  # the hand-written launches of the step at this batch, per dispatch (vaa_prof_*)
-                op = next((o for sub, o in KERNEL_OPS if sub in name), "other")
-                hot_b[op] = hot_b.get(op, 0.0) + us / n_p
-            head_us = [us for name, us in recs_b if "head_stats_kernel" in name]
-            per_rank[f"bs{b}"] = {"ms_per_step": dt_b / n_b * 1e3, "images_per_s": b * n_b / dt_b, "images_per_s_vs_bs%d" % B: (b * n_b / dt_b) / ips64,
-                                  "projected_speedup_%d_ranks_before_comm" % (B // b): (B // b) * (b * n_b / dt_b) / ips64,
-                                  "host_cpu_ms_per_step": cpu_b * 1e3, "host_enqueue_ms_per_step": enq_b * 1e3, "labelled_rows": rb.R,
-                                  "hot_path_us_per_step": sum(hot_b.values()), "hot_path_ops_us": hot_b}
-            if head_us and cfg_m is not None:  # the fused LM head (a 263 MB weight stream at the 7B shape): in-step duration and HBM rate
-                hb = 2 * 32064 * cfg_m.llm_dim
-                per_rank[f"bs{b}"]["fused_head"] = {"kernel": "head_stats_kernel", "mean_us": float(np.mean(head_us)), "algo_bytes": hb,
-                                                    "achieved_GBs": hb / float(np.mean(head_us)) / 1e3, "frac": hb / float(np.mean(head_us)) / 1e3 / HBM_PEAK_GBS}
-            del rb
-        per_rank["note"] = ("full-model step (same code path as the timed region) at the per-rank batches of the strong-scaling runs — global 64 over 2 / 4 / 8 "
-                            "ranks -> bs = 32 / 16 / 8 (BASELINE config 3; config 4: 32 over 4 -> 8), config 5: 32 over 8 -> bs=4 — on this one GPU; projected "
-                            "speedup = ranks x images/s at that batch / images/s at bs=%d, i.e. the strong-scaling ceiling before the 30 KB all-reduce" % B)
-
+        # N > 1 is the two timed regions and nothing else: the collectives are over, every rank leaves the group now (UADA_ddp.py:214-221)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
         return
 
-    # ---- per-kernel durations inside the timed region: every dispatch's own begin/end timestamps (vaa_prof_*) ----
-    per = {}
-    for name, us in recs:
-        per.setdefault(name, []).append(us)
-    esz = 2 if use_rows and args.model == "openvla-7b" else 4
-    cfg = getattr(model, "cfg", None)
-    embed_width = (cfg.dino.dim + cfg.siglip.dim) if cfg is not None and hasattr(cfg, "dino") else 1024 + 1152  # K2': dY row width of both towers
-    kern, op_us = {}, {}
-    for name, ts in per.items():
-        op = next((o for sub, o in KERNEL_OPS if sub in name), "other")
-        t = np.asarray(ts)
-        kern[name] = {"op": op, "launches": len(ts), "launches_per_step": len(ts) / psteps, "mean_us": float(t.mean()), "median_us": float(np.median(t)),
-                      "min_us": float(t.min()), "max_us": float(t.max())}
-        op_us[op] = op_us.get(op, 0.0) + float(t.sum()) / psteps
-    fused = tr.embed_with is not None
-    if fused and "K2" in op_us:  # the TILED scatter + reduce belong to K2'
+    # ---- N=1 only: the per-rank steps of the strong-scaling configs and the inner steps of BASELINE configs 2 / 4 / 5 ----
+    per_rank = cfg_steps = None
+    if world == 1 and headline:
+        if not args.no_per_rank:
+            per_rank = per_rank_block(model, dev, B, patch_shape, args.steps, B * args.steps / dt)
+        if not args.no_configs:
+            cfg_steps = config_block(model, dev, args.steps)
+
+    # ---- per-kernel durations inside the step: every dispatch's own begin/end timestamps (vaa_prof_*) ----
+    kern, op_us = kernel_table(recs, max(psteps, 1))
+    fused_embed = tr.embed_with is not None
+    if fused_embed and "K2" in op_us:  # the TILED scatter + reduce belong to K2'
         op_us["K2e"] = op_us.get("K2e", 0.0) + op_us.pop("K2")
-    op_bytes = {"K1": algo_bytes("K1", B, patch_shape[1], patch_shape[2]), "K2": algo_bytes("K2", B, patch_shape[1], patch_shape[2]),
-                "K2e": algo_bytes("K2e", B, patch_shape[1], patch_shape[2], embed_width=embed_width),
-                "K3": algo_bytes("K3_slice" if use_rows else "K3", B, rows=R, esize=esz), "K4": algo_bytes("K4", B, patch_shape[1], patch_shape[2])}
-    if "K3h" in op_us and cfg is not None and hasattr(cfg, "llm_dim"):  # LM head fused with K3's statistics: the head weight streamed once + the hidden rows
-        op_bytes["K3h"] = 2 * 32064 * cfg.llm_dim + 2 * R * cfg.llm_dim
-    hot_ops = {o: {"us_per_step": u, "algo_bytes": op_bytes.get(o), "achieved_GBs": (op_bytes[o] / u / 1e3 if o in op_bytes else None),
-                   "frac": (op_bytes[o] / u / 1e3 / HBM_PEAK_GBS if o in op_bytes else None)} for o, u in op_us.items()}
-    k1name = next((n for n in kern if "patch_apply_tiles_kernel" in n or "patch_apply_fwd_kernel" in n), None)
-    hname = next((n for n in kern if "head_stats_kernel" in n), None)
-    tfile = next((f for f in ("profiles/traffic_r04.json", "profiles/traffic_r03.json", "profiles/traffic_r02.json") if os.path.exists(os.path.join(ROOT, f))), None)
+    tfile = next((f for f in ("profiles/traffic_r05.json", "profiles/traffic_r04.json", "profiles/traffic_r03.json") if os.path.exists(os.path.join(ROOT, f))), None)
     tr_all = json.load(open(os.path.join(ROOT, tfile))) if tfile else {}
     tr_ops = tr_all.get("ops", {})
 
     def roofline_of(kname, label, nb, traffic):
-        """the contract's roofline object for ONE hand-written kernel of the timed region (HBM-bound byte work)"""
+        """the contract's roofline object for ONE hand-written kernel of the timed region (HBM-bound byte work), in-step per dispatch"""
         k = kern[kname]
-        r = {"kernel": f"{kname} ({label})", "bound": "hbm", "achieved": nb / k["mean_us"] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": nb / k["mean_us"] / 1e3 / HBM_PEAK_GBS, "mean_us": k["mean_us"], "min_us": k["min_us"], "samples": k["launches"],
-             "algo_bytes": nb, "traffic": traffic,
-             "traffic_source": (tfile or "none") + " (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated on a 512 MiB copy in the same passes; not re-measured by this run)",
-             "timing": "IN-STEP, per dispatch: after the (un-profiled) timed region the same steps run once more with the library's per-dispatch timer armed — "
-                       "every launch of the library goes through hipExtLaunchKernel with its own start/stop event pair, which the runtime binds to that dispatch's "
-                       "begin/end timestamps, the quantity rocprofv3 --kernel-trace reports (profiles/r04_bench_kernel_stats.csv is the rocprofv3 summary of "
-                       "the same command); mean over all launches of that pass, no marker brackets, no subtraction"}
-        # builder-side cross reference (NOT measured by this run): rocprofv3's average for the same kernel in the committed summary of the same command
-        ref = os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv")
-        if os.path.exists(ref):
-            import csv
+        return {"kernel": f"{kname.strip('() ')} ({label})", "bound": "hbm", "achieved": nb / k["mean_us"] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": nb / k["mean_us"] / 1e3 / HBM_PEAK_GBS, "mean_us": k["mean_us"], "min_us": k["min_us"], "samples": k["launches"],
+                "algo_bytes": int(nb), "traffic": traffic}
 
-            for row in csv.DictReader(open(ref)):
-                if kname.strip("() ").split("(")[0] in row["Name"]:  # ("(head_stats_kernel<4>)" / "patch_apply_tiles_kernel": the launch site's spelling)
-                    us = float(row["AverageNs"]) * 1e-3
-                    r["rocprofv3_reference"] = {"file": "profiles/r04_bench_kernel_stats.csv", "calls": int(row["Calls"]), "mean_us": us,
-                                                "frac": nb / us / 1e3 / HBM_PEAK_GBS,
-                                                "note": "committed rocprofv3 --kernel-trace --stats summary of `bench.py --steps 20 --warmup 3 --no-cpu-baseline "
-                                                        "--no-kernel-suite --no-per-rank`; the per-dispatch events of an un-profiled run read 0.3-1.8 us above it "
-                                                        "(they include the dispatch's start-up after the preceding command), so the line's frac is the lower one"}
-                    break
-        return r
-
-    # the dominant kernel = the hand-written kernel of the timed region with the most algorithmic bytes (and, at the 7B shape, the longest): the
-    # LM head fused with K3's statistics when the step runs it (263 MB weight stream), else K1; the other one is reported beside it
+    # the dominant kernel = the hand-written kernel the timed region actually ran with the most algorithmic bytes (and, at the 7B shape, the
+    # longest): the LM head fused with K3's statistics when the step dispatches it (263 MB weight stream), else K1; K1 is reported beside it
     roofline = roofline_k1 = roofline_head = None
+    k1name = next((n for n in kern if "patch_apply" in n), None)
+    hname = next((n for n in kern if "head_stats_kernel" in n), None)
     if k1name:
-        roofline_k1 = roofline_of(k1name, "K1", op_bytes["K1"],
-                                  tr_ops.get("K1t_patch_apply_fwd_tiles" if "tiles" in k1name else "K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch"))
-    if hname and "K3h" in op_bytes:
+        roofline_k1 = roofline_of(k1name, "K1", kernel_bytes(k1name, model, runner, B, patch_shape),
+                                  tr_ops.get("K1t_patch_apply_fwd_tiles" if "tiles" in k1name else "K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch")
+                                  if (B == 64 and patch_shape == [3, 50, 50]) else None)
+    if hname and kernel_bytes(hname, model, runner, B, patch_shape):
         t_head = next((v.get("hbm_bytes_per_launch") for kk, v in tr_all.items() if "head_stats_kernel" in kk and isinstance(v, dict)), None)
         if R != 128 or args.model != "openvla-7b":
             t_head = None  # the committed PMC passes ran the 7B head at 128 rows
-        roofline_head = roofline_of(hname, "K3h: LM head + K3 statistics, one pass over the head weight", op_bytes["K3h"], t_head)
+        roofline_head = roofline_of(hname, "K3h", kernel_bytes(hname, model, runner, B, patch_shape), t_head)
     roofline = max((r for r in (roofline_k1, roofline_head) if r), key=lambda r: r["algo_bytes"], default=None)
-    if roofline:
-        by = {o: b for o, b in op_bytes.items() if o in op_us and b}
-        roofline["note"] = ("dominant = the hand-written kernel of the timed region with the most algorithmic bytes (%.1f of ~%.0f MB per step); every hand-written "
-                            "kernel of the timed region is listed in roofline_kernels, per-operator sums in hot_path_ops, K1 in roofline_k1"
-                            % (roofline["algo_bytes"] / 1e6, sum(by.values()) / 1e6))
 
-    extra = {"host_enqueue_ms_per_step": host_enqueue * 1e3 if run_weak else None, "host_cpu_ms_per_step": host_cpu * 1e3 if run_weak else None,
-             "host_overhead_note": "host_cpu = CPU time of the launching thread per step (python + HIP launches): what N ranks on one host need N times in parallel; "
-                                   "host_enqueue = wall time inside step() without an explicit sync (it also contains waits on a full launch queue / staged H2D copies, "
-                                   "so it scales with the GPU work); the step is GPU-bound while ms_per_step exceeds host_cpu",
-             "hot_path_us_per_step": sum(op_us.values()), "hot_path_launches_per_step": sum(k["launches_per_step"] for k in kern.values())}
-    if not args.no_kernel_suite:
+    extra_full = {}
+    k2_fracs = k1_standalone = copy_bw = None
+    if not args.no_kernel_suite and world == 1:
         del runner, model, tr  # the transform holds the model (embed_with)
         torch.cuda.empty_cache()
         from roboticattack_amd.benchmarks import device_copy_bandwidth, k1_sweep, rank_shapes
 
         copy_bw = device_copy_bandwidth(device=str(dev))
-        extra["measured_device_copy_GBs"] = copy_bw
-        extra["roofline_kernels_standalone"] = kernel_suite(B, patch_shape[1], patch_shape[2], device=str(dev))
-        for v in extra["roofline_kernels_standalone"].values():
+        ks = kernel_suite(B, patch_shape[1], patch_shape[2], device=str(dev))
+        for v in ks.values():
             v["frac_of_measured_copy_bw"] = v["achieved_GBs"] / copy_bw
-        extra["k2_sweep"] = k2_sweep(device=str(dev))
-        extra["k1_sweep"] = k1_sweep(device=str(dev))
-        extra["rank_shapes"] = rank_shapes(device=str(dev))
-        ks = extra["roofline_kernels_standalone"]
-        used_k2 = "K2e_patch_embed_grad_gather" if fused else "K2_patch_grad_gather"
-        gpu_ops_s = sum(v["mean_us"] for k, v in ks.items() if (not k.startswith("K2") or k == used_k2) and k not in ("K3_full_rows_fwd_bwd", "K3_full_one_launch_optin", "K3h_head_loss_rows_stats", "K3h_gemm_path_for_comparison")) * 1e-6
-        extra["gpu_patch_path_steps_per_s"] = 1.0 / gpu_ops_s
-        # the same kernels launched back to back (hipGraph replays of 10 launches between two events, same process) next to the in-step figures
-        for r, key in ((roofline_k1, "K1_patch_apply_fwd"), (roofline_head, "K3h_head_loss_rows_stats")):
-            if r and key in ks:
-                k = ks[key]
-                r.update({"measured_device_copy_GBs": copy_bw, "standalone_mean_us": k["mean_us"], "standalone_achieved": k["achieved_GBs"],
-                          "standalone_frac": k["achieved_GBs"] / HBM_PEAK_GBS, "frac_of_measured_copy_bw": r["achieved"] / copy_bw,
-                          "standalone_frac_of_measured_copy_bw": k["achieved_GBs"] / copy_bw})
-    cpu = None
+        k2s = k2_sweep(device=str(dev))
+        extra_full.update({"measured_device_copy_GBs": copy_bw, "roofline_kernels_standalone": ks, "k2_sweep": k2s, "k1_sweep": k1_sweep(device=str(dev)),
+                           "rank_shapes": rank_shapes(device=str(dev))})
+        k2_fracs = [e["frac_of_8TBs"] for e in k2s]
+        k1_standalone = ks.get("K1t_patch_apply_fwd_tiles", ks.get("K1_patch_apply_fwd", {})).get("achieved_GBs")
+    cpu_c = cpu_f = None
     if not args.no_cpu_baseline and world == 1:  # host-CPU leg only at N=1 (rank 0), as the bench contract asks
-        cpu = cpu_baseline(B, patch_shape, args.cpu_budget)
+        cpu_c, cpu_f = cpu_baseline(B, patch_shape, args.cpu_budget)
 
-    env_rec = {k: v for k, v in sorted(os.environ.items())
-               if k.startswith(("NCCL_", "RCCL_", "HSA_", "VAA_", "TORCH_NCCL", "PYTORCH_TUNABLEOP", "HIP_VISIBLE", "ROCR_VISIBLE", "CUDA_VISIBLE", "GPU_MAX_HW_QUEUES"))}
-    config = {"workload": f"UADA_wrapper_ddp inner step: bs={B} per rank (global {B * world}), patch {args.patch}, geometry=True, maskidx=[0], "
-                          f"{model_desc}; frames resident in HBM as u8",
+    # ---------------------------------------------------------------- the records ----------------------------------------------------------------
+    workload = {"uada_ddp": f"UADA_wrapper_ddp inner step: bs={B}/rank (global {B * world}), patch {args.patch}, geometry={geometry}, maskidx={maskidx or [0]}",
+                "uada": f"UADA single-GPU inner step (MSE + 1/CE): bs={B}, patch {args.patch}, geometry={geometry}",
+                "tma": f"TMA inner step (CE gradient): bs={B}, patch {args.patch}, geometry={geometry}",
+                "upa": f"UPA inner step: bs={B}, patch {args.patch}, resize_patch={args.resize_patch}, geometry={geometry}"}[args.attack]
+    config = {"workload": f"{workload}; {model_desc}; u8 frames resident in HBM",
               "global_batch": B * world, "images_per_s": (B * world * args.steps / dt) if run_weak else None, "parallelism": f"dp{world}",
               "regions": ("weak" if world == 1 else args.regions),
               "backend": (os.environ.get("VAA_DIST_BACKEND") or "nccl (RCCL)") if world > 1 else None,
-              "visible_gpus": torch.cuda.device_count(),
-              "labelled_rows_per_rank": R, "tunableop_entries_loaded": tun, "tunableop_entries_loaded_min_over_ranks": tun_min,
-              "lm_head": "labelled rows only" if use_rows else "full logits",
+              "visible_gpus": torch.cuda.device_count(), "labelled_rows_per_rank": R, "tunableop_entries_loaded_min_over_ranks": tun_min,
+              "lm_head": ("fused K3h" if hname else "GEMM + K3 rows") if use_rows else "full logits",
               "h2d_stage_ms_per_outer_iteration": stage_ms,
-              "pcie_inclusive_value_if_restaged_every_step": (world * args.steps / (dt + args.steps * stage_ms * 1e-3)) if run_weak else None,
-              "env": env_rec}
-    if world > 1:  # the collective, where `parsed.config` keeps it
+              "pcie_inclusive_value_if_restaged_every_step": (world * args.steps / (dt + args.steps * stage_ms * 1e-3)) if run_weak else None}
+    if world > 1:  # the collective
         config["allreduce_us_per_step"] = comm_w["mean_us_min_over_ranks"] if comm_w else None
         config["allreduce_us_per_step_max_over_ranks"] = comm_w["mean_us_max_over_ranks"] if comm_w else None
         config["comm_frac"] = comm_w["comm_frac"] if comm_w else None
         config["allreduce_back_to_back_us"] = b2b["event_us_per_call"] if b2b else None
         if strong:
+            config["strong_per_rank_bs"] = strong["per_rank_bs"]
             config["strong_images_per_s"] = strong["images_per_s"]
             config["strong_ms_per_step"] = strong["ms_per_step"]
             config["strong_comm_frac"] = strong["comm_frac"]
+            config["strong_allreduce_us_per_step"] = strong["allreduce_us_per_step"]["mean_us_min_over_ranks"] if strong["allreduce_us_per_step"] else None
             config["strong_speedup_vs_one_rank_weak_step"] = strong.get("speedup_vs_one_rank_weak_step")
-    if per_rank:  # N=1: the per-rank ratios of the strong-scaling configs, where `parsed.config` keeps them
+    if per_rank:  # N=1: the per-rank ratios of the strong-scaling configs
         for b in (32, 16, 8, 4):
             pr = per_rank.get(f"bs{b}")
             if pr:
@@ -612,31 +822,60 @@ def main():
             pr = per_rank.get(f"bs{B // n_r}")
             if pr:
                 config[f"projected_strong_speedup_{n_r}_before_comm"] = pr["projected_speedup_%d_ranks_before_comm" % n_r]
-    line = {
-        "metric": "attack-steps/sec (bs=64, 3x50x50 patch, OpenVLA-7B)", "value": (world * args.steps / dt) if run_weak else None,
-        "unit": "attack-steps/s (one unit = one bs-64 inner step on one rank; whole job = ranks x synchronous steps)",
-        "sync_steps_per_s": (args.steps / dt) if run_weak else None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": (dt / args.steps * 1e3) if run_weak else None,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": config,
-        "roofline": roofline, "roofline_k1": roofline_k1 if roofline is not roofline_k1 else None, "strong_scaling": strong, "allreduce_us_per_step": comm_w, "comm_frac": comm_w["comm_frac"] if comm_w else None,
-        "allreduce_back_to_back": b2b, "per_rank_step": per_rank, "hot_path_ops": hot_ops, "roofline_kernels": kern, "cpu_baseline": cpu,
-        "peak_mem_GiB": peak_mem, "loss_finite": finite and (strong is None or strong["loss_finite_all_ranks"]),
-        "profiled_pass_steps": psteps if run_weak else 0,
-    }
+    if cfg_steps:  # N=1: BASELINE configs 2 / 4 / 5, end to end
+        for tag, e in cfg_steps.items():
+            config[f"{tag}_ms_per_step"] = e["ms_per_step"]
+            config[f"{tag}_hot_path_us"] = e["hot_path_us_per_step"]
+            if e.get("dominant"):
+                config[f"{tag}_dominant_kernel"] = e["dominant"]["kernel"].split("<")[0].split("(")[0].strip()
+                config[f"{tag}_dominant_frac"] = e["dominant"]["frac"]
+    if k2_fracs:
+        config["k2_sweep_frac_B64_256_1024_4096"] = k2_fracs
+    if k1_standalone:
+        config["k1_standalone_GBs"] = k1_standalone
+    if copy_bw:
+        config["measured_device_copy_GBs"] = copy_bw
+
+    metric = "attack-steps/sec (bs=64, 3x50x50 patch, OpenVLA-7B)"
+    head = {"metric": metric, "value": (world * args.steps / dt) if run_weak else None, "unit": "attack-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": (dt / args.steps * 1e3) if run_weak else None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic"}
+    tail = {"hot_path_us_per_step": sum(op_us.values()), "hot_path_launches_per_step": sum(k["launches_per_step"] for k in kern.values()),
+            "hot_path_ops_us": op_us, "host_cpu_ms_per_step": host_cpu * 1e3 if run_weak else None,
+            "peak_mem_GiB": peak_mem, "loss_finite": finite and (strong is None or strong["loss_finite_all_ranks"]),
+            "profiled_pass_steps": psteps if run_weak else 0}
+    wall = {"setup": t_setup, "warmup_and_timed_region": t_region, "total": time.perf_counter() - t_main}
+
+    env_rec = {k: v for k, v in sorted(os.environ.items())
+               if k.startswith(("NCCL_", "RCCL_", "HSA_", "VAA_", "TORCH_NCCL", "PYTORCH_TUNABLEOP", "HIP_VISIBLE", "ROCR_VISIBLE", "CUDA_VISIBLE", "GPU_MAX_HW_QUEUES"))}
+    full = dict(head)
+    full.update({"config": dict(config, env=env_rec, traffic_source=tfile), "roofline": roofline, "roofline_k1": roofline_k1 if roofline is not roofline_k1 else None,
+                 "roofline_kernels": kern, "strong_scaling": strong, "allreduce_us_per_step": comm_w, "allreduce_back_to_back": b2b,
+                 "per_rank_step": per_rank, "config_steps": cfg_steps, "cpu_baseline": cpu_f, "host_enqueue_ms_per_step": host_enqueue * 1e3 if run_weak else None})
+    full.update(tail)
+    full.update(extra_full)
+    full["wall_s"] = wall
+    full["argv"] = sys.argv[1:]
+    full_path = write_full(args.full_out, full)
+
+    line = dict(head)
+    line.update({"config": config, "roofline": roofline, "roofline_k1": roofline_k1 if roofline is not roofline_k1 else None, "cpu_baseline": cpu_c})
+    line.update(tail)
+    line["wall_s"] = wall["total"]
+    line["full_record"] = full_path
     if not run_weak:
-        line["note"] = "--regions strong: a functional / diagnostic run of the strong-scaling region only; `value` (the weak-scaling headline) was not measured"
-    line.update(extra)
-    # where this process's wall time went (imports excluded): model + batch set-up, warm-up + timed region, everything reported beside it
-    line["wall_s"] = {"setup": t_setup, "warmup_and_timed_region": t_region, "total": time.perf_counter() - t_main}
+        line["diagnostic"] = "regions=strong only: value not measured"
+    # least important first: dropped only if the line would not fit
+    optional = ["hot_path_ops_us", "config.pcie_inclusive_value_if_restaged_every_step", "config.h2d_stage_ms_per_outer_iteration", "config.visible_gpus",
+                "config.bs4_ms_per_step", "config.bs8_ms_per_step", "config.bs16_ms_per_step", "config.bs32_ms_per_step", "config.measured_device_copy_GBs",
+                "config.k1_standalone_GBs", "config.cfg2_hot_path_us", "config.cfg4_hot_path_us", "config.cfg5_hot_path_us", "roofline.min_us", "roofline_k1.min_us",
+                "host_cpu_ms_per_step", "profiled_pass_steps", "config.images_per_s", "config.lm_head"]
+    out = encode_line(line, optional)
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)
     os.close(stdout_fd)
-    print(json.dumps(line), flush=True)
+    print(out, flush=True)
     os.dup2(2, 1)  # whatever the teardown prints goes to stderr as well
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -56,6 +56,25 @@ class OpenVLAAttacker(AttackBase):
                 so2 += int(pred[idx] == 31872)
         return s02, n0, s12, n1, so2, no
 
+    def inner_step(self, patch, optimizer, pixel_values, input_ids, attention_mask, newlabels, geometry, colorjitter, scalars_out, k,
+                   accumulate_steps=1, do_step=True):
+        """One iteration of the hot inner loop (TMA.py:131-175): K1 -> model -> GEMM head + K3 (CE gradient over every logit of the labelled rows) ->
+        backward -> K2 / K2' -> K4. Without gradient accumulation the step ends with ONE launch: K2's final sum + the optimiser (AdamW or PGD
+        sign step) + clamp. Returns (full-vocabulary predictions, whether the update ran inside that launch)."""
+        sink = self.fused_update_sink(optimizer) if (accumulate_steps == 1 and geometry) else None
+        pix = self._images(pixel_values, patch, geometry, colorjitter, grad_sink=sink)
+        total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, newlabels, ops.LOSS_CE, scale=1.0 / accumulate_steps)
+        total.backward()
+        fused = sink is not None and "partials" in sink
+        if fused:
+            self.fused_update(sink, patch, optimizer, scalars)
+            optimizer.zero_grad()
+        elif do_step:
+            scalars_out[k, 8:10] = optimizer.step()
+            optimizer.zero_grad()
+        scalars_out[k, :8] = scalars
+        return pred, fused
+
     def patchattack_unconstrained(self, train_dataloader, val_dataloader, num_iter=5000, target_action=np.zeros(7),
                                   patch_size=[3, 50, 50], alpha=1 / 255, accumulate_steps=1, maskidx=[], warmup=20,
                                   filterGripTrainTo1=False, geometry=False, colorjitter=False, innerLoop=1, args=None):
@@ -83,20 +102,10 @@ class OpenVLAAttacker(AttackBase):
             rel = []
             fused_row = None
             for inner_loop in range(innerLoop):
-                # without gradient accumulation the step ends with ONE launch: K2's final sum + the optimiser (AdamW or PGD sign step) + clamp
-                sink = self.fused_update_sink(optimizer) if (accumulate_steps == 1 and geometry) else None
-                pix = self._images(pixel_values, patch, geometry, colorjitter, grad_sink=sink)
-                total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, newlabels, ops.LOSS_CE, scale=1.0 / accumulate_steps)
-                total.backward()
-                if sink is not None and "partials" in sink:
-                    self.fused_update(sink, patch, optimizer, scalars)
+                pred, fused = self.inner_step(patch, optimizer, pixel_values, input_ids, attention_mask, newlabels, geometry, colorjitter, scal, inner_loop,
+                                              accumulate_steps=accumulate_steps, do_step=do_step)
+                if fused:
                     fused_row = inner_loop
-                    optimizer.zero_grad()
-                elif do_step:
-                    stats = optimizer.step()
-                    scal[inner_loop, 8:10] = stats
-                    optimizer.zero_grad()
-                scal[inner_loop, :8] = scalars
                 rel.append(pred)
             if scheduler is not None and do_step:
                 scheduler.step()

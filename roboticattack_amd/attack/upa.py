@@ -51,6 +51,18 @@ class OpenVLAAttacker(AttackBase):
             return ops.LOSS_UPA, 1.0
         return ops.LOSS_CE, -1.0  # loss = -output.loss (UPA.py:150)
 
+    def inner_step(self, patch, optimizer, pixel_values, input_ids, attention_mask, labels, geometry, mode, scale, scalars_out, k, do_step=True):
+        """One iteration of the hot inner loop (UPA.py:127-159): [K0 per-image patch resize ->] K1 -> model -> K3 (K3h when the loss lives in the
+        action slice) -> backward -> K2 / K2' (MULTI forms with resize_patch) -> K4 with the L1 clip (UPA.py:157) in front of AdamW."""
+        pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std, geometry=geometry)
+        total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, mode, alpha=self.alpha, beta=self.belta, scale=scale)
+        total.backward()
+        if do_step:
+            scalars_out[k, 8:10] = optimizer.step()  # K4: L1 clip 1e-3 -> AdamW -> clamp
+            optimizer.zero_grad()
+        scalars_out[k, :8] = scalars
+        return pred
+
     def patchattack_unconstrained(self, train_dataloader, val_dataloader, num_iter=5000, target_action=np.zeros(7),
                                   patch_size=[3, 50, 50], lr=1 / 255, accumulate_steps=1, maskidx=[], warmup=20,
                                   filterGripTrainTo1=False, geometry=False, innerLoop=1, guide=False, reverse_direction=False, args=None):
@@ -78,13 +90,7 @@ class OpenVLAAttacker(AttackBase):
                 labels = self.change_target(labels)
             do_step = (i + 1) % accumulate_steps == 0 or (i + 1) == len(train_dataloader)
             for inner_loop in range(innerLoop):
-                pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std, geometry=geometry)
-                total, scalars, _ = self.model_loss(input_ids, attention_mask, pix, labels, mode, alpha=self.alpha, beta=self.belta, scale=scale)
-                total.backward()
-                if do_step:
-                    scal[inner_loop, 8:10] = optimizer.step()  # K4: L1 clip 1e-3 -> AdamW -> clamp
-                    optimizer.zero_grad()
-                scal[inner_loop, :8] = scalars
+                self.inner_step(patch, optimizer, pixel_values, input_ids, attention_mask, labels, geometry, mode, scale, scal, inner_loop, do_step=do_step)
             if scheduler is not None and do_step:
                 scheduler.step()
             host = scal[:innerLoop].cpu().numpy()
