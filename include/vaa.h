@@ -66,10 +66,11 @@ const char* vaa_last_error(void);
 int vaa_version(void);
 /*
  * Device-side failures surface here and NEVER as a silent NaN: a kernel that has to give up (today only the opt-in one-launch K3, when its
- * grid-wide hand-over runs out of polls) NaN-poisons its outputs AND sets a bit in a pinned host word; every later library call on any
- * stream of the process returns VAA_E_LAUNCH (with the reason in vaa_last_error()) once for it. vaa_async_error() is the explicit poll —
- * the attack loops call it behind their once-per-outer-iteration read-back, before anything is written to disk (UADA.py:257-275).
- * Returns VAA_OK or VAA_E_LAUNCH; reporting clears the word.
+ * grid-wide hand-over runs out of polls) NaN-poisons its outputs AND sets a bit in a pinned host word. The word is process-wide and STICKY:
+ * from then on EVERY library call on any stream or thread returns VAA_E_LAUNCH (reason in vaa_last_error()) — the failure is not attributed
+ * to a stream, and no call consumes it — until vaa_async_error() is called: the explicit poll reports the failure (VAA_E_LAUNCH) and clears
+ * the word. The attack loops poll it behind their once-per-outer-iteration read-back, before anything is written to disk (UADA.py:257-275).
+ * Returns VAA_OK or VAA_E_LAUNCH.
  */
 int vaa_async_error(void);
 /* VAA_OK when a gfx950 device is visible to the HIP runtime, else VAA_E_NODEVICE. */
@@ -211,7 +212,7 @@ int vaa_loss_fwd_bwd_ex(const void* logits, int dtype, int layout, const int64_t
  *             round 4: 2.8 us per call against a residency assumption no launch API guarantees) and when the grid takes at most half
  *             of the device's resident slots, the stream is not being captured and no other stream of the process has such a launch
  *             in flight; else two launches with the same bits in every output. A hand-over that times out NaN-poisons the gradient AND
- *             raises vaa_async_error() (every later library call fails once with VAA_E_LAUNCH).
+ *             raises vaa_async_error() (every later library call fails with VAA_E_LAUNCH until the word is polled).
  */
 size_t vaa_loss_rowmap_bytes(int B, int L);
 int vaa_loss_rowmap_build(const int64_t* labels, int B, int L, void* rowmap, size_t rowmap_bytes, void* stream);
@@ -323,7 +324,8 @@ int vaa_patch_embed_grad_gather_multi_tiles(const uint16_t* dy0, int D0, const u
 /*
  * K4 — replaces transformers.AdamW.step + `patch.data.clamp(0,1)` + zero_grad (UADA.py:155-157; UADA_ddp.py:208-209),
  * optional `clip_grad_norm_([patch], l1_clip, norm_type=1)` (UPA.py:157) and the PGD sign step (TMA.py:171-175).
- *   patch,m,v dev [n] float32 in place; g dev [n] float32 (sum over ranks when grad_scale = 1/world, DDP mean)
+ *   patch,m,v dev [n] float32 in place; g dev [n] float32 (sum over ranks when grad_scale = 1/world, DDP mean); g must not alias
+ *            patch, m or v (VAA_E_INVALID): several workgroups read the whole gradient while others already write their elements
  *   step     1-based Adam step count t; lr already multiplied by the cosine schedule (UADA.py:109-115,162-164)
  *   stats    dev [2] float32 out or NULL: {sum|g*grad_scale|, mean(g*grad_scale)} (the logged TRAIN_patch_gradient)
  */

@@ -13,7 +13,7 @@ import pickle
 import numpy as np
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from ..action_tokenizer import ActionTokenizer
 from ..constants import MEAN0, MEAN1, STD0, STD1
 from ..transform import RandomPatchTransform
@@ -191,11 +191,17 @@ class AttackBase:
         ops.step_epilogue(sink["partials"], msg, scalars, update=optimizer.fused_update_args())
 
     # ---- fail loud, never NaN: once per outer iteration, behind the read-back that synchronises anyway ----
-    def assert_finite_state(self, patch, optimizer, host_scalars, where: str):
+    def assert_finite_state(self, patch, optimizer, host_scalars, where: str, all_ranks: bool = False):
         """`host_scalars`: the loss scalars of the outer iteration's inner steps, already on the host (their read-back was the sync).
         AdamW's m / v are the sticky witnesses of any non-finite gradient of ANY inner step (a NaN that entered them never leaves, while the
-        clamp turns the patch itself into a finite 0), the library's failure word covers kernels that had to give up (vaa_async_error)."""
-        ops.async_error_check()
+        clamp turns the patch itself into a finite 0), the library's failure word covers kernels that had to give up (vaa_async_error: a
+        per-PROCESS word). `all_ranks` (the data-parallel loop): the verdict is all-reduced (MIN) before anyone raises, so that every rank
+        leaves the loop together instead of one rank raising while the others wait in the next all-reduce until the RCCL timeout."""
+        device_failure = None
+        try:
+            ops.async_error_check()
+        except _lib.VaaError as e:  # reported like every other non-finite state (and cleared: the poll is the consumer of the sticky word)
+            device_failure = str(e)
         ok_dev = torch.isfinite(patch.detach()).all()
         if getattr(optimizer, "m", None) is not None:
             ok_dev = ok_dev & torch.isfinite(optimizer.m).all() & torch.isfinite(optimizer.v).all()
@@ -203,9 +209,20 @@ class AttackBase:
         if stats is not None:
             ok_dev = ok_dev & torch.isfinite(stats).all()
         ok_host = bool(np.isfinite(np.asarray(host_scalars, dtype=np.float64)).all())
-        if not (ok_host and bool(ok_dev)):
+        ok_local = ok_host and bool(ok_dev) and device_failure is None
+        ok = ok_local
+        if all_ranks:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float32, device=patch.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(flag.item() > 0.5)
+        if not ok:
             raise NonFiniteAttackState(f"{where}: non-finite attack state (loss scalars finite: {ok_host}; patch / moments / gradient statistics "
-                                       f"finite: {bool(ok_dev)}) — nothing was saved for this iteration")
+                                       f"finite: {bool(ok_dev)}; device-side failure: {device_failure or 'none'}"
+                                       + ("" if ok_local else "; detected on THIS rank") + (" — raised on every rank" if all_ranks else "")
+                                       + ") — nothing was saved for this iteration")
 
     # ---- metrics (host, once per outer iteration) ----
     def decode_pred_gt(self, pred: torch.Tensor, labels: torch.Tensor):

@@ -139,7 +139,7 @@ class OpenVLAAttacker(AttackBase):
                 optimizer.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4, DDP mean folded in
             scheduler.step()
             s = (s_sum * inv_world).cpu().numpy()
-            self.assert_finite_state(patch, optimizer, s, f"{self.attack_type} (data parallel) outer iteration {i}")
+            self.assert_finite_state(patch, optimizer, s, f"{self.attack_type} (data parallel) outer iteration {i}", all_ranks=True)
             # UADA_ddp.py:207,216-217: `patch.grad.mean()` AFTER DistributedDataParallel averaged the gradient, i.e. the mean of the averaged
             # gradient (identical on every rank, so the reference's MAX all-reduce of it is the value itself): K4 reports it
             log_patch_grad = float(optimizer.last_stats[1].item())

@@ -22,8 +22,8 @@ void set_error(const char* fmt, ...) {
 
 // ---- asynchronous device-side failures (vaa_async_error) ----
 // One word of pinned, device-mapped host memory per process: a kernel that has to give up (today: the one-launch K3's grid-wide hand-over
-// running out of polls) ORs a bit into it through its device alias; the host reads it without synchronising — in every check_launch() and in
-// vaa_async_error() — so the failure surfaces as VAA_E_LAUNCH on the next library call after the kernel ran, never as a silent NaN.
+// running out of polls) ORs a bit into it through its device alias; the host reads it without synchronising — in every check_launch() (peek) and in
+// vaa_async_error() (report + clear) — so the failure surfaces as VAA_E_LAUNCH on every library call after the kernel ran, never as a silent NaN.
 static std::atomic<unsigned*> g_async_word{nullptr};
 static std::mutex g_async_mu;
 
@@ -43,14 +43,17 @@ unsigned* async_error_word() {
     return reinterpret_cast<unsigned*>(p);
 }
 
-// VAA_OK, or VAA_E_LAUNCH (+ message) once per recorded failure: the word is cleared by the call that reports it
-int async_error_poll(const char* what) {
+// VAA_OK, or VAA_E_LAUNCH (+ message) while a failure is recorded. The word is STICKY: every check_launch() of every library call reads it
+// without clearing (so the call whose outputs were poisoned, and every call after it, fails — on whichever stream or thread it runs); only the
+// explicit poll vaa_async_error() (clear = true) reports AND clears it, so the attack loops' once-per-outer-iteration check always sees it.
+int async_error_poll(const char* what, bool clear) {
     unsigned* w = g_async_word.load(std::memory_order_acquire);
     if (!w) return VAA_OK;
-    const unsigned bits = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);
+    const unsigned bits = clear ? __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(w, __ATOMIC_ACQUIRE);
     if (bits == 0u) return VAA_OK;
-    set_error("%s: an earlier kernel of this process reported a device-side failure (bits 0x%x%s): its outputs are NaN-poisoned", what, bits,
-              (bits & VAA_ASYNC_K3_HANDOVER_TIMEOUT) ? ": the one-launch K3 hand-over timed out — unset VAA_K3_ONE_PASS" : "");
+    set_error("%s: a kernel of this process reported a device-side failure (bits 0x%x%s): its outputs are NaN-poisoned%s", what, bits,
+              (bits & VAA_ASYNC_K3_HANDOVER_TIMEOUT) ? ": the one-launch K3 hand-over timed out — unset VAA_K3_ONE_PASS" : "",
+              clear ? "" : "; library calls keep failing until vaa_async_error() is polled");
     return VAA_E_LAUNCH;
 }
 
@@ -60,7 +63,7 @@ int check_launch(const char* what) {
         set_error("%s: %s", what, hipGetErrorString(e));
         return VAA_E_LAUNCH;
     }
-    return async_error_poll(what);
+    return async_error_poll(what, false);
 }
 
 // ---- per-dispatch profiler (vaa_prof_*) ----
@@ -134,7 +137,7 @@ int vaa_prof_get(int i, const char** name, float* usec) {
 
 const char* vaa_last_error(void) { return vaa::g_err; }
 
-int vaa_async_error(void) { return vaa::async_error_poll("vaa_async_error"); }
+int vaa_async_error(void) { return vaa::async_error_poll("vaa_async_error", true); }
 
 int vaa_version(void) { return 100; /* 0.1.0 */ }
 

@@ -20,7 +20,7 @@ namespace vaa {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);  // the HIP runtime's last error, then async_error_poll()
 unsigned* async_error_word();        // pinned, device-mapped word kernels OR failure bits into (nullptr: allocation failed)
-int async_error_poll(const char* what);
+int async_error_poll(const char* what, bool clear);
 constexpr unsigned VAA_ASYNC_K3_HANDOVER_TIMEOUT = 1u;
 // vaa_patch_grad.hip: gpatch[e] = sum_p partial[p][e] (p < nparts, e < n) in a fixed order with fp64 accumulation
 int launch_partial_reduce(const float* partial, float* gpatch, int n, int nparts, hipStream_t st, const char* who);

@@ -24,6 +24,8 @@
 //   head_finish_kernel      grid = R' workgroups: folds a row's ceil(V / 128) PartStats into ONE (stored in K3's workspace layout, the other
 //       parts neutral), computes the action-slice statistics with the arithmetic of rows_stats_kernel (same bits for the same logits) and
 //       — UADA_DDP — writes the gradient slice. vaa_step_epilogue then folds the rows exactly as it does behind vaa_loss_rows_stats.
+#include <atomic>
+
 #include "vaa_common.h"
 #include "vaa_rows.h"
 
@@ -152,9 +154,11 @@ __global__ __launch_bounds__(kHT) void head_stats_kernel(HeadArgs a) {
                 tile[(rh * (ROWS / RH) + q * 16 + g * 4 + r) * kHTileS + cg * (16 * CBW) + cb * 16 + c] = bf16_bits_to_f32(f32_to_bf16_bits(acc[cb][q][r]));
     __syncthreads();
     const int ncols = min(kHCols, a.V - n0);
-    // per-row statistics: 2 threads per row, thread `part` takes the columns part, part + 2, ...
+    // per-row statistics: TPR (= 4 with 8 waves) threads per row, thread `part` takes the columns part, part + TPR, ...
     {
         constexpr int TPR = kHT / kHRowsMax;  // threads per row
+        static_assert(kHT % kHRowsMax == 0 && TPR >= 1 && (TPR & (TPR - 1)) == 0 && TPR <= 64,
+                      "VAA_HEAD_WAVES * 64 must be a power-of-two multiple of kHRowsMax: the per-row folds below are xor-shuffles over TPR lanes");
         const int row = tid / TPR, part = tid % TPR;
         const bool live = row < ROWS && row < a.R;
         float m = -INFINITY;
@@ -338,8 +342,36 @@ extern "C" size_t vaa_head_loss_ws_bytes(int R, int V) {
     return vaa::head_ws_slice_offset(R, V) + vaa::head_ws_align((size_t)R * vaa::kNA * sizeof(uint16_t));
 }
 
+namespace vaa {
+
+static size_t head_lds_bytes(int nrb) {
+    const size_t lds_h = (size_t)kHRing * (nrb * 32 + kHCols) * kHSA * sizeof(uint16_t), lds_t = (size_t)nrb * 32 * kHTileS * sizeof(float);
+    return lds_h > lds_t ? lds_h : lds_t;
+}
+
+// the LDS a workgroup may ask for on the CURRENT device (gfx950: 160 KB), queried once per device
+static size_t device_lds_limit() {
+    static std::atomic<long> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 64 * 1024; }
+    long v = cached[dev].load(std::memory_order_acquire);
+    if (v == 0) {
+        int per_block = 0, optin = 0;  // the larger of the default and the opt-in limit (runtimes differ in which of the two carries the 160 KB)
+        if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); per_block = 0; }
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess) { (void)hipGetLastError(); optin = 0; }
+        v = per_block > optin ? per_block : optin;
+        if (v <= 0) v = 64 * 1024;
+        cached[dev].store(v, std::memory_order_release);
+    }
+    return (size_t)v;
+}
+
+}  // namespace vaa
+
 extern "C" int vaa_head_loss_rows_applies(int R, int D, int V) {
-    return (R > 0 && R <= vaa::kHRowsMax && D >= vaa::kHK && (D % vaa::kHK) == 0 && V >= vaa::kA0 + vaa::kNA && (V % 8) == 0 && V <= 131072) ? 1 : 0;
+    if (!(R > 0 && R <= vaa::kHRowsMax && D >= vaa::kHK && (D % vaa::kHK) == 0 && V >= vaa::kA0 + vaa::kNA && (V % 8) == 0 && V <= 131072)) return 0;
+    // the weight ring + hidden rows of this row count must fit the device's LDS (128 KB at > 64 rows: a 160 KB-LDS part)
+    return vaa::head_lds_bytes(R <= 32 ? 1 : (R <= 64 ? 2 : 4)) <= vaa::device_lds_limit() ? 1 : 0;
 }
 
 extern "C" int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* w_head, int D, const void* rowmap, int R, int B, int L, int V, int mode,
@@ -378,12 +410,25 @@ extern "C" int vaa_head_loss_rows_stats(const uint16_t* hidden, const uint16_t* 
     a.logits_dbg = logits_dbg;
     a.R = R; a.D = D; a.V = V;
     const int nrb = R <= 32 ? 1 : (R <= 64 ? 2 : 4);
-    const size_t lds_h = (size_t)kHRing * (nrb * 32 + kHCols) * kHSA * sizeof(uint16_t), lds_t = (size_t)nrb * 32 * kHTileS * sizeof(float);
-    const size_t lds = lds_h > lds_t ? lds_h : lds_t;
-    const void* fn = nrb == 1 ? (const void*)head_stats_kernel<1> : (nrb == 2 ? (const void*)head_stats_kernel<2> : (const void*)head_stats_kernel<4>);
-    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        set_error("%s: hipFuncSetAttribute failed", who);
-        return VAA_E_LAUNCH;
+    const size_t lds = head_lds_bytes(nrb);
+    if (lds > device_lds_limit()) {
+        set_error("%s: %zu B of LDS for %d rows exceed this device's %zu B per workgroup (ask vaa_head_loss_rows_applies first)", who, lds, R, device_lds_limit());
+        return VAA_E_UNSUPPORTED;
+    }
+    // the dynamic-LDS opt-in is a property of the kernel function: set once per instantiation and device, not on every call of the step's
+    // critical launch path
+    static std::atomic<unsigned long long> attr_done[3];  // bit = device ordinal
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int inst = nrb == 1 ? 0 : (nrb == 2 ? 1 : 2);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (lds > 64 * 1024 && !(attr_done[inst].load(std::memory_order_acquire) & bit)) {
+        const void* fn = nrb == 1 ? (const void*)head_stats_kernel<1> : (nrb == 2 ? (const void*)head_stats_kernel<2> : (const void*)head_stats_kernel<4>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute failed", who);
+            return VAA_E_LAUNCH;
+        }
+        attr_done[inst].fetch_or(bit, std::memory_order_acq_rel);
     }
     const dim3 grid((unsigned)a.nwg), blk(kHT);
     if (nrb == 1) VAA_LAUNCH((head_stats_kernel<1>), grid, blk, lds, st, a);

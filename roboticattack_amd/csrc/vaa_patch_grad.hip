@@ -665,7 +665,8 @@ struct EmbedArgs {
     float* geff;                // [B,256,588], indexed by tile (ty*16 + tx); only the flagged tiles are written
     float* geff2;               // non-null: room for the pair layout of tower_split ({tower 0, tower 1} per element, in geff)
     int B, D0, D1, round_bf16;
-    int tower_split;            // one tower per workgroup (grid.z = 2): halves the per-workgroup chain while the launch is far from filling the chip
+    int tower_split;            // one tower per workgroup: halves the per-workgroup chain while the launch is far from filling the chip
+    int ny;                     // 64-tile row groups of an image that go to separate workgroups (1: a workgroup walks them in sequence)
     float istd6[6];
 };
 
@@ -911,9 +912,14 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     uint16_t* sA = reinterpret_cast<uint16_t*>(embed_smem);
     __shared__ int16_t tiles[256];
     __shared__ int wave_cnt[4];
+    // A UNIT of work = (image b, 64-tile row group mg0 of ny, tower): its nch column-range workgroups read the same dY rows, so they share
+    // blockIdx.x % 8 = one XCD and one L2 (the rows are fetched from HBM once); different units touch disjoint rows and are dealt round-robin
+    // over the 8 XCDs — unit = (tower * ny + mg0) * B + b, so that a full batch keeps image b on XCD b % 8 for both towers, while a small batch
+    // with large per-image patches (resize_patch: 4 images x 4 row groups x 2 towers) still covers all 8 XCDs instead of B of them.
     const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
-    const int b = (slot_id / nch) * 8 + xcd, ch = slot_id % nch;
-    if (b >= a.B) return;
+    const int unit = (slot_id / nch) * 8 + xcd, ch = slot_id % nch, ny = a.ny;
+    if (unit >= a.B * ny * (SPLIT ? 2 : 1)) return;
+    const int b = unit % a.B, mg0 = (unit / a.B) % ny;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
 #ifdef VAA_K2_TIMING
     long long tacc[6] = {0, 0, 0, 0, 0, 0};
@@ -948,10 +954,10 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
         s0[j] = a.istd6[c3];
         s1[j] = a.istd6[c3 + 3];
     }
-    for (int mg = blockIdx.y; mg * 64 < M; mg += gridDim.y) {  // 64-tile row groups: spread over grid.y when the patch can cover more
+    for (int mg = mg0; mg * 64 < M; mg += ny) {  // 64-tile row groups: separate units when the patch can cover more than 64 tiles
         const int rows = min(64, M - mg * 64), nq = (rows + 15) >> 4;  // workgroup-uniform
         float res[NB][4][4];  // [column block][row block][r]: tower 0's scaled contribution, then + tower 1's
-        const int t_lo = SPLIT ? (int)blockIdx.z : 0;
+        const int t_lo = SPLIT ? unit / (a.B * ny) : 0;
 #pragma unroll
         for (int tt = 0; tt < (SPLIT ? 1 : 2); ++tt) {
             const int tower = SPLIT ? t_lo : tt;
@@ -1097,17 +1103,20 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
     const unsigned ny = (unsigned)(tiles_bound <= 64 ? 1 : (tiles_bound <= 128 ? 2 : 4));
     const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
     e.tower_split = 0;
+    e.ny = (int)ny;
     if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
-        // Workgroups per image. A workgroup's time is a chain — tile list, staging of a tower's rows, k-loop, (second tower), store —, so while
-        // the launch fits ONE residency wave of the 256 CUs a workgroup takes ONE tower (grid.z = 2: its chain halves; the gather adds the two
-        // towers' tile gradients — the very fp32 add the unsplit kernel does) and as few column blocks as that leaves room for:
-        //   B <= 24: 5 x 2 workgroups per image, 1 block per wave;  B <= 40: 3 x 2, <= 2 blocks;  B <= 64: 2 x 2, <= 3 blocks (256 workgroups at 64)
-        // beyond that the batch fills the chip several times over and the unsplit form (3 per image, both towers, no second buffer) is kept.
+        // Workgroups per unit (image, row group). A workgroup's time is a chain — tile list, staging of a tower's rows, k-loop, (second tower), store —,
+        // so while the launch fits ONE residency wave of the 256 CUs a workgroup takes ONE tower (its chain halves; the gather adds the two towers'
+        // tile gradients — the very fp32 add the unsplit kernel does) and as few column blocks as that leaves room for:
+        //   <= 24 (image, row group) units: 5 x 2 workgroups each, 1 block per wave;  <= 40: 3 x 2, <= 2 blocks;  <= 64: 2 x 2, <= 3 blocks (256 workgroups at 64)
+        // beyond that the batch fills the chip several times over and the unsplit form (3 per unit, both towers, no second buffer) is kept.
+        // Per-image patches (resize_patch, ny > 1) count B * ny units: round 4 ran them unsplit on B of the 8 XCDs (B=4, 61..139 px: 31-40 us).
         const long Bpad = (B + 7) / 8 * 8;
+        const long eff = ny == 1 ? Bpad : (long)B * ny;
         int nch = 3;
-        if (ny == 1 && e.geff2 && Bpad <= 64) {
+        if (e.geff2 && eff <= 64) {
             e.tower_split = 1;
-            nch = Bpad <= 24 ? 5 : (Bpad <= 40 ? 3 : 2);
+            nch = eff <= 24 ? 5 : (eff <= 40 ? 3 : 2);
         }
         const int nbmax = ((kNBlocks + nch - 1) / nch + VAA_EMBED_WAVES - 1) / VAA_EMBED_WAVES;  // 1, 2 or 3
         const void* fn = nullptr;
@@ -1117,7 +1126,8 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
             set_error("%s: hipFuncSetAttribute failed", who);
             return VAA_E_LAUNCH;
         }
-        const dim3 grid((unsigned)Bpad * nch, ny, e.tower_split ? 2 : 1), blk(kEmbedFastThreads);
+        const long units = (long)B * ny * (e.tower_split ? 2 : 1);
+        const dim3 grid((unsigned)((units + 7) / 8 * 8 * nch)), blk(kEmbedFastThreads);
         if (!e.tower_split) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<false, 2>), grid, blk, lds_fast, st, e, nch);
         else if (nbmax == 1) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 1>), grid, blk, lds_fast, st, e, nch);
         else if (nbmax == 2) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 2>), grid, blk, lds_fast, st, e, nch);

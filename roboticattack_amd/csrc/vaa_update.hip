@@ -1,7 +1,7 @@
 // vaa_update.hip — K4: fused pixel update of the patch: [DDP 1/world scale] -> [L1 grad-norm clip] ->
-// HF-AdamW or PGD-sign step -> clamp to [0,1], plus the logged gradient statistics. One workgroup:
-// the patch has 7,500 (50x50) to ~58,000 (139x139) elements, so the op is launch-latency bound and the
-// L1 norm needs a grid-wide reduction anyway.
+// HF-AdamW or PGD-sign step -> clamp to [0,1], plus the logged gradient statistics. The patch has 7,500 (50x50) to 30,000 (100x100; any size
+// up to the frame is accepted) elements: the op is latency bound, and the L1 norm / the statistics need the whole gradient first — every
+// workgroup computes them redundantly (bitwise the same), then updates its share of the elements.
 //
 // Replaces (UADA.py:154-157, UADA_ddp.py:207-209): `patch.grad.mean().item()`, `optimizer.step()`
 // (transformers==4.40.1 AdamW [3p]: m=b1*m+(1-b1)g; v=b2*v+(1-b2)g^2; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps),
@@ -13,30 +13,46 @@
 
 namespace vaa {
 
-constexpr int kUpdRegs = 8;  // elements a thread keeps in registers: patches up to 8,192 elements (3x50x50 = 7,500) make ONE memory round trip
+constexpr int kUpdRegsSmall = 8;  // statistics pass: gradient elements a thread holds — patches up to 8,192 elements (3x50x50 = 7,500) ...
+constexpr int kUpdRegsMid = 32;   // ... and up to 32,768 elements (3x100x100 = 30,000, UPA's resize_patch base patch): ONE memory round trip
+constexpr int kUpdPer = 2;        // elements a thread UPDATES: the update is spread over R / kUpdPer workgroups (4 at 50x50, 16 at 100x100)
 
-// SMALL: n <= 1024 * kUpdRegs — gradient, patch and both moments are requested at once and stay in registers across the statistics, so the
-// op is one load latency + one block reduction + the stores (7.2 -> 5.x us); larger patches re-read the gradient after the reduction.
-template <bool SMALL>
+// The statistics of the logged gradient / the L1 clip need the WHOLE gradient before any element can be updated, and the patch is small
+// (30 KB .. 120 KB of gradient): every workgroup computes the statistics of the whole gradient itself — the same loads (L2 hits after the
+// first workgroup), the same per-thread order, the same tree, hence the same bits in every workgroup, no grid-wide hand-over — and then
+// updates ITS rows of the [R][1024] element layout: row e of workgroup b is e = b + j * G (j < PER). One workgroup doing all of it was
+// bound by ONE CU's issue rate and L2 port: sqrt + divide + clamp on 32 elements per thread and 840 KB through one CU took 25-30 us at
+// 3x100x100 (the UPA step with resize_patch), 5.x us at 3x50x50.
+//   R = 0: any n, one workgroup, streaming (patches beyond 32,768 elements).
+// All forms add a thread's elements in the same increasing-index order, so statistics, clip coefficient and updates agree bitwise.
+template <int R>
 __global__ __launch_bounds__(1024) void patch_update_kernel(UpdArgs a) {
     __shared__ double sh_abs[16], sh_sum[16];
     __shared__ float coef_sh;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int RR = R > 0 ? R : 1, PER = R > 0 ? kUpdPer : 1, G = R > 0 ? R / kUpdPer : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, bid = blockIdx.x;
     const bool adam = a.mode == VAA_OPT_ADAMW_HF;
-    float gq[kUpdRegs], pq[kUpdRegs], mq[kUpdRegs], vq[kUpdRegs];
+    float gq[RR], g2[PER], p2[PER], m2[PER], v2[PER];
     double sa = 0.0, ss = 0.0;
-    if (SMALL) {
+    if (R > 0) {
+        // this workgroup's own elements first (nothing of them depends on the statistics), then the whole gradient: all loads in flight together
 #pragma unroll
-        for (int e = 0; e < kUpdRegs; ++e) {
-            const int i = tid + e * 1024;
-            gq[e] = 0.0f; pq[e] = 0.0f; mq[e] = 0.0f; vq[e] = 0.0f;
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + (bid + j * G) * 1024;
+            g2[j] = 0.0f; p2[j] = 0.0f; m2[j] = 0.0f; v2[j] = 0.0f;
             if (i < a.n) {
-                gq[e] = a.g[i]; pq[e] = a.patch[i];
-                if (adam) { mq[e] = a.m[i]; vq[e] = a.v[i]; }
+                g2[j] = a.g[i]; p2[j] = a.patch[i];
+                if (adam) { m2[j] = a.m[i]; v2[j] = a.v[i]; }
             }
         }
 #pragma unroll
-        for (int e = 0; e < kUpdRegs; ++e) {  // the same increasing-index order per thread as the streaming form below
+        for (int e = 0; e < RR; ++e) {
+            const int i = tid + e * 1024;
+            gq[e] = 0.0f;
+            if (i < a.n) gq[e] = a.g[i];
+        }
+#pragma unroll
+        for (int e = 0; e < RR; ++e) {  // the same increasing-index order per thread as the streaming form below
             if (tid + e * 1024 < a.n) {
                 const float g = gq[e] * a.grad_scale;
                 sa += fabs((double)g);
@@ -63,18 +79,18 @@ __global__ __launch_bounds__(1024) void patch_update_kernel(UpdArgs a) {
             coef = c < 1.0f ? c : 1.0f;
         }
         coef_sh = coef;
-        if (a.stats) { a.stats[0] = (float)ta; a.stats[1] = (float)(ts / a.n); }
+        if (a.stats && bid == 0) { a.stats[0] = (float)ta; a.stats[1] = (float)(ts / a.n); }
     }
     __syncthreads();
     const float coef = coef_sh;
-    if (SMALL) {
+    if (R > 0) {
 #pragma unroll
-        for (int e = 0; e < kUpdRegs; ++e) {
-            const int i = tid + e * 1024;
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + (bid + j * G) * 1024;
             if (i < a.n) {
-                const float g = gq[e] * a.grad_scale * coef;
-                float m = mq[e], v = vq[e];
-                const float p = update_one(a, g, pq[e], m, v);
+                const float g = g2[j] * a.grad_scale * coef;
+                float m = m2[j], v = v2[j];
+                const float p = update_one(a, g, p2[j], m, v);
                 if (adam) { a.m[i] = m; a.v[i] = v; }
                 a.patch[i] = p;
             }
@@ -99,6 +115,10 @@ extern "C" int vaa_patch_update(float* patch, const float* g, float* m, float* v
         set_error("vaa_patch_update: null pointer argument");
         return VAA_E_INVALID;
     }
+    if (g == patch || g == m || g == v) {
+        set_error("vaa_patch_update: the gradient must not alias the patch or a moment buffer");
+        return VAA_E_INVALID;
+    }
     if (n <= 0 || (mode != VAA_OPT_ADAMW_HF && mode != VAA_OPT_PGD_SIGN) || (mode == VAA_OPT_ADAMW_HF && step < 1)) {
         set_error("vaa_patch_update: bad sizes/mode (n=%d mode=%d step=%d)", n, mode, step);
         return VAA_E_INVALID;
@@ -111,7 +131,9 @@ extern "C" int vaa_patch_update(float* patch, const float* g, float* m, float* v
     a.one_m_b1 = (float)(1.0 - b1);
     a.one_m_b2 = (float)(1.0 - b2);
     a.step_size = (mode == VAA_OPT_ADAMW_HF) ? (float)((double)lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step))) : 0.0f;
-    if (n <= 1024 * kUpdRegs) VAA_LAUNCH(patch_update_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
-    else VAA_LAUNCH(patch_update_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    // (the gradient must not alias the patch or the moments: a workgroup reads the whole gradient while others already write their rows)
+    if (n <= 1024 * kUpdRegsSmall) VAA_LAUNCH(patch_update_kernel<kUpdRegsSmall>, dim3(kUpdRegsSmall / kUpdPer), dim3(1024), 0, (hipStream_t)stream, a);
+    else if (n <= 1024 * kUpdRegsMid) VAA_LAUNCH(patch_update_kernel<kUpdRegsMid>, dim3(kUpdRegsMid / kUpdPer), dim3(1024), 0, (hipStream_t)stream, a);
+    else VAA_LAUNCH(patch_update_kernel<0>, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     return check_launch("vaa_patch_update");
 }

@@ -671,9 +671,16 @@ def head_loss_rows_applies(R: int, D: int, V: int) -> bool:
 
 def head_loss_rows_stats(hidden, w_head, rowmap: "LossRowMap", mode: int = LOSS_UADA_DDP, w: float = 5.0, alpha: float = 0.8, beta: float = 0.2,
                          scale: float = 1.0, grad=None, want_logits: bool = False):
-    """vaa_head_loss_rows_stats: LM head on the labelled rows fused with K3's statistics (SURVEY.md 8f-2) — `hidden` [R,D] bf16, `w_head` [V,D]
-    bf16; the [R,V] logits are never written. Returns the K3 workspace for ops.step_epilogue(loss_ws=...) exactly like loss_rows_stats
+    """vaa_head_loss_rows_stats (see _head_stats): returns the K3 workspace for ops.step_epilogue(loss_ws=...) exactly like loss_rows_stats
     (and the bf16 logits [R,V] the statistics were made of when want_logits: tests)."""
+    ws, _, dbg = _head_stats(hidden, w_head, rowmap, mode, w, alpha, beta, scale, grad, want_logits)
+    return (ws, dbg) if want_logits else ws
+
+
+def _head_stats(hidden, w_head, rowmap, mode, w, alpha, beta, scale, grad, want_logits):
+    """vaa_head_loss_rows_stats: LM head on the labelled rows fused with K3's statistics (SURVEY.md 8f-2) — `hidden` [R,D] bf16, `w_head` [V,D]
+    bf16; the [R,V] logits are never written. Returns (K3 workspace, the head's own workspace [per-workgroup PartStats + slice logits] — the
+    very tensor vaa_head_loss_rows_finish must be handed, not a second look-up of the cache —, debug logits | None)."""
     R, D = int(hidden.shape[0]), int(hidden.shape[1])
     V = int(w_head.shape[0])
     _need(hidden, torch.bfloat16, "hidden", (R, D))
@@ -689,7 +696,7 @@ def head_loss_rows_stats(hidden, w_head, rowmap: "LossRowMap", mode: int = LOSS_
                                         _lib.f32x([w, alpha, beta, scale]), grad.data_ptr() if grad is not None else None, ws.data_ptr(), ws.numel(),
                                         hws.data_ptr(), hws.numel(), dbg.data_ptr() if dbg is not None else None, _stream())
     _lib.check(rc, "vaa_head_loss_rows_stats")
-    return (ws, dbg) if want_logits else ws
+    return ws, hws, dbg
 
 
 def head_loss_rows_fwd_bwd(hidden, w_head, rowmap: "LossRowMap", mode: int, w: float = 5.0, alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0,
@@ -704,10 +711,8 @@ def head_loss_rows_fwd_bwd(hidden, w_head, rowmap: "LossRowMap", mode: int, w: f
     V = int(w_head.shape[0])
     dev = hidden.device
     grad = torch.empty((R, N_ACTION), dtype=torch.bfloat16, device=dev) if want_grad else None
-    out = head_loss_rows_stats(hidden, w_head, rowmap, mode, w, alpha, beta, scale, grad=grad if mode == LOSS_UADA_DDP else None, want_logits=want_logits)
-    ws, lg = out if want_logits else (out, None)
+    ws, hws, lg = _head_stats(hidden, w_head, rowmap, mode, w, alpha, beta, scale, grad if mode == LOSS_UADA_DDP else None, want_logits)
     L = _lib.lib()
-    hws = _workspace(dev, L.vaa_head_loss_ws_bytes(R, V), "k3h")
     scalars = torch.empty(8, dtype=torch.float32, device=dev)
     pred = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=dev) if want_pred else None
     pred_full = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=dev) if want_pred else None

@@ -90,3 +90,42 @@ def test_local_device_follows_local_rank(monkeypatch):
     monkeypatch.setenv("VAA_DIST_BACKEND", "gloo")
     assert vdist.local_device() == torch.device("cuda:1")
 
+
+
+def _finite_worker(rank, world, port, out_dir):
+    import sys
+    import types
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from roboticattack_amd import dist as vdist
+    from roboticattack_amd.attack.engine import AttackBase, NonFiniteAttackState
+
+    vdist.init_process_group("gloo")
+    patch = torch.rand(3, 8, 8)
+    opt = types.SimpleNamespace(m=torch.zeros(3, 8, 8), v=torch.zeros(3, 8, 8), last_stats=torch.zeros(2))
+    res = []
+    # round 0: every rank finite -> nobody raises; round 1: rank 1's moments are poisoned -> BOTH ranks raise, and rank 0 says it was not its own state
+    for rnd in range(2):
+        if rnd == 1 and rank == 1:
+            opt.m[0, 0, 0] = float("nan")
+        try:
+            AttackBase.assert_finite_state(None, patch, opt, np.zeros((2, 8)), f"round {rnd}", all_ranks=True)
+            res.append("ok")
+        except NonFiniteAttackState as e:
+            res.append("raised-local" if "detected on THIS rank" in str(e) else "raised-remote")
+    with open(os.path.join(out_dir, f"f{rank}.txt"), "w") as f:
+        f.write(",".join(res))
+    dist.barrier()  # both ranks get here: nobody was left waiting in a collective
+    dist.destroy_process_group()
+
+
+def test_finite_state_verdict_is_rank_consistent(tmp_path):
+    """in the data-parallel loop the non-finite verdict is all-reduced (MIN) before anyone raises — a rank whose own state is fine
+    raises together with the rank that saw the NaN instead of blocking in the next all-reduce until the collective times out."""
+    world = 2
+    mp.spawn(_finite_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "f0.txt").read_text() == "ok,raised-remote"
+    assert (tmp_path / "f1.txt").read_text() == "ok,raised-local"

@@ -1448,7 +1448,8 @@ def test_k3_full_rows_under_capture_and_beyond_half_residency(ops):
 def test_k3_one_pass_handover_timeout_fails_loudly(ops, monkeypatch):
     """Fail loud, never NaN: the opt-in one-launch K3 whose grid-wide hand-over runs out of polls (forced here with
     VAA_K3_HANDOVER_POLLS=0: every waiting workgroup gives up at once) NaN-poisons the gradient AND raises the library's failure word — the NEXT
-    library call of the process returns VAA_E_LAUNCH with the reason, once; vaa_async_error() is the explicit poll. The default form (two launches)
+    library call of the process returns VAA_E_LAUNCH with the reason, and so does every later one (the word is sticky) until vaa_async_error(), the
+    explicit poll, reports and clears it. The default form (two launches)
     has no hand-over and is unaffected."""
     from roboticattack_amd import _lib
     from roboticattack_amd.labels import mask_labels
@@ -1471,13 +1472,17 @@ def test_k3_one_pass_handover_timeout_fails_loudly(ops, monkeypatch):
     torch.cuda.synchronize()
     assert torch.isnan(g.float()).any()  # poisoned, never stale or silently partial
     patch = torch.rand(3, 8, 8, device=DEV)
-    with pytest.raises(_lib.VaaError, match="hand-over timed out"):  # the next library call, whatever it is, reports the failure ...
-        ops.patch_update(patch, torch.rand_like(patch), torch.zeros_like(patch), torch.zeros_like(patch), ops.OPT_ADAMW_HF, 1e-3, 1)
-    ops.async_error_check()                                           # ... once: the word is cleared by the report
-    ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=g)
-    torch.cuda.synchronize()
-    with pytest.raises(_lib.VaaError, match="vaa_async_error"):       # the explicit poll
+    for _ in range(2):  # every later library call, whatever it is, reports the failure: the word is sticky, no call consumes it ...
+        with pytest.raises(_lib.VaaError, match="hand-over timed out"):
+            ops.patch_update(patch, torch.rand_like(patch), torch.zeros_like(patch), torch.zeros_like(patch), ops.OPT_ADAMW_HF, 1e-3, 1)
+    with pytest.raises(_lib.VaaError, match="vaa_async_error"):       # ... until the explicit poll reports and clears it
         ops.async_error_check()
+    ops.async_error_check()                                           # clean again
+    ops.patch_update(patch, torch.rand_like(patch), torch.zeros_like(patch), torch.zeros_like(patch), ops.OPT_ADAMW_HF, 1e-3, 1)
+    with pytest.raises(_lib.VaaError, match="hand-over timed out"):  # the failing call itself already sees its own failure if the kernel has run by its check;
+        ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=g)  # (it has not: launches are asynchronous) ...
+        torch.cuda.synchronize()
+        ops.async_error_check()                                       # ... so the poll behind the synchronisation is what raises
     monkeypatch.delenv("VAA_K3_HANDOVER_POLLS")
     g2 = torch.zeros_like(logits)
     ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=g2)  # un-forced: the one-launch form works and agrees
@@ -1555,6 +1560,43 @@ def test_head_loss_rows_stats_vs_oracle_and_gemm_path(ops, B, maskidx, D):
     sc3 = torch.zeros(8, device=DEV)
     ops.step_epilogue(parts, msg, sc3, rowmap=rm, R=R, V=V, mode=ops.LOSS_UADA_DDP, w=5.0, loss_ws=ws)
     assert torch.equal(gs3.view(torch.int16), gs.view(torch.int16)) and torch.equal(sc3, sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,maskidx", [(64, [0]), (32, [0]), (8, [0, 1, 2])])
+def test_head_stats_production_launch_equals_dumping_launch(ops, B, maskidx):
+    """K3h's oracle check goes through the test-only logits dump (`logits_dbg`) — so the PRODUCTION launch (no dump) is tied
+    to the dumping launch directly: at OpenVLA's head (D = 4096) and 128 / 64 / 32 labelled rows both launches leave the SAME bytes in the
+    head's workspace (every workgroup's PartStat of every row + the bf16 action-slice logits) and in K3's workspace (the folded per-row
+    statistics head_finish_kernel writes), and the same gradient slice. Both workspaces are filled with a byte pattern before each launch, so
+    a part one launch wrote and the other did not would differ."""
+    from roboticattack_amd import _lib
+    from roboticattack_amd.labels import mask_labels
+
+    V, D = 32064, 4096
+    _, labels, _ = synthetic.synth_text_batch(700 + B, B)
+    labels = mask_labels(labels, maskidx)
+    R = int((labels[:, 1:] != -100).sum())
+    assert R == B * (len(maskidx) + 1)
+    g = torch.Generator(device=DEV).manual_seed(3 * B + 1)
+    W = (torch.randn(V, D, device=DEV, generator=g) * (1.3 / np.sqrt(D))).to(torch.bfloat16)
+    h = torch.randn(R, D, device=DEV, generator=g).to(torch.bfloat16)
+    rm = ops.LossRowMap(labels.to(DEV))
+    L = _lib.lib()
+    n_ws, n_hws = L.vaa_loss_rows_ws_bytes(R), L.vaa_head_loss_ws_bytes(R, V)
+    got = []
+    for dump in (False, True):
+        for kind, nb in (("k3", n_ws), ("k3h", n_hws)):
+            ops._workspace(torch.device(DEV), nb, kind).fill_(0xAB)
+        gs = torch.full((R, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ws, hws, lg = ops._head_stats(h, W, rm, ops.LOSS_UADA_DDP, 5.0, 0.8, 0.2, 1.0, gs, dump)
+        torch.cuda.synchronize()
+        assert (lg is not None) == dump
+        got.append((ws[:n_ws].clone(), hws[:n_hws].clone(), gs.view(torch.int16).clone()))
+    (ws0, hws0, g0), (ws1, hws1, g1) = got
+    assert torch.equal(hws0, hws1), "per-workgroup PartStats / slice logits differ between the production and the dumping launch"
+    assert torch.equal(ws0, ws1) and torch.equal(g0, g1)
+    assert int((hws0 != 0xAB).sum()) > R * 251 * 8 and not bool(torch.isnan(got[0][2].view(torch.bfloat16).float()).any())  # ... and they were written
 
 
 @pytest.mark.gpu
