@@ -16,6 +16,8 @@ int vaa_model_rope(const uint16_t* x, long sb, long st, long sh, const float* co
 /* y = silu(gate) * up over n contiguous bf16 elements (n % 8 == 0), and its backward. */
 int vaa_model_swiglu_fwd(const uint16_t* gate, const uint16_t* up, uint16_t* y, long n, void* stream);
 int vaa_model_swiglu_bwd(const uint16_t* dy, const uint16_t* gate, const uint16_t* up, uint16_t* dgate, uint16_t* dup, long n, void* stream);
+/* LayerScale + residual: out[r, :] = x[r, :] + a[r, :] * ls (ls bf16 [D], D % 8 == 0; x may be NULL: out = a * ls). */
+int vaa_model_scale_add(const uint16_t* x, const uint16_t* a, const uint16_t* ls, uint16_t* out, long rows, int D, void* stream);
 /* RMSNorm over rows of D bf16 (weight bf16 [D], HF LlamaRMSNorm rounding) saving rstd float32 [rows]; the backward adds the
  * residual pass-through gradient gpass (may be NULL): gx = gpass + rstd*(gh*w - xhat*mean(gh*w*xhat)). */
 int vaa_model_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* h, float* rstd, long rows, int D, float eps, void* stream);

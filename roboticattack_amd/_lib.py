@@ -20,7 +20,7 @@ GRAD_FULL, GRAD_SLICE = 0, 1
 OPT_ADAMW_HF, OPT_PGD_SIGN = 0, 1
 
 MODEL_OP_EXPORTS = ("vaa_model_rope", "vaa_model_swiglu_fwd", "vaa_model_swiglu_bwd", "vaa_model_rmsnorm_fwd", "vaa_model_rmsnorm_bwd",
-                    "vaa_model_attention_fwd", "vaa_model_attention_bwd", "vaa_model_layernorm_fwd", "vaa_model_layernorm_bwd")
+                    "vaa_model_attention_fwd", "vaa_model_attention_bwd", "vaa_model_layernorm_fwd", "vaa_model_layernorm_bwd", "vaa_model_scale_add")
 
 EXPORTS = (
     "vaa_last_error",
@@ -217,6 +217,8 @@ def lib() -> C.CDLL:
     L.vaa_model_swiglu_fwd.argtypes = [vp, vp, vp, lng, vp]
     L.vaa_model_swiglu_bwd.restype = i32
     L.vaa_model_swiglu_bwd.argtypes = [vp, vp, vp, vp, vp, lng, vp]
+    L.vaa_model_scale_add.restype = i32
+    L.vaa_model_scale_add.argtypes = [vp, vp, vp, vp, lng, i32, vp]
     L.vaa_model_rmsnorm_fwd.restype = i32
     L.vaa_model_rmsnorm_fwd.argtypes = [vp, vp, vp, vp, lng, i32, f32, vp]
     L.vaa_model_rmsnorm_bwd.restype = i32

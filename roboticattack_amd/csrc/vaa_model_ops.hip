@@ -5,6 +5,8 @@
 // copy kernels of the Llama layers (RoPE = neg + cat + 2 mul + add per tensor, SwiGLU = silu + mul and their multi-kernel
 // backwards); the two kernels below replace those chains by single HBM-bound passes. The model falls back to the eager
 // PyTorch ops when they are disabled (VAA_NO_FUSED_MODEL_OPS=1) or the tensors are not bf16 on a ROCm device.
+#include <stdlib.h>
+
 #include "vaa_common.h"
 
 namespace vaa {
@@ -96,6 +98,21 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint16_t* __restr
     }
 }
 
+
+// ---- LayerScale + residual of the DINOv2 blocks: out = x + a * ls (ls bf16 [D] broadcast over the rows; x == nullptr: out = a * ls, the
+//      backward's d a = g * ls). torch.addcmul with the broadcast operand runs its strided fallback at 0.8 TB/s (128 us for three 34 MB tensors). ----
+__global__ __launch_bounds__(256) void scale_add_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ a, const uint16_t* __restrict__ ls,
+                                                         uint16_t* __restrict__ out, long nvec, int dvec) {
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        float av[8], lv[8], xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
+        unpack8(reinterpret_cast<const uint4*>(a)[v], av);
+        unpack8(reinterpret_cast<const uint4*>(ls)[v % dvec], lv);
+        if (x) unpack8(reinterpret_cast<const uint4*>(x)[v], xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(av[e], lv[e], xv[e]);
+        reinterpret_cast<uint4*>(out)[v] = pack8(o);
+    }
+}
 
 // ---- RMSNorm with residual pass-through: h = x * rstd * w ; backward: gx = g_pass + rstd*(gh*w - xhat*mean(gh*w*xhat)) ----
 // One 256-thread workgroup per row of D bf16 (D % 8 == 0, D <= 8192); the row lives in registers between the two passes.
@@ -277,6 +294,105 @@ __global__ __launch_bounds__(kNormThreads) void layernorm_bwd_kernel(const uint1
     }
 }
 
+// ---- the same two operators for NARROW rows (the ViT towers: D = 1024 / 1152, 2 KB rows): ONE WAVE per row, four rows per workgroup, no
+//      LDS and no workgroup barrier — the row's sums are wave reductions. One 256-thread workgroup per 2 KB row left half its threads idle at
+//      D = 1024 and paid two (fwd: four) barriers per row: 75 us forward / 98 us backward for 16,448 rows at bs=64 = 0.9-1.0 TB/s, the slowest
+//      streams of the step (profiles/r04_bench_kernel_stats.csv). NV = 16-byte vectors per lane (D <= NV * 512). Same arithmetic per element;
+//      only the order of the fp32 row sums differs. ----
+constexpr int kNormWaveRows = 4;
+
+template <int NV>
+__global__ __launch_bounds__(64 * kNormWaveRows) void layernorm_fwd_wave_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                                                 const uint16_t* __restrict__ b, uint16_t* __restrict__ h,
+                                                                                 float* __restrict__ stats, long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * kNormWaveRows + (threadIdx.x >> 6);
+    if (row >= rows) return;  // wave-uniform
+    const int nv = D >> 3;
+    float xv[NV][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int q = lane + c * 64;
+        if (q < nv) {
+            unpack8(reinterpret_cast<const uint4*>(x + row * D)[q], xv[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += xv[c][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        if (lane + c * 64 < nv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xv[c][e] -= mean; ss += xv[c][e] * xv[c][e]; }
+        }
+    }
+    const float r = rsqrtf(wave_sum(ss) / (float)D + eps);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = r; }
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int q = lane + c * 64;
+        if (q < nv) {
+            float wv[8], bv[8], o[8];
+            unpack8(reinterpret_cast<const uint4*>(w)[q], wv);
+            unpack8(reinterpret_cast<const uint4*>(b)[q], bv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = xv[c][e] * r * wv[e] + bv[e];
+            reinterpret_cast<uint4*>(h + row * D)[q] = pack8(o);
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(64 * kNormWaveRows) void layernorm_bwd_wave_kernel(const uint16_t* __restrict__ gh, const uint16_t* __restrict__ gpass,
+                                                                                 const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                                                 const float* __restrict__ stats, uint16_t* __restrict__ gx, long rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * kNormWaveRows + (threadIdx.x >> 6);
+    if (row >= rows) return;  // wave-uniform
+    const int nv = D >> 3;
+    const float mean = stats[2 * row], r = stats[2 * row + 1];
+    float xh[NV][8], gw[NV][8], gp[NV][8];
+    float sg = 0.0f, dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int q = lane + c * 64;
+        if (q < nv) {  // all of the row's loads (x, gh, g_pass) in flight before the first use
+            float wv[8];
+            unpack8(reinterpret_cast<const uint4*>(x + row * D)[q], xh[c]);
+            unpack8(reinterpret_cast<const uint4*>(gh + row * D)[q], gw[c]);
+            if (gpass) unpack8(reinterpret_cast<const uint4*>(gpass + row * D)[q], gp[c]);
+            unpack8(reinterpret_cast<const uint4*>(w)[q], wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[c][e] = (xh[c][e] - mean) * r;
+                gw[c][e] *= wv[e];
+                sg += gw[c][e];
+                dot += gw[c][e] * xh[c][e];
+            }
+        }
+    }
+    sg = wave_sum(sg) / (float)D;
+    dot = wave_sum(dot) / (float)D;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int q = lane + c * 64;
+        if (q < nv) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (gpass ? gp[c][e] : 0.0f) + r * (gw[c][e] - sg - xh[c][e] * dot);
+            reinterpret_cast<uint4*>(gx + row * D)[q] = pack8(o);
+        }
+    }
+}
+
+static bool ln_wave_enabled() {  // VAA_LN_WAVE=0: the one-workgroup-per-row kernels for every width (A/B)
+    static const bool on = [] { const char* e = getenv("VAA_LN_WAVE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static unsigned stream_grid(long nvec) {
     long b = (nvec + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -310,6 +426,14 @@ extern "C" int vaa_model_swiglu_bwd(const uint16_t* dy, const uint16_t* gate, co
     return check_launch("vaa_model_swiglu_bwd");
 }
 
+extern "C" int vaa_model_scale_add(const uint16_t* x, const uint16_t* a, const uint16_t* ls, uint16_t* out, long rows, int D, void* stream) {
+    using namespace vaa;
+    if (!a || !ls || !out || rows <= 0 || D <= 0 || (D % 8) != 0) { set_error("vaa_model_scale_add: bad arguments (D must be a positive multiple of 8)"); return VAA_E_INVALID; }
+    const long nvec = rows * (long)(D / 8);
+    hipLaunchKernelGGL(scale_add_kernel, dim3(stream_grid(nvec)), dim3(256), 0, (hipStream_t)stream, x, a, ls, out, nvec, D / 8);
+    return check_launch("vaa_model_scale_add");
+}
+
 extern "C" int vaa_model_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* h, float* rstd, long rows, int D, float eps, void* stream) {
     using namespace vaa;
     if (!x || !w || !h || !rstd || rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * kNormThreads * kNormMaxVec) {
@@ -338,7 +462,11 @@ extern "C" int vaa_model_layernorm_fwd(const uint16_t* x, const uint16_t* w, con
         set_error("vaa_model_layernorm_fwd: bad arguments (D must be a multiple of 8, <= 8192)");
         return VAA_E_INVALID;
     }
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, x, w, b, h, stats, D, eps);
+    const dim3 wgrid((unsigned)((rows + kNormWaveRows - 1) / kNormWaveRows)), wblk(64 * kNormWaveRows);
+    if (!ln_wave_enabled()) hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, x, w, b, h, stats, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_fwd_wave_kernel<2>, wgrid, wblk, 0, (hipStream_t)stream, x, w, b, h, stats, rows, D, eps);
+    else if (D <= 1536) hipLaunchKernelGGL(layernorm_fwd_wave_kernel<3>, wgrid, wblk, 0, (hipStream_t)stream, x, w, b, h, stats, rows, D, eps);
+    else hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, x, w, b, h, stats, D, eps);
     return check_launch("vaa_model_layernorm_fwd");
 }
 
@@ -349,6 +477,10 @@ extern "C" int vaa_model_layernorm_bwd(const uint16_t* gh, const uint16_t* gpass
         set_error("vaa_model_layernorm_bwd: bad arguments");
         return VAA_E_INVALID;
     }
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, gh, gpass, x, w, stats, gx, D);
+    const dim3 wgrid((unsigned)((rows + kNormWaveRows - 1) / kNormWaveRows)), wblk(64 * kNormWaveRows);
+    if (!ln_wave_enabled()) hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, gh, gpass, x, w, stats, gx, D);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_wave_kernel<2>, wgrid, wblk, 0, (hipStream_t)stream, gh, gpass, x, w, stats, gx, rows, D);
+    else if (D <= 1536) hipLaunchKernelGGL(layernorm_bwd_wave_kernel<3>, wgrid, wblk, 0, (hipStream_t)stream, gh, gpass, x, w, stats, gx, rows, D);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)rows), dim3(kNormThreads), 0, (hipStream_t)stream, gh, gpass, x, w, stats, gx, D);
     return check_launch("vaa_model_layernorm_bwd");
 }

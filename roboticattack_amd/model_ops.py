@@ -1,4 +1,4 @@
-"""Optional fused elementwise operators for the PyTorch-ROCm model (include/vaa_model_ops.h): RoPE and SwiGLU.
+"""Optional fused elementwise operators for the PyTorch-ROCm model (include/vaa_model_ops.h): RoPE, SwiGLU, the norms, LayerScale + residual, attention.
 
 Outside the hot-path contract (SURVEY.md §8a-5 keeps the model as stock PyTorch): they only shave the eager elementwise
 chains that rocprofv3 shows around the GEMMs. `enabled(x)` is False for non-bf16 / non-ROCm tensors or when
@@ -72,6 +72,37 @@ class SwiGLUFn(torch.autograd.Function):
         _lib.check(_lib.lib().vaa_model_swiglu_bwd(dy.data_ptr(), gate.data_ptr(), up.data_ptr(), dg.data_ptr(), du.data_ptr(), gate.numel(), _stream()),
                    "vaa_model_swiglu_bwd")
         return dg, du
+
+
+def _scale_add(x, a, ls):
+    D = a.shape[-1]
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().vaa_model_scale_add(x.data_ptr() if x is not None else None, a.data_ptr(), ls.data_ptr(), out.data_ptr(), a.numel() // D, D,
+                                              _stream()), "vaa_model_scale_add")
+    return out
+
+
+class ScaleAddFn(torch.autograd.Function):
+    """x + a * ls (LayerScale + residual, ls [D] frozen): one streaming kernel; backward: dx = g (passed through), da = g * ls."""
+
+    @staticmethod
+    def forward(ctx, x, a, ls):
+        ctx.save_for_backward(ls)
+        return _scale_add(x.contiguous(), a.contiguous(), ls.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        (ls,) = ctx.saved_tensors
+        g = g.contiguous()
+        return g, _scale_add(None, g, ls.contiguous()), None
+
+
+def scale_add(x: torch.Tensor, a: torch.Tensor, ls: torch.Tensor) -> torch.Tensor:
+    """torch.addcmul(x, a, ls) for a LayerScale vector ls [D]; the fused kernel for bf16 ROCm tensors of equal shape, D % 8 == 0."""
+    if (enabled(x) and a.dtype == x.dtype and ls.dtype == x.dtype and x.shape == a.shape and ls.dim() == 1 and ls.shape[0] == x.shape[-1]
+            and x.shape[-1] % 8 == 0 and os.environ.get("VAA_MODEL_SCALE_ADD", "1") != "0"):
+        return ScaleAddFn.apply(x, a, ls)
+    return torch.addcmul(x, a, ls)
 
 
 class ResidualRMSNormFn(torch.autograd.Function):

@@ -106,13 +106,13 @@ class VitBlock(nn.Module):
             qkv = qkv.permute(2, 0, 3, 1, 4)
             a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, T, D)
         a = self.proj(a)
-        x = torch.addcmul(x, a, self.ls1) if self.ls1 is not None else x + a  # LayerScale + residual in one pass
+        x = model_ops.scale_add(x, a, self.ls1) if self.ls1 is not None else x + a  # LayerScale + residual in one pass
         if fused_ln:
             x, h = model_ops.ResidualLayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         else:
             h = self.norm2(x)
         h = self.fc2(F.gelu(self.fc1(h)))
-        return torch.addcmul(x, h, self.ls2) if self.ls2 is not None else x + h
+        return model_ops.scale_add(x, h, self.ls2) if self.ls2 is not None else x + h
 
 
 class Vit(nn.Module):

@@ -62,6 +62,25 @@ def test_swiglu_fwd_bwd_matches_eager():
     assert (ub.grad.float() - ua.grad).abs().max() <= 2 ** -6 * ua.grad.abs().max()
 
 
+def test_scale_add_matches_addcmul():
+    """LayerScale + residual (vaa_model_scale_add) == torch.addcmul bit for bit (one fp32 FMA, one rounding), and its autograd."""
+    from roboticattack_amd import model_ops
+
+    torch.manual_seed(6)
+    x = torch.randn(3, 261, 1024, device=DEV).to(torch.bfloat16)
+    a = torch.randn(3, 261, 1024, device=DEV).to(torch.bfloat16)
+    ls = (0.1 * torch.randn(1024, device=DEV)).to(torch.bfloat16)
+    xa, aa = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    xb, ab = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    ref = torch.addcmul(xa, aa, ls)
+    got = model_ops.scale_add(xb, ab, ls)
+    assert "ScaleAddFn" in type(got.grad_fn).__name__ and torch.equal(got, ref)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    got.backward(g)
+    assert torch.equal(xb.grad, xa.grad) and torch.equal(ab.grad, aa.grad)
+
+
 def test_residual_rmsnorm_fwd_bwd_matches_eager():
     import torch.nn.functional as F
 
@@ -256,7 +275,7 @@ def test_rope_attention_fused_backward(hd):
         assert (a - b).abs().max() <= 2 ** -6 * b.abs().max()
 
 
-@pytest.mark.parametrize("D", [1024, 1152, 48])
+@pytest.mark.parametrize("D", [1024, 1152, 48, 2048])  # one wave per row up to 1536 (2 / 3 vectors per lane), one workgroup per row beyond
 def test_residual_layernorm_fwd_bwd_matches_eager(D):
     from roboticattack_amd import model_ops
 
