@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The gather ("one lane per patch texel") formulation of K2 against the product's scatter: parity and time (GPU box).
 
-    python tools/k2_gather_probe.py            # builds tools/probe/k2_gather_probe.hip -> tools/scratch/libk2gather.so if missing
+    python tools/k2_gather_probe.py            # builds tools/probe/k2_gather_probe.hip -> tools/probe/libk2gather.so if missing
 """
 import ctypes as C
 import os
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from roboticattack_amd import benchmarks, ops, synthetic  # noqa: E402
 
-SO = os.path.join(ROOT, "tools", "scratch", "libk2gather.so")
+SO = os.path.join(ROOT, "tools", "probe", "libk2gather.so")
 
 
 def build():

@@ -20,21 +20,23 @@ cp "$(stats_csv /tmp/prof_kb)" "${out}/kbench_kernel_stats.csv" 2>/dev/null
 timeout 400 python tools/pmc_traffic.py > "${out}/traffic.log" 2>&1 && cp gpurun_out/traffic.json "${out}/traffic.json"
 
 # the driver's N=1 command under rocprofv3 (20 steps like the driver's run; the CPU baseline and the stand-alone suite are not GPU work of the step)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank > "${out}/bench_under_rocprof.json" 2> "${out}/bench_under_rocprof.err"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank --no-configs > "${out}/bench_under_rocprof.json" 2> "${out}/bench_under_rocprof.err"
 cp "$(stats_csv /tmp/prof_b)" "${out}/bench_kernel_stats.csv" 2>/dev/null
 # the same command un-profiled: its in-step per-dispatch figures are what the record carries
-timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank > "${out}/bench_same_cmd.json" 2> "${out}/bench_same_cmd.err"
+timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank --no-configs > "${out}/bench_same_cmd.json" 2> "${out}/bench_same_cmd.err"
 
-timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "${out}/bench_no_cpu.json" 2> "${out}/bench_no_cpu.err"
-timeout 1200 python bench.py > "${out}/bench.json" 2> "${out}/bench.err"
+timeout 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --full-out gpurun_out/measure/bench_no_cpu_full.json > "${out}/bench_no_cpu.json" 2> "${out}/bench_no_cpu.err"
+timeout 1200 python bench.py --full-out gpurun_out/measure/bench_full.json > "${out}/bench.json" 2> "${out}/bench.err"
+# the form the driver runs at round end: ONE compact line on stdout (+ the full record beside it)
+timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 --full-out gpurun_out/measure/bench_driver_cmd_full.json > "${out}/bench_driver_cmd.json" 2> "${out}/bench_driver_cmd.err"
 # two ranks on the one GPU over gloo: the N > 1 code path at full size, both timed regions (functional evidence, not a scaling number)
-timeout 900 python bench.py --gpus 2 --steps 4 --warmup 1 --no-kernel-suite > "${out}/bench_2ranks_one_gpu.json" 2> "${out}/bench_2ranks_one_gpu.err"
+timeout 900 python bench.py --gpus 2 --steps 4 --warmup 1 --full-out gpurun_out/measure/bench_2ranks_one_gpu_full.json > "${out}/bench_2ranks_one_gpu.json" 2> "${out}/bench_2ranks_one_gpu.err"
 # eight ranks on the one GPU, the strong-scaling region alone (bs = 8 per rank, BASELINE config 3's split): the full-size 8-rank functional run.
 # VAA_NO_TN_DGRAD=1 drops the 12.9 GB of resident transposed weights per rank so that eight copies of the model fit the 288 GB
-VAA_NO_TN_DGRAD=1 timeout 1500 python bench.py --gpus 8 --steps 3 --warmup 1 --regions strong --no-cpu-baseline --no-kernel-suite > "${out}/bench_8ranks_one_gpu.json" 2> "${out}/bench_8ranks_one_gpu.err"
+VAA_NO_TN_DGRAD=1 timeout 1500 python bench.py --gpus 8 --steps 3 --warmup 1 --regions strong --full-out gpurun_out/measure/bench_8ranks_one_gpu_full.json > "${out}/bench_8ranks_one_gpu.json" 2> "${out}/bench_8ranks_one_gpu.err"
 timeout 200 python tools/k3_onepass_check.py > "${out}/k3_onepass.txt" 2>&1
 timeout 300 python tools/head_bench.py 128 64 16 > "${out}/head_bench.txt" 2>&1
 # the per-rank step of BASELINE config 3 (bs = 8: the LM head runs fused with K3's statistics) under rocprofv3
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b8 -o b8 -- python bench.py --bs 8 --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank > "${out}/bench_bs8_under_rocprof.json" 2> "${out}/bench_bs8_under_rocprof.err"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b8 -o b8 -- python bench.py --bs 8 --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-suite --no-per-rank --no-configs > "${out}/bench_bs8_under_rocprof.json" 2> "${out}/bench_bs8_under_rocprof.err"
 cp "$(stats_csv /tmp/prof_b8)" "${out}/bench_bs8_kernel_stats.csv" 2>/dev/null
 ls -la "${out}"
