@@ -666,6 +666,37 @@ def test_k4_adamw_pgd_clip_vs_oracle(ops):
     assert np.allclose(pg.cpu().numpy(), ref_port.pgd_step(torch.from_numpy(p0), torch.from_numpy(g), 0.05).numpy(), atol=1e-7)
 
 
+@pytest.mark.parametrize("shape", [(3, 1, 1), (3, 17, 31), (3, 52, 52), (2, 64, 64), (3, 53, 53), (3, 100, 100), (2, 128, 128), (3, 105, 105), (3, 139, 139)])
+@pytest.mark.parametrize("mode", ["adamw_clip", "adamw", "pgd"])
+def test_k4_every_form_vs_oracle(ops, shape, mode):
+    """K4 in its three forms — 4 workgroups (n <= 8,192, incl. the exact boundary 2x64x64), 16 workgroups (n <= 32,768: UPA's 3x100x100 base patch, boundary 2x128x128)
+    and the one-workgroup stream beyond — against the C oracle over three steps: patch / moments <= 1e-6, the logged statistics, and rows that straddle a
+    workgroup's share. Every workgroup of the first two forms computes the whole gradient's statistics itself; the clip coefficient must come out the same in all."""
+    rs = np.random.RandomState(sum(shape) + len(mode))
+    n = int(np.prod(shape))
+    p0 = rs.rand(*shape).astype(np.float32)
+    p, m, v = _t(p0), torch.zeros(shape, device=DEV), torch.zeros(shape, device=DEV)
+    pc, mc, vc = p0.copy().ravel(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for t in range(1, 4):
+        g = (rs.randn(*shape) * 10.0 ** rs.uniform(-6, -2, shape)).astype(np.float32)
+        if mode == "pgd":
+            st = ops.patch_update(p, _t(g), None, None, ops.OPT_PGD_SIGN, 0.01, t)
+            l1 = c_oracle.patch_update(pc, g.ravel(), mc, vc, 1, 0.01, t)
+        else:
+            clip = 1e-3 if mode == "adamw_clip" else 0.0
+            st = ops.patch_update(p, _t(g), m, v, ops.OPT_ADAMW_HF, 2e-3, t, l1_clip=clip, grad_scale=0.5)
+            l1 = c_oracle.patch_update(pc, (g * np.float32(0.5)).ravel(), mc, vc, 0, 2e-3, t, l1_clip=clip)
+        assert np.abs(p.cpu().numpy().ravel() - pc).max() < 1e-6
+        if mode != "pgd":
+            assert np.abs(m.cpu().numpy().ravel() - mc).max() <= 1e-6 * max(np.abs(mc).max(), 1e-30) + 1e-12
+            assert np.abs(v.cpu().numpy().ravel() - vc).max() <= 1e-6 * max(np.abs(vc).max(), 1e-30) + 1e-15
+        s = st.cpu().numpy()
+        scale = 0.5 if mode != "pgd" else 1.0
+        assert abs(s[0] - l1) <= 1e-5 * l1 and abs(s[1] - scale * g.mean()) <= 1e-6 * abs(g).mean() + 1e-9
+    with pytest.raises(Exception, match="alias"):
+        ops.patch_update(p, p, m, v, ops.OPT_ADAMW_HF, 1e-3, 1)
+
+
 @pytest.mark.parametrize("mode,maskidx,dtype", [("UADA_DDP", [0], torch.bfloat16), ("UADA_DDP", [0, 1, 2], torch.float32), ("UADA", [0], torch.float32),
                                                 ("UPA", None, torch.float32), ("UPA", None, torch.bfloat16), ("CE", [0, 2, 5], torch.float32),
                                                 ("CE", list(range(7)), torch.bfloat16)])
