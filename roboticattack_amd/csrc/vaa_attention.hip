@@ -16,6 +16,9 @@
 // (batch, head) are placed on the same XCD (blockIdx % 8) so that its K/V stay in that XCD's L2.
 #include "vaa_common.h"
 
+#include <cstdlib>
+#include <mutex>
+
 #include "../../include/vaa_model_ops.h"
 
 namespace vaa {
@@ -126,46 +129,58 @@ __device__ __forceinline__ bool block_to_pair(int nblk, int npairs, int& pair, i
 }
 
 // ---------------------------------------------------------------- forward ----------------------------------------------------------------
-template <int KS, int NT, bool CAUSAL>
+// G = 16-query column groups per wave (1 or 2): with G = 2 a workgroup covers 128 queries and every K / V fragment read from LDS feeds two
+// MFMAs (one per group), i.e. half the LDS traffic and half the tile loads per unit of work; per query the arithmetic and its order are
+// those of G = 1 (same bits).
+template <int KS, int NT, bool CAUSAL, int G>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     constexpr int HDP = KS * 32;
     constexpr int SK = HDP + 8;   // K tile row stride (bf16): dword stride = 4 mod 8 -> conflict-free 16-byte row reads
     constexpr int SV = HDP + 16;  // V tile row stride: dword stride = 8 mod 16 -> conflict-free transpose reads
+    constexpr int QB = kTile * G, QW = 16 * G;  // queries per workgroup / per wave
     __shared__ __attribute__((aligned(16))) uint16_t sK[kTile * SK];
     __shared__ __attribute__((aligned(16))) uint16_t sV[kTile * SV];
 
-    const int nqb = (a.T + kTile - 1) / kTile;
+    const int nqb = (a.T + QB - 1) / QB;
     int pair, qb;
     if (!block_to_pair(nqb, a.B * a.H, pair, qb)) return;
     const int b = pair / a.H, h = pair - b * a.H;
     const SeqInfo si = seq_info(a.cu, b, a.T);
     const int T = si.T;
-    if (qb * kTile >= T) return;  // block beyond this sample's length (packed batches)
+    if (qb * QB >= T) return;  // block beyond this sample's length (packed batches)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int q0 = qb * kTile + wv * 16;  // this wave's 16 queries
-    const int q = q0 + c;                 // this lane's query (column of every S^T / O^T tile)
+    const int q0 = qb * QB + wv * QW;  // this wave's first query; group j holds queries q0 + 16 j + [0, 16)
 
     const uint16_t* qp = a.q + row_base(a.sq, si, b, h);
     const uint16_t* kp = a.k + row_base(a.sk, si, b, h);
     const uint16_t* vp = a.v + row_base(a.sv, si, b, h);
 
-    // Q^T fragments: lane (c,g), k-step ks <-> Q[q][32 ks + 8 g .. +8]
-    v8s qf[KS];
+    // Q^T fragments: lane (c,g), group j, k-step ks <-> Q[q0 + 16 j + c][32 ks + 8 g .. +8]
+    v8s qf[G][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int d0 = ks * 32 + g * 8;
-        uint4 r = make_uint4(0, 0, 0, 0);
-        if (q < T && d0 < a.hd) r = *reinterpret_cast<const uint4*>(qp + (long)q * a.sq.t + d0);
-        qf[ks] = *reinterpret_cast<v8s*>(&r);
+    for (int j = 0; j < G; ++j) {
+        const int q = q0 + 16 * j + c;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            uint4 r = make_uint4(0, 0, 0, 0);
+            if (q < T && d0 < a.hd) r = *reinterpret_cast<const uint4*>(qp + (long)q * a.sq.t + d0);
+            qf[j][ks] = *reinterpret_cast<v8s*>(&r);
+        }
     }
 
-    const int kend = CAUSAL ? min(T, (qb + 1) * kTile) : T;  // keys [0, kend) are visible to this workgroup
+    const int kend = CAUSAL ? min(T, (qb + 1) * QB) : T;  // keys [0, kend) are visible to this workgroup
     const int ntile = (kend + kTile - 1) / kTile;
 
-    v4f acc[NT];
+    v4f acc[G][NT];
+    float m[G], lsum[G];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, lsum = 0.0f;
+    for (int j = 0; j < G; ++j) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[j][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        m[j] = -INFINITY;
+        lsum[j] = 0.0f;
+    }
 
     const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, T, a.hd), vrs = slice_rsrc(vp, a.sv.t, T, a.hd);
     const int kst = (int)a.sk.t * 2, vst = (int)a.sv.t * 2;
@@ -182,9 +197,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
             rv.load(vrs, vst, (kt + 1) * kTile);
         }
         const int key0 = kt * kTile;
-        if (CAUSAL && key0 > q0 + 15) continue;  // nothing visible to this wave in this tile (wave-uniform)
+        if (CAUSAL && key0 > q0 + QW - 1) continue;  // nothing visible to this wave in this tile (wave-uniform)
 
-        v4f st[4];
+        v4f st[G][4];
 #pragma unroll
         for (int rp = 0; rp < 2; ++rp) {  // all fragment reads of two 16-key tiles first, then their MFMAs
             v8s kfr[2][KS];
@@ -193,73 +208,87 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) kfr[rl][ks] = *reinterpret_cast<const v8s*>(&sK[((2 * rp + rl) * 16 + c) * SK + ks * 32 + g * 8]);
 #pragma unroll
-            for (int rl = 0; rl < 2; ++rl) {
-                v4f t = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < G; ++j)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[rl][ks], qf[ks], t, 0, 0, 0);
-                st[2 * rp + rl] = t;
-            }
+                for (int rl = 0; rl < 2; ++rl) {
+                    v4f t = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[rl][ks], qf[j][ks], t, 0, 0, 0);
+                    st[j][2 * rp + rl] = t;
+                }
         }
-        const bool need_mask = (key0 + kTile > T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform
-        if (need_mask) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int qj0 = q0 + 16 * j, q = qj0 + c;
+            const bool need_mask = (key0 + kTile > T) || (CAUSAL && key0 + kTile - 1 > qj0);  // wave-uniform
+            if (need_mask) {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + rt * 16 + g * 4 + r;
+                        if (key >= T || (CAUSAL && key > q)) st[j][rt][r] = -INFINITY;
+                    }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[j][rt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[j], mx * a.scale_log2);  // scale > 0: max commutes with the scaling
+            const float mu = (mn == -INFINITY) ? 0.0f : mn;
+            const float alpha = fast_exp2(m[j] - mu);  // m = -inf -> 0
+            m[j] = mn;
+            float ps = 0.0f;
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + rt * 16 + g * 4 + r;
-                    if (key >= T || (CAUSAL && key > q)) st[rt][r] = -INFINITY;
+                    const float p = fast_exp2(__builtin_fmaf(st[j][rt][r], a.scale_log2, -mu));
+                    st[j][rt][r] = p;
+                    ps += p;
                 }
+            lsum[j] = lsum[j] * alpha + ps;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[j][nt] *= alpha;
         }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[rt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx * a.scale_log2);  // scale > 0: max commutes with the scaling
-        const float mu = (mn == -INFINITY) ? 0.0f : mn;
-        const float alpha = fast_exp2(m - mu);  // m = -inf -> 0
-        m = mn;
-        float ps = 0.0f;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(__builtin_fmaf(st[rt][r], a.scale_log2, -mu));
-                st[rt][r] = p;
-                ps += p;
-            }
-        lsum = lsum * alpha + ps;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] *= alpha;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const v8s pf = pack8(st[2 * half], st[2 * half + 1]);
             const uint16_t* vrow = &sV[(half * 32 + 4 * g + (c >> 2)) * SV + (c & 3) * 4];
             v8s vfr[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) vfr[nt] = cat8(lds_tr16(vrow + nt * 16), lds_tr16(vrow + 16 * SV + nt * 16));
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[nt], pf, acc[nt], 0, 0, 0);
-        }
-    }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
-    if (q < T) {
-        const float inv = lsum > 0.0f ? 1.0f / lsum : 0.0f;
-        uint16_t* op = a.o + row_base(a.so, si, b, h) + (long)q * a.so.t;
+            for (int j = 0; j < G; ++j) {
+                const v8s pf = pack8(st[j][2 * half], st[j][2 * half + 1]);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int d0 = nt * 16 + g * 4;
-            if (d0 < a.hd) {
-                uint2 w;
-                w.x = cvt_pk_bf16(acc[nt][0] * inv, acc[nt][1] * inv);
-                w.y = cvt_pk_bf16(acc[nt][2] * inv, acc[nt][3] * inv);
-                *reinterpret_cast<uint2*>(op + d0) = w;
+                for (int nt = 0; nt < NT; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[nt], pf, acc[j][nt], 0, 0, 0);
             }
         }
-        if (g == 0) a.lse[((long)b * a.H + h) * a.T + q] = (m + __builtin_log2f(lsum)) * 0.69314718055994531f;
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int q = q0 + 16 * j + c;
+        float ls = lsum[j];
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        if (q < T) {
+            const float inv = ls > 0.0f ? 1.0f / ls : 0.0f;
+            uint16_t* op = a.o + row_base(a.so, si, b, h) + (long)q * a.so.t;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int d0 = nt * 16 + g * 4;
+                if (d0 < a.hd) {
+                    uint2 w;
+                    w.x = cvt_pk_bf16(acc[j][nt][0] * inv, acc[j][nt][1] * inv);
+                    w.y = cvt_pk_bf16(acc[j][nt][2] * inv, acc[j][nt][3] * inv);
+                    *reinterpret_cast<uint2*>(op + d0) = w;
+                }
+            }
+            if (g == 0) a.lse[((long)b * a.H + h) * a.T + q] = (m[j] + __builtin_log2f(ls)) * 0.69314718055994531f;
+        }
     }
 }
 
@@ -341,51 +370,73 @@ __device__ __forceinline__ v4f tile_dot(const uint16_t* tile, int stride, int rt
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// A-operand fragments of rows [rt*16, rt*16+16) of an LDS tile (lane (c,g), k-step ks <-> row rt*16+c, columns 32 ks + 8 g .. +8)
+template <int KS>
+__device__ __forceinline__ void load_tile_frags(v8s (&af)[KS], const uint16_t* tile, int stride, int rt, int c, int g) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const v8s*>(&tile[(rt * 16 + c) * stride + ks * 32 + g * 8]);
+}
+template <int KS>
+__device__ __forceinline__ v4f frag_dot(const v8s (&af)[KS], const v8s (&bf)[KS]) {
+    v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf[ks], acc, 0, 0, 0);
+    return acc;
+}
+
 // dQ^T = sum over key tiles of K^T dS^T, with S^T = K Q^T and dP^T = V dO^T recomputed; dS^T = P^T o (dP^T - D). One workgroup =
-// 64 queries; a lane's column is its query, so lse and D are per-lane scalars. Also produces D for the dk/dv kernel.
-template <int KS, int NT, bool CAUSAL>
+// 64 G queries (G column groups of 16 per wave: every K / V fragment read feeds G MFMAs); a lane's column is its query, so lse and D are
+// per-lane scalars. Also produces D for the dk/dv kernel.
+template <int KS, int NT, bool CAUSAL, int G>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     constexpr int HDP = KS * 32;
     constexpr int SK = HDP + 16, SV = HDP + 8;  // K is read by rows (16) AND transposed (32 reads): its stride favours the transpose reads
+    constexpr int QB = kTile * G, QW = 16 * G;
     __shared__ __attribute__((aligned(16))) uint16_t sK[kTile * SK];
     __shared__ __attribute__((aligned(16))) uint16_t sV[kTile * SV];
 
-    const int nqb = (a.T + kTile - 1) / kTile;
+    const int nqb = (a.T + QB - 1) / QB;
     int pair, qb;
     if (!block_to_pair(nqb, a.B * a.H, pair, qb)) return;
     const int b = pair / a.H, h = pair - b * a.H;
     const SeqInfo si = seq_info(a.cu, b, a.T);
     const int T = si.T;
-    if (qb * kTile >= T) return;  // block beyond this sample's length (packed batches)
+    if (qb * QB >= T) return;  // block beyond this sample's length (packed batches)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int q0 = qb * kTile + wv * 16, q = q0 + c;
-    const bool qv = q < T;
+    const int q0 = qb * QB + wv * QW;
 
     const uint16_t* kp = a.k + row_base(a.sk, si, b, h);
     const uint16_t* vp = a.v + row_base(a.sv, si, b, h);
-    v8s qf[KS], dof[KS];
-    load_row_frags<KS>(qf, a.q + row_base(a.sq, si, b, h) + (long)q * a.sq.t, qv, g, a.hd);
-    load_row_frags<KS>(dof, a.dout + row_base(a.sdo, si, b, h) + (long)q * a.sdo.t, qv, g, a.hd);
-    float Dq = 0.0f;
-    {
+    v8s qf[G][KS], dof[G][KS];
+    float Dq[G], lse2[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int q = q0 + 16 * j + c;
+        const bool qv = q < T;
+        load_row_frags<KS>(qf[j], a.q + row_base(a.sq, si, b, h) + (long)q * a.sq.t, qv, g, a.hd);
+        load_row_frags<KS>(dof[j], a.dout + row_base(a.sdo, si, b, h) + (long)q * a.sdo.t, qv, g, a.hd);
+        float dq_ = 0.0f;
         v8s of[KS];
         load_row_frags<KS>(of, a.o + row_base(a.so, si, b, h) + (long)q * a.so.t, qv, g, a.hd);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Dq += bf16_bits_to_f32((uint16_t)of[ks][j]) * bf16_bits_to_f32((uint16_t)dof[ks][j]);
-        Dq += __shfl_xor(Dq, 16, 64);
-        Dq += __shfl_xor(Dq, 32, 64);
+            for (int e = 0; e < 8; ++e) dq_ += bf16_bits_to_f32((uint16_t)of[ks][e]) * bf16_bits_to_f32((uint16_t)dof[j][ks][e]);
+        dq_ += __shfl_xor(dq_, 16, 64);
+        dq_ += __shfl_xor(dq_, 32, 64);
+        Dq[j] = dq_;
+        const long rowid = ((long)b * a.H + h) * a.T + q;
+        if (qv && g == 0) a.dsum[rowid] = dq_;
+        lse2[j] = qv ? a.lse[rowid] * 1.4426950408889634f : INFINITY;  // invalid query -> P = 0
     }
-    const long rowid = ((long)b * a.H + h) * a.T + q;
-    if (qv && g == 0) a.dsum[rowid] = Dq;
-    const float lse2 = qv ? a.lse[rowid] * 1.4426950408889634f : INFINITY;  // invalid query -> P = 0
 
-    const int kend = CAUSAL ? min(T, (qb + 1) * kTile) : T;
+    const int kend = CAUSAL ? min(T, (qb + 1) * QB) : T;
     const int ntile = (kend + kTile - 1) / kTile;
-    v4f acc[NT];
+    v4f acc[G][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[j][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, T, a.hd), vrs = slice_rsrc(vp, a.sv.t, T, a.hd);
     const int kst = (int)a.sk.t * 2, vst = (int)a.sv.t * 2;
@@ -402,80 +453,101 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
             rv.load(vrs, vst, (kt + 1) * kTile);
         }
         const int key0 = kt * kTile;
-        if (CAUSAL && key0 > q0 + 15) continue;
-        const bool need_mask = (key0 + kTile > T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform
+        if (CAUSAL && key0 > q0 + QW - 1) continue;
+        const bool need_mask = (key0 + kTile > T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform (q0 = the wave's smallest query)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if (CAUSAL && key0 + half * 32 > q0 + 15) continue;
-            v4f ds[2];
+            if (CAUSAL && key0 + half * 32 > q0 + QW - 1) continue;
+            v4f ds[G][2];
 #pragma unroll
             for (int rl = 0; rl < 2; ++rl) {
                 const int rt = 2 * half + rl;
-                const v4f st = tile_dot<KS>(sK, SK, rt, c, g, qf);
-                const v4f dp = tile_dot<KS>(sV, SV, rt, c, g, dof);
+                v8s ak[KS], av[KS];
+                load_tile_frags<KS>(ak, sK, SK, rt, c, g);
+                load_tile_frags<KS>(av, sV, SV, rt, c, g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p = fast_exp2(__builtin_fmaf(st[r], a.scale_log2, -lse2));
-                    if (need_mask) {
-                        const int key = key0 + rt * 16 + g * 4 + r;
-                        if (key >= T || (CAUSAL && key > q)) p = 0.0f;
+                for (int j = 0; j < G; ++j) {
+                    const v4f st = frag_dot<KS>(ak, qf[j]);
+                    const v4f dp = frag_dot<KS>(av, dof[j]);
+                    const int q = q0 + 16 * j + c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = fast_exp2(__builtin_fmaf(st[r], a.scale_log2, -lse2[j]));
+                        if (need_mask) {
+                            const int key = key0 + rt * 16 + g * 4 + r;
+                            if (key >= T || (CAUSAL && key > q)) p = 0.0f;
+                        }
+                        ds[j][rl][r] = p * (dp[r] - Dq[j]);
                     }
-                    ds[rl][r] = p * (dp[r] - Dq);
                 }
             }
-            const v8s dsf = pack8(ds[0], ds[1]);
             const uint16_t* krow = &sK[(half * 32 + 4 * g + (c >> 2)) * SK + (c & 3) * 4];
             v8s kfr[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) kfr[nt] = cat8(lds_tr16(krow + nt * 16), lds_tr16(krow + 16 * SK + nt * 16));
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[nt], dsf, acc[nt], 0, 0, 0);
+            for (int j = 0; j < G; ++j) {
+                const v8s dsf = pack8(ds[j][0], ds[j][1]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[nt], dsf, acc[j][nt], 0, 0, 0);
+            }
         }
     }
-    if (qv) {
-        const long ro = (si.tok0 + q) * (a.hd >> 1);
-        store_grad_row<NT>(a.dq + row_base(a.sdq, si, b, h) + (long)q * a.sdq.t, acc, a.scale, g, a.hd,
-                           a.rope_cos ? a.rope_cos + ro : nullptr, a.rope_cos ? a.rope_sin + ro : nullptr);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int q = q0 + 16 * j + c;
+        if (q < T) {
+            const long ro = (si.tok0 + q) * (a.hd >> 1);
+            store_grad_row<NT>(a.dq + row_base(a.sdq, si, b, h) + (long)q * a.sdq.t, acc[j], a.scale, g, a.hd,
+                               a.rope_cos ? a.rope_cos + ro : nullptr, a.rope_cos ? a.rope_sin + ro : nullptr);
+        }
     }
 }
 
 // dK^T += Q^T dS, dV^T += dO^T P over query tiles, with S = Q K^T and dP = dO V^T recomputed (A = Q / dO rows from LDS, B = K^T / V^T
-// fragments of this wave's 16 keys held in registers): a lane's column is its KEY, rows are queries, so lse and D come from LDS.
-template <int KS, int NT, bool CAUSAL>
+// fragments of this wave's 16 G keys held in registers: every Q / dO fragment read feeds G MFMAs): a lane's column is its KEY, rows are
+// queries, so lse and D come from LDS.
+template <int KS, int NT, bool CAUSAL, int G>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     constexpr int HDP = KS * 32;
     constexpr int SQ = HDP + 16;  // both tiles are read by rows AND transposed; the transpose reads are twice as many -> their stride
+    constexpr int KB = kTile * G, KW = 16 * G;  // keys per workgroup / per wave
     __shared__ __attribute__((aligned(16))) uint16_t sQ[kTile * SQ];
     __shared__ __attribute__((aligned(16))) uint16_t sDO[kTile * SQ];
     __shared__ float sL[kTile], sD[kTile];
 
-    const int nkb = (a.T + kTile - 1) / kTile;
+    const int nkb = (a.T + KB - 1) / KB;
     int pair, kb;
     if (!block_to_pair(nkb, a.B * a.H, pair, kb, !CAUSAL)) return;  // causal: early key blocks see the most queries -> first
     const int b = pair / a.H, h = pair - b * a.H;
     const SeqInfo si = seq_info(a.cu, b, a.T);
     const int T = si.T;
-    if (kb * kTile >= T) return;  // block beyond this sample's length (packed batches)
+    if (kb * KB >= T) return;  // block beyond this sample's length (packed batches)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int key0w = kb * kTile + wv * 16, key = key0w + c;
-    const bool kv = key < T;
+    const int key0w = kb * KB + wv * KW;  // the wave's first key; group j holds keys key0w + 16 j + [0, 16)
 
-    v8s kf[KS], vf[KS];
-    load_row_frags<KS>(kf, a.k + row_base(a.sk, si, b, h) + (long)key * a.sk.t, kv, g, a.hd);
-    load_row_frags<KS>(vf, a.v + row_base(a.sv, si, b, h) + (long)key * a.sv.t, kv, g, a.hd);
+    v8s kf[G][KS], vf[G][KS];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int key = key0w + 16 * j + c;
+        load_row_frags<KS>(kf[j], a.k + row_base(a.sk, si, b, h) + (long)key * a.sk.t, key < T, g, a.hd);
+        load_row_frags<KS>(vf[j], a.v + row_base(a.sv, si, b, h) + (long)key * a.sv.t, key < T, g, a.hd);
+    }
     const uint16_t* qp = a.q + row_base(a.sq, si, b, h);
     const uint16_t* dop = a.dout + row_base(a.sdo, si, b, h);
     const float* lsep = a.lse + ((long)b * a.H + h) * a.T;
     const float* dsp = a.dsum + ((long)b * a.H + h) * a.T;
 
-    v4f dk[NT], dv[NT];
+    v4f dk[G][NT], dv[G][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        dk[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
-        dv[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            dk[j][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+            dv[j][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
     const int nqt = (T + kTile - 1) / kTile;
-    const int qt0 = CAUSAL ? kb : 0;
+    const int qt0 = CAUSAL ? kb * G : 0;  // the first query tile that sees a key of this workgroup
     TileRegs<HDP> rq, rdo;
     float rstat = 0.0f;  // threads 0..63: lse of query tid (log2 units, +inf when invalid); 64..127: D
     auto load_stats = [&](int qbase) {
@@ -504,59 +576,95 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         }
         const int qb0 = qt * kTile;
         if (CAUSAL && qb0 + kTile - 1 < key0w) continue;  // every query of the tile precedes this wave's keys
-        const bool need_mask = CAUSAL && qb0 < key0w + 15;  // wave-uniform: some (query, key) pair of this tile is hidden
+        const bool need_mask = CAUSAL && qb0 < key0w + KW - 1;  // wave-uniform: some (query, key) pair of this tile is hidden
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (CAUSAL && qb0 + half * 32 + 31 < key0w) continue;
-            v4f p[2], ds[2];
+            v4f p[G][2], ds[G][2];
 #pragma unroll
             for (int rl = 0; rl < 2; ++rl) {
                 const int rt = 2 * half + rl;
-                const v4f s = tile_dot<KS>(sQ, SQ, rt, c, g, kf);
-                const v4f dp = tile_dot<KS>(sDO, SQ, rt, c, g, vf);
+                v8s aq[KS], ado[KS];
+                load_tile_frags<KS>(aq, sQ, SQ, rt, c, g);
+                load_tile_frags<KS>(ado, sDO, SQ, rt, c, g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ql = rt * 16 + g * 4 + r;
-                    float pe = fast_exp2(__builtin_fmaf(s[r], a.scale_log2, -sL[ql]));  // invalid query: lse = +inf -> 0
-                    if (CAUSAL && need_mask && key > qb0 + ql) pe = 0.0f;
-                    p[rl][r] = pe;
-                    ds[rl][r] = pe * (dp[r] - sD[ql]);
+                for (int j = 0; j < G; ++j) {
+                    const v4f s = frag_dot<KS>(aq, kf[j]);
+                    const v4f dp = frag_dot<KS>(ado, vf[j]);
+                    const int key = key0w + 16 * j + c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ql = rt * 16 + g * 4 + r;
+                        float pe = fast_exp2(__builtin_fmaf(s[r], a.scale_log2, -sL[ql]));  // invalid query: lse = +inf -> 0
+                        if (CAUSAL && need_mask && key > qb0 + ql) pe = 0.0f;
+                        p[j][rl][r] = pe;
+                        ds[j][rl][r] = pe * (dp[r] - sD[ql]);
+                    }
                 }
             }
-            const v8s pf = pack8(p[0], p[1]), dsf = pack8(ds[0], ds[1]);
             const int ro = (half * 32 + 4 * g + (c >> 2)) * SQ + (c & 3) * 4;
             {
                 v8s fr[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) fr[nt] = cat8(lds_tr16(&sDO[ro + nt * 16]), lds_tr16(&sDO[ro + 16 * SQ + nt * 16]));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[nt], pf, dv[nt], 0, 0, 0);
+                for (int j = 0; j < G; ++j) {
+                    const v8s pf = pack8(p[j][0], p[j][1]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) dv[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[nt], pf, dv[j][nt], 0, 0, 0);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) fr[nt] = cat8(lds_tr16(&sQ[ro + nt * 16]), lds_tr16(&sQ[ro + 16 * SQ + nt * 16]));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) dk[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[nt], dsf, dk[nt], 0, 0, 0);
+                for (int j = 0; j < G; ++j) {
+                    const v8s dsf = pack8(ds[j][0], ds[j][1]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) dk[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[nt], dsf, dk[j][nt], 0, 0, 0);
+                }
             }
         }
     }
-    if (kv) {
-        const long ro = (si.tok0 + key) * (a.hd >> 1);
-        store_grad_row<NT>(a.dk + row_base(a.sdk, si, b, h) + (long)key * a.sdk.t, dk, a.scale, g, a.hd,
-                           a.rope_cos ? a.rope_cos + ro : nullptr, a.rope_cos ? a.rope_sin + ro : nullptr);
-        store_grad_row<NT>(a.dv + row_base(a.sdv, si, b, h) + (long)key * a.sdv.t, dv, 1.0f, g, a.hd, nullptr, nullptr);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int key = key0w + 16 * j + c;
+        if (key < T) {
+            const long ro = (si.tok0 + key) * (a.hd >> 1);
+            store_grad_row<NT>(a.dk + row_base(a.sdk, si, b, h) + (long)key * a.sdk.t, dk[j], a.scale, g, a.hd,
+                               a.rope_cos ? a.rope_cos + ro : nullptr, a.rope_cos ? a.rope_sin + ro : nullptr);
+            store_grad_row<NT>(a.dv + row_base(a.sdv, si, b, h) + (long)key * a.sdv.t, dv[j], 1.0f, g, a.hd, nullptr, nullptr);
+        }
     }
+}
+
+// row groups per wave of each kernel: VAA_ATTN_G = "fqk" digits (forward, dq, dk/dv), e.g. "212"; default below
+static void attn_groups(int hd, int& gf, int& gq, int& gk) {
+    static int cfg[3] = {0, 0, 0};
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* ev = getenv("VAA_ATTN_G");
+        for (int i = 0; i < 3; ++i) cfg[i] = (ev && ev[0] && ev[1] && ev[2] && (ev[i] == '1' || ev[i] == '2')) ? ev[i] - '0' : 0;
+    });
+    gf = cfg[0] ? cfg[0] : 1;
+    gq = cfg[1] ? cfg[1] : 1;
+    gk = cfg[2] ? cfg[2] : 1;
+    (void)hd;
 }
 
 template <bool CAUSAL>
 static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
-    const int nb = (a.T + kTile - 1) / kTile;
-    const unsigned grid = (unsigned)(((long)a.B * a.H + 7) / 8 * 8 * nb);
-#define VAA_ATT_BWD(KS, NT)                                                                                   \
-    do {                                                                                                      \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, NT, CAUSAL>), dim3(grid), dim3(256), 0, st, a);            \
-        int rc = check_launch("vaa_model_attention_bwd(dq)");                                                 \
-        if (rc != VAA_OK) return rc;                                                                          \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, NT, CAUSAL>), dim3(grid), dim3(256), 0, st, a);           \
-        return check_launch("vaa_model_attention_bwd(dkv)");                                                  \
+    int gf, gq, gk;
+    attn_groups(a.hd, gf, gq, gk);
+    const unsigned pairs8 = (unsigned)(((long)a.B * a.H + 7) / 8 * 8);
+    const unsigned grid_q = pairs8 * (unsigned)((a.T + kTile * gq - 1) / (kTile * gq)), grid_k = pairs8 * (unsigned)((a.T + kTile * gk - 1) / (kTile * gk));
+#define VAA_ATT_BWD(KS, NT)                                                                                                  \
+    do {                                                                                                                     \
+        if (gq == 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, NT, CAUSAL, 2>), dim3(grid_q), dim3(256), 0, st, a);         \
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, NT, CAUSAL, 1>), dim3(grid_q), dim3(256), 0, st, a);                 \
+        int rc = check_launch("vaa_model_attention_bwd(dq)");                                                                \
+        if (rc != VAA_OK) return rc;                                                                                         \
+        if (gk == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, NT, CAUSAL, 2>), dim3(grid_k), dim3(256), 0, st, a);        \
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, NT, CAUSAL, 1>), dim3(grid_k), dim3(256), 0, st, a);                \
+        return check_launch("vaa_model_attention_bwd(dkv)");                                                                 \
     } while (0)
     if (a.hd <= 64) VAA_ATT_BWD(2, 4);
     else if (a.hd <= 80) VAA_ATT_BWD(3, 5);
@@ -567,12 +675,19 @@ static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
 
 template <bool CAUSAL>
 static int launch_fwd(const AttnFwdArgs& a, hipStream_t st) {
-    const int nqb = (a.T + kTile - 1) / kTile;
-    const unsigned grid = (unsigned)(((long)a.B * a.H + 7) / 8 * 8 * nqb);
-    if (a.hd <= 64) hipLaunchKernelGGL((attn_fwd_kernel<2, 4, CAUSAL>), dim3(grid), dim3(256), 0, st, a);
-    else if (a.hd <= 80) hipLaunchKernelGGL((attn_fwd_kernel<3, 5, CAUSAL>), dim3(grid), dim3(256), 0, st, a);
-    else if (a.hd <= 96) hipLaunchKernelGGL((attn_fwd_kernel<3, 6, CAUSAL>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<4, 8, CAUSAL>), dim3(grid), dim3(256), 0, st, a);
+    int gf, gq, gk;
+    attn_groups(a.hd, gf, gq, gk);
+    const unsigned grid = (unsigned)(((long)a.B * a.H + 7) / 8 * 8) * (unsigned)((a.T + kTile * gf - 1) / (kTile * gf));
+#define VAA_ATT_FWD(KS, NT)                                                                                          \
+    do {                                                                                                             \
+        if (gf == 2) hipLaunchKernelGGL((attn_fwd_kernel<KS, NT, CAUSAL, 2>), dim3(grid), dim3(256), 0, st, a);      \
+        else hipLaunchKernelGGL((attn_fwd_kernel<KS, NT, CAUSAL, 1>), dim3(grid), dim3(256), 0, st, a);              \
+    } while (0)
+    if (a.hd <= 64) VAA_ATT_FWD(2, 4);
+    else if (a.hd <= 80) VAA_ATT_FWD(3, 5);
+    else if (a.hd <= 96) VAA_ATT_FWD(3, 6);
+    else VAA_ATT_FWD(4, 8);
+#undef VAA_ATT_FWD
     return check_launch("vaa_model_attention_fwd");
 }
 
