@@ -636,7 +636,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     }
 }
 
-// row groups per wave of each kernel: VAA_ATTN_G = "fqk" digits (forward, dq, dk/dv), e.g. "212"; default below
+// Row groups per wave of each kernel. Measured alone at the bs=64 shapes (tools/attn_sweep.sh, profiles/r05_attn_sweep.txt): two groups
+// help the 72-wide SigLIP heads (forward 66.7 -> 61.0, dq 90.5 -> 82.0, dk/dv 115.4 -> 97.4 us), change nothing at 64 (DINOv2) and cost
+// occupancy at 128 (Llama: dk/dv 360 -> 423 us) — these kernels are bound by the bytes a CU keeps in flight, not by LDS or MFMA issue
+// (MFMA 14 %, LDS 11-29 % busy, 41 % of the wave time in memory waits at 2-3 workgroups per CU). VAA_ATTN_G = "fqk" digits (forward, dq,
+// dk/dv; each 1 or 2) overrides the choice for experiments.
 static void attn_groups(int hd, int& gf, int& gq, int& gk) {
     static int cfg[3] = {0, 0, 0};
     static std::once_flag once;
@@ -644,10 +648,10 @@ static void attn_groups(int hd, int& gf, int& gq, int& gk) {
         const char* ev = getenv("VAA_ATTN_G");
         for (int i = 0; i < 3; ++i) cfg[i] = (ev && ev[0] && ev[1] && ev[2] && (ev[i] == '1' || ev[i] == '2')) ? ev[i] - '0' : 0;
     });
-    gf = cfg[0] ? cfg[0] : 1;
-    gq = cfg[1] ? cfg[1] : 1;
-    gk = cfg[2] ? cfg[2] : 1;
-    (void)hd;
+    const int dflt = (hd > 64 && hd <= 80) ? 2 : 1;
+    gf = cfg[0] ? cfg[0] : dflt;
+    gq = cfg[1] ? cfg[1] : dflt;
+    gk = cfg[2] ? cfg[2] : dflt;
 }
 
 template <bool CAUSAL>

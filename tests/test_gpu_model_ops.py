@@ -420,3 +420,42 @@ def test_model_fused_qkv_matches_separate_projections(monkeypatch):
         lyr.k_proj.weight.mul_(2.0)
     w_new, wt_new = lyr._wcat(("q_proj", "k_proj", "v_proj"))
     assert w_new is not w_old and torch.equal(w_new[256:512], lyr.k_proj.weight) and torch.equal(wt_new, w_new.t())
+
+
+def test_attention_two_row_groups_per_wave_matches_fp32():
+    """The attention kernels with TWO 16-row groups per wave (the default only for the 72-wide SigLIP heads; VAA_ATTN_G forces it for every
+    head width) against fp32 softmax attention at the three shapes of the step — a separate process, because the grouping is read once."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cfg in ("222", "111"):
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_bench.py"), "--check", "--bs", "2", "--iters", "1"],
+                           env=dict(os.environ, VAA_ATTN_G=cfg), cwd=root, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        assert p.stdout.count('"ok": true') == 3, p.stdout
+
+
+def test_residual_prefetch_bitwise(monkeypatch):
+    """The Llama stack with the residual copies of o_proj / down_proj started on the side stream (model_ops.residual_prefetch) gives the
+    bits of the plain out-of-place addmm: rows and the pixel gradient."""
+    from roboticattack_amd import synthetic
+    from roboticattack_amd.labels import mask_labels
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+
+    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, True, True), siglip=VitCfg(144, 3, 2, 288, 0, False, False),
+                     llm_dim=256, llm_layers=3, llm_heads=2, llm_mlp=512)
+    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=9)
+    ids, labels, _ = synthetic.synth_text_batch(8, 3, 18, 22)
+    labels = mask_labels(labels, [0]).to(DEV)
+    pix0 = torch.randn(3, 6, 224, 224, device=DEV).to(torch.bfloat16)
+    outs = []
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("VAA_RES_PREFETCH", mode)
+        pix = pix0.clone().requires_grad_(True)
+        rows = m.forward_rows(ids.to(DEV), pix, labels)
+        rows.float().square().mean().backward()
+        outs.append((rows.detach().clone(), pix.grad.detach().clone()))
+    for r, g in outs[1:]:
+        assert torch.equal(r, outs[0][0]) and torch.equal(g, outs[0][1])
