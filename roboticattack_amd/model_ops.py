@@ -171,33 +171,6 @@ def tn_dgrad_enabled() -> bool:
     return not os.environ.get("VAA_NO_TN_DGRAD")
 
 
-_PREFETCH_STREAMS: dict = {}
-
-
-def residual_prefetch_enabled(x: torch.Tensor) -> bool:
-    return x.is_cuda and os.environ.get("VAA_RES_PREFETCH", "1") != "0"
-
-
-def residual_prefetch(res: torch.Tensor):
-    """Start the copy of a residual tensor into a fresh buffer on a SIDE stream and return (buffer, event): `torch.addmm(res, a, W^T)` out of
-    place first copies `res` into its output (a device-to-device copy of [M,4096] bf16 in front of every o_proj / down_proj GEMM: 64 copies of
-    157 MB, ~3.4 ms per bs=64 step, HBM-bound); issued here — as soon as `res` exists — the copy runs UNDER the compute-bound GEMMs between this
-    point and the projection, which then accumulates in place into the buffer (FrozenLinearsFn with `res_copy`). Same arithmetic, same bits."""
-    dev = res.device
-    side = _PREFETCH_STREAMS.get(dev)
-    if side is None:
-        side = _PREFETCH_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    cur = torch.cuda.current_stream(dev)
-    with torch.no_grad():
-        buf = torch.empty_like(res, memory_format=torch.contiguous_format)  # allocated on (and later consumed by) the current stream
-        side.wait_stream(cur)  # `res` is produced on the current stream
-        with torch.cuda.stream(side):
-            buf.copy_(res)
-            ev = torch.cuda.Event()
-            ev.record(side)
-    return buf, ev
-
-
 class FrozenLinearsFn(torch.autograd.Function):
     """(x, res, W_0, Wt_0, W_1, Wt_1, ...) -> tuple of x @ W_i^T (+ res for a single weight, fused as the GEMM epilogue).
 
@@ -233,26 +206,6 @@ class FrozenLinearsFn(torch.autograd.Function):
         dx = dx.view(ctx.xshape) if dx is not None else None
         dres = dys[0] if ctx.has_res else None
         return (dx, dres) + (None,) * (2 * len(ctx.wt))
-
-
-class FrozenLinearResPrefetchedFn(torch.autograd.Function):
-    """(x, res, (buffer, event), W, Wt) -> res + x @ W^T like FrozenLinearsFn with `res`, but accumulated IN PLACE into the buffer that
-    `residual_prefetch(res)` is filling / has filled on the side stream (`res` itself is an input only so that autograd routes its gradient)."""
-
-    @staticmethod
-    def forward(ctx, x, res, pre, w, wt):
-        buf, ev = pre
-        ctx.wt = wt
-        ctx.xshape = x.shape
-        torch.cuda.current_stream(buf.device).wait_event(ev)
-        out = buf.view(-1, w.shape[0])
-        out.addmm_(x.reshape(-1, x.shape[-1]), w.t())
-        return out.view(*x.shape[:-1], w.shape[0])
-
-    @staticmethod
-    def backward(ctx, dy):
-        dx = torch.nn.functional.linear(dy.reshape(-1, dy.shape[-1]), ctx.wt).view(ctx.xshape)
-        return dx, dy, None, None, None
 
 
 def _str3(x: torch.Tensor):

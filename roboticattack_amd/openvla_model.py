@@ -233,11 +233,9 @@ class LlamaLayer(nn.Module):
         mode = os.environ.get("VAA_FUSED_QKV", "auto")
         return mode == "1" or (mode != "0" and rows < 8192)
 
-    def _lin(self, x, names, res=None, pre=None):
+    def _lin(self, x, names, res=None):
         from . import model_ops
 
-        if pre is not None:  # the residual's copy was started on the side stream (model_ops.residual_prefetch): accumulate into it
-            return (model_ops.FrozenLinearResPrefetchedFn.apply(x, res, pre, getattr(self, names[0]).weight, self._wt(names[0])),)
         ws = []
         for n in names:
             ws += [getattr(self, n).weight, self._wt(n)]
@@ -252,10 +250,6 @@ class LlamaLayer(nn.Module):
         hd = D // self.heads
         fused = rope_tab is not None and model_ops.enabled(x) and hd % 16 == 0 and D % 8 == 0 and D <= 8192
         tn = fused and model_ops.tn_dgrad_enabled()
-        # the out-of-place `res + a @ W^T` of o_proj / down_proj starts with a copy of the residual: started HERE on a side stream, it runs under
-        # the GEMMs in between (rows-only last layer: the residual is a 128-row gather, nothing to hide)
-        prefetch = tn and rows is None and model_ops.residual_prefetch_enabled(x)
-        pre_o = model_ops.residual_prefetch(x) if prefetch else None
         if fused:
             x, h = model_ops.ResidualRMSNormFn.apply(x, self.input_layernorm.weight, self.input_layernorm.eps)
         else:
@@ -307,8 +301,7 @@ class LlamaLayer(nn.Module):
             x = x.reshape(-1, D).index_select(0, rows)[None]
             B, T = 1, a.shape[1]
         if tn:
-            (x,) = self._lin(a, ("o_proj",), res=x, pre=pre_o)  # residual in the GEMM epilogue
-            pre_d = model_ops.residual_prefetch(x) if prefetch else None
+            (x,) = self._lin(a, ("o_proj",), res=x)  # residual in the GEMM epilogue
         else:
             x = torch.addmm(x.reshape(-1, D), a.reshape(-1, D), self.o_proj.weight.t()).view(B, T, D)
         if fused:
@@ -318,7 +311,7 @@ class LlamaLayer(nn.Module):
         if fused and (h.shape[0] * h.shape[1] * self.gate_proj.out_features) % 8 == 0:
             if tn:
                 g, u = self._lin(h, ("gate_proj", "up_proj"))
-                (x,) = self._lin(model_ops.SwiGLUFn.apply(g, u), ("down_proj",), res=x, pre=pre_d)
+                (x,) = self._lin(model_ops.SwiGLUFn.apply(g, u), ("down_proj",), res=x)
                 return x[0] if rows is not None else x
             y = model_ops.SwiGLUFn.apply(self.gate_proj(h), self.up_proj(h))
             x = torch.addmm(x.reshape(-1, D), y.reshape(-1, y.shape[-1]), self.down_proj.weight.t()).view(B, T, D)

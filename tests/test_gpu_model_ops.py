@@ -435,27 +435,3 @@ def test_attention_two_row_groups_per_wave_matches_fp32():
                            env=dict(os.environ, VAA_ATTN_G=cfg), cwd=root, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
         assert p.stdout.count('"ok": true') == 3, p.stdout
-
-
-def test_residual_prefetch_bitwise(monkeypatch):
-    """The Llama stack with the residual copies of o_proj / down_proj started on the side stream (model_ops.residual_prefetch) gives the
-    bits of the plain out-of-place addmm: rows and the pixel gradient."""
-    from roboticattack_amd import synthetic
-    from roboticattack_amd.labels import mask_labels
-    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
-
-    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, True, True), siglip=VitCfg(144, 3, 2, 288, 0, False, False),
-                     llm_dim=256, llm_layers=3, llm_heads=2, llm_mlp=512)
-    m = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=9)
-    ids, labels, _ = synthetic.synth_text_batch(8, 3, 18, 22)
-    labels = mask_labels(labels, [0]).to(DEV)
-    pix0 = torch.randn(3, 6, 224, 224, device=DEV).to(torch.bfloat16)
-    outs = []
-    for mode in ("1", "0", "1"):
-        monkeypatch.setenv("VAA_RES_PREFETCH", mode)
-        pix = pix0.clone().requires_grad_(True)
-        rows = m.forward_rows(ids.to(DEV), pix, labels)
-        rows.float().square().mean().backward()
-        outs.append((rows.detach().clone(), pix.grad.detach().clone()))
-    for r, g in outs[1:]:
-        assert torch.equal(r, outs[0][0]) and torch.equal(g, outs[0][1])
