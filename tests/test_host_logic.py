@@ -306,3 +306,35 @@ def test_vit_accepts_precomputed_patch_embeds():
     e = (torch.nn.functional.linear(ops.unfold_tiles(pix[:, :3]), w0, b0), torch.nn.functional.linear(ops.unfold_tiles(pix[:, 3:]), w1, b1))
     assert torch.allclose(m.forward_rows(ids, pix, labels), m.forward_rows(ids, None, labels, patch_embeds=e), atol=1e-5)
     assert m.patch_embed_params() is None  # CPU / fp32 / widths not multiples of 64: the fused backward does not apply
+
+
+def test_bench_compact_line_is_strict_json():
+    """bench.py's stdout record (the driver parses it): < 4 KB, ASCII, strict JSON — non-finite floats become null, optional keys are dropped
+    in order when the line would not fit, a line that still does not fit or carries NaN / Infinity anywhere is refused."""
+    import importlib.util
+    import json
+    import os
+
+    import pytest
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def refuse(name):
+        raise AssertionError(name)
+
+    rec = {"metric": "m", "value": float("nan"), "ms_per_step": float("inf"), "config": {"a": np.float32(1.23456789), "n": np.int64(3), "pad": "x" * 3000,
+                                                                                          "pad2": "y" * 3000}, "t": (1, 2.5)}
+    line = bench.encode_line(rec, optional=["config.pad", "config.pad2"])
+    assert len(line) < bench.LINE_LIMIT and line.isascii() and "NaN" not in line and "Infinity" not in line and "\n" not in line
+    d = json.loads(line, parse_constant=refuse)
+    assert d["value"] is None and d["ms_per_step"] is None and d["config"]["n"] == 3 and abs(d["config"]["a"] - 1.23457) < 1e-6
+    assert "pad" not in d["config"] and "pad2" in d["config"] and d["t"] == [1, 2.5]  # least important first, only as many as needed
+    with pytest.raises(RuntimeError):
+        bench.encode_line({"note": "x" * 5000})
+    with pytest.raises(RuntimeError):
+        bench.encode_line({"note": "256 MB Infinity Cache"})
+    with pytest.raises(RuntimeError):
+        bench.encode_line({"note": "café NaN"})
