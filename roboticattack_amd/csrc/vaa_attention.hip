@@ -132,7 +132,7 @@ __device__ __forceinline__ bool block_to_pair(int nblk, int npairs, int& pair, i
 // G = 16-query column groups per wave (1 or 2): with G = 2 a workgroup covers 128 queries and every K / V fragment read from LDS feeds two
 // MFMAs (one per group), i.e. half the LDS traffic and half the tile loads per unit of work; per query the arithmetic and its order are
 // those of G = 1 (same bits).
-template <int KS, int NT, bool CAUSAL, int G, int PF>
+template <int KS, int NT, bool CAUSAL, int G>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     constexpr int HDP = KS * 32;
     constexpr int SK = HDP + 8;   // K tile row stride (bf16): dword stride = 4 mod 8 -> conflict-free 16-byte row reads
@@ -184,19 +184,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
 
     const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, T, a.hd), vrs = slice_rsrc(vp, a.sv.t, T, a.hd);
     const int kst = (int)a.sk.t * 2, vst = (int)a.sv.t * 2;
-    // PF = tiles requested ahead (1 or 2): with 2 a second register set keeps another K/V tile in flight — these kernels are bound by the bytes a
-    // CU has in flight (profiles/r05_attn_sweep.txt) — same tiles in the same order, same bits
-    auto tile_step = [&](int kt, TileRegs<HDP>& rk, TileRegs<HDP>& rv) {
+    TileRegs<HDP> rk, rv;
+    rk.load(krs, kst, 0);
+    rv.load(vrs, vst, 0);
+    for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();  // every wave is done reading the previous tile
         rk.store(sK, SK);
         rv.store(sV, SV);
         __syncthreads();
-        if (kt + PF < ntile) {  // the loads of tile kt + PF fly during the MFMAs
-            rk.load(krs, kst, (kt + PF) * kTile);
-            rv.load(vrs, vst, (kt + PF) * kTile);
+        if (kt + 1 < ntile) {  // next tile's loads fly during the MFMAs
+            rk.load(krs, kst, (kt + 1) * kTile);
+            rv.load(vrs, vst, (kt + 1) * kTile);
         }
         const int key0 = kt * kTile;
-        if (CAUSAL && key0 > q0 + QW - 1) return;  // nothing visible to this wave in this tile (wave-uniform)
+        if (CAUSAL && key0 > q0 + QW - 1) continue;  // nothing visible to this wave in this tile (wave-uniform)
 
         v4f st[G][4];
 #pragma unroll
@@ -266,22 +267,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
                 for (int nt = 0; nt < NT; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[nt], pf, acc[j][nt], 0, 0, 0);
             }
         }
-    };
-    TileRegs<HDP> rk, rv;
-    rk.load(krs, kst, 0);
-    rv.load(vrs, vst, 0);
-    if constexpr (PF == 2) {
-        TileRegs<HDP> rk2, rv2;
-        if (1 < ntile) {
-            rk2.load(krs, kst, kTile);
-            rv2.load(vrs, vst, kTile);
-        }
-        for (int kt = 0; kt < ntile; kt += 2) {
-            tile_step(kt, rk, rv);
-            if (kt + 1 < ntile) tile_step(kt + 1, rk2, rv2);
-        }
-    } else {
-        for (int kt = 0; kt < ntile; ++kt) tile_step(kt, rk, rv);
     }
 #pragma unroll
     for (int j = 0; j < G; ++j) {
@@ -402,7 +387,7 @@ __device__ __forceinline__ v4f frag_dot(const v8s (&af)[KS], const v8s (&bf)[KS]
 // dQ^T = sum over key tiles of K^T dS^T, with S^T = K Q^T and dP^T = V dO^T recomputed; dS^T = P^T o (dP^T - D). One workgroup =
 // 64 G queries (G column groups of 16 per wave: every K / V fragment read feeds G MFMAs); a lane's column is its query, so lse and D are
 // per-lane scalars. Also produces D for the dk/dv kernel.
-template <int KS, int NT, bool CAUSAL, int G, int PF>
+template <int KS, int NT, bool CAUSAL, int G>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     constexpr int HDP = KS * 32;
     constexpr int SK = HDP + 16, SV = HDP + 8;  // K is read by rows (16) AND transposed (32 reads): its stride favours the transpose reads
@@ -455,17 +440,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 
     const __amdgpu_buffer_rsrc_t krs = slice_rsrc(kp, a.sk.t, T, a.hd), vrs = slice_rsrc(vp, a.sv.t, T, a.hd);
     const int kst = (int)a.sk.t * 2, vst = (int)a.sv.t * 2;
-    auto tile_step = [&](int kt, TileRegs<HDP>& rk, TileRegs<HDP>& rv) {  // PF: as in attn_fwd_kernel
+    TileRegs<HDP> rk, rv;
+    rk.load(krs, kst, 0);
+    rv.load(vrs, vst, 0);
+    for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();
         rk.store(sK, SK);
         rv.store(sV, SV);
         __syncthreads();
-        if (kt + PF < ntile) {
-            rk.load(krs, kst, (kt + PF) * kTile);
-            rv.load(vrs, vst, (kt + PF) * kTile);
+        if (kt + 1 < ntile) {
+            rk.load(krs, kst, (kt + 1) * kTile);
+            rv.load(vrs, vst, (kt + 1) * kTile);
         }
         const int key0 = kt * kTile;
-        if (CAUSAL && key0 > q0 + QW - 1) return;
+        if (CAUSAL && key0 > q0 + QW - 1) continue;
         const bool need_mask = (key0 + kTile > T) || (CAUSAL && key0 + kTile - 1 > q0);  // wave-uniform (q0 = the wave's smallest query)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -504,22 +492,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
                 for (int nt = 0; nt < NT; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[nt], dsf, acc[j][nt], 0, 0, 0);
             }
         }
-    };
-    TileRegs<HDP> rk, rv;
-    rk.load(krs, kst, 0);
-    rv.load(vrs, vst, 0);
-    if constexpr (PF == 2) {
-        TileRegs<HDP> rk2, rv2;
-        if (1 < ntile) {
-            rk2.load(krs, kst, kTile);
-            rv2.load(vrs, vst, kTile);
-        }
-        for (int kt = 0; kt < ntile; kt += 2) {
-            tile_step(kt, rk, rv);
-            if (kt + 1 < ntile) tile_step(kt + 1, rk2, rv2);
-        }
-    } else {
-        for (int kt = 0; kt < ntile; ++kt) tile_step(kt, rk, rv);
     }
 #pragma unroll
     for (int j = 0; j < G; ++j) {
@@ -535,7 +507,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 // dK^T += Q^T dS, dV^T += dO^T P over query tiles, with S = Q K^T and dP = dO V^T recomputed (A = Q / dO rows from LDS, B = K^T / V^T
 // fragments of this wave's 16 G keys held in registers: every Q / dO fragment read feeds G MFMAs): a lane's column is its KEY, rows are
 // queries, so lse and D come from LDS.
-template <int KS, int NT, bool CAUSAL, int G, int PF>
+template <int KS, int NT, bool CAUSAL, int G>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     constexpr int HDP = KS * 32;
     constexpr int SQ = HDP + 16;  // both tiles are read by rows AND transposed; the transpose reads are twice as many -> their stride
@@ -576,8 +548,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         }
     const int nqt = (T + kTile - 1) / kTile;
     const int qt0 = CAUSAL ? kb * G : 0;  // the first query tile that sees a key of this workgroup
-    // threads 0..63 carry the lse of query tid (log2 units, +inf when invalid), 64..127 its D
-    auto load_stats = [&](float& rstat, int qbase) {
+    TileRegs<HDP> rq, rdo;
+    float rstat = 0.0f;  // threads 0..63: lse of query tid (log2 units, +inf when invalid); 64..127: D
+    auto load_stats = [&](int qbase) {
         if (tid < 128) {
             const int qq = qbase + (tid & 63);
             if (tid < 64) rstat = qq < T ? lsep[qq] * 1.4426950408889634f : INFINITY;
@@ -586,20 +559,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     };
     const __amdgpu_buffer_rsrc_t qrs = slice_rsrc(qp, a.sq.t, T, a.hd), dors = slice_rsrc(dop, a.sdo.t, T, a.hd);
     const int qst = (int)a.sq.t * 2, dost = (int)a.sdo.t * 2;
-    auto tile_step = [&](int qt, TileRegs<HDP>& rq, TileRegs<HDP>& rdo, float& rstat) {  // PF: as in attn_fwd_kernel
+    rq.load(qrs, qst, qt0 * kTile);
+    rdo.load(dors, dost, qt0 * kTile);
+    load_stats(qt0 * kTile);
+    for (int qt = qt0; qt < nqt; ++qt) {
         __syncthreads();
         rq.store(sQ, SQ);
         rdo.store(sDO, SQ);
         if (tid < 64) sL[tid] = rstat;
         else if (tid < 128) sD[tid - 64] = rstat;
         __syncthreads();
-        if (qt + PF < nqt) {
-            rq.load(qrs, qst, (qt + PF) * kTile);
-            rdo.load(dors, dost, (qt + PF) * kTile);
-            load_stats(rstat, (qt + PF) * kTile);
+        if (qt + 1 < nqt) {
+            rq.load(qrs, qst, (qt + 1) * kTile);
+            rdo.load(dors, dost, (qt + 1) * kTile);
+            load_stats((qt + 1) * kTile);
         }
         const int qb0 = qt * kTile;
-        if (CAUSAL && qb0 + kTile - 1 < key0w) return;  // every query of the tile precedes this wave's keys
+        if (CAUSAL && qb0 + kTile - 1 < key0w) continue;  // every query of the tile precedes this wave's keys
         const bool need_mask = CAUSAL && qb0 < key0w + KW - 1;  // wave-uniform: some (query, key) pair of this tile is hidden
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -647,26 +623,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
                 }
             }
         }
-    };
-    TileRegs<HDP> rq, rdo;
-    float rstat = 0.0f;
-    rq.load(qrs, qst, qt0 * kTile);
-    rdo.load(dors, dost, qt0 * kTile);
-    load_stats(rstat, qt0 * kTile);
-    if constexpr (PF == 2) {
-        TileRegs<HDP> rq2, rdo2;
-        float rstat2 = 0.0f;
-        if (qt0 + 1 < nqt) {
-            rq2.load(qrs, qst, (qt0 + 1) * kTile);
-            rdo2.load(dors, dost, (qt0 + 1) * kTile);
-            load_stats(rstat2, (qt0 + 1) * kTile);
-        }
-        for (int qt = qt0; qt < nqt; qt += 2) {
-            tile_step(qt, rq, rdo, rstat);
-            if (qt + 1 < nqt) tile_step(qt + 1, rq2, rdo2, rstat2);
-        }
-    } else {
-        for (int qt = qt0; qt < nqt; ++qt) tile_step(qt, rq, rdo, rstat);
     }
 #pragma unroll
     for (int j = 0; j < G; ++j) {
@@ -698,43 +654,21 @@ static void attn_groups(int hd, int& gf, int& gq, int& gk) {
     gk = cfg[2] ? cfg[2] : dflt;
 }
 
-// Tiles requested ahead by each kernel (forward, dq, dk/dv): VAA_ATTN_PF = "fqk" digits, each 1 or 2.
-static void attn_prefetch(int hd, int& pf, int& pq, int& pk) {
-    static int cfg[3] = {0, 0, 0};
-    static std::once_flag once;
-    std::call_once(once, [] {
-        const char* ev = getenv("VAA_ATTN_PF");
-        for (int i = 0; i < 3; ++i) cfg[i] = (ev && ev[0] && ev[1] && ev[2] && (ev[i] == '1' || ev[i] == '2')) ? ev[i] - '0' : 0;
-    });
-    const int dflt = 1;
-    pf = cfg[0] ? cfg[0] : dflt;
-    pq = cfg[1] ? cfg[1] : dflt;
-    pk = cfg[2] ? cfg[2] : dflt;
-    (void)hd;
-}
-
-#define VAA_ATT_PICK(KERNEL, KS, NT, G, PF, GRID)                                                                       \
-    do {                                                                                                                 \
-        if ((G) == 2 && (PF) == 2) hipLaunchKernelGGL((KERNEL<KS, NT, CAUSAL, 2, 2>), dim3(GRID), dim3(256), 0, st, a);     \
-        else if ((G) == 2) hipLaunchKernelGGL((KERNEL<KS, NT, CAUSAL, 2, 1>), dim3(GRID), dim3(256), 0, st, a);            \
-        else if ((PF) == 2) hipLaunchKernelGGL((KERNEL<KS, NT, CAUSAL, 1, 2>), dim3(GRID), dim3(256), 0, st, a);           \
-        else hipLaunchKernelGGL((KERNEL<KS, NT, CAUSAL, 1, 1>), dim3(GRID), dim3(256), 0, st, a);                        \
-    } while (0)
-
 template <bool CAUSAL>
 static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
-    int gf, gq, gk, pf, pq, pk;
+    int gf, gq, gk;
     attn_groups(a.hd, gf, gq, gk);
-    attn_prefetch(a.hd, pf, pq, pk);
     const unsigned pairs8 = (unsigned)(((long)a.B * a.H + 7) / 8 * 8);
     const unsigned grid_q = pairs8 * (unsigned)((a.T + kTile * gq - 1) / (kTile * gq)), grid_k = pairs8 * (unsigned)((a.T + kTile * gk - 1) / (kTile * gk));
-#define VAA_ATT_BWD(KS, NT)                                                    \
-    do {                                                                       \
-        VAA_ATT_PICK(attn_bwd_dq_kernel, KS, NT, gq, pq, grid_q);              \
-        int rc = check_launch("vaa_model_attention_bwd(dq)");                  \
-        if (rc != VAA_OK) return rc;                                           \
-        VAA_ATT_PICK(attn_bwd_dkv_kernel, KS, NT, gk, pk, grid_k);             \
-        return check_launch("vaa_model_attention_bwd(dkv)");                   \
+#define VAA_ATT_BWD(KS, NT)                                                                                                  \
+    do {                                                                                                                     \
+        if (gq == 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, NT, CAUSAL, 2>), dim3(grid_q), dim3(256), 0, st, a);         \
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, NT, CAUSAL, 1>), dim3(grid_q), dim3(256), 0, st, a);                 \
+        int rc = check_launch("vaa_model_attention_bwd(dq)");                                                                \
+        if (rc != VAA_OK) return rc;                                                                                         \
+        if (gk == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, NT, CAUSAL, 2>), dim3(grid_k), dim3(256), 0, st, a);        \
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, NT, CAUSAL, 1>), dim3(grid_k), dim3(256), 0, st, a);                \
+        return check_launch("vaa_model_attention_bwd(dkv)");                                                                 \
     } while (0)
     if (a.hd <= 64) VAA_ATT_BWD(2, 4);
     else if (a.hd <= 80) VAA_ATT_BWD(3, 5);
@@ -745,17 +679,21 @@ static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
 
 template <bool CAUSAL>
 static int launch_fwd(const AttnFwdArgs& a, hipStream_t st) {
-    int gf, gq, gk, pf, pq, pk;
+    int gf, gq, gk;
     attn_groups(a.hd, gf, gq, gk);
-    attn_prefetch(a.hd, pf, pq, pk);
     const unsigned grid = (unsigned)(((long)a.B * a.H + 7) / 8 * 8) * (unsigned)((a.T + kTile * gf - 1) / (kTile * gf));
-    if (a.hd <= 64) VAA_ATT_PICK(attn_fwd_kernel, 2, 4, gf, pf, grid);
-    else if (a.hd <= 80) VAA_ATT_PICK(attn_fwd_kernel, 3, 5, gf, pf, grid);
-    else if (a.hd <= 96) VAA_ATT_PICK(attn_fwd_kernel, 3, 6, gf, pf, grid);
-    else VAA_ATT_PICK(attn_fwd_kernel, 4, 8, gf, pf, grid);
+#define VAA_ATT_FWD(KS, NT)                                                                                          \
+    do {                                                                                                             \
+        if (gf == 2) hipLaunchKernelGGL((attn_fwd_kernel<KS, NT, CAUSAL, 2>), dim3(grid), dim3(256), 0, st, a);      \
+        else hipLaunchKernelGGL((attn_fwd_kernel<KS, NT, CAUSAL, 1>), dim3(grid), dim3(256), 0, st, a);              \
+    } while (0)
+    if (a.hd <= 64) VAA_ATT_FWD(2, 4);
+    else if (a.hd <= 80) VAA_ATT_FWD(3, 5);
+    else if (a.hd <= 96) VAA_ATT_FWD(3, 6);
+    else VAA_ATT_FWD(4, 8);
+#undef VAA_ATT_FWD
     return check_launch("vaa_model_attention_fwd");
 }
-#undef VAA_ATT_PICK
 
 static bool strides_ok(const int64_t* s) { return s && (s[0] % 8) == 0 && (s[1] % 8) == 0 && (s[2] % 8) == 0; }
 static AttnStr mk(const int64_t* s) { AttnStr r; r.b = s[0]; r.t = s[1]; r.h = s[2]; return r; }

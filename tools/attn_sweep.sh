@@ -5,7 +5,7 @@
 set -uo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 out="${root}/gpurun_out/attn"; mkdir -p "${out}"; export TMPDIR=/tmp; cd "${root}"
-# ATTN_CFGS: "G:PF" pairs (row groups per wave : tiles requested ahead; three digits each = forward / dq / dk-dv; "-" = the library's default)
+# ATTN_CFGS: "G:PF" pairs (row groups per wave : tiles requested ahead [VAA_ATTN_PF: only in the experiment build of commit 0dd8d0c]; three digits each = forward / dq / dk-dv; "-" = default)
 for cfg in ${ATTN_CFGS:-111:111 211:111 121:111 112:111 222:111}; do
   g="${cfg%%:*}"; pf="${cfg##*:}"; envs=""
   [ "${g}" != "-" ] && envs="${envs} VAA_ATTN_G=${g}"; [ "${pf}" != "-" ] && envs="${envs} VAA_ATTN_PF=${pf}"
