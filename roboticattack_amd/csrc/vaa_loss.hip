@@ -989,8 +989,11 @@ __device__ __forceinline__ FoldOut rows_fold(const RowsArgs& a, bool publish, do
 }
 
 // grid = R x split (full-row gradients) or R (slice / no gradient); every workgroup folds the statistics in the same fixed order.
+// fold_wg >= 0 (VAA_LOSS_CE with a full-row gradient: d total / d z = scale / nrow (softmax - onehot) needs the row's own parts and the row COUNT
+// of the map, nothing of other rows): workgroup fold_wg — one past the gradient workgroups — folds and publishes the scalars, every other
+// workgroup goes straight to its gradient (same parts, same formulas: the bits of the all-fold form) instead of waiting for a fold it does not use.
 template <typename T, int kRowsT>
-__global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsplit) {
+__global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsplit, int fold_wg) {
     constexpr int N = Vec<T>::N;
     const int r = blockIdx.x / gsplit, h = blockIdx.x - r * gsplit;
     const int tid = threadIdx.x;
@@ -1034,7 +1037,18 @@ __global__ __launch_bounds__(kRowsT) void rows_finish_kernel(RowsArgs a, int gsp
             u.set(q, t);
         }
     };
-    const FoldOut f = rows_fold<kRowsT>(a, blockIdx.x == 0, sh);
+    FoldOut f;
+    if (fold_wg < 0) {
+        f = rows_fold<kRowsT>(a, blockIdx.x == 0, sh);
+    } else if ((int)blockIdx.x == fold_wg) {
+        (void)rows_fold<kRowsT>(a, true, sh);
+        return;
+    } else {  // what rows_fold returns for VAA_LOSS_CE, as far as the gradient reads it
+        f.Rn = min(a.R, a.rowmap[0]);
+        f.nrow = (double)f.Rn;
+        f.nact = 0.0; f.aux1 = 0.0;
+        f.dce = (double)a.scale;
+    }
     const int Rn = f.Rn;
     const double nrow = f.nrow, nact = f.nact, dce = f.dce, aux1 = f.aux1;
     if (!a.grad || r >= Rn) return;
@@ -1458,13 +1472,18 @@ extern "C" int vaa_loss_rows_fwd_bwd(const void* logits, int dtype, const void* 
     const int nt = rows_threads(V);
     const bool full_rows = grad && grad_kind == VAA_GRAD_FULL;
     const int gsplit = full_rows ? a.split : 1;
-    const unsigned G = full_rows ? (unsigned)(R * gsplit) : ((grad && mode == VAA_LOSS_UPA) ? (unsigned)R : 1u);
+    unsigned G = full_rows ? (unsigned)(R * gsplit) : ((grad && mode == VAA_LOSS_UPA) ? (unsigned)R : 1u);
+    // CE full-row gradient: the fold moves to a workgroup of its own (rows_finish_kernel); VAA_K3_CE_FOLD_WG=0 keeps the all-fold form
+    const char* ce_ev = getenv("VAA_K3_CE_FOLD_WG");
+    const bool ce_fold_wg = !(ce_ev && ce_ev[0] == '0');
+    const int fold_wg = (full_rows && mode == VAA_LOSS_CE && ce_fold_wg) ? (int)G : -1;
+    if (fold_wg >= 0) ++G;
     if (dtype == VAA_DTYPE_F32) {
-        if (nt == 256) VAA_LAUNCH((rows_finish_kernel<float, 256>), dim3(G), dim3(256), 0, st, a, gsplit);
-        else VAA_LAUNCH((rows_finish_kernel<float, 512>), dim3(G), dim3(512), 0, st, a, gsplit);
+        if (nt == 256) VAA_LAUNCH((rows_finish_kernel<float, 256>), dim3(G), dim3(256), 0, st, a, gsplit, fold_wg);
+        else VAA_LAUNCH((rows_finish_kernel<float, 512>), dim3(G), dim3(512), 0, st, a, gsplit, fold_wg);
     } else {
-        if (nt == 256) VAA_LAUNCH((rows_finish_kernel<uint16_t, 256>), dim3(G), dim3(256), 0, st, a, gsplit);
-        else VAA_LAUNCH((rows_finish_kernel<uint16_t, 512>), dim3(G), dim3(512), 0, st, a, gsplit);
+        if (nt == 256) VAA_LAUNCH((rows_finish_kernel<uint16_t, 256>), dim3(G), dim3(256), 0, st, a, gsplit, fold_wg);
+        else VAA_LAUNCH((rows_finish_kernel<uint16_t, 512>), dim3(G), dim3(512), 0, st, a, gsplit, fold_wg);
     }
     return check_launch("vaa_loss_rows_fwd_bwd(finish)");
 }
@@ -1500,8 +1519,8 @@ extern "C" int vaa_head_loss_rows_finish(const void* rowmap, int R, int B, int L
     a.zcol0 = kA0;
     hipStream_t st = (hipStream_t)stream;
     const unsigned G = grad_slice ? (unsigned)R : 1u;  // one workgroup per row writes its slice; the scalars alone take one workgroup
-    if (rows_threads(V) == 256) VAA_LAUNCH((rows_finish_kernel<uint16_t, 256>), dim3(G), dim3(256), 0, st, a, 1);
-    else VAA_LAUNCH((rows_finish_kernel<uint16_t, 512>), dim3(G), dim3(512), 0, st, a, 1);
+    if (rows_threads(V) == 256) VAA_LAUNCH((rows_finish_kernel<uint16_t, 256>), dim3(G), dim3(256), 0, st, a, 1, -1);
+    else VAA_LAUNCH((rows_finish_kernel<uint16_t, 512>), dim3(G), dim3(512), 0, st, a, 1, -1);
     return check_launch(who);
 }
 

@@ -1704,3 +1704,28 @@ def test_head_loss_rows_stats_argument_checks(ops):
     assert L.vaa_head_loss_rows_finish(*f, ops.LOSS_UPA, prm, p, 1 << 20, p, 16, p, None, None, p, st) == -4
     assert L.vaa_head_loss_rows_finish(*f, ops.LOSS_UPA, prm, p, 16, p, 1 << 24, p, None, None, p, st) == -4
     assert L.vaa_head_loss_rows_finish(*f, ops.LOSS_UPA, prm, p, 1 << 20, p, 1 << 24, None, None, None, None, st) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,maskidx,dtype", [(8, list(range(7)), torch.bfloat16), (64, [0], torch.bfloat16), (16, [0, 1], torch.float32)])
+def test_k3_ce_gradient_with_the_fold_in_its_own_workgroup(ops, monkeypatch, B, maskidx, dtype):
+    """TMA's CE gradient (TMA.py:148): the finishing launch with the fold moved to one extra workgroup (the gradient workgroups need the row's own
+    parts and the row count only) gives the bits of the form in which every workgroup folds — scalars, prediction maps, gradient."""
+    from roboticattack_amd.labels import mask_labels
+
+    _, labels, _ = synthetic.synth_text_batch(777 + B, B)
+    labels = mask_labels(labels, maskidx).to(DEV)
+    R = int((labels[:, 1:] != -100).sum())
+    g0 = torch.Generator(device=DEV).manual_seed(B)
+    logits = (torch.randn(R, 32064, device=DEV, generator=g0) * 2).to(dtype)
+    rm = ops.LossRowMap(labels)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VAA_K3_CE_FOLD_WG", mode)
+        g = torch.full_like(logits, float("nan"))
+        sc, pred, pred_full, _ = ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_CE, w=5.0, scale=0.25, grad_kind=ops.GRAD_FULL, grad=g)
+        torch.cuda.synchronize()
+        assert torch.isfinite(g.float()).all() and torch.isfinite(sc).all()
+        outs.append((sc.clone(), pred.clone(), pred_full.clone(), g.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y)
