@@ -149,10 +149,12 @@ def test_tma_upa_loops_run_and_improve(tmp_path, which):
     assert os.path.exists(os.path.join(str(tmp_path), "last", "patch.pt"))
 
 
-@pytest.mark.parametrize("tag", ["tma_adamw", "tma_pgd", "upa"])
+@pytest.mark.parametrize("tag", ["tma_adamw", "tma_pgd", "upa", "upa_resize"])
 def test_tma_upa_trajectories_vs_reference_loops(tmp_path, tag):
     """Replays runs of the REFERENCE's own TMA.patchattack_unconstrained (AdamW and PGD, paste_patch_fix path) and
-    UPA.patchattack_unconstrained (reverse_direction loss, L1 grad clip) made by tools/gen_golden.py:gen_trajectory_tma_upa."""
+    UPA.patchattack_unconstrained (reverse_direction loss, L1 grad clip) made by tools/gen_golden.py:gen_trajectory_tma_upa;
+    "upa_resize" = BASELINE config 5 as a loop (gen_trajectory_upa_resize): resize_patch=True with a 3x100x100 base patch — K0 and its
+    adjoint, the per-image K1 / K2 (or K2'), K3 (UPA), the L1 clip and AdamW on every step."""
     import types
 
     from roboticattack_amd.surrogate import SurrogateVLA
@@ -177,9 +179,10 @@ def test_tma_upa_trajectories_vs_reference_loops(tmp_path, tag):
         from roboticattack_amd.attack.upa import OpenVLAAttacker
         from roboticattack_amd.optim import PatchOptimizer
 
-        att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="adamW", alpha=float(d["alpha"]), belta=float(d["belta"]))
+        resize = tag == "upa_resize"
+        att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="adamW", resize_patch=resize, alpha=float(d["alpha"]), belta=float(d["belta"]))
         run = lambda: att.patchattack_unconstrained(  # noqa: E731
-            train, val, num_iter=n_it, patch_size=[3, 50, 50], lr=float(d["lr"]), accumulate_steps=1, maskidx=list(d["maskidx"]),
+            train, val, num_iter=n_it, patch_size=[3, 100, 100] if resize else [3, 50, 50], lr=float(d["lr"]), accumulate_steps=1, maskidx=list(d["maskidx"]),
             warmup=int(d["warmup"]), geometry=True, innerLoop=inner, guide=False, reverse_direction=True, args=args)
     att.val_batches = 2
     orig_step = PatchOptimizer.step
@@ -199,6 +202,9 @@ def test_tma_upa_trajectories_vs_reference_loops(tmp_path, tag):
     if "patches" in d:
         ref = d["patches"]
         assert len(snaps) == len(ref)
+        if "patches_stride" in d:  # fixture size: the snapshots of a large patch are kept on a pixel lattice
+            st = int(d["patches_stride"])
+            snaps = [a[:, ::st, ::st] for a in snaps]
         err = [float(np.abs(a - b).max()) for a, b in zip(snaps, ref)]
         assert max(err) <= 1e-4, err
         assert np.abs(last - d["last_saved"]).max() <= 1e-4

@@ -671,6 +671,35 @@ def gen_trajectory_tma_upa():
         "upa", dict(lr=2e-2, warmup=1, maskidx=np.array([0, 1, 2]), alpha=0.8, belta=0.2, **common))
 
 
+def gen_trajectory_upa_resize():
+    """BASELINE config 5 as a LOOP: the reference's own UPA.patchattack_unconstrained with resize_patch=True (3x100x100 base patch, per-image
+    scale s~U(0.61,1.39), appply_random_transform.py:113-118 with the A-D2 repair of ref_import.load_transform_d2_repaired), reverse_direction
+    loss, L1 gradient clip, HF AdamW: K0 + its adjoint, the per-image K1 / K2, K3 (UPA), K4 over several steps."""
+    UPA = ref.UPA
+    TR2 = ref_import.load_transform_d2_repaired()
+    n_it, inner, bs = 3, 2, 3
+    common = dict(num_iter=n_it, inner=inner, bs=bs, train_seed0=8300, val_seed=8400)
+
+    def make(v, p, s_):
+        att = UPA.OpenVLAAttacker(v, p, s_, optimizer="adamW", resize_patch=True, alpha=0.8, belta=0.2)
+        att.randomPatchTransform = TR2.RandomPatchTransform(v.device, True)  # the D2-repaired transform (every image scales the BASE patch)
+        return att
+
+    _run_ref_loop(
+        UPA, make,
+        lambda att, args: att.patchattack_unconstrained(
+            _fresh_loader([8300 + i for i in range(n_it)], bs), _fresh_loader([8400], 1), num_iter=n_it, patch_size=[3, 100, 100], lr=2e-2,
+            accumulate_steps=1, maskidx=[0, 1, 2], warmup=1, filterGripTrainTo1=False, geometry=True, innerLoop=inner, guide=False,
+            reverse_direction=True, args=args),
+        "upa_resize", dict(lr=2e-2, warmup=1, maskidx=np.array([0, 1, 2]), alpha=0.8, belta=0.2, **common))
+    # fixture size: the per-step snapshots of the 3x100x100 patch are kept on a 3-pixel lattice (the last saved patch stays whole)
+    path = os.path.join(GOLD, "traj_upa_resize.npz")
+    d = dict(np.load(path))
+    d["patches"] = np.ascontiguousarray(d["patches"][:, :, ::3, ::3])
+    d["patches_stride"] = np.int32(3)
+    np.savez_compressed(path, **d)
+
+
 # ------------------------------------------------------------------------------------------------
 # eval-time paste: RandomPatchTransform.simulation_random_patch (appply_random_transform.py:43-78)
 # ------------------------------------------------------------------------------------------------
@@ -695,8 +724,8 @@ def gen_sim():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1k2", "resize", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "trajk2e", "sim"]
+    which = sys.argv[1:] or ["k1k2", "resize", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "trajk2e", "traj3", "sim"]
     fns = dict(k1k2=gen_k1k2, resize=gen_resize, rng=gen_rng_stream, labels=gen_labels_tokenizer, k3=gen_k3, sched=gen_sched, fmt=gen_patch_format,
-               traj=gen_trajectory, traj2=gen_trajectory_tma_upa, trajk2e=gen_trajectory_k2e, sim=gen_sim)
+               traj=gen_trajectory, traj2=gen_trajectory_tma_upa, trajk2e=gen_trajectory_k2e, traj3=gen_trajectory_upa_resize, sim=gen_sim)
     for w in which:
         fns[w]()
