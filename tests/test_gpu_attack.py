@@ -149,12 +149,13 @@ def test_tma_upa_loops_run_and_improve(tmp_path, which):
     assert os.path.exists(os.path.join(str(tmp_path), "last", "patch.pt"))
 
 
-@pytest.mark.parametrize("tag", ["tma_adamw", "tma_pgd", "upa", "upa_resize"])
+@pytest.mark.parametrize("tag", ["tma_adamw", "tma_pgd", "tma_geo7", "upa", "upa_resize"])
 def test_tma_upa_trajectories_vs_reference_loops(tmp_path, tag):
     """Replays runs of the REFERENCE's own TMA.patchattack_unconstrained (AdamW and PGD, paste_patch_fix path) and
     UPA.patchattack_unconstrained (reverse_direction loss, L1 grad clip) made by tools/gen_golden.py:gen_trajectory_tma_upa;
     "upa_resize" = BASELINE config 5 as a loop (gen_trajectory_upa_resize): resize_patch=True with a 3x100x100 base patch — K0 and its
-    adjoint, the per-image K1 / K2 (or K2'), K3 (UPA), the L1 clip and AdamW on every step."""
+    adjoint, the per-image K1 / K2 (or K2'), K3 (UPA), the L1 clip and AdamW on every step; "tma_geo7" = BASELINE config 4's shape as a loop
+    (gen_trajectory_tma_geo7): the 7-DoF target, geometry=True (the reference loop with its A-D3 TypeError resolved as SURVEY.md records)."""
     import types
 
     from roboticattack_amd.surrogate import SurrogateVLA
@@ -174,7 +175,8 @@ def test_tma_upa_trajectories_vs_reference_loops(tmp_path, tag):
         att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer=str(d["optimizer"]))
         run = lambda: att.patchattack_unconstrained(  # noqa: E731
             train, val, num_iter=n_it, target_action=float(d["target_action"]) * np.ones(7), patch_size=[3, 50, 50], alpha=float(d["lr"]),
-            accumulate_steps=1, maskidx=list(d["maskidx"]), warmup=int(d["warmup"]), geometry=False, colorjitter=False, innerLoop=inner, args=args)
+            accumulate_steps=1, maskidx=[int(v) for v in d["maskidx"]], warmup=int(d["warmup"]), geometry=bool(d["geometry"]) if "geometry" in d else False,
+            colorjitter=False, innerLoop=inner, args=args)
     else:
         from roboticattack_amd.attack.upa import OpenVLAAttacker
         from roboticattack_amd.optim import PatchOptimizer
@@ -192,6 +194,13 @@ def test_tma_upa_trajectories_vs_reference_loops(tmp_path, tag):
         snaps.append(self.patch.detach().cpu().numpy().copy())
         return r
 
+    orig_fused = att.fused_update
+
+    def rec_fused(sink, patch, optimizer, scalars):  # steps that end in ONE launch (K2's final sum + the optimiser, geometry=True loops)
+        orig_fused(sink, patch, optimizer, scalars)
+        snaps.append(patch.detach().cpu().numpy().copy())
+
+    att.fused_update = rec_fused
     PatchOptimizer.step = rec
     try:
         run()

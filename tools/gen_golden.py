@@ -671,6 +671,29 @@ def gen_trajectory_tma_upa():
         "upa", dict(lr=2e-2, warmup=1, maskidx=np.array([0, 1, 2]), alpha=0.8, belta=0.2, **common))
 
 
+def gen_trajectory_tma_geo7():
+    """BASELINE config 4 as a LOOP: the reference's own TMA.patchattack_unconstrained with the 7-DoF target (maskidx 0..6), geometry=True
+    (apply_random_patch_batch with the random rotation / shear, TMA.py:131-175), HF AdamW."""
+    TMA = ref.TMA
+    n_it, inner, bs = 3, 2, 3
+    common = dict(num_iter=n_it, inner=inner, bs=bs, train_seed0=8500, val_seed=8600)
+    def make(v, p, s_):
+        att = TMA.OpenVLAAttacker(v, p, s_, optimizer="adamW", resize_patch=False)
+        # A-D3 (SURVEY.md Appendix A): TMA.py:137-141 passes `colorjitter=` (always False, TMA.py:82) to a function that does not take it, so the
+        # shipped loop raises TypeError whenever geometry=True; the resolution the survey records — ignore the argument — applied to THIS instance
+        orig = att.randomPatchTransform.apply_random_patch_batch
+        att.randomPatchTransform.apply_random_patch_batch = lambda *a, colorjitter=None, **k: orig(*a, **k)
+        return att
+
+    _run_ref_loop(
+        TMA, make,
+        lambda att, args: att.patchattack_unconstrained(
+            _fresh_loader([8500 + i for i in range(n_it)], bs), _fresh_loader([8600], 1), num_iter=n_it, target_action=0.0 * np.ones(7),
+            patch_size=[3, 50, 50], alpha=2e-2, accumulate_steps=1, maskidx=list(range(7)), warmup=1, filterGripTrainTo1=False,
+            geometry=True, colorjitter=False, innerLoop=inner, args=args),
+        "tma_geo7", dict(lr=2e-2, warmup=1, maskidx=np.arange(7), target_action=0.0, optimizer="adamW", geometry=True, **common))
+
+
 def gen_trajectory_upa_resize():
     """BASELINE config 5 as a LOOP: the reference's own UPA.patchattack_unconstrained with resize_patch=True (3x100x100 base patch, per-image
     scale s~U(0.61,1.39), appply_random_transform.py:113-118 with the A-D2 repair of ref_import.load_transform_d2_repaired), reverse_direction
@@ -724,8 +747,8 @@ def gen_sim():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1k2", "resize", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "trajk2e", "traj3", "sim"]
+    which = sys.argv[1:] or ["k1k2", "resize", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "trajk2e", "traj3", "traj4", "sim"]
     fns = dict(k1k2=gen_k1k2, resize=gen_resize, rng=gen_rng_stream, labels=gen_labels_tokenizer, k3=gen_k3, sched=gen_sched, fmt=gen_patch_format,
-               traj=gen_trajectory, traj2=gen_trajectory_tma_upa, trajk2e=gen_trajectory_k2e, traj3=gen_trajectory_upa_resize, sim=gen_sim)
+               traj=gen_trajectory, traj2=gen_trajectory_tma_upa, trajk2e=gen_trajectory_k2e, traj3=gen_trajectory_upa_resize, traj4=gen_trajectory_tma_geo7, sim=gen_sim)
     for w in which:
         fns[w]()
