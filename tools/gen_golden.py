@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import ref_import  # noqa: E402
 from roboticattack_amd import synthetic  # noqa: E402
 
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("VAA_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")  # VAA_GOLDEN_OUT: regenerate elsewhere (the pinning test)
 os.makedirs(GOLD, exist_ok=True)
 torch.set_num_threads(8)
 
