@@ -355,18 +355,6 @@ __device__ __forceinline__ void load_row_frags(v8s (&f)[KS], const uint16_t* row
     }
 }
 
-// sum_ks mfma(A = rows [rt*16, rt*16+16) of an LDS tile, B = register fragments): a 16x16 tile of (tile rows) x (lane columns)
-template <int KS>
-__device__ __forceinline__ v4f tile_dot(const uint16_t* tile, int stride, int rt, int c, int g, const v8s (&bf)[KS]) {
-    v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
-    v8s af[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const v8s*>(&tile[(rt * 16 + c) * stride + ks * 32 + g * 8]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf[ks], acc, 0, 0, 0);
-    return acc;
-}
-
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 

@@ -178,8 +178,7 @@ class FrozenLinearsFn(torch.autograd.Function):
     GEMM, which hipBLASLt runs 20-25 % slower on gfx950 than the TN layout of the forward (tools/gemm_layout.py:
     19200x11008x4096 1440 vs 1134 us). With 288 GB of HBM the transposed copy W_i^T (`Wt_i`, [in,out] contiguous) of every
     Llama projection is simply kept resident (+12.9 GB), which turns each dgrad into a TN GEMM of an already-tuned forward
-    shape; the sum over i runs in the GEMM epilogue (addmm beta=1) instead of autograd's separate accumulation kernels.
-"""
+    shape; the sum over i runs in the GEMM epilogue (addmm beta=1) instead of autograd's separate accumulation kernels."""
 
     @staticmethod
     def forward(ctx, x, res, *ws):
