@@ -283,6 +283,38 @@ int vaa_head_loss_rows_finish(const void* rowmap, int R, int B, int L, int V, in
                               void* grad_slice, void* stream);
 
 /*
+ * K3s — the SLICE-ONLY head: LM head on the labelled rows restricted to the 256 action columns + slice statistics + loss gradient + the head's
+ * backward, ONE launch per inner step for the modes whose loss lives in those columns (VAA_LOSS_UADA_DDP: UADA_ddp.py:99-124; VAA_LOSS_UPA:
+ * UPA.py:367-387). Replaces vaa_head_loss_rows_stats (+ finish) and the `grad_slice @ W[31744:32000]` GEMM on the steps whose full-vocabulary CE
+ * and argmax nobody reads: the reference reads `celoss` once per OUTER iteration (the last inner step's value, UADA_ddp.py:214-221) and never in
+ * UPA's reverse-direction mode (UPA.py:145-186), so the 263 MB weight stream runs on those steps only and this kernel (2.1 MB of weights) on all.
+ *   hidden    dev bf16 [R,D];  w_head dev bf16 [V,D] (rows 31744..31999 are read);  w_slice_t dev bf16 [D,256] = the slice transposed, written
+ *             ONCE per weight by vaa_head_slice_pack (frozen weights: pack at model load, keep resident); may be NULL when dhidden is NULL
+ *   rowmap, R, B, L, V, mode, params: as vaa_loss_rows_stats (mode UADA_DDP or UPA, else VAA_E_UNSUPPORTED)
+ *   dhidden   dev bf16 [R,D] out or NULL (forward only): d total / d hidden = g [R,256] x W[31744:32000] with g rounded to bf16 (fp32 MFMA sums)
+ *   grad_slice dev bf16 [R,256] out or NULL: g itself (tests; bit for bit the slice vaa_head_loss_rows_stats / _finish write for the same rows)
+ *   loss_ws   dev >= vaa_loss_rows_ws_bytes(R): the SliceStats in K3's layout and NEUTRAL full-vocabulary parts {m = -inf, s = 0}: the fold
+ *             (vaa_step_epilogue[_update], or this kernel's own when scalars != NULL) then reports CE = 0 ("not evaluated on this step") and
+ *             pred_full = -1; calling vaa_head_loss_rows_stats AFTERWARDS on the same loss_ws (the steps whose CE is read) replaces the parts
+ *             with real ones and rewrites the same SliceStat bits
+ *   scalars   dev f32[8] or NULL; pred_tokens / pred_full_tokens dev i32 [B,L-1] or NULL: folded and published by the launch itself (NULL:
+ *             left to vaa_step_epilogue)
+ *   ws        dev >= vaa_head_slice_ws_bytes(R): the [ceil16(R),128] action logits as 64-bit words {launch tag, logit 2q+1, logit 2q} (bf16) — the
+ *             SAME MFMA sequence per element as vaa_head_loss_rows_stats (same k order), hence bit for bit its slice logits, statistics and
+ *             gradient slice
+ * One launch needs workgroups that wait for each other (<= 128; they poll the tagged words they are going to use): admitted when the device keeps twice the grid resident, the stream is not being
+ * captured and no other stream of the process has a waiting grid in flight; otherwise (or VAA_K3S_ONE_LAUNCH=0) the same kernel runs as two
+ * launches with the same bits. A hand-over that times out NaN-poisons dhidden / the statistics AND raises vaa_async_error().
+ * Covers vaa_head_slice_applies(R, D, V) == 1: R <= 128, D a multiple of 64 up to 4096, V <= 32768.
+ */
+int vaa_head_slice_applies(int R, int D, int V);
+size_t vaa_head_slice_ws_bytes(int R);
+int vaa_head_slice_pack(const uint16_t* w_head, int D, int V, uint16_t* w_slice_t, void* stream);
+int vaa_head_slice_fwd_bwd(const uint16_t* hidden, const uint16_t* w_head, const uint16_t* w_slice_t, int D, const void* rowmap, int R, int B, int L,
+                           int V, int mode, const float* params, uint16_t* dhidden, uint16_t* grad_slice, void* loss_ws, size_t loss_ws_bytes,
+                           float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, void* ws, size_t ws_bytes, void* stream);
+
+/*
  * K2' (for callers that own the model's patch-embed weights) — K2 fed by the gradient of the ViT patch-embed OUTPUTS instead of the pixel gradient: the
  * patch-embed backward (modeling_prismatic.py:120-123 -> timm PatchEmbed, Conv2d(3, D, 14, stride 14) == a GEMM over 588-pixel
  * tiles) is evaluated by MFMA only for the 14x14 tiles that carry kept patch pixels and consumed in place by the gather.

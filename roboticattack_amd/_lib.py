@@ -58,6 +58,10 @@ EXPORTS = (
     "vaa_head_loss_rows_applies",
     "vaa_head_loss_rows_stats",
     "vaa_head_loss_rows_finish",
+    "vaa_head_slice_applies",
+    "vaa_head_slice_ws_bytes",
+    "vaa_head_slice_pack",
+    "vaa_head_slice_fwd_bwd",
     "vaa_step_epilogue",
     "vaa_step_epilogue_update",
     "vaa_async_error",
@@ -196,6 +200,14 @@ def lib() -> C.CDLL:
     L.vaa_head_loss_rows_stats.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, sz, vp, sz, vp, vp]
     L.vaa_head_loss_rows_finish.restype = i32
     L.vaa_head_loss_rows_finish.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, sz, vp, vp, vp, vp, vp]
+    L.vaa_head_slice_applies.restype = i32
+    L.vaa_head_slice_applies.argtypes = [i32, i32, i32]
+    L.vaa_head_slice_ws_bytes.restype = sz
+    L.vaa_head_slice_ws_bytes.argtypes = [i32]
+    L.vaa_head_slice_pack.restype = i32
+    L.vaa_head_slice_pack.argtypes = [vp, i32, i32, vp, vp]
+    L.vaa_head_slice_fwd_bwd.restype = i32
+    L.vaa_head_slice_fwd_bwd.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, vp, vp, sz, vp, vp, vp, vp, sz, vp]
     L.vaa_step_epilogue.restype = i32
     L.vaa_step_epilogue.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.POINTER(f32), vp, sz, vp, vp, vp, vp, vp]
     L.vaa_step_epilogue_update.restype = i32

@@ -1,0 +1,640 @@
+// vaa_head_slice.hip — K3s: the LM head on the labelled rows restricted to the 256 ACTION columns, fused with the slice statistics, the loss
+// gradient and the head's backward. ONE launch per inner step for the modes whose loss lives in the action columns (UADA_DDP, UPA).
+//
+// What a step of those loops consumes (UADA_ddp.py:99-124,196-221; UPA.py:139-186,367-387): the soft-argmax / MSE (or cos / dist) statistics of
+// logits[:, 31744:32000] and their gradient. The full-vocabulary CE and argmax are read on the LAST inner step of an outer iteration only
+// (UADA_ddp.py:214-221 logs `celoss` once per outer iteration) and never in UPA's reverse-direction mode — so the 263 MB weight stream of
+// vaa_head.hip (K3h) runs on those steps only, and every step runs this kernel: [R' <= 128, D] x W[31744:32000]^T, 2.1 MB of weights.
+//
+//   grid = ceil(R'/16) row blocks x 16 workgroups of 4 waves; workgroup (rb, j):
+//     phase 1  logits tile [16 rows of block rb] x [16 action columns 16 j ..]: H and W rows go global -> LDS by LDS-DMA in full 128-byte lines
+//              (8 rows x 128 B per instruction, the slot image and XOR placement of head_stats_kernel), a ring of slot groups of four k-chunks,
+//              counted vmcnt waits and ONE raw s_barrier per group; wave 0 runs the single mfma_f32_16x16x32_bf16 accumulator chain over K in
+//              the k-chunk order of the K3h workgroup that owns these columns (start chunk (5 w) mod D/64): the SAME instruction sequence per
+//              output element, so the bf16-rounded logits are bit for bit K3h's. The tile goes to a [R',256] bf16 scratch by agent-scope stores.
+//     hand-over  two-level arrival count + a {generation} word (the scheme of rows_stats_kernel<.., ONEPASS>): the grid is <= 128 workgroups and
+//              admitted only when the device keeps twice that resident; otherwise the same kernel runs as two launches (phases 1, then 2).
+//     phase 2  every workgroup of row block rb reads the block's 16 x 256 logits and recomputes — with the arithmetic of head_finish_kernel /
+//              rows_stats_kernel, two rows per wave instruction — {alse, E, argmax} and the gradient slice
+//              g = kE p_a ((a+1) - E) (UADA_ddp.py:99-114; UPA: kE from the batch means, UPA.py:375-387, all rows folded in the fixed order
+//              of rows_fold) as a bf16 [16,256] MFMA operand in LDS. Workgroups j = 0 leave the SliceStats (and NEUTRAL full-vocabulary parts)
+//              in K3's workspace layout: vaa_step_epilogue folds them as ever; or workgroup 0 folds and publishes scalars + prediction maps itself.
+//     phase 3  dH[16 rows, 256 j .. 256 j + 256) = g [16,256] x W[31744:32000, those columns]: the B fragments come from a [D,256] transposed copy
+//              of the slice (vaa_head_slice_pack, once per weight) and are requested BEFORE the hand-over wait, so the wait hides their latency.
+//   Bytes per launch at R' = 128, D = 4096: H 1.05 MB + W slice 2.10 MB + transposed slice 2.10 MB read, dH 1.05 MB written = 6.3 MB
+//   (K3h + finish + the 256-column GEMM: 263.7 + 1.05 + ~4.3 MB).
+#include <stdlib.h>
+
+#include <atomic>
+#include <type_traits>
+
+#include "vaa_common.h"
+#include "vaa_rows.h"
+#include "vaa_rows_fold.h"
+
+namespace vaa {
+
+typedef short v8s_s __attribute__((ext_vector_type(8)));
+typedef float v4f_s __attribute__((ext_vector_type(4)));
+
+constexpr int kST = 512;                    // 8 waves: 2 half waves x 8 = the 16 rows of a block in phase 2, 16 output tiles of 16 columns in phase 3
+constexpr int kSK = 64;                     // k-chunk: one 128-byte line per row (head_stats_kernel's)
+constexpr int kSGrp = 4;                    // k-chunks per group: one barrier, sixteen fragment reads, eight MFMAs
+constexpr int kSGroups = 16;                // D = 4096: 64 k-chunks
+#ifndef VAA_SLICE_RING
+#define VAA_SLICE_RING 8
+#endif
+constexpr int kSRing = VAA_SLICE_RING;      // groups of 16 KB in LDS: kSRing - 1 in flight (two 1 KB instructions per wave and group)
+constexpr int kSRows = 32;                  // rows per slot: 16 hidden + 16 weight
+constexpr int kSSlot = kSRows * kSK;        // elements per chunk image
+constexpr int kSGS = kNA + 8;               // row stride (bf16) of the gradient / output tiles in LDS
+constexpr int kSRowsMax = 128;
+constexpr int kSTPW = 2;                    // 16-column output tiles per wave in phase 3: 16 workgroups x 8 waves x 2 tiles x 16 = D <= 4096
+
+struct SliceHeadArgs {
+    const uint16_t* h;   // [R, D] bf16 hidden rows (final norm applied)
+    const uint16_t* w;   // [V, D] bf16 LM-head weight (rows 31744..31999 are read)
+    const uint16_t* wt;  // [D, 256] bf16: wt[d][a] = w[31744 + a][d]
+    unsigned long long* zs;  // [ceil16(R)][128] self-validating words {launch tag : 32 | logit 2q+1 : 16 | logit 2q : 16} (workspace)
+    uint16_t* gs;        // [R][256] bf16 gradient slice or nullptr (tests)
+    uint16_t* dh;        // [R][D] bf16 or nullptr (forward only)
+    RowsArgs ra;         // row map, K3 workspace (part / slice), scalars, prediction maps, sizes, mode, params
+    unsigned tag;        // this launch's tag (process-unique, never a plausible stale word)
+    unsigned* err_word;
+    int max_polls;
+    int D, phases, publish;  // phases: bit 0 = logits, bit 1 = statistics / gradient / dH; publish: workgroup 0 folds scalars + prediction maps
+};
+
+// the slice statistics of NR rows, each held by a HALF wave (32 lanes x 8 logits), the rows' dependent shuffle chains side by side: the arithmetic of
+// head_finish_kernel / rows_stats_kernel — whose 64-lane butterflies start at offset 32 against neutral upper lanes (-inf, 0), and whose separate
+// wave_max of the lane maxima IS the value the argmax butterfly ends with (max is exact) — hence the same bits
+// lane ^ O within a half wave: DPP quad permutes (O = 1, 2) and ds_swizzle's bit-mask mode (O = 4, 8, 16; it works on 32-lane halves) — no
+// address register and a shorter round trip than __shfl_xor's ds_bpermute; pure data movement, the same bits
+template <int O>
+__device__ __forceinline__ int xor_lane_i(int v) {
+    if (O == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    if (O == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    return __builtin_amdgcn_ds_swizzle(v, (O << 10) | 0x1F);                       // {xor = O, or = 0, and = 0x1f}
+}
+template <int O>
+__device__ __forceinline__ float xor_lane(float v) { return __int_as_float(xor_lane_i<O>(__float_as_int(v))); }
+
+template <int NR>
+__device__ __forceinline__ void slice_stats_half(const float (&x)[NR][8], int hl, float (&alse)[NR], float (&E)[NR], int (&pred)[NR]) {
+    float bestv[NR], es[NR], ew[NR];
+    int besti[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        int ai = 0;
+#pragma unroll
+        for (int e = 1; e < 8; ++e) if (x[n][e] > x[n][ai]) ai = e;
+        bestv[n] = x[n][ai];
+        besti[n] = hl * 8 + ai;
+    }
+#define K3S_ARGMAX_STEP(O)                                                                                   \
+    _Pragma("unroll") for (int n = 0; n < NR; ++n) {                                                        \
+        const float ov = xor_lane<O>(bestv[n]);                                                             \
+        const int oi = xor_lane_i<O>(besti[n]);                                                             \
+        if (ov > bestv[n] || (ov == bestv[n] && oi < besti[n])) { bestv[n] = ov; besti[n] = oi; }           \
+    }
+    K3S_ARGMAX_STEP(16) K3S_ARGMAX_STEP(8) K3S_ARGMAX_STEP(4) K3S_ARGMAX_STEP(2) K3S_ARGMAX_STEP(1)
+#undef K3S_ARGMAX_STEP
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        es[n] = 0.0f;
+        ew[n] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ex = expf(x[n][e] - bestv[n]);
+            es[n] += ex;
+            ew[n] += ex * (float)(hl * 8 + e + 1);
+        }
+    }
+#define K3S_SUM_STEP(O)                                              \
+    _Pragma("unroll") for (int n = 0; n < NR; ++n) {                    \
+        es[n] += xor_lane<O>(es[n]);                                    \
+        ew[n] += xor_lane<O>(ew[n]);                                    \
+    }
+    K3S_SUM_STEP(16) K3S_SUM_STEP(8) K3S_SUM_STEP(4) K3S_SUM_STEP(2) K3S_SUM_STEP(1)
+#undef K3S_SUM_STEP
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        E[n] = ew[n] / es[n];
+        alse[n] = bestv[n] + logf(es[n]);
+        pred[n] = kA0 + besti[n];
+    }
+}
+
+// The hand-over needs no counters: every 64-bit word of the logits scratch carries the launch's tag beside its two logits, so a consumer polls the
+// very words it is going to use (agent-scope loads go past the per-XCD L2) — two memory round trips between the last MFMA of a producer and the
+// first exp of a consumer (an arrival count + a published flag + the data costs five: 26.7 against 22.1 us for two launches at R' = 128).
+__device__ __forceinline__ void decode_logits8(const unsigned long long (&wq)[4], float (&x)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { x[2 * q] = bf16_bits_to_f32((unsigned)wq[q] & 0xffffu); x[2 * q + 1] = bf16_bits_to_f32(((unsigned)wq[q] >> 16) & 0xffffu); }
+}
+
+// s_waitcnt vmcnt(n) for an n the unrolled loop knows at compile time
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// timing probe (build with -DVAA_K3S_TIMING; tools/probe/k3s_stamps.py): thread 0 of every workgroup leaves wall-clock stamps (10 ns units) behind the
+// first 512 KB of the logits scratch — where the kernel's time goes, phase by phase
+#ifdef VAA_K3S_TIMING
+#define K3S_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.zs) + (512 << 10))[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define K3S_STAMP(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
+    extern __shared__ __align__(16) uint16_t smem[];  // phase 1: the ring [kSRing][4 chunks][32 rows][64]; afterwards the gradient and output tiles
+    __shared__ float sAlse[kSRowsMax], sE[kSRowsMax];
+    __shared__ double shf[kST / 64][7];
+    __shared__ int bar_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int rb = blockIdx.x >> 4, j = blockIdx.x & 15;
+    const int R = a.ra.R, D = a.D;
+    const int nchunks = D / kSK;
+    uint16_t* gt = smem;             // gradient tile [16][kSGS] ...
+    uint16_t* ot = gt + 16 * kSGS;   // ... and output tile [16][kSGS]
+    const int hl = lane & 31, hw = lane >> 5;
+    K3S_STAMP(0);
+    // what phase 2 will want from global memory is requested now: the row map entry of this half wave's own row and the counts
+    const RowMap* rm = reinterpret_cast<const RowMap*>(a.ra.rowmap + 4);
+    const int Rdev = a.ra.rowmap[0], Rn = min(R, Rdev), nact = a.ra.rowmap[1];
+    const int own_lr = 2 * wv + hw, own_row = rb * 16 + own_lr;  // 8 waves x 2 half waves = the block's 16 rows
+    const RowMap me = own_row < Rn ? rm[own_row] : RowMap{0, 0, -1, 0};
+
+    if (a.phases & 1) {
+        // ---- phase 1: 16 x 16 logits over all of K, in the k-chunk order of the K3h workgroup that owns columns 16 j .. (vaa_head.hip) ----
+        const int k3h_wg = kA0 / kHeadCols + (j * 16) / kHeadCols;
+        const int kstart = (int)(((unsigned)k3h_wg * 5u) % (unsigned)nchunks);
+        auto kchunk = [&](int ch) { const int cc = ch + kstart; return cc >= nchunks ? cc - nchunks : cc; };
+        auto lds_off = [](int row, int piece) { return row * kSK + ((piece ^ (row & 7)) << 3); };
+        v4f_s acc = (v4f_s){0.f, 0.f, 0.f, 0.f};
+        if (nchunks == kSGroups * kSGrp) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass does not know the LDS-DMA builtin)
+            // D = 4096: sixteen groups of four 64-wide k-chunks. A chunk of the 16 hidden + 16 weight rows is 4 KB = four LDS-DMA instructions
+            // (8 rows x 128 B: full lines, no staging registers — three register-staged forms ended in scratch memory or drained loads, 20 us
+            // for the phase); the eight waves take the two chunk parities x four row octets, so a wave requests TWO instructions per group. A
+            // ring of kSRing groups: group g + kSRing - 1 is requested in step g into the slots group g - 1 was read from, EXACT request counts
+            // (the waits count down over the last groups: spare requests behind the end cost 2.6 us), counted vmcnt waits + ONE raw s_barrier
+            // per group. Wave 0 reads a group's sixteen fragments, then runs its eight dependent MFMAs back to back (a read -> wait -> MFMA
+            // per k-step: 9.4 against 7.0 us for the phase). The fetch path of a CU moves 22-29 B/clk of L2 hits with eight waves issuing
+            // (tools/probe/cu_fetch_probe.hip): ~4.5 us for the workgroup's 256 KB is this phase's floor.
+            const int wvu = __builtin_amdgcn_readfirstlane(wv);  // the DMA destination (M0) is per wave
+            const int cw = wvu >> 2, r8 = (wvu & 3) * 8;         // this wave's chunk parity within a pair and its row octet of the slot
+            const int lrow = lane >> 3, lpiece = (lane & 7) ^ lrow;
+            const uint16_t* src = r8 < 16 ? a.h + (size_t)min(rb * 16 + r8 + lrow, R - 1) * D + lpiece * 8
+                                          : a.w + (size_t)(kA0 + j * 16 + (r8 - 16) + lrow) * D + lpiece * 8;
+            auto request_group = [&](int gi) {
+                uint16_t* grp = smem + (size_t)(gi % kSRing) * (kSGrp * kSSlot);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = 2 * h + cw;
+                    auto* dst = (__attribute__((address_space(3))) void*)(grp + q * kSSlot + r8 * kSK);
+                    __builtin_amdgcn_global_load_lds(src + kchunk(gi * kSGrp + q) * kSK, dst, 16, 0, 0);
+                }
+            };
+#pragma unroll
+            for (int gi = 0; gi < kSRing - 1; ++gi) request_group(gi);
+#pragma unroll
+            for (int gi = 0; gi < kSGroups; ++gi) {
+                wait_vmcnt(2 * (kSGroups - 1 - gi < kSRing - 2 ? kSGroups - 1 - gi : kSRing - 2));  // this wave's share of group gi has landed
+                __builtin_amdgcn_s_barrier();                                                        // ... everybody's; wave 0 is done with group gi - 1
+                if (gi + kSRing - 1 < kSGroups) request_group(gi + kSRing - 1);                      // into the slots of group gi - 1
+                if (wv == 0) {
+                    const uint16_t* grp = smem + (size_t)(gi % kSRing) * (kSGrp * kSSlot);
+                    v8s_s af[kSGrp * 2], bf[kSGrp * 2];
+#pragma unroll
+                    for (int qq = 0; qq < kSGrp; ++qq)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            af[qq * 2 + jj] = *reinterpret_cast<const v8s_s*>(grp + qq * kSSlot + lds_off(c, jj * 4 + g));
+                            bf[qq * 2 + jj] = *reinterpret_cast<const v8s_s*>(grp + qq * kSSlot + lds_off(16 + c, jj * 4 + g));
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s8 = 0; s8 < kSGrp * 2; ++s8) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s8], bf[s8], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#endif
+        } else {  // any other D (a multiple of 64): one chunk (4 KB = a 16-byte piece for each of 256 threads) per barrier pair
+            const int cw = tid >> 8, lr = (tid & 255) >> 3, lp = tid & 7;
+            const uint16_t* src = lr < 16 ? a.h + (size_t)min(rb * 16 + lr, R - 1) * D + lp * 8 : a.w + (size_t)(kA0 + j * 16 + (lr - 16)) * D + lp * 8;
+            const int my_off = lds_off(lr, lp);
+            for (int ch = 0; ch < nchunks; ++ch) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (cw == 0) v = *reinterpret_cast<const uint4*>(src + kchunk(ch) * kSK);
+                __syncthreads();
+                if (cw == 0) *reinterpret_cast<uint4*>(smem + my_off) = v;
+                __syncthreads();
+                if (wv == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < kSK / 32; ++jj) {
+                        const v8s_s af1 = *reinterpret_cast<const v8s_s*>(smem + lds_off(c, jj * 4 + g));
+                        const v8s_s bf1 = *reinterpret_cast<const v8s_s*>(smem + lds_off(16 + c, jj * 4 + g));
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        K3S_STAMP(1);
+        if (wv == 0) {  // C/D layout: column = lane & 15, row = 4 (lane >> 4) + r; two columns + the tag per 64-bit agent-scope store
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned z = f32_to_bf16_bits(acc[r]);
+                const unsigned zn = (unsigned)__shfl_xor((int)z, 1, 64);
+                if (!(c & 1))
+                    __hip_atomic_store(a.zs + (size_t)(rb * 16 + g * 4 + r) * (kNA / 2) + ((j * 16 + c) >> 1), ((unsigned long long)a.tag << 32) | z | (zn << 16),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        K3S_STAMP(2);
+        if (a.phases == 1) return;
+    }
+    // forward only: just the workgroups that leave statistics (j = 0 for a later fold) or fold them (workgroup 0) have something left to do
+    if (!(a.dh != nullptr || a.gs != nullptr || blockIdx.x == 0 || (!a.publish && j == 0))) return;
+
+    // ---- phase 2: statistics of the rows this workgroup needs (polled out of the scratch), then the gradient tile of its own 16 rows ----
+    const bool pub_wg = a.publish && blockIdx.x == 0;
+    const bool all_rows = a.ra.mode == VAA_LOSS_UPA || pub_wg;
+    const bool writes_stats = a.publish ? pub_wg : (j == 0);  // who leaves the SliceStats (+ neutral parts) in K3's workspace, and for which rows
+    const int wlo = a.publish ? 0 : rb * 16, whi = a.publish ? R : min(R, rb * 16 + 16);
+    // a half wave's rows: 16 it + 2 wv + hw; the block's OWN rows (the gradient's) are it = rb, which comes FIRST
+    const int nit = all_rows ? max((R + 15) / 16, rb + 1) : 1;
+    auto it_of = [&](int i) { return i == 0 ? rb : (i - 1 < rb ? i - 1 : i); };  // every iteration of [0, nit) once: the own one, then the others
+    auto row_of = [&](int it) { return min(16 * it + own_lr, R - 1); };            // a row beyond the end repeats the last one (same values, same place)
+    auto request = [&](int i, unsigned long long (&wq)[4]) {
+        const unsigned long long* p = a.zs + (size_t)row_of(it_of(min(i, nit - 1))) * (kNA / 2) + hl * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wq[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto valid = [&](const unsigned long long (&wq)[4]) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(wq[q] >> 32) == a.tag;
+        return ok;
+    };
+    auto leave = [&](int it, float alse, float E, int pred) {  // one row's statistics: LDS for this workgroup, K3's workspace for the fold
+        const int rr = row_of(it);
+        if (hl == 0) {
+            sAlse[rr] = alse; sE[rr] = E;
+            if (writes_stats && rr >= wlo && rr < whi) {
+                SliceStat ss;
+                ss.alse = alse; ss.E = E; ss.pred = pred; ss.pad = 0;
+                a.ra.slice[rr] = ss;
+                PartStat nz;  // neutral element of the fold: "no full-vocabulary statistics on this step" (rows_fold)
+                nz.m = -INFINITY; nz.s = 0.0f; nz.zlab = -INFINITY; nz.amax = 0x7fffffff;
+                for (int q = 0; q < a.ra.split; ++q) a.ra.part[(size_t)rr * a.ra.split + q] = nz;
+            }
+        }
+    };
+    auto give_up = [&]() {  // NaN statistics and gradient (never stale ones) AND the process-wide failure word (vaa_async_error)
+        if (lane == 0) {
+            bar_ok = 0;
+            if (a.err_word) __hip_atomic_store(a.err_word, VAA_ASYNC_K3_HANDOVER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    auto grad_row = [&](const float (&x)[8], float alse, float E, float kE) {  // g = kE p_a ((a + 1) - E), bf16, into the MFMA operand tile (+ the test output)
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = own_row < Rn ? kE * expf(x[e] - alse) * ((float)(hl * 8 + e + 1) - E) : 0.0f;
+        uint4 pk;
+        pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
+        pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+        pk.z = f32_to_bf16_bits(o[4]) | (f32_to_bf16_bits(o[5]) << 16);
+        pk.w = f32_to_bf16_bits(o[6]) | (f32_to_bf16_bits(o[7]) << 16);
+        *reinterpret_cast<uint4*>(gt + own_lr * kSGS + hl * 8) = pk;
+        if (a.gs && j == 0 && own_row < R) *reinterpret_cast<uint4*>(a.gs + (size_t)own_row * kNA + hl * 8) = pk;
+    };
+    if (tid == 0) bar_ok = 1;
+    // wave 0 is past its fragment reads of phase 1 (it left the loop through its last barrier-free group): before anybody writes the tiles that
+    // reuse the ring, one barrier — raw, behind an LDS-only wait
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    K3S_STAMP(3);
+    unsigned long long w0[4];
+    request(0, w0);
+    bool own_gave_up = false;
+    {   // poll for the own row with NOTHING else in flight: loads return in order, a retry must not queue behind other requests
+        int polls = 0;
+        while (!__all(valid(w0))) {
+            if (++polls > a.max_polls) { own_gave_up = true; break; }  // a launch that never became fully resident gives up instead of hanging
+            __builtin_amdgcn_s_sleep(1);
+            request(0, w0);
+        }
+    }
+    K3S_STAMP(4);
+    // ---- phase 3's B operand: fragments of the transposed slice, requested now — statistics and gradient hide them ----
+    v8s_s bfr[kSTPW][kNA / 32];
+    if (a.dh) {
+#pragma unroll
+        for (int t = 0; t < kSTPW; ++t) {
+            const int d = min(((j * (kST / 64) + wv) * kSTPW + t) * 16 + c, D - 1);  // columns beyond D re-read the last one: never stored
+#pragma unroll
+            for (int ks = 0; ks < kNA / 32; ++ks) bfr[t][ks] = *reinterpret_cast<const v8s_s*>(a.wt + (size_t)d * kNA + ks * 32 + g * 8);
+        }
+    }
+    float xo[8], own_alse, own_E;
+    {   // the own row
+        if (own_gave_up) give_up();
+        float x[1][8], alse[1], E[1];
+        int pred[1];
+        decode_logits8(w0, x[0]);
+        slice_stats_half<1>(x, hl, alse, E, pred);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xo[e] = x[0][e];
+        if (own_gave_up) { alse[0] = __uint_as_float(0x7fc00000u); E[0] = alse[0]; }
+        own_alse = alse[0];
+        own_E = E[0];
+        leave(rb, alse[0], E[0], pred[0]);
+        if (a.ra.mode == VAA_LOSS_UADA_DDP && (a.dh || a.gs)) {  // the gradient needs this row and the row COUNT only: straight from the registers
+            float kE = 0.0f;
+            if (me.lab > 2 && nact > 0) {
+                const double q = (double)own_E / 256.0, t = (me.lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10)
+                kE = (float)((double)a.ra.w * a.ra.w * 2.0 * (q - t) / nact / 256.0);
+            }
+            if (own_gave_up) kE = __uint_as_float(0x7fc00000u);  // NaN gradient, never a stale one
+            grad_row(xo, own_alse, own_E, kE);
+        }
+    }
+    K3S_STAMP(5);
+    if (all_rows) {
+        for (int i0 = 1; i0 < nit; i0 += 2) {  // the other rows (UPA's batch means, the publishing workgroup's fold): two iterations side by side
+            unsigned long long wq[2][4];
+            request(i0, wq[0]);
+            request(i0 + 1, wq[1]);
+            int polls = 0;
+            bool gave_up = false;
+            while (!__all(valid(wq[0]) && valid(wq[1]))) {
+                if (++polls > a.max_polls) { gave_up = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+                request(i0, wq[0]);
+                request(i0 + 1, wq[1]);
+            }
+            if (gave_up) give_up();
+            float x[2][8], alse[2], E[2];
+            int pred[2];
+            decode_logits8(wq[0], x[0]);
+            decode_logits8(wq[1], x[1]);
+            slice_stats_half<2>(x, hl, alse, E, pred);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (i0 + u >= nit) continue;
+                if (gave_up) { alse[u] = __uint_as_float(0x7fc00000u); E[u] = alse[u]; }
+                leave(it_of(i0 + u), alse[u], E[u], pred[u]);
+            }
+        }
+    }
+    if (a.ra.mode == VAA_LOSS_UPA) {  // UPA.py:375-387: the gradient needs the batch mean of ||e' - l'||, i.e. every row's E
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool poisoned = !bar_ok;
+        // the fold in rows_fold's order (thread t takes row t; lanes by xor-shuffle, then waves in order): rows_fold<256> has thread t of 256 take
+        // rows t, t + 256, ...; R' <= 128 leaves the upper waves empty, so the first four waves' sums in wave order are its bits (adding the
+        // other waves' exact zeros changes nothing)
+        double accd[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int rr = tid; rr < Rn; rr += kST) {
+            const RowMap m = rm[rr];
+            if (m.ord == 0 && rr + 2 < Rn) {
+                Upa3 u3;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    RowStat t;
+                    t.E = sE[rr + q];
+                    t.lab = rm[rr + q].lab;
+                    u3.set(q, t);
+                }
+                double c1, nd;
+                u3.terms(c1, nd);
+                accd[5] += c1;
+                accd[6] += nd;
+            }
+        }
+        block_sums<7, kST>(accd, shf);
+        const double aux1 = 1.0 / (accd[6] / a.ra.B + 1e-3);  // UPA.py:384
+        if (a.dh || a.gs) {
+            float kE = 0.0f;
+            if (own_row < Rn && me.ord < 3 && own_row - me.ord >= 0 && own_row - me.ord + 2 < Rn) {
+                Upa3 u3;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    RowStat t;
+                    t.E = sE[own_row - me.ord + q];
+                    t.lab = rm[own_row - me.ord + q].lab;
+                    u3.set(q, t);
+                }
+                kE = (float)(u3.dE(me.ord, (double)a.ra.alpha, (double)a.ra.beta, aux1, a.ra.B) / 255.0);
+            }
+            if (poisoned) kE = __uint_as_float(0x7fc00000u);
+            grad_row(xo, own_alse, own_E, kE);
+        }
+    }
+    K3S_STAMP(6);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    K3S_STAMP(7);
+
+    // ---- phase 3: dH tile = g [16, 256] x slice [256, these 256 columns of D] ----
+    if (a.dh) {
+        v4f_s acc3[kSTPW];
+#pragma unroll
+        for (int t = 0; t < kSTPW; ++t) acc3[t] = (v4f_s){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < kNA / 32; ++ks) {
+            const v8s_s af = *reinterpret_cast<const v8s_s*>(gt + c * kSGS + ks * 32 + g * 8);
+#pragma unroll
+            for (int t = 0; t < kSTPW; ++t) acc3[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[t][ks], acc3[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < kSTPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[(g * 4 + r) * kSGS + (wv * kSTPW + t) * 16 + c] = (uint16_t)f32_to_bf16_bits(acc3[t][r]);
+        K3S_STAMP(8);
+        __syncthreads();
+        const int orow = tid >> 5, col = (tid & 31) * 8, d = j * kNA + col;  // 16 rows x 32 pieces of 16 bytes
+        if (rb * 16 + orow < R && d < D) *reinterpret_cast<uint4*>(a.dh + (size_t)(rb * 16 + orow) * D + d) = *reinterpret_cast<const uint4*>(ot + orow * kSGS + col);
+    }
+    K3S_STAMP(9);
+    // ---- publication (callers without a step epilogue): workgroup 0 folds the rows it has just written into scalars[8] + the prediction maps ----
+    if (pub_wg) {
+        __syncthreads();  // this workgroup's SliceStat / PartStat stores are visible to all of its threads
+        (void)rows_fold<kST>(a.ra, true, shf);  // (512 threads: the upper waves add exact zeros to rows_fold<256>'s sums — the same bits)
+    }
+}
+
+// wt[d][a] = w[31744 + a][d]: one 64 x 64 tile per workgroup through LDS
+__global__ __launch_bounds__(256) void head_slice_pack_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ wt, int D) {
+    __shared__ uint16_t tile[64][66];
+    const int d0 = blockIdx.x * 64, a0 = blockIdx.y * 64, tid = threadIdx.x;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int ar = e >> 6, dc = e & 63;
+        tile[ar][dc] = (d0 + dc < D) ? w[(size_t)(kA0 + a0 + ar) * D + d0 + dc] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int dr = e >> 6, ac = e & 63;
+        if (d0 + dr < D) wt[(size_t)(d0 + dr) * kNA + a0 + ac] = tile[ac][dr];
+    }
+}
+
+// resident workgroups of head_slice_kernel on the current device (occupancy x CUs), queried once per device; 0 = unknown
+static size_t slice_lds_bytes() { return (size_t)kSRing * kSGrp * kSSlot * sizeof(uint16_t); }  // the ring (the 2 x 16 x kSGS tiles reuse it)
+
+static long slice_resident_slots() {
+    static std::atomic<long> slots[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 0; }
+    long have = slots[dev].load(std::memory_order_relaxed);
+    if (have == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel, kST, slice_lds_bytes()) != hipSuccess) {
+            (void)hipGetLastError();
+            have = -1;
+        } else {
+            have = (long)cus * per_cu;
+        }
+        slots[dev].store(have, std::memory_order_relaxed);
+    }
+    return have > 0 ? have : 0;
+}
+
+}  // namespace vaa
+
+extern "C" size_t vaa_loss_rows_ws_bytes(int R);
+
+extern "C" int vaa_head_slice_applies(int R, int D, int V) {
+    // V <= 32,768: the fold arithmetic this kernel shares with rows_finish_kernel is its 256-thread form
+    return (R > 0 && R <= vaa::kSRowsMax && D >= vaa::kSK && (D % vaa::kSK) == 0 && D <= 16 * (vaa::kST / 64) * vaa::kSTPW * 16 && V >= vaa::kA0 + vaa::kNA && (V % 8) == 0 &&
+            V <= 32768) ? 1 : 0;
+}
+
+extern "C" size_t vaa_head_slice_ws_bytes(int R) {
+    if (R <= 0) return 0;
+    return (size_t)((R + 15) / 16) * 16 * (vaa::kNA / 2) * sizeof(unsigned long long);  // two logits + the launch tag per 64-bit word
+}
+
+extern "C" int vaa_head_slice_pack(const uint16_t* w_head, int D, int V, uint16_t* w_slice_t, void* stream) {
+    using namespace vaa;
+    const char* who = "vaa_head_slice_pack";
+    if (!w_head || !w_slice_t) {
+        set_error("%s: null pointer argument", who);
+        return VAA_E_INVALID;
+    }
+    if (D <= 0 || V < kA0 + kNA) {
+        set_error("%s: bad sizes (D=%d V=%d)", who, D, V);
+        return VAA_E_INVALID;
+    }
+    VAA_LAUNCH(head_slice_pack_kernel, dim3((unsigned)((D + 63) / 64), kNA / 64), dim3(256), 0, (hipStream_t)stream, w_head, w_slice_t, D);
+    return check_launch(who);
+}
+
+extern "C" int vaa_head_slice_fwd_bwd(const uint16_t* hidden, const uint16_t* w_head, const uint16_t* w_slice_t, int D, const void* rowmap, int R, int B,
+                                      int L, int V, int mode, const float* params, uint16_t* dhidden, uint16_t* grad_slice, void* loss_ws,
+                                      size_t loss_ws_bytes, float* scalars, int32_t* pred_tokens, int32_t* pred_full_tokens, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    using namespace vaa;
+    const char* who = "vaa_head_slice_fwd_bwd";
+    if (!hidden || !w_head || !rowmap || !params || !loss_ws || !ws || (dhidden && !w_slice_t)) {
+        set_error("%s: null pointer argument", who);
+        return VAA_E_INVALID;
+    }
+    if (mode != VAA_LOSS_UADA_DDP && mode != VAA_LOSS_UPA) {
+        set_error("%s: mode %d has a cross-entropy term — its loss does not live in the action columns (vaa_head_loss_rows_stats / the LM-head GEMM)", who, mode);
+        return VAA_E_UNSUPPORTED;
+    }
+    if (!vaa_head_slice_applies(R, D, V) || B <= 0 || L <= 1 || (long)R > (long)B * (L - 1)) {
+        set_error("%s: shape not covered (R=%d <= %d rows, D=%d a multiple of %d up to %d, V=%d <= 32768; B=%d L=%d)", who, R, kSRowsMax, D, kSK,
+                  16 * (kST / 64) * kSTPW * 16, V, B, L);
+        return VAA_E_UNSUPPORTED;
+    }
+    if ((((uintptr_t)hidden) | ((uintptr_t)w_head) | ((uintptr_t)w_slice_t) | ((uintptr_t)dhidden) | ((uintptr_t)grad_slice) | ((uintptr_t)ws)) & 15u) {
+        set_error("%s: hidden, w_head, w_slice_t, dhidden, grad_slice and ws must be 16-byte aligned", who);
+        return VAA_E_INVALID;
+    }
+    if (loss_ws_bytes < vaa_loss_rows_ws_bytes(R) || ws_bytes < vaa_head_slice_ws_bytes(R)) {
+        set_error("%s: workspace too small (loss %zu of %zu B, slice %zu of %zu B)", who, loss_ws_bytes, vaa_loss_rows_ws_bytes(R), ws_bytes,
+                  vaa_head_slice_ws_bytes(R));
+        return VAA_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    SliceHeadArgs a = {};
+    a.h = hidden; a.w = w_head; a.wt = w_slice_t;
+    a.zs = (unsigned long long*)ws; a.gs = grad_slice; a.dh = dhidden;
+    a.ra.logits = nullptr; a.ra.rowmap = (const int*)rowmap;
+    a.ra.part = (PartStat*)loss_ws; a.ra.slice = (SliceStat*)((char*)loss_ws + (size_t)R * 4 * sizeof(PartStat));
+    a.ra.grad = nullptr; a.ra.scalars = scalars; a.ra.pred_tokens = pred_tokens; a.ra.pred_full = pred_full_tokens;
+    a.ra.R = R; a.ra.B = B; a.ra.L = L; a.ra.V = V; a.ra.mode = mode; a.ra.split = rows_split(R, V); a.ra.grad_slice = 1;
+    a.ra.ldz = kNA; a.ra.zcol0 = kA0;
+    a.ra.w = params[0]; a.ra.alpha = params[1]; a.ra.beta = params[2]; a.ra.scale = params[3];
+    a.D = D; a.publish = scalars ? 1 : 0;
+    const size_t lds = slice_lds_bytes();
+    static_assert(2 * 16 * kSGS <= kSRing * kSGrp * kSSlot, "the tiles reuse the ring");
+    static std::atomic<unsigned long long> attr_done;  // bit = device ordinal: the dynamic-LDS opt-in (128 KB) is set once per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (lds > 64 * 1024 && !(attr_done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute((const void*)head_slice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute failed", who);
+            return VAA_E_LAUNCH;
+        }
+        attr_done.fetch_or(bit, std::memory_order_acq_rel);
+    }
+    const unsigned grid = (unsigned)((R + 15) / 16) * 16u;
+    // the launch's tag: unique in the process (one counter for all streams and devices), scrambled so that no plausible stale content of the
+    // scratch (small integers, bf16 pairs, an old launch's tag) equals it
+    static std::atomic<unsigned> tag_counter{0u};
+    a.tag = (tag_counter.fetch_add(1u, std::memory_order_relaxed) + 1u) * 2654435761u | 0x80000001u;
+    a.err_word = async_error_word();
+    a.max_polls = 1 << 22;
+    const char* pv = getenv("VAA_K3_HANDOVER_POLLS");  // test hook: 0 makes every waiting workgroup give up at once
+    if (pv && *pv) a.max_polls = atoi(pv);
+    // ONE launch when a grid that waits on itself is admissible: the device keeps at least TWICE the grid resident (a second waiting grid of
+    // another process still finds room), the stream is not being captured and no other stream of this process has a waiting grid in flight;
+    // else the same kernel twice (phase 1, then phases 2 + 3): the same bits. VAA_K3S_ONE_LAUNCH=0 forces two.
+    const char* ev = getenv("VAA_K3S_ONE_LAUNCH");
+    bool one = !(ev && ev[0] == '0');
+    if (one) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const hipError_t ce = hipStreamIsCapturing(st, &cs);
+        if (ce != hipSuccess) (void)hipGetLastError();
+        const bool capturing = ce != hipSuccess || cs != hipStreamCaptureStatusNone;
+        one = !capturing && 2l * grid <= slice_resident_slots() && rows_one_pass_stream_ok(st);
+    }
+    const char* dbg = getenv("VAA_K3S_DEBUG_PHASES");  // measurement hook (tools/k3s_bench.py): run phase 1 or phases 2 + 3 alone
+    if (dbg && (dbg[0] == '1' || dbg[0] == '2')) {
+        static unsigned last_tag;  // phase 2 alone polls for the words the last phase-1 run left
+        if (dbg[0] == '2') a.tag = last_tag;
+        last_tag = a.tag;
+        a.phases = dbg[0] - '0';
+        VAA_LAUNCH(head_slice_kernel, dim3(grid), dim3(kST), lds, st, a);
+        return check_launch(who);
+    }
+    if (one) {
+        a.phases = 3;
+        VAA_LAUNCH(head_slice_kernel, dim3(grid), dim3(kST), lds, st, a);
+        return check_launch(who);
+    }
+    a.phases = 1;
+    VAA_LAUNCH(head_slice_kernel, dim3(grid), dim3(kST), lds, st, a);
+    int rc = check_launch("vaa_head_slice_fwd_bwd(logits)");
+    if (rc != VAA_OK) return rc;
+    a.phases = 2;
+    VAA_LAUNCH(head_slice_kernel, dim3(grid), dim3(kST), lds, st, a);
+    return check_launch("vaa_head_slice_fwd_bwd(gradient)");
+}

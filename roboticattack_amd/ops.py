@@ -724,6 +724,65 @@ def head_loss_rows_fwd_bwd(hidden, w_head, rowmap: "LossRowMap", mode: int, w: f
     return (scalars, pred, pred_full, grad, lg) if want_logits else (scalars, pred, pred_full, grad)
 
 
+_slice_t_cache = []  # [(weakref to the weight tensor, its _version when packed, [D,256] transposed action slice)]
+
+
+def head_slice_applies(R: int, D: int, V: int) -> bool:
+    return bool(_lib.lib().vaa_head_slice_applies(int(R), int(D), int(V)))
+
+
+def head_slice_packed(w_head: torch.Tensor) -> torch.Tensor:
+    """[D,256] bf16 transposed copy of the action rows of the LM-head weight (vaa_head_slice_pack), built once per weight TENSOR OBJECT (held by a
+    weak reference: an address can be recycled by the allocator, an object cannot) and kept resident — the weights are frozen (UADA_ddp.py:50-51);
+    an in-place edit of the weight (its _version) rebuilds it."""
+    import weakref
+
+    V, D = int(w_head.shape[0]), int(w_head.shape[1])
+    _need(w_head, torch.bfloat16, "w_head", (V, D))
+    live = [e for e in _slice_t_cache if e[0]() is not None]
+    if len(live) != len(_slice_t_cache):
+        _slice_t_cache[:] = live
+    for ref, ver, wt in _slice_t_cache:
+        if ref() is w_head and ver == w_head._version and wt.device == w_head.device:
+            return wt
+    wt = torch.empty((D, N_ACTION), dtype=torch.bfloat16, device=w_head.device)
+    _lib.check(_lib.lib().vaa_head_slice_pack(w_head.data_ptr(), D, V, wt.data_ptr(), _stream()), "vaa_head_slice_pack")
+    _slice_t_cache[:] = [e for e in _slice_t_cache if e[0]() is not w_head][-7:] + [(weakref.ref(w_head), w_head._version, wt)]
+    return wt
+
+
+def head_slice_fwd_bwd(hidden, w_head, rowmap: "LossRowMap", mode: int, w: float = 5.0, alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0,
+                       want_dh: bool = True, want_scalars: bool = True, want_grad_slice: bool = False):
+    """K3s (vaa_head_slice_fwd_bwd): slice-only LM head + statistics + gradient + head backward in one launch (modes UADA_DDP / UPA).
+    Returns dict(dh [R,D] bf16 | None, ws = the K3 workspace (SliceStats + neutral parts: step_epilogue(loss_ws=...) folds it),
+    scalars f32[8] | None, pred, pred_full i32 [B,L-1] | None (pred_full = -1: no full-vocabulary argmax on a slice-only step),
+    grad_slice [R,256] bf16 | None)."""
+    if mode not in SLICE_MODES:
+        raise _lib.VaaError(f"head_slice_fwd_bwd: mode {mode} has a cross-entropy term — its loss does not live in the action columns")
+    R, D = int(hidden.shape[0]), int(hidden.shape[1])
+    V = int(w_head.shape[0])
+    _need(hidden, torch.bfloat16, "hidden", (R, D))
+    _need(w_head, torch.bfloat16, "w_head", (V, D))
+    dev = hidden.device
+    L = _lib.lib()
+    wt = head_slice_packed(w_head) if want_dh else None
+    lws = _workspace(dev, L.vaa_loss_rows_ws_bytes(R), "k3")
+    zws = _workspace(dev, L.vaa_head_slice_ws_bytes(R), "k3s")
+    dh = torch.empty((R, D), dtype=torch.bfloat16, device=dev) if want_dh else None
+    gs = torch.empty((R, N_ACTION), dtype=torch.bfloat16, device=dev) if want_grad_slice else None
+    scalars = torch.empty(8, dtype=torch.float32, device=dev) if want_scalars else None
+    pred = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=dev) if want_scalars else None
+    pred_full = torch.empty((rowmap.B, rowmap.L - 1), dtype=torch.int32, device=dev) if want_scalars else None
+    with _timed("K3s_head_slice_fwd_bwd", rows=R, D=D):
+        rc = L.vaa_head_slice_fwd_bwd(hidden.data_ptr(), w_head.data_ptr(), wt.data_ptr() if wt is not None else None, D, rowmap.buf.data_ptr(), R,
+                                      rowmap.B, rowmap.L, V, int(mode), _lib.f32x([w, alpha, beta, scale]), dh.data_ptr() if dh is not None else None,
+                                      gs.data_ptr() if gs is not None else None, lws.data_ptr(), lws.numel(),
+                                      scalars.data_ptr() if scalars is not None else None, pred.data_ptr() if pred is not None else None,
+                                      pred_full.data_ptr() if pred_full is not None else None, zws.data_ptr(), zws.numel(), _stream())
+    _lib.check(rc, "vaa_head_slice_fwd_bwd")
+    return {"dh": dh, "ws": lws, "zs": zws, "scalars": scalars, "pred": pred, "pred_full": pred_full, "grad_slice": gs}
+
+
 def step_epilogue(partials, msg, scalars, rowmap: LossRowMap = None, R: int = 0, V: int = 32064, mode: int = LOSS_UADA_DDP, w: float = 5.0,
                   alpha: float = 0.8, beta: float = 0.2, scale: float = 1.0, loss_ws=None, want_pred: bool = True, update=None):
     """vaa_step_epilogue: msg[0..n) = fixed-order sum of K2's partial tiles [parts, n]; with `rowmap` (+ the workspace loss_rows_stats left)
