@@ -50,6 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LINE_LIMIT = 4096  # bytes of the stdout record
+INNER_LOOP = 50    # UADA_wrapper_ddp.py:104 (--innerLoop): one full-vocabulary CE evaluation per INNER_LOOP steps (UADA_ddp.py:196-221)
 
 
 def parse():
@@ -294,21 +295,30 @@ class StepRunner:
         self.scal = torch.zeros(8, device=dev)
         self.pick = torch.tensor([1, 2, 7, 0], dtype=torch.int64, device=dev)
         self.R = int((self.labels[:, 1:] != -100).sum())
+        # the loop's cadence (attack/uada_ddp.py = UADA_ddp.py:196-221): the full-vocabulary CE / argmax is read on the LAST inner step of an
+        # outer iteration only, innerLoop = 50 (UADA_wrapper_ddp.py:104): steps count through outer iterations, warm-up included
+        self.full_ce_every = INNER_LOOP
+        self.k = 0
+        self.force_ce = None  # the per-dispatch-profiled blocks pin the step kind (True / False); None = the cadence
 
     def step(self):  # attack/uada_ddp.py inner step
         a, ops = self.att, self.ops
+        full_ce = ((self.k + 1) % self.full_ce_every == 0) if self.force_ce is None else bool(self.force_ce)
+        self.k += 1
+        self.ce_steps = getattr(self, "ce_steps", 0) + int(full_ce)
         self.opt.zero_grad()
         if self.fused and self.world == 1:
-            # host draws -> K1 (tile-major) -> model -> K3 statistics -> backward -> K2' tiles + scatter -> epilogue incl. K4 (nothing to exchange)
-            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, self.geometry, 5.0, self.sync.buf, self.scal, optimizer=self.opt)
+            # host draws -> K1 (tile-major) -> model -> K3s (+ K3h on CE steps) -> backward -> K2' tiles + scatter -> epilogue incl. K4 (nothing to exchange)
+            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, self.geometry, 5.0, self.sync.buf, self.scal, optimizer=self.opt,
+                             full_ce=full_ce)
             return
         if self.fused:
             # ... -> epilogue: the message is in sync.buf -> all-reduce -> K4
-            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, self.geometry, 5.0, self.sync.buf, self.scal)
+            a.fused_ddp_step(self.img, self.patch, self.input_ids, self.attn, self.labels, self.geometry, 5.0, self.sync.buf, self.scal, full_ce=full_ce)
             g_sum, _ = self.sync.allreduce_packed()  # [grad | CE, MSE, UAD, total]: one all-reduce per step
         else:
             pix = self.tr.apply_random_patch_batch(self.img, self.patch, mean=a.mean, std=a.std, geometry=self.geometry)  # host RNG draws + K1
-            total, scalars, _ = a.model_loss(self.input_ids, self.attn, pix, self.labels, ops.LOSS_UADA_DDP, w=5.0)  # model + LM head + K3
+            total, scalars, _ = a.model_loss(self.input_ids, self.attn, pix, self.labels, ops.LOSS_UADA_DDP, w=5.0, full_ce=full_ce)  # model + LM head + K3
             total.backward()  # ... -> K2 (or K2' fed by the patch-embed output gradients)
             g_sum, _ = self.sync.allreduce_step(self.patch.grad, scalars, self.pick)
             self.scal.copy_(scalars)
@@ -465,7 +475,7 @@ def timed_steps(runner, steps, warmup, world, dev, profile=False, comm=False):
 
 # kernel name (substring of the launch site's name) -> operator of the hot path
 KERNEL_OPS = (("patch_apply_fwd_kernel", "K1"), ("patch_apply_tiles_kernel", "K1"), ("patch_apply", "K1"), ("embed_dgrad", "K2e"), ("patch_grad_scatter", "K2"), ("patch_grad_reduce", "K2"),
-              ("patch_grad", "K2"), ("head_stats_kernel", "K3h"), ("head_finish_kernel", "K3h"), ("rows_stats_kernel", "K3"), ("rows_finish_kernel", "K3"), ("rows_", "K3"),
+              ("patch_grad", "K2"), ("head_slice", "K3s"), ("head_stats_kernel", "K3h"), ("head_finish_kernel", "K3h"), ("rows_stats_kernel", "K3"), ("rows_finish_kernel", "K3"), ("rows_", "K3"),
               ("loss_stats_kernel", "K3"), ("loss_grad_kernel", "K3"), ("loss_", "K3"), ("step_epilogue_kernel", "EPI"), ("patch_update_kernel", "K4"), ("patch_resize", "K0"), ("resize", "K0"))
 
 
@@ -527,7 +537,7 @@ def per_rank_block(model, dev, B, patch_shape, steps, ips_ref):
             continue
         torch.cuda.empty_cache()
         rb = StepRunner(model, dev, b, patch_shape, 0, 1)
-        n_b = max(steps, 10) if b <= 8 else max(steps // 2, 6)
+        n_b = 6  # (the blocks beside the headline are 6 timed steps each)
         dt_b, enq_b, cpu_b, _, _ = timed_steps(rb, n_b, 3, 1, dev)  # un-profiled, like the headline it is compared with
         n_p = min(n_b, 5)
         _, _, _, recs_b, _ = timed_steps(rb, n_p, 0, 1, dev, profile=True)
@@ -561,7 +571,7 @@ def config_block(model, dev, steps):
     for tag, kind, b, pshape, geo, resize, what in CONFIG_STEPS:
         torch.cuda.empty_cache()
         r = LoopRunner(kind, model, dev, b, pshape, geometry=geo, resize_patch=resize)
-        n = max(steps, 10)
+        n = 6
         dt, enq, cpu, _, _ = timed_steps(r, n, 3, 1, dev)
         n_p = 5
         _, _, _, recs, _ = timed_steps(r, n_p, 0, 1, dev, profile=True)
@@ -588,6 +598,8 @@ def kernel_bytes(name, model, runner, B, pshape):
     width = (cfg.dino.dim + cfg.siglip.dim) if cfg is not None and hasattr(cfg, "dino") else 1024 + 1152
     if "patch_apply" in name:
         return algo_bytes("K1", B, ph, pw)
+    if "head_slice_kernel" in name and cfg is not None and hasattr(cfg, "llm_dim"):
+        return 2 * (2 * R * cfg.llm_dim) + 2 * (2 * 256 * cfg.llm_dim)  # hidden rows in, d hidden out, the weight slice and its transposed copy
     if "head_stats_kernel" in name and head_bytes(cfg):
         return head_bytes(cfg) + 2 * R * cfg.llm_dim
     if "embed_dgrad" in name or ("patch_grad_scatter" in name and getattr(runner.tr, "embed_with", None) is not None):
@@ -682,14 +694,22 @@ def main():
     # ---- the timed region: weak scaling, bs = args.bs PER RANK (reference semantics, UADA_ddp.py:158). UN-profiled, like the strong region ----
     t_setup = time.perf_counter() - t_main
     dt = host_enqueue = host_cpu = None
-    recs, comm_w, finite = [], None, True
+    recs, recs_ce, comm_w, finite = [], [], None, True
     if run_weak:
         dt, host_enqueue, host_cpu, _, crecs = timed_steps(runner, args.steps, args.warmup, world, dev, comm=True)
         comm_w = comm_summary(crecs, world, args.steps, dt, dev)
         finite = bool(torch.isfinite(runner.scal).all())
-        # ---- the same steps once more, SEPARATELY, with the library's per-dispatch timer armed: the in-step kernel durations ----
+        # ---- the same steps once more, SEPARATELY, with the library's per-dispatch timer armed: the in-step kernel durations, per step KIND
+        #      (slice-only steps, then steps that also evaluate the full-vocabulary CE: 1 of INNER_LOOP in the loop) ----
         if psteps > 0:
+            cadenced = hasattr(runner, "force_ce")
+            if cadenced:
+                runner.force_ce = False
             _, _, _, recs, _ = timed_steps(runner, psteps, 1, world, dev, profile=True)
+            if cadenced:
+                runner.force_ce = True
+                _, _, _, recs_ce, _ = timed_steps(runner, min(psteps, 4), 1, world, dev, profile=True)
+                runner.force_ce = None
     t_region = time.perf_counter() - t_main - t_setup
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
     b2b = allreduce_back_to_back(runner.sync, world) if world > 1 else None
@@ -737,25 +757,37 @@ def main():
 
     # ---- per-kernel durations inside the step: every dispatch's own begin/end timestamps (vaa_prof_*) ----
     kern, op_us = kernel_table(recs, max(psteps, 1))
+    kern_ce, op_us_ce = kernel_table(recs_ce, max(min(psteps, 4), 1))
     fused_embed = tr.embed_with is not None
-    if fused_embed and "K2" in op_us:  # the TILED scatter + reduce belong to K2'
-        op_us["K2e"] = op_us.get("K2e", 0.0) + op_us.pop("K2")
-    tfile = next((f for f in ("profiles/traffic_r05.json", "profiles/traffic_r04.json", "profiles/traffic_r03.json") if os.path.exists(os.path.join(ROOT, f))), None)
+    for o_ in (op_us, op_us_ce):
+        if fused_embed and "K2" in o_:  # the TILED scatter + reduce belong to K2'
+            o_["K2e"] = o_.get("K2e", 0.0) + o_.pop("K2")
+    # the AVERAGE step of the loop: slice-only steps + 1 / INNER_LOOP of what a CE step adds (K3h's stream + finish)
+    every = getattr(runner, "full_ce_every", None) if recs_ce else None
+    ce_timed = sum(1 for g_ in range(args.warmup, args.warmup + args.steps) if (g_ + 1) % every == 0) if (every and run_weak) else None
+    launches_slice = sum(k_["launches_per_step"] for k_ in kern.values())
+    launches_avg = launches_slice + ((sum(k_["launches_per_step"] for k_ in kern_ce.values()) - launches_slice) / every if every else 0.0)
+    op_us_slice = dict(op_us)
+    if every:
+        op_us = {o_: op_us_slice.get(o_, 0.0) + (op_us_ce.get(o_, 0.0) - op_us_slice.get(o_, 0.0)) / every for o_ in set(op_us_slice) | set(op_us_ce)}
+    tfile = next((f for f in ("profiles/traffic_r06.json", "profiles/traffic_r05.json", "profiles/traffic_r04.json") if os.path.exists(os.path.join(ROOT, f))), None)
     tr_all = json.load(open(os.path.join(ROOT, tfile))) if tfile else {}
     tr_ops = tr_all.get("ops", {})
 
-    def roofline_of(kname, label, nb, traffic):
+    def roofline_of(kname, label, nb, traffic, table=None):
         """the contract's roofline object for ONE hand-written kernel of the timed region (HBM-bound byte work), in-step per dispatch"""
-        k = kern[kname]
+        k = (kern if table is None else table)[kname]
         return {"kernel": f"{kname.strip('() ')} ({label})", "bound": "hbm", "achieved": nb / k["mean_us"] / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": nb / k["mean_us"] / 1e3 / HBM_PEAK_GBS, "mean_us": k["mean_us"], "min_us": k["min_us"], "samples": k["launches"],
                 "algo_bytes": int(nb), "traffic": traffic}
 
     # the dominant kernel = the hand-written kernel the timed region actually ran with the most algorithmic bytes (and, at the 7B shape, the
     # longest): the LM head fused with K3's statistics when the step dispatches it (263 MB weight stream), else K1; K1 is reported beside it
-    roofline = roofline_k1 = roofline_head = None
+    roofline = roofline_k1 = roofline_head = roofline_k3s = None
     k1name = next((n for n in kern if "patch_apply" in n), None)
     hname = next((n for n in kern if "head_stats_kernel" in n), None)
+    sname = next((n for n in kern if "head_slice_kernel" in n), None)
+    hname_ce = next((n for n in kern_ce if "head_stats_kernel" in n), None)
     if k1name:
         roofline_k1 = roofline_of(k1name, "K1", kernel_bytes(k1name, model, runner, B, patch_shape),
                                   tr_ops.get("K1t_patch_apply_fwd_tiles" if "tiles" in k1name else "K1_patch_apply_fwd", {}).get("hbm_bytes_per_launch")
@@ -765,10 +797,31 @@ def main():
         if R != 128 or args.model != "openvla-7b":
             t_head = None  # the committed PMC passes ran the 7B head at 128 rows
         roofline_head = roofline_of(hname, "K3h", kernel_bytes(hname, model, runner, B, patch_shape), t_head)
-    roofline = max((r for r in (roofline_k1, roofline_head) if r), key=lambda r: r["algo_bytes"], default=None)
+    if hname_ce and not hname and kernel_bytes(hname_ce, model, runner, B, patch_shape):  # K3h runs on the CE steps only: measured there
+        t_head = next((v.get("hbm_bytes_per_launch") for kk, v in tr_all.items() if "head_stats_kernel" in kk and isinstance(v, dict)), None)
+        if R != 128 or args.model != "openvla-7b":
+            t_head = None
+        roofline_head = roofline_of(hname_ce, "K3h, on the CE steps: 1 of %d" % every, kernel_bytes(hname_ce, model, runner, B, patch_shape), t_head, table=kern_ce)
+        roofline_head["launches_per_average_step"] = 1.0 / every
+    if sname and kernel_bytes(sname, model, runner, B, patch_shape):
+        t_k3s = next((v.get("hbm_bytes_per_launch") for kk, v in tr_all.items() if "head_slice_kernel" in kk and isinstance(v, dict)), None)
+        roofline_k3s = roofline_of(sname, "K3s", kernel_bytes(sname, model, runner, B, patch_shape), t_k3s if (R == 128 and args.model == "openvla-7b") else None)
+    # the dominant kernel = the hand-written kernel with the most algorithmic bytes per AVERAGE step of the loop (a kernel that runs on 1 of
+    # INNER_LOOP steps counts 1 / INNER_LOOP of its bytes): K1 at the headline shape (48.2 MB against K3s's 6.3 MB and K3h's 263.7 / 50 = 5.3 MB)
+    def _avg_bytes(r):
+        return r["algo_bytes"] * r.get("launches_per_average_step", 1.0)
+    roofline = max((r for r in (roofline_k1, roofline_head, roofline_k3s) if r), key=_avg_bytes, default=None)
 
     extra_full = {}
     k2_fracs = k1_standalone = copy_bw = None
+    cpu_c = cpu_f = None
+    cpu_thread = None
+    if not args.no_cpu_baseline and world == 1:  # host-CPU leg only at N=1 (rank 0), as the bench contract asks: separate processes, started now so
+        import threading                            # that they run while the GPU kernel suite below (one mostly idle host thread) does
+
+        cpu_box = {}
+        cpu_thread = threading.Thread(target=lambda: cpu_box.update(zip(("c", "f"), cpu_baseline(B, patch_shape, args.cpu_budget))), daemon=True)
+        cpu_thread.start()
     if not args.no_kernel_suite and world == 1:
         del runner, model, tr  # the transform holds the model (embed_with)
         torch.cuda.empty_cache()
@@ -783,9 +836,9 @@ def main():
                            "rank_shapes": rank_shapes(device=str(dev))})
         k2_fracs = [e["frac_of_8TBs"] for e in k2s]
         k1_standalone = ks.get("K1t_patch_apply_fwd_tiles", ks.get("K1_patch_apply_fwd", {})).get("achieved_GBs")
-    cpu_c = cpu_f = None
-    if not args.no_cpu_baseline and world == 1:  # host-CPU leg only at N=1 (rank 0), as the bench contract asks
-        cpu_c, cpu_f = cpu_baseline(B, patch_shape, args.cpu_budget)
+    if cpu_thread is not None:
+        cpu_thread.join()
+        cpu_c, cpu_f = cpu_box.get("c"), cpu_box.get("f")
 
     # ---------------------------------------------------------------- the records ----------------------------------------------------------------
     workload = {"uada_ddp": f"UADA_wrapper_ddp inner step: bs={B}/rank (global {B * world}), patch {args.patch}, geometry={geometry}, maskidx={maskidx or [0]}",
@@ -797,7 +850,8 @@ def main():
               "regions": ("weak" if world == 1 else args.regions),
               "backend": (os.environ.get("VAA_DIST_BACKEND") or "nccl (RCCL)") if world > 1 else None,
               "visible_gpus": torch.cuda.device_count(), "labelled_rows_per_rank": R, "tunableop_entries_loaded_min_over_ranks": tun_min,
-              "lm_head": ("fused K3h" if hname else "GEMM + K3 rows") if use_rows else "full logits",
+              "lm_head": (("K3s every step + K3h on CE steps" if sname else ("fused K3h" if hname else "GEMM + K3 rows")) if use_rows else "full logits"),
+              "full_ce_every": every, "ce_steps_in_timed_region": ce_timed, "traffic_source": tfile,
               "h2d_stage_ms_per_outer_iteration": stage_ms,
               "pcie_inclusive_value_if_restaged_every_step": (world * args.steps / (dt + args.steps * stage_ms * 1e-3)) if run_weak else None}
     if world > 1:  # the collective
@@ -840,7 +894,8 @@ def main():
     head = {"metric": metric, "value": (world * args.steps / dt) if run_weak else None, "unit": "attack-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": (dt / args.steps * 1e3) if run_weak else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic"}
-    tail = {"hot_path_us_per_step": sum(op_us.values()), "hot_path_launches_per_step": sum(k["launches_per_step"] for k in kern.values()),
+    tail = {"hot_path_us_per_step": sum(op_us.values()), "hot_path_launches_per_step": launches_avg,
+            "hot_path_us_slice_step": sum(op_us_slice.values()) if every else None, "hot_path_us_ce_step": sum(op_us_ce.values()) if every else None,
             "hot_path_ops_us": op_us, "host_cpu_ms_per_step": host_cpu * 1e3 if run_weak else None,
             "peak_mem_GiB": peak_mem, "loss_finite": finite and (strong is None or strong["loss_finite_all_ranks"]),
             "profiled_pass_steps": psteps if run_weak else 0}
@@ -849,8 +904,9 @@ def main():
     env_rec = {k: v for k, v in sorted(os.environ.items())
                if k.startswith(("NCCL_", "RCCL_", "HSA_", "VAA_", "TORCH_NCCL", "PYTORCH_TUNABLEOP", "HIP_VISIBLE", "ROCR_VISIBLE", "CUDA_VISIBLE", "GPU_MAX_HW_QUEUES"))}
     full = dict(head)
-    full.update({"config": dict(config, env=env_rec, traffic_source=tfile), "roofline": roofline, "roofline_k1": roofline_k1 if roofline is not roofline_k1 else None,
-                 "roofline_kernels": kern, "strong_scaling": strong, "allreduce_us_per_step": comm_w, "allreduce_back_to_back": b2b,
+    full.update({"config": dict(config, env=env_rec), "roofline": roofline, "roofline_k1": roofline_k1 if roofline is not roofline_k1 else None,
+                 "roofline_head": roofline_head if roofline is not roofline_head else None, "roofline_k3s": roofline_k3s if roofline is not roofline_k3s else None,
+                 "roofline_kernels": kern, "roofline_kernels_ce_steps": kern_ce, "hot_path_ops_us_slice_step": op_us_slice, "hot_path_ops_us_ce_step": op_us_ce, "strong_scaling": strong, "allreduce_us_per_step": comm_w, "allreduce_back_to_back": b2b,
                  "per_rank_step": per_rank, "config_steps": cfg_steps, "cpu_baseline": cpu_f, "host_enqueue_ms_per_step": host_enqueue * 1e3 if run_weak else None})
     full.update(tail)
     full.update(extra_full)
@@ -859,7 +915,11 @@ def main():
     full_path = write_full(args.full_out, full)
 
     line = dict(head)
-    line.update({"config": config, "roofline": roofline, "roofline_k1": roofline_k1 if roofline is not roofline_k1 else None, "cpu_baseline": cpu_c})
+    def _short(r):  # the secondary roofline objects of the line: the figures only
+        return {k_: r[k_] for k_ in ("kernel", "achieved", "frac", "mean_us", "samples", "algo_bytes", "traffic") if k_ in r} if r else None
+    line.update({"config": config, "roofline": roofline, "roofline_k1": roofline_k1 if roofline is not roofline_k1 else None,
+                 "roofline_head": _short(roofline_head) if roofline is not roofline_head else None,
+                 "roofline_k3s": _short(roofline_k3s) if roofline is not roofline_k3s else None, "cpu_baseline": cpu_c})
     line.update(tail)
     line["wall_s"] = wall["total"]
     line["full_record"] = full_path
@@ -869,7 +929,8 @@ def main():
     optional = ["hot_path_ops_us", "config.pcie_inclusive_value_if_restaged_every_step", "config.h2d_stage_ms_per_outer_iteration", "config.visible_gpus",
                 "config.bs4_ms_per_step", "config.bs8_ms_per_step", "config.bs16_ms_per_step", "config.bs32_ms_per_step", "config.measured_device_copy_GBs",
                 "config.k1_standalone_GBs", "config.cfg2_hot_path_us", "config.cfg4_hot_path_us", "config.cfg5_hot_path_us", "roofline.min_us", "roofline_k1.min_us",
-                "host_cpu_ms_per_step", "profiled_pass_steps", "config.images_per_s", "config.lm_head"]
+                "host_cpu_ms_per_step", "profiled_pass_steps", "config.images_per_s", "config.lm_head", "roofline_k3s.traffic", "roofline_head.samples",
+                "roofline_k3s.samples", "hot_path_us_slice_step", "hot_path_us_ce_step"]
     try:
         out = encode_line(line, optional)
     except RuntimeError as e:  # never leave the driver without a line: fall back to the contract's keys alone (the full record has the rest)

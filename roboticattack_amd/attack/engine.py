@@ -64,8 +64,13 @@ class AttackBase:
         self.n_img_tokens = vla.vision_backbone.featurizer.patch_embed.num_patches
 
     # ---- the model + loss leg of a step ----
-    def model_loss(self, input_ids, attention_mask, pix, labels, mode, w=5.0, alpha=0.8, beta=0.2, scale=1.0, need_grad=True):
+    def model_loss(self, input_ids, attention_mask, pix, labels, mode, w=5.0, alpha=0.8, beta=0.2, scale=1.0, need_grad=True, full_ce=True):
         """Returns (total [autograd scalar or None], scalars f32[8] device, pred i32 [B,L-1] device).
+
+        `full_ce=False` (slice modes — UADA_DDP, UPA — on a model that exposes its hidden rows): the caller will not read this step's
+        full-vocabulary CE (scalars[1]) nor the full argmax (`pred`): the reference reads them on the LAST inner step of an outer iteration
+        only (UADA_ddp.py:214-221) and never in UPA's reverse-direction mode (UPA.py:145-186). The step then runs K3s alone — 2.1 MB of head
+        weights instead of the 263 MB stream; scalars[1] = 0, pred = -1. The gradient path is the same on every step either way.
 
         `pred` is the argmax over the WHOLE vocabulary at every labelled position (-1 elsewhere), i.e. the reference's
         `action_logits.argmax(dim=2)` (UADA.py:165-167, TMA.py:148-149) that its relative-distance / L1 / ASR metrics and the
@@ -80,12 +85,20 @@ class AttackBase:
                 W = self.vla.lm_head.weight
                 # ... and with the LM head FUSED into K3's statistics there (K3h: no [R,V] logits at all); UADA's 1/CE and TMA's CE gradients need
                 # every logit and keep the GEMM head
+                if mode in ops.SLICE_MODES and self._slice_head(int(h.shape[0]), h, W):
+                    # K3s: slice-only head + statistics + gradient + head backward in ONE launch, on every step; K3h's 263 MB stream only
+                    # behind it on the steps whose CE / full argmax is read
+                    total, scalars, _, pred_full = ops.HeadSliceLoss.apply(h, W, self._row_map, mode, w, alpha, beta, scale, bool(full_ce))
+                    return total, scalars, pred_full
                 head = ops.HeadLossRowsFused if (mode in ops.SLICE_MODES and self._fused_head(int(h.shape[0]), h, W)) else ops.HeadLossRows
                 total, scalars, _, pred_full = head.apply(h, W, self._row_map, mode, w, alpha, beta, scale)
                 return total, scalars, pred_full
             if not need_grad and hasattr(self.vla, "hidden_rows") and self._row_count > 0 and self._fused_head(self._row_count, None, self.vla.lm_head.weight):
                 # evaluation only (validation passes, every mode): head + statistics + fold without logits in memory when K3h covers the shape
                 h = self.vla.hidden_rows(input_ids, None if pe is not None else pix, self._row_index, patch_embeds=pe, pack=pack)
+                if not full_ce and mode in ops.SLICE_MODES and self._slice_head(self._row_count, h, self.vla.lm_head.weight):
+                    o = ops.head_slice_fwd_bwd(h.detach().contiguous(), self.vla.lm_head.weight, self._row_map, mode, w, alpha, beta, scale, want_dh=False)
+                    return None, o["scalars"], o["pred_full"]
                 if h.dtype == torch.bfloat16:
                     scalars, _, pred_full, _ = ops.head_loss_rows_fwd_bwd(h.detach().contiguous(), self.vla.lm_head.weight, self._row_map, mode, w, alpha, beta,
                                                                           scale, want_grad=False)
@@ -143,7 +156,17 @@ class AttackBase:
             return False
         return ops.head_loss_rows_applies(R, int(W.shape[1]), int(W.shape[0]))
 
-    def fused_ddp_step(self, pixel_values, patch, input_ids, attention_mask, labels, geometry, w, msg, scalars, optimizer=None):
+    @staticmethod
+    def _slice_head(R, h, W) -> bool:
+        """K3s (vaa_head_slice_fwd_bwd) for this shape? bf16, up to 128 labelled rows, D a multiple of 64 up to 4096. VAA_HEAD_EVERY_STEP=1
+        restores the round-5 behaviour (K3h + finish + the 256-column GEMM on every step), VAA_FUSED_HEAD=0 the GEMM head."""
+        if os.environ.get("VAA_HEAD_EVERY_STEP", "0") == "1" or os.environ.get("VAA_FUSED_HEAD", "auto") == "0":
+            return False
+        if (h is not None and h.dtype != torch.bfloat16) or W.dtype != torch.bfloat16 or not W.is_cuda:
+            return False
+        return ops.head_slice_applies(R, int(W.shape[1]), int(W.shape[0]))
+
+    def fused_ddp_step(self, pixel_values, patch, input_ids, attention_mask, labels, geometry, w, msg, scalars, optimizer=None, full_ce=True):
         """The UADA_ddp inner step (UADA_ddp.py:189-206) up to the gradient exchange, six hand-written launches around the model:
         K1 -> [ViTs, Llama, LM head on the labelled rows] -> K3 statistics + gradient slice -> [head / model backward] -> K2' tile GEMM ->
         scatter -> epilogue. On return `msg` (f32 [3*ph*pw + 4]) holds [patch gradient | CE, w^2*MSE, UAD, total] of THIS rank, ready for
@@ -158,6 +181,17 @@ class AttackBase:
         h = self.vla.hidden_rows(input_ids, None, self._row_index, patch_embeds=pe, pack=pack)
         W = self.vla.lm_head.weight
         R = int(h.shape[0])
+        if self._slice_head(R, h, W):
+            # K3s: slice logits -> statistics -> gradient slice -> d total / d hidden in ONE launch (2.1 MB of head weights); the full-vocabulary
+            # stream (K3h, 263 MB) runs behind it only on the steps whose CE / full argmax is read (`full_ce`: UADA_ddp.py:214-221)
+            hd = h.detach().contiguous()
+            o = ops.head_slice_fwd_bwd(hd, W, self._row_map, ops.LOSS_UADA_DDP, w, want_dh=True, want_scalars=False)
+            ws = ops.head_loss_rows_stats(hd, W, self._row_map, ops.LOSS_UADA_DDP, w) if full_ce else o["ws"]
+            h.backward(o["dh"])
+            _, pred_full = ops.step_epilogue(sink["partials"], msg, scalars, rowmap=self._row_map, R=R, V=int(W.shape[0]),
+                                             mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws,
+                                             update=optimizer.fused_update_args() if optimizer is not None else None)
+            return pred_full
         gsl = torch.empty((R, ops.N_ACTION), dtype=h.dtype, device=h.device)
         if self._fused_head(R, h, W):
             # SURVEY.md 8f-2 as the survey wrote it: LM head + K3 statistics in ONE weight-streaming kernel — the [R,V] logits are never written

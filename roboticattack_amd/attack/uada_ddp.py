@@ -120,20 +120,22 @@ class OpenVLAAttacker(AttackBase):
             labels = self._prepare_labels(labels)
             for inner_loop in range(self.innerLoop):
                 optimizer.zero_grad()
+                # the loop reads the loss scalars of the LAST inner step only (UADA_ddp.py:214-221, below): the full-vocabulary CE is evaluated there
+                full_ce = inner_loop == self.innerLoop - 1 or os.environ.get("VAA_FULL_CE_EVERY_STEP", "0") == "1"  # (=1: K3h behind K3s on every step; same patch bits)
                 if fused and world_size == 1:  # nothing to exchange: K4 runs inside the epilogue launch (five launches per step)
                     self.fused_ddp_step(pixel_values, patch, input_ids, attention_mask, labels, self.geometry, float(self.MSE_weights),
-                                        sync.buf, scalars, optimizer=optimizer)
+                                        sync.buf, scalars, optimizer=optimizer, full_ce=full_ce)
                     s_sum = sync.buf[sync.n_grad :]
                     continue
                 if fused:
                     self.fused_ddp_step(pixel_values, patch, input_ids, attention_mask, labels, self.geometry, float(self.MSE_weights),
-                                        sync.buf, scalars)
+                                        sync.buf, scalars, full_ce=full_ce)
                     g_sum, s_sum = sync.allreduce_packed()  # C3 + C4 in one message: [grad | CE, MSE, UAD, total]
                 else:
                     pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
                                                                               geometry=self.geometry)
                     total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, self._loss_mode(), w=float(self.MSE_weights),
-                                                           alpha=self.alpha, beta=self.belta)
+                                                           alpha=self.alpha, beta=self.belta, full_ce=full_ce)
                     total.backward()  # K2 inside
                     g_sum, s_sum = sync.allreduce_step(patch.grad, scalars, pick)
                 optimizer.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4, DDP mean folded in

@@ -55,7 +55,8 @@ class OpenVLAAttacker(AttackBase):
         """One iteration of the hot inner loop (UPA.py:127-159): [K0 per-image patch resize ->] K1 -> model -> K3 (K3h when the loss lives in the
         action slice) -> backward -> K2 / K2' (MULTI forms with resize_patch) -> K4 with the L1 clip (UPA.py:157) in front of AdamW."""
         pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std, geometry=geometry)
-        total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, mode, alpha=self.alpha, beta=self.belta, scale=scale)
+        # the reverse-direction loop never reads output.loss nor a full-vocabulary argmax (UPA.py:145-150,171-186): slice-only head (K3s)
+        total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, mode, alpha=self.alpha, beta=self.belta, scale=scale, full_ce=False)
         total.backward()
         if do_step:
             scalars_out[k, 8:10] = optimizer.step()  # K4: L1 clip 1e-3 -> AdamW -> clamp
@@ -122,7 +123,7 @@ class OpenVLAAttacker(AttackBase):
                 if not reverse_direction:
                     labels = self.mask_labels(labels, maskidx)
                 _, scalars, _ = self.model_loss(input_ids, attention_mask, modified_images, labels, mode, alpha=self.alpha,
-                                                beta=self.belta, scale=scale, need_grad=False)
+                                                beta=self.belta, scale=scale, need_grad=False, full_ce=False)
                 s = scalars.cpu().numpy()
                 avg_angle += float(s[3])
                 avg_dist += float(s[4])

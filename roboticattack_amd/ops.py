@@ -880,6 +880,31 @@ class HeadLossRowsFused(torch.autograd.Function):
         return dh, None, None, None, None, None, None, None
 
 
+class HeadSliceLoss(torch.autograd.Function):
+    """The slice modes' head + loss + head backward as K3s (head_slice_fwd_bwd: ONE launch; d total / d hidden is produced in the forward and
+    handed back by the backward). `full_ce` — a step whose full-vocabulary CE / argmax is READ (the last inner step of an outer iteration,
+    UADA_ddp.py:214-221; validation passes that log CE) — adds K3h's statistics pass + fold for the scalars and prediction maps: the
+    gradient path is K3s's on every step, so the patch trajectory does not depend on which steps evaluate CE.
+    Returns (total, scalars f32[8], pred_slice, pred_full); scalars[1] (CE) = 0 and pred_full = -1 on slice-only steps."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, rowmap, mode, w, alpha, beta, scale, full_ce):
+        h = hidden.detach().contiguous()
+        o = head_slice_fwd_bwd(h, weight, rowmap, mode, w, alpha, beta, scale, want_dh=True, want_scalars=not full_ce)
+        if full_ce:  # K3s left the SliceStats + neutral parts; K3h now writes the real parts (and the same SliceStat bits) into the same workspace
+            scalars, pred, pred_full, _ = head_loss_rows_fwd_bwd(h, weight, rowmap, mode, w, alpha, beta, scale, want_grad=False)
+        else:
+            scalars, pred, pred_full = o["scalars"], o["pred"], o["pred_full"]
+        ctx.save_for_backward(o["dh"])
+        ctx.mark_non_differentiable(scalars, pred, pred_full)
+        return scalars[0].clone(), scalars, pred, pred_full
+
+    @staticmethod
+    def backward(ctx, gtotal, _gs, _gp, _gf):
+        (dh,) = ctx.saved_tensors
+        return dh * gtotal.to(dh.dtype), None, None, None, None, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------------
 # K4
 # ------------------------------------------------------------------------------------------------------

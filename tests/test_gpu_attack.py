@@ -300,6 +300,70 @@ def test_ddp_attacker_single_rank(tmp_path, attack, monkeypatch):
     assert os.path.exists(os.path.join(str(tmp_path), "0", "patch.pt"))
 
 
+def test_ddp_attacker_slice_head_cadence(tmp_path, monkeypatch):
+    """the data-parallel UADA loop runs K3s (slice-only head, ONE launch) on every inner step and K3h's full-vocabulary stream
+    only on the LAST inner step of an outer iteration — the only one whose CE the loop reads (UADA_ddp.py:214-221). Against the same run with
+    the full-vocabulary CE evaluated on EVERY step (VAA_FULL_CE_EVERY_STEP=1): the patch after every optimiser step and the train log of every
+    outer iteration (CE, MSE, UAD) are bit for bit the same — the gradient path is K3s's either way — and the launch counts show the cadence.
+    Against the round-5 path (VAA_HEAD_EVERY_STEP=1: K3h + finish + the 256-column GEMM every step): the head's backward sums in another order, so
+    patches agree to 2e-5 and the logged scalars to 2e-3."""
+    import socket
+
+    from roboticattack_amd import ops
+    from roboticattack_amd.attack import uada_ddp
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+    from roboticattack_amd.synthetic import SyntheticLoader
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    for k, v in dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, False, True), siglip=VitCfg(192, 3, 2, 384, 0, False, False), llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
+    inner, iters = 4, 3
+    runs = {}
+    for tag, env in (("cadence", {}), ("every", {"VAA_FULL_CE_EVERY_STEP": "1"}), ("r5", {"VAA_HEAD_EVERY_STEP": "1"})):
+        for k in ("VAA_FULL_CE_EVERY_STEP", "VAA_HEAD_EVERY_STEP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _seed()
+        snaps = []
+
+        class Att(uada_ddp.OpenVLAAttacker):
+            val_every = 10 ** 9
+
+            def assert_finite_state(self, patch, optimizer, host, where, all_ranks=False):
+                snaps.append(patch.detach().cpu().numpy().copy())
+                return super().assert_finite_state(patch, optimizer, host, where, all_ranks=all_ranks)
+
+        att = Att(vla_path="x", dataset_name="synthetic", save_dir=str(tmp_path / tag), patch_size=[3, 50, 50], lr=0.02, bs=3, warmup=1, num_iter=iters, maskidx=[0],
+                  innerLoop=inner, geometry=True, use_wandb=False, MSE_weights=5,
+                  model_factory=lambda path, dev: build_openvla(cfg, device=dev, dtype=torch.bfloat16, seed=13),
+                  dataset_factory=lambda name, bs, rank, world: (SyntheticLoader(bs, seed=1, kind="smooth"), SyntheticLoader(bs, seed=2, kind="smooth", length=2)))
+        assert att.fused_ddp_available()
+        att.validate = lambda i, patch, rank: None
+        ops.prof_start(4096)
+        patch = att.attack(0, 1)
+        names = [n for n, _ in ops.prof_collect()]
+        runs[tag] = (snaps, dict(att.last_train_log), names, patch.detach().cpu().numpy().copy())
+    n_steps = inner * iters
+    nm = runs["cadence"][2]
+    assert sum("head_slice_kernel" in n for n in nm) == n_steps and sum("head_stats_kernel" in n for n in nm) == iters  # K3s every step, K3h once per outer iteration
+    nm = runs["every"][2]
+    assert sum("head_slice_kernel" in n for n in nm) == n_steps and sum("head_stats_kernel" in n for n in nm) == n_steps
+    nm = runs["r5"][2]
+    assert not any("head_slice_kernel" in n for n in nm) and sum("head_stats_kernel" in n for n in nm) == n_steps
+    for a, b in zip(runs["cadence"][0], runs["every"][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(runs["cadence"][3], runs["every"][3]) and runs["cadence"][1] == runs["every"][1]
+    assert runs["cadence"][1]["TRAIN_attack_loss(CE)"] > 0
+    assert np.abs(runs["cadence"][3] - runs["r5"][3]).max() <= 2e-5 and np.abs(runs["cadence"][3] - runs["cadence"][0][0]).max() > 1e-3  # (it moved)
+    for k in ("TRAIN_attack_loss(CE)", "TRAIN_attack_loss (MSE_Distance)", "TRAIN_UAD"):
+        assert runs["cadence"][1][k] == pytest.approx(runs["r5"][1][k], rel=2e-3, abs=1e-5)
+
+
 def _two_rank_worker(rank, world, port, out_dir, attack, num_iter, inner, bs, resize=False, psize=50):
     """One rank of the PRODUCT data-parallel attacker; both ranks share cuda:0, gloo carries the all-reduce through the host."""
     import sys
@@ -647,20 +711,24 @@ def test_bench_contract_line_tiny(model, extra_env, tmp_path):
     k1 = next(v for n, v in k.items() if "patch_apply_" in n)
     assert k1["launches"] == 2 and 1.0 < k1["mean_us"] < 200.0 and d["roofline"]["samples"] == 2
     hot = d["hot_path_ops_us"]
-    fused = model == "tiny" and not extra_env  # K1 tile-major, LM head + K3 statistics, K2' tile GEMM + gather, epilogue incl. K4: 6 launches per step at N=1
+    fused = model == "tiny" and not extra_env  # K1 tile-major, K3s, K2' tile GEMM + gather, epilogue incl. K4: 5 launches per slice-only step at N=1
     if fused:
-        # the LM head runs fused with K3's statistics (two launches, head_stats + head_finish, instead of GEMM + statistics); the roofline names
-        # the kernel the step actually ran with the most algorithmic bytes (the 7B head: 263 MB against K1's 48 MB; the tiny model's 64-wide head
-        # is smaller than K1), K1 is reported beside it
-        assert set(hot) >= {"K1", "K3h", "K2e", "EPI"} and "K4" not in hot and d["hot_path_launches_per_step"] == 6 and d["config"]["lm_head"] == "fused K3h"
-        kh = next(v for n, v in k.items() if "head_stats_kernel" in n)
-        if "head_stats_kernel" in d["roofline"]["kernel"]:
-            assert d["roofline_k1"]["kernel"].startswith("patch_apply_")
-            assert d["roofline"]["achieved"] == pytest.approx(d["roofline"]["algo_bytes"] / kh["mean_us"] / 1e3, rel=1e-4)
-            assert d["roofline_k1"]["achieved"] == pytest.approx(d["roofline_k1"]["algo_bytes"] / k1["mean_us"] / 1e3, rel=1e-4)
-        else:
-            assert d["roofline"]["kernel"].startswith("patch_apply_") and d["roofline_k1"] is None
-            assert d["roofline"]["achieved"] == pytest.approx(d["roofline"]["algo_bytes"] / k1["mean_us"] / 1e3, rel=1e-4)
+        # the loop's cadence: K3s (slice-only head + statistics + gradient + head backward, ONE launch) on every step, K3h's full-vocabulary stream
+        # + finish behind it on 1 of 50 steps (UADA_ddp.py:196-221): the average step is 5 + 2/50 launches, the operator table carries 1/50 of K3h,
+        # the roofline names the kernel with the most algorithmic bytes per AVERAGE step (K1), K3h is reported as measured on the CE steps
+        assert set(hot) >= {"K1", "K3s", "K3h", "K2e", "EPI"} and "K4" not in hot and d["hot_path_launches_per_step"] == pytest.approx(5 + 2 / 50)
+        assert d["config"]["lm_head"] == "K3s every step + K3h on CE steps" and d["config"]["full_ce_every"] == 50 and d["config"]["ce_steps_in_timed_region"] == 0
+        assert d["config"]["traffic_source"].startswith("profiles/traffic_r")
+        kce = full["roofline_kernels_ce_steps"]
+        kh = next(v for n, v in kce.items() if "head_stats_kernel" in n)
+        ks = next(v for n, v in k.items() if "head_slice_kernel" in n)
+        assert not any("head_stats_kernel" in n for n in k) and ks["launches_per_step"] == 1.0 and kh["launches_per_step"] == 1.0
+        assert hot["K3h"] == pytest.approx(full["hot_path_ops_us_ce_step"]["K3h"] / 50, rel=1e-4) and hot["K3s"] == pytest.approx(ks["mean_us"], rel=0.1)  # (+ 1/50 of its CE-step figure)
+        assert d["hot_path_us_ce_step"] > d["hot_path_us_slice_step"] and d["hot_path_us_slice_step"] < d["hot_path_us_per_step"] < d["hot_path_us_ce_step"]
+        assert d["roofline"]["kernel"].startswith("patch_apply_") and d["roofline_k1"] is None
+        assert d["roofline"]["achieved"] == pytest.approx(d["roofline"]["algo_bytes"] / k1["mean_us"] / 1e3, rel=1e-4)
+        assert "head_stats_kernel" in d["roofline_head"]["kernel"] and d["roofline_head"]["achieved"] == pytest.approx(d["roofline_head"]["algo_bytes"] / kh["mean_us"] / 1e3, rel=1e-4)
+        assert "head_slice_kernel" in d["roofline_k3s"]["kernel"]
     else:
         k4 = next(v for n, v in k.items() if "patch_update_kernel" in n)
         assert k4["launches"] == 2 and set(hot) >= {"K1", "K3", "K4"}
@@ -714,7 +782,9 @@ def test_bench_attack_loops_tiny(attack, extra, tmp_path):
     d, full = _bench_records(out.stdout, full_path)
     assert d["loss_finite"] and d["value"] > 0 and attack.upper() in d["config"]["workload"] and full["per_rank_step"] is None
     hot = d["hot_path_ops_us"]
-    assert "K1" in hot and ("K3" in hot or "K3h" in hot) and (("K0" in hot) == (attack == "upa"))
+    assert "K1" in hot and ("K3" in hot or "K3h" in hot or "K3s" in hot) and (("K0" in hot) == (attack == "upa"))
+    if attack == "upa":  # the reverse-direction loop never reads CE nor a full argmax (UPA.py:145-186): the slice-only head alone
+        assert "K3s" in hot and "K3h" not in hot and "K3" not in hot
 
 
 def test_ddp_wrapper_cli_under_torchrun_two_ranks(tmp_path):
