@@ -157,6 +157,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #define K3S_STAMP(i) do { } while (0)
 #endif
 
+template <int NRB>
 __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     extern __shared__ __align__(16) uint16_t smem[];  // phase 1: the ring [kSRing][4 chunks][32 rows][64]; afterwards the gradient and output tiles
     __shared__ float sAlse[kSRowsMax], sE[kSRowsMax];
@@ -166,15 +167,26 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     const int rb = blockIdx.x >> 4, j = blockIdx.x & 15;
     const int R = a.ra.R, D = a.D;
     const int nchunks = D / kSK;
-    uint16_t* gt = smem;             // gradient tile [16][kSGS] ...
-    uint16_t* ot = gt + 16 * kSGS;   // ... and output tile [16][kSGS]
+    // phases 2 and 3 work on a GROUP of NRB consecutive row blocks: workgroup (rb, j) of group rg = rb / NRB computes the gradient rows of all
+    // 16 NRB rows and the dH tile [those rows] x [256 / NRB columns of D]: the B operand of phase 3 is 128 KB / NRB per workgroup instead of 128 KB
+    // (a CU's fetch path moves ~56 GB/s: the 128 KB stalled the statistics behind their issue for 2 us and skewed the waves by 1.8 us at NRB = 1)
+    constexpr int kDW = kNA / NRB;          // columns of D per workgroup
+    constexpr int kOS = kDW + 8;            // row stride (bf16) of the output tile
+    uint16_t* gt = smem;                    // gradient tile [16 NRB][kSGS] ...
+    uint16_t* ot = gt + 16 * NRB * kSGS;    // ... and output tile [16 NRB][kOS]
+    const int rg = rb / NRB, mb = rb % NRB; // group, member
     const int hl = lane & 31, hw = lane >> 5;
     K3S_STAMP(0);
     // what phase 2 will want from global memory is requested now: the row map entry of this half wave's own row and the counts
     const RowMap* rm = reinterpret_cast<const RowMap*>(a.ra.rowmap + 4);
     const int Rdev = a.ra.rowmap[0], Rn = min(R, Rdev), nact = a.ra.rowmap[1];
-    const int own_lr = 2 * wv + hw, own_row = rb * 16 + own_lr;  // 8 waves x 2 half waves = the block's 16 rows
-    const RowMap me = own_row < Rn ? rm[own_row] : RowMap{0, 0, -1, 0};
+    const int own_lr = 2 * wv + hw;  // 8 waves x 2 half waves = the 16 rows of a block; this half wave takes row own_lr of each block of the group
+    RowMap me[NRB];
+#pragma unroll
+    for (int u = 0; u < NRB; ++u) {
+        const int row = (rg * NRB + u) * 16 + own_lr;
+        me[u] = row < Rn ? rm[row] : RowMap{0, 0, -1, 0};
+    }
 
     if (a.phases & 1) {
         // ---- phase 1: 16 x 16 logits over all of K, in the k-chunk order of the K3h workgroup that owns columns 16 j .. (vaa_head.hip) ----
@@ -268,15 +280,16 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     // forward only: just the workgroups that leave statistics (j = 0 for a later fold) or fold them (workgroup 0) have something left to do
     if (!(a.dh != nullptr || a.gs != nullptr || blockIdx.x == 0 || (!a.publish && j == 0))) return;
 
-    // ---- phase 2: statistics of the rows this workgroup needs (polled out of the scratch), then the gradient tile of its own 16 rows ----
+    // ---- phase 2: statistics of the rows this workgroup needs (polled out of the scratch), then the gradient tile of its group's 16 NRB rows ----
     const bool pub_wg = a.publish && blockIdx.x == 0;
     const bool all_rows = a.ra.mode == VAA_LOSS_UPA || pub_wg;
     const bool writes_stats = a.publish ? pub_wg : (j == 0);  // who leaves the SliceStats (+ neutral parts) in K3's workspace, and for which rows
     const int wlo = a.publish ? 0 : rb * 16, whi = a.publish ? R : min(R, rb * 16 + 16);
-    // a half wave's rows: 16 it + 2 wv + hw; the block's OWN rows (the gradient's) are it = rb, which comes FIRST
-    const int nit = all_rows ? max((R + 15) / 16, rb + 1) : 1;
-    auto it_of = [&](int i) { return i == 0 ? rb : (i - 1 < rb ? i - 1 : i); };  // every iteration of [0, nit) once: the own one, then the others
-    auto row_of = [&](int it) { return min(16 * it + own_lr, R - 1); };            // a row beyond the end repeats the last one (same values, same place)
+    // a half wave's rows: 16 it + own_lr for row blocks it; the group's OWN blocks (the gradient's) come FIRST
+    const int nblk = (R + 15) / 16;
+    const int nit = all_rows ? max(nblk, rg * NRB + NRB) : NRB;
+    auto it_of = [&](int i) { return i < NRB ? rg * NRB + i : (i - NRB < rg * NRB ? i - NRB : i); };  // every block of [0, nit) once: the own ones, then the others
+    auto row_of = [&](int it) { return min(16 * it + own_lr, R - 1); };  // a row beyond the end repeats the last one (same values, same place)
     auto request = [&](int i, unsigned long long (&wq)[4]) {
         const unsigned long long* p = a.zs + (size_t)row_of(it_of(min(i, nit - 1))) * (kNA / 2) + hl * 4;
 #pragma unroll
@@ -308,17 +321,18 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
             if (a.err_word) __hip_atomic_store(a.err_word, VAA_ASYNC_K3_HANDOVER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     };
-    auto grad_row = [&](const float (&x)[8], float alse, float E, float kE) {  // g = kE p_a ((a + 1) - E), bf16, into the MFMA operand tile (+ the test output)
+    auto grad_row = [&](int u, const float (&x)[8], float alse, float E, float kE) {  // g = kE p_a ((a + 1) - E), bf16, into the MFMA operand tile (+ the test output)
+        const int row = (rg * NRB + u) * 16 + own_lr;
         float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = own_row < Rn ? kE * expf(x[e] - alse) * ((float)(hl * 8 + e + 1) - E) : 0.0f;
+        for (int e = 0; e < 8; ++e) o[e] = row < Rn ? kE * expf(x[e] - alse) * ((float)(hl * 8 + e + 1) - E) : 0.0f;
         uint4 pk;
         pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
         pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
         pk.z = f32_to_bf16_bits(o[4]) | (f32_to_bf16_bits(o[5]) << 16);
         pk.w = f32_to_bf16_bits(o[6]) | (f32_to_bf16_bits(o[7]) << 16);
-        *reinterpret_cast<uint4*>(gt + own_lr * kSGS + hl * 8) = pk;
-        if (a.gs && j == 0 && own_row < R) *reinterpret_cast<uint4*>(a.gs + (size_t)own_row * kNA + hl * 8) = pk;
+        *reinterpret_cast<uint4*>(gt + (u * 16 + own_lr) * kSGS + hl * 8) = pk;
+        if (a.gs && j == 0 && u == mb && row < R) *reinterpret_cast<uint4*>(a.gs + (size_t)row * kNA + hl * 8) = pk;
     };
     if (tid == 0) bar_ok = 1;
     // wave 0 is past its fragment reads of phase 1 (it left the loop through its last barrier-free group): before anybody writes the tiles that
@@ -326,54 +340,67 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     K3S_STAMP(3);
-    unsigned long long w0[4];
-    request(0, w0);
-    bool own_gave_up = false;
-    {   // poll for the own row with NOTHING else in flight: loads return in order, a retry must not queue behind other requests
-        int polls = 0;
-        while (!__all(valid(w0))) {
-            if (++polls > a.max_polls) { own_gave_up = true; break; }  // a launch that never became fully resident gives up instead of hanging
-            __builtin_amdgcn_s_sleep(1);
-            request(0, w0);
-        }
-    }
-    K3S_STAMP(4);
-    // ---- phase 3's B operand: fragments of the transposed slice, requested now — statistics and gradient hide them ----
-    v8s_s bfr[kSTPW][kNA / 32];
+    // ---- phase 3's B operand: fragments of the transposed slice, requested now: the fetch path is idle while the logits travel (about 1.9 us
+    //      from a producer's store to a consumer's load), and the poll's words queue behind these requests — they come back when both are
+    //      done. (Requested behind a successful poll they held the statistics back by their 2 us of issue; in front of phase 1 they delay the
+    //      logits.) The workgroup's 16 output tiles: NRB row tiles x kDW / 16 column tiles; a wave's two tiles share their column tile when
+    //      NRB > 1, so it fetches ONE tile's fragments ----
+    constexpr int kDT = kDW / 16;            // column tiles
+    constexpr int kNB = NRB == 1 ? 2 : 1;    // distinct column tiles of a wave's two output tiles
+    const int dbase = (mb * 16 + j) * kDW;
+    const int dt0 = NRB == 1 ? 2 * wv : wv % kDT, rt0 = NRB == 1 ? 0 : (wv / kDT) * 2;  // tiles (rt0, dt0), (rt0 + 1, dt0) — or (0, dt0), (0, dt0 + 1) at NRB = 1
+    v8s_s bfr[kNB][kNA / 32];
     if (a.dh) {
 #pragma unroll
-        for (int t = 0; t < kSTPW; ++t) {
-            const int d = min(((j * (kST / 64) + wv) * kSTPW + t) * 16 + c, D - 1);  // columns beyond D re-read the last one: never stored
+        for (int t = 0; t < kNB; ++t) {
+            const int d = min(dbase + (dt0 + t) * 16 + c, D - 1);  // columns beyond D re-read the last one: never stored
 #pragma unroll
             for (int ks = 0; ks < kNA / 32; ++ks) bfr[t][ks] = *reinterpret_cast<const v8s_s*>(a.wt + (size_t)d * kNA + ks * 32 + g * 8);
         }
     }
-    float xo[8], own_alse, own_E;
-    {   // the own row
-        if (own_gave_up) give_up();
-        float x[1][8], alse[1], E[1];
-        int pred[1];
-        decode_logits8(w0, x[0]);
-        slice_stats_half<1>(x, hl, alse, E, pred);
+    unsigned long long w0[NRB][4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xo[e] = x[0][e];
-        if (own_gave_up) { alse[0] = __uint_as_float(0x7fc00000u); E[0] = alse[0]; }
-        own_alse = alse[0];
-        own_E = E[0];
-        leave(rb, alse[0], E[0], pred[0]);
-        if (a.ra.mode == VAA_LOSS_UADA_DDP && (a.dh || a.gs)) {  // the gradient needs this row and the row COUNT only: straight from the registers
-            float kE = 0.0f;
-            if (me.lab > 2 && nact > 0) {
-                const double q = (double)own_E / 256.0, t = (me.lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10)
-                kE = (float)((double)a.ra.w * a.ra.w * 2.0 * (q - t) / nact / 256.0);
+    for (int u = 0; u < NRB; ++u) request(u, w0[u]);
+    bool own_gave_up = false;
+    {
+        int polls = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < NRB; ++u) ok = ok && valid(w0[u]);
+            if (__all(ok)) break;
+            if (++polls > a.max_polls) { own_gave_up = true; break; }  // a launch that never became fully resident gives up instead of hanging
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int u = 0; u < NRB; ++u) request(u, w0[u]);
+        }
+    }
+    K3S_STAMP(4);
+    float xo[NRB][8], own_alse[NRB], own_E[NRB];
+    {   // the own rows, their dependent shuffle chains side by side
+        if (own_gave_up) give_up();
+        int pred[NRB];
+#pragma unroll
+        for (int u = 0; u < NRB; ++u) decode_logits8(w0[u], xo[u]);
+        slice_stats_half<NRB>(xo, hl, own_alse, own_E, pred);
+#pragma unroll
+        for (int u = 0; u < NRB; ++u) {
+            if (own_gave_up) { own_alse[u] = __uint_as_float(0x7fc00000u); own_E[u] = own_alse[u]; }
+            leave(rg * NRB + u, own_alse[u], own_E[u], pred[u]);
+            if (a.ra.mode == VAA_LOSS_UADA_DDP && (a.dh || a.gs)) {  // the gradient needs this row and the row COUNT only: straight from the registers
+                float kE = 0.0f;
+                if (me[u].lab > 2 && nact > 0) {
+                    const double q = (double)own_E[u] / 256.0, t = (me[u].lab > 31872) ? 0.0 : 1.0;  // UADA.py:390-394 (A-D10)
+                    kE = (float)((double)a.ra.w * a.ra.w * 2.0 * (q - t) / nact / 256.0);
+                }
+                if (own_gave_up) kE = __uint_as_float(0x7fc00000u);  // NaN gradient, never a stale one
+                grad_row(u, xo[u], own_alse[u], own_E[u], kE);
             }
-            if (own_gave_up) kE = __uint_as_float(0x7fc00000u);  // NaN gradient, never a stale one
-            grad_row(xo, own_alse, own_E, kE);
         }
     }
     K3S_STAMP(5);
     if (all_rows) {
-        for (int i0 = 1; i0 < nit; i0 += 2) {  // the other rows (UPA's batch means, the publishing workgroup's fold): two iterations side by side
+        for (int i0 = NRB; i0 < nit; i0 += 2) {  // the other rows (UPA's batch means, the publishing workgroup's fold): two blocks side by side
             unsigned long long wq[2][4];
             request(i0, wq[0]);
             request(i0 + 1, wq[1]);
@@ -427,20 +454,24 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
         block_sums<7, kST>(accd, shf);
         const double aux1 = 1.0 / (accd[6] / a.ra.B + 1e-3);  // UPA.py:384
         if (a.dh || a.gs) {
-            float kE = 0.0f;
-            if (own_row < Rn && me.ord < 3 && own_row - me.ord >= 0 && own_row - me.ord + 2 < Rn) {
-                Upa3 u3;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    RowStat t;
-                    t.E = sE[own_row - me.ord + q];
-                    t.lab = rm[own_row - me.ord + q].lab;
-                    u3.set(q, t);
+            for (int u = 0; u < NRB; ++u) {
+                const int row = (rg * NRB + u) * 16 + own_lr;
+                float kE = 0.0f;
+                if (row < Rn && me[u].ord < 3 && row - me[u].ord >= 0 && row - me[u].ord + 2 < Rn) {
+                    Upa3 u3;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        RowStat t;
+                        t.E = sE[row - me[u].ord + q];
+                        t.lab = rm[row - me[u].ord + q].lab;
+                        u3.set(q, t);
+                    }
+                    kE = (float)(u3.dE(me[u].ord, (double)a.ra.alpha, (double)a.ra.beta, aux1, a.ra.B) / 255.0);
                 }
-                kE = (float)(u3.dE(me.ord, (double)a.ra.alpha, (double)a.ra.beta, aux1, a.ra.B) / 255.0);
+                if (poisoned) kE = __uint_as_float(0x7fc00000u);
+                grad_row(u, xo[u], own_alse[u], own_E[u], kE);
             }
-            if (poisoned) kE = __uint_as_float(0x7fc00000u);
-            grad_row(xo, own_alse, own_E, kE);
         }
     }
     K3S_STAMP(6);
@@ -448,25 +479,30 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     __builtin_amdgcn_s_barrier();
     K3S_STAMP(7);
 
-    // ---- phase 3: dH tile = g [16, 256] x slice [256, these 256 columns of D] ----
+    // ---- phase 3: dH tile = g [16 NRB, 256] x slice [256, these kDW columns of D] ----
     if (a.dh) {
-        v4f_s acc3[kSTPW];
-#pragma unroll
-        for (int t = 0; t < kSTPW; ++t) acc3[t] = (v4f_s){0.f, 0.f, 0.f, 0.f};
+        v4f_s acc3[2];
+        acc3[0] = (v4f_s){0.f, 0.f, 0.f, 0.f};
+        acc3[1] = (v4f_s){0.f, 0.f, 0.f, 0.f};
+        const int rt1 = NRB == 1 ? 0 : rt0 + 1;
 #pragma unroll
         for (int ks = 0; ks < kNA / 32; ++ks) {
-            const v8s_s af = *reinterpret_cast<const v8s_s*>(gt + c * kSGS + ks * 32 + g * 8);
-#pragma unroll
-            for (int t = 0; t < kSTPW; ++t) acc3[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[t][ks], acc3[t], 0, 0, 0);
+            const v8s_s af0 = *reinterpret_cast<const v8s_s*>(gt + (rt0 * 16 + c) * kSGS + ks * 32 + g * 8);
+            const v8s_s af1 = NRB == 1 ? af0 : *reinterpret_cast<const v8s_s*>(gt + (rt1 * 16 + c) * kSGS + ks * 32 + g * 8);
+            acc3[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bfr[0][ks], acc3[0], 0, 0, 0);
+            acc3[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bfr[kNB - 1][ks], acc3[1], 0, 0, 0);
         }
 #pragma unroll
-        for (int t = 0; t < kSTPW; ++t)
+        for (int t = 0; t < 2; ++t) {
+            const int rt = NRB == 1 ? 0 : rt0 + t, dt = NRB == 1 ? dt0 + t : dt0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[(g * 4 + r) * kSGS + (wv * kSTPW + t) * 16 + c] = (uint16_t)f32_to_bf16_bits(acc3[t][r]);
+            for (int r = 0; r < 4; ++r) ot[(rt * 16 + g * 4 + r) * kOS + dt * 16 + c] = (uint16_t)f32_to_bf16_bits(acc3[t][r]);
+        }
         K3S_STAMP(8);
         __syncthreads();
-        const int orow = tid >> 5, col = (tid & 31) * 8, d = j * kNA + col;  // 16 rows x 32 pieces of 16 bytes
-        if (rb * 16 + orow < R && d < D) *reinterpret_cast<uint4*>(a.dh + (size_t)(rb * 16 + orow) * D + d) = *reinterpret_cast<const uint4*>(ot + orow * kSGS + col);
+        // 16 NRB rows x kDW columns = 4096 elements = one 16-byte piece per thread
+        const int orow = tid / (kDW / 8), col = (tid % (kDW / 8)) * 8, d = dbase + col, grow = rg * NRB * 16 + orow;
+        if (grow < R && d < D) *reinterpret_cast<uint4*>(a.dh + (size_t)grow * D + d) = *reinterpret_cast<const uint4*>(ot + orow * kOS + col);
     }
     K3S_STAMP(9);
     // ---- publication (callers without a step epilogue): workgroup 0 folds the rows it has just written into scalars[8] + the prediction maps ----
@@ -491,26 +527,42 @@ __global__ __launch_bounds__(256) void head_slice_pack_kernel(const uint16_t* __
     }
 }
 
-// resident workgroups of head_slice_kernel on the current device (occupancy x CUs), queried once per device; 0 = unknown
-static size_t slice_lds_bytes() { return (size_t)kSRing * kSGrp * kSSlot * sizeof(uint16_t); }  // the ring (the 2 x 16 x kSGS tiles reuse it)
+static size_t slice_lds_bytes() { return (size_t)kSRing * kSGrp * kSSlot * sizeof(uint16_t); }  // the ring (the gradient / output tiles reuse it)
 
-static long slice_resident_slots() {
-    static std::atomic<long> slots[16];
+static const void* slice_kernel_fn(int nrb_group) {
+    return nrb_group == 1 ? (const void*)head_slice_kernel<1> : (nrb_group == 2 ? (const void*)head_slice_kernel<2> : (const void*)head_slice_kernel<4>);
+}
+
+// resident workgroups of head_slice_kernel<NRB> on the current device (occupancy x CUs), queried once per device and instantiation; 0 = unknown
+static long slice_resident_slots(int nrb_group) {
+    static std::atomic<long> slots[3][16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 0; }
-    long have = slots[dev].load(std::memory_order_relaxed);
+    const int inst = nrb_group == 1 ? 0 : (nrb_group == 2 ? 1 : 2);
+    long have = slots[inst][dev].load(std::memory_order_relaxed);
     if (have == 0) {
         int cus = 0, per_cu = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel, kST, slice_lds_bytes()) != hipSuccess) {
+        hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) {
+            if (nrb_group == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<1>, kST, slice_lds_bytes());
+            else if (nrb_group == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<2>, kST, slice_lds_bytes());
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<4>, kST, slice_lds_bytes());
+        }
+        if (e != hipSuccess) {
             (void)hipGetLastError();
             have = -1;
         } else {
             have = (long)cus * per_cu;
         }
-        slots[dev].store(have, std::memory_order_relaxed);
+        slots[inst][dev].store(have, std::memory_order_relaxed);
     }
     return have > 0 ? have : 0;
+}
+
+static void slice_launch(int nrb_group, unsigned grid, size_t lds, hipStream_t st, const SliceHeadArgs& a) {
+    if (nrb_group == 1) VAA_LAUNCH(head_slice_kernel<1>, dim3(grid), dim3(kST), lds, st, a);
+    else if (nrb_group == 2) VAA_LAUNCH(head_slice_kernel<2>, dim3(grid), dim3(kST), lds, st, a);
+    else VAA_LAUNCH(head_slice_kernel<4>, dim3(grid), dim3(kST), lds, st, a);
 }
 
 }  // namespace vaa
@@ -523,9 +575,25 @@ extern "C" int vaa_head_slice_applies(int R, int D, int V) {
             V <= 32768) ? 1 : 0;
 }
 
+namespace vaa {
+// row blocks per group of phases 2 / 3 and the padded block count (a multiple of it): 1, 2 or 4 blocks (R' <= 16, <= 32, more)
+static void slice_groups(int R, int& nrb_group, int& nblk_pad) {
+    const int nblk = (R + 15) / 16;
+    // ONE row block per workgroup: grouping 2 / 4 blocks (VAA_K3S_GROUP) divides phase 3's B fetch (128 KB per workgroup) by as much but multiplies
+    // the redundant statistics + gradient work, which is VALU-bound (16 accurate expf per logit octet and wave): 13.1 -> 26 us at four blocks
+    nrb_group = 1;
+    const char* ev = getenv("VAA_K3S_GROUP");
+    if (ev && (ev[0] == '2' || ev[0] == '4')) nrb_group = (ev[0] - '0') <= nblk || nblk >= 3 ? (ev[0] - '0') : nblk;
+    if (nrb_group == 4 && nblk < 3) nrb_group = nblk >= 2 ? 2 : 1;
+    nblk_pad = (nblk + nrb_group - 1) / nrb_group * nrb_group;
+}
+}  // namespace vaa
+
 extern "C" size_t vaa_head_slice_ws_bytes(int R) {
     if (R <= 0) return 0;
-    return (size_t)((R + 15) / 16) * 16 * (vaa::kNA / 2) * sizeof(unsigned long long);  // two logits + the launch tag per 64-bit word
+    int g = 1, nb = 1;
+    vaa::slice_groups(R, g, nb);
+    return (size_t)nb * 16 * (vaa::kNA / 2) * sizeof(unsigned long long);  // two logits + the launch tag per 64-bit word, padded to whole groups of row blocks
 }
 
 extern "C" int vaa_head_slice_pack(const uint16_t* w_head, int D, int V, uint16_t* w_slice_t, void* stream) {
@@ -583,19 +651,22 @@ extern "C" int vaa_head_slice_fwd_bwd(const uint16_t* hidden, const uint16_t* w_
     a.ra.w = params[0]; a.ra.alpha = params[1]; a.ra.beta = params[2]; a.ra.scale = params[3];
     a.D = D; a.publish = scalars ? 1 : 0;
     const size_t lds = slice_lds_bytes();
-    static_assert(2 * 16 * kSGS <= kSRing * kSGrp * kSSlot, "the tiles reuse the ring");
-    static std::atomic<unsigned long long> attr_done;  // bit = device ordinal: the dynamic-LDS opt-in (128 KB) is set once per device
+    static_assert(16 * 4 * kSGS + 16 * 4 * (kNA / 4 + 8) <= kSRing * kSGrp * kSSlot && 2 * 16 * kSGS <= kSRing * kSGrp * kSSlot, "the tiles reuse the ring");
+    int nrb_group = 1, nblk_pad = 1;
+    slice_groups(R, nrb_group, nblk_pad);
+    static std::atomic<unsigned long long> attr_done[3];  // [instantiation] bit = device ordinal: the dynamic-LDS opt-in (128 KB) is set once per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
-    if (lds > 64 * 1024 && !(attr_done.load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute((const void*)head_slice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    const int inst = nrb_group == 1 ? 0 : (nrb_group == 2 ? 1 : 2);
+    if (lds > 64 * 1024 && !(attr_done[inst].load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(slice_kernel_fn(nrb_group), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             set_error("%s: hipFuncSetAttribute failed", who);
             return VAA_E_LAUNCH;
         }
-        attr_done.fetch_or(bit, std::memory_order_acq_rel);
+        attr_done[inst].fetch_or(bit, std::memory_order_acq_rel);
     }
-    const unsigned grid = (unsigned)((R + 15) / 16) * 16u;
+    const unsigned grid = (unsigned)nblk_pad * 16u;
     // the launch's tag: unique in the process (one counter for all streams and devices), scrambled so that no plausible stale content of the
     // scratch (small integers, bf16 pairs, an old launch's tag) equals it
     static std::atomic<unsigned> tag_counter{0u};
@@ -614,7 +685,7 @@ extern "C" int vaa_head_slice_fwd_bwd(const uint16_t* hidden, const uint16_t* w_
         const hipError_t ce = hipStreamIsCapturing(st, &cs);
         if (ce != hipSuccess) (void)hipGetLastError();
         const bool capturing = ce != hipSuccess || cs != hipStreamCaptureStatusNone;
-        one = !capturing && 2l * grid <= slice_resident_slots() && rows_one_pass_stream_ok(st);
+        one = !capturing && 2l * grid <= slice_resident_slots(nrb_group) && rows_one_pass_stream_ok(st);
     }
     const char* dbg = getenv("VAA_K3S_DEBUG_PHASES");  // measurement hook (tools/k3s_bench.py): run phase 1 or phases 2 + 3 alone
     if (dbg && (dbg[0] == '1' || dbg[0] == '2')) {
@@ -622,19 +693,19 @@ extern "C" int vaa_head_slice_fwd_bwd(const uint16_t* hidden, const uint16_t* w_
         if (dbg[0] == '2') a.tag = last_tag;
         last_tag = a.tag;
         a.phases = dbg[0] - '0';
-        VAA_LAUNCH(head_slice_kernel, dim3(grid), dim3(kST), lds, st, a);
+        slice_launch(nrb_group, grid, lds, st, a);
         return check_launch(who);
     }
     if (one) {
         a.phases = 3;
-        VAA_LAUNCH(head_slice_kernel, dim3(grid), dim3(kST), lds, st, a);
+        slice_launch(nrb_group, grid, lds, st, a);
         return check_launch(who);
     }
     a.phases = 1;
-    VAA_LAUNCH(head_slice_kernel, dim3(grid), dim3(kST), lds, st, a);
+    slice_launch(nrb_group, grid, lds, st, a);
     int rc = check_launch("vaa_head_slice_fwd_bwd(logits)");
     if (rc != VAA_OK) return rc;
     a.phases = 2;
-    VAA_LAUNCH(head_slice_kernel, dim3(grid), dim3(kST), lds, st, a);
+    slice_launch(nrb_group, grid, lds, st, a);
     return check_launch("vaa_head_slice_fwd_bwd(gradient)");
 }

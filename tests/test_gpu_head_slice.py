@@ -206,7 +206,7 @@ def test_head_slice_argument_checks(ops):
     L = _lib.lib()
     assert L.vaa_head_slice_applies(128, 4096, V) == 1 and L.vaa_head_slice_applies(129, 4096, V) == 0
     assert L.vaa_head_slice_applies(16, 4160, V) == 0 and L.vaa_head_slice_applies(16, 96, V) == 0 and L.vaa_head_slice_applies(16, 64, 40000) == 0
-    assert L.vaa_head_slice_ws_bytes(17) == 32 * 1024 and L.vaa_head_slice_ws_bytes(0) == 0
+    assert L.vaa_head_slice_ws_bytes(17) == 32 * 1024 and L.vaa_head_slice_ws_bytes(40) == 48 * 1024 and L.vaa_head_slice_ws_bytes(128) == 128 * 1024 and L.vaa_head_slice_ws_bytes(0) == 0
     with pytest.raises(_lib.VaaError, match="cross-entropy"):
         ops.head_slice_fwd_bwd(h, W, rm, ops.LOSS_UADA)
     p = _lib.f32x([5.0, 0.8, 0.2, 1.0])
