@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-kernel-suite", action="store_true")
     ap.add_argument("--no-per-rank", action="store_true", help="skip the bs = 32 / 16 / 8 / 4 per-rank step block of the N=1 record")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE config 2 / 4 / 5 step block of the N=1 record")
+    ap.add_argument("--no-val", action="store_true", help="skip the validation-pass block of the N=1 record (config.val_ms_per_batch_bs8)")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host CPU work for cpu_baseline")
     ap.add_argument("--regions", type=str, default="both", choices=["weak", "strong", "both"],
                     help="N > 1: which timed regions run (weak = bs per rank, the headline; strong = the global batch split over the ranks). "
@@ -555,6 +556,35 @@ def per_rank_block(model, dev, B, patch_shape, steps, ips_ref):
     return out
 
 
+def val_block(model, dev, bs=8, batches=12):
+    """The validation pass of the data-parallel loop (attack/uada_ddp.py validate = UADA_ddp.py:233-281: no-grad forwards over the rank's validation
+    batches, bs = 8 per rank in BASELINE config 3, K1 -> model -> K3h with the CE that is logged) through the PRODUCT's own `validate`, un-synchronised
+    (one read-back behind the last batch) and with the round-5 per-batch read-back (VAA_VAL_SYNC_EVERY_BATCH=1): ms per batch, host included."""
+    from roboticattack_amd.attack import uada_ddp
+    from roboticattack_amd.synthetic import SyntheticLoader
+
+    class Att(uada_ddp.OpenVLAAttacker):
+        val_batches = batches
+
+    att = Att(vla_path="resident", dataset_name="synthetic", save_dir="", patch_size=[3, 50, 50], lr=1e-3, bs=bs, warmup=20, num_iter=1, maskidx=[0], innerLoop=1,
+              geometry=True, use_wandb=False, MSE_weights=5, device=dev, model_factory=lambda path, d: model,
+              dataset_factory=lambda name, b, rank, world: (SyntheticLoader(b, seed=1, kind="noise"), SyntheticLoader(b, seed=2, kind="noise")))
+    patch = torch.rand(3, 50, 50, device=dev)
+    out = {}
+    for tag, env in (("sync_every_batch", "1"), ("one_readback", "0"), ("sync_every_batch_2", "1"), ("one_readback_2", "0")):
+        os.environ["VAA_VAL_SYNC_EVERY_BATCH"] = env
+        att.validate(0, patch, rank=1)  # warm (rank != 0: nothing is written)
+        torch.cuda.synchronize()
+        t0, c0 = time.perf_counter(), time.thread_time()
+        att.validate(0, patch, rank=1)
+        torch.cuda.synchronize()
+        out[tag] = {"ms_per_batch": (time.perf_counter() - t0) / batches * 1e3, "host_cpu_ms_per_batch": (time.thread_time() - c0) / batches * 1e3}
+    os.environ.pop("VAA_VAL_SYNC_EVERY_BATCH", None)
+    return {"bs": bs, "batches": batches, "what": "attack/uada_ddp.py validate (UADA_ddp.py:233-281), A B A B", **out,
+            "ms_per_batch": min(out["one_readback"]["ms_per_batch"], out["one_readback_2"]["ms_per_batch"]),
+            "ms_per_batch_sync_every_batch": min(out["sync_every_batch"]["ms_per_batch"], out["sync_every_batch_2"]["ms_per_batch"])}
+
+
 CONFIG_STEPS = (
     # tag, loop, per-rank batch, patch, geometry, resize_patch, what BASELINE.json calls it
     ("cfg2", "uada", 16, [3, 50, 50], False, False, "UADA single-GPU: bs=16, geometry=False, loss = MSE + 1/CE (UADA.py:133-159)"),
@@ -748,8 +778,11 @@ def main():
         return
 
     # ---- N=1 only: the per-rank steps of the strong-scaling configs and the inner steps of BASELINE configs 2 / 4 / 5 ----
-    per_rank = cfg_steps = None
+    per_rank = cfg_steps = val_rec = None
     if world == 1 and headline:
+        if not args.no_val:
+            torch.cuda.empty_cache()
+            val_rec = val_block(model, dev)
         if not args.no_per_rank:
             per_rank = per_rank_block(model, dev, B, patch_shape, args.steps, B * args.steps / dt)
         if not args.no_configs:
@@ -883,6 +916,9 @@ def main():
             if e.get("dominant"):
                 config[f"{tag}_dominant_kernel"] = e["dominant"]["kernel"].split("<")[0].split("(")[0].strip()
                 config[f"{tag}_dominant_frac"] = e["dominant"]["frac"]
+    if val_rec:  # N=1: the validation pass (f-1), un-synchronised against the per-batch read-back
+        config["val_ms_per_batch_bs8"] = val_rec["ms_per_batch"]
+        config["val_ms_per_batch_bs8_sync_every_batch"] = val_rec["ms_per_batch_sync_every_batch"]
     if k2_fracs:
         config["k2_sweep_frac_B64_256_1024_4096"] = k2_fracs
     if k1_standalone:
@@ -907,7 +943,7 @@ def main():
     full.update({"config": dict(config, env=env_rec), "roofline": roofline, "roofline_k1": roofline_k1 if roofline is not roofline_k1 else None,
                  "roofline_head": roofline_head if roofline is not roofline_head else None, "roofline_k3s": roofline_k3s if roofline is not roofline_k3s else None,
                  "roofline_kernels": kern, "roofline_kernels_ce_steps": kern_ce, "hot_path_ops_us_slice_step": op_us_slice, "hot_path_ops_us_ce_step": op_us_ce, "strong_scaling": strong, "allreduce_us_per_step": comm_w, "allreduce_back_to_back": b2b,
-                 "per_rank_step": per_rank, "config_steps": cfg_steps, "cpu_baseline": cpu_f, "host_enqueue_ms_per_step": host_enqueue * 1e3 if run_weak else None})
+                 "per_rank_step": per_rank, "config_steps": cfg_steps, "validation_pass": val_rec, "cpu_baseline": cpu_f, "host_enqueue_ms_per_step": host_enqueue * 1e3 if run_weak else None})
     full.update(tail)
     full.update(extra_full)
     full["wall_s"] = wall

@@ -33,6 +33,45 @@ def wandb_enabled(args) -> bool:
     return wandb is not None and args is not None and getattr(args, "wandb_project", "false") != "false"
 
 
+class ValReadback:
+    """What a validation pass reads back from the device — the loss scalars of every batch and, where the metrics need them, the prediction
+    and label maps — kept ON the device while the batches are enqueued and fetched ONCE at the end (one [batches, 8] copy + one copy of
+    the concatenated maps). The reference calls `.item()` / `.cpu()` several times per batch (UADA.py:229-246); round 5 still read
+    `scalars.cpu()` once per batch, i.e. the host waited for every forward before it enqueued the next one.
+    VAA_VAL_SYNC_EVERY_BATCH=1 restores the per-batch read-back (A/B measurements). The accumulation below runs in the order of the
+    batches on the host, in the reference's precision: the same numbers as the per-batch form."""
+
+    def __init__(self, batches: int, device):
+        self.scal = torch.zeros((max(batches, 1), 8), dtype=torch.float32, device=device)
+        self.k = 0
+        self.maps = []  # per batch: (pred i32 [B,L-1] device, labels[:,1:] i64 device) or None
+        self.sync_every = os.environ.get("VAA_VAL_SYNC_EVERY_BATCH", "0") == "1"
+
+    def add(self, scalars, pred=None, labels=None):
+        self.scal[self.k].copy_(scalars)
+        self.maps.append((pred, labels[:, 1:]) if pred is not None else None)
+        self.k += 1
+        if self.sync_every:
+            self.scal[self.k - 1].cpu()
+
+    def read(self):
+        """-> (scalars float64 [batches, 8] on the host, [(pred, gt) numpy int arrays per batch | None])."""
+        host = self.scal[: self.k].cpu().numpy().astype(np.float64)
+        have = [m for m in self.maps if m is not None]
+        out = [None] * len(self.maps)
+        if have:
+            flat = torch.cat([m[0].reshape(-1).to(torch.int64) for m in have] + [m[1].reshape(-1) for m in have]).cpu().numpy()
+            sizes = [int(m[0].numel()) for m in have]
+            off, off2, j = 0, sum(sizes), 0
+            for i, m in enumerate(self.maps):
+                if m is None:
+                    continue
+                n = sizes[j]
+                out[i] = (flat[off : off + n].reshape(tuple(m[0].shape)), flat[off2 : off2 + n].reshape(tuple(m[1].shape)))
+                off, off2, j = off + n, off2 + n, j + 1
+        return host, out
+
+
 class AttackBase:
     """State every OpenVLAAttacker variant shares (UADA.py:34-74, UPA.py:31-71, TMA.py:29-64)."""
 
@@ -263,6 +302,12 @@ class AttackBase:
         """Continuous predicted / ground-truth actions of the action rows, (b,k) order (UADA.py:165-175)."""
         p = pred.detach().cpu().numpy()
         gt = labels[:, 1:].detach().cpu().numpy()
+        m = gt > self.action_tokenizer.action_token_begin_idx
+        return (torch.tensor(self.action_tokenizer.decode_token_ids_to_actions(p[m])),
+                torch.tensor(self.action_tokenizer.decode_token_ids_to_actions(gt[m])))
+
+    def decode_pred_gt_np(self, p: np.ndarray, gt: np.ndarray):
+        """decode_pred_gt on maps that are already on the host (ValReadback.read): p [B,L-1] predictions, gt = labels[:, 1:]."""
         m = gt > self.action_tokenizer.action_token_begin_idx
         return (torch.tensor(self.action_tokenizer.decode_token_ids_to_actions(p[m])),
                 torch.tensor(self.action_tokenizer.decode_token_ids_to_actions(gt[m])))

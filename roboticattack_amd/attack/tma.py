@@ -15,7 +15,7 @@ import torch
 from .. import ops
 from ..labels import tma_target_labels, tma_target_tokens
 from ..optim import CosineWarmupSchedule, PatchOptimizer
-from .engine import AttackBase, next_or_restart, to_dev, wandb, wandb_enabled
+from .engine import AttackBase, ValReadback, next_or_restart, to_dev, wandb, wandb_enabled
 
 
 class OpenVLAAttacker(AttackBase):
@@ -141,11 +141,15 @@ class OpenVLAAttacker(AttackBase):
         val_rel = 0.0
         asr6 = [0] * 6
         cont_pred = cont_gt = modified_images = None
+        gripper = len(maskidx) == 1 and maskidx[0] == 6
+        rb = ValReadback(self.val_batches, self.device)  # scalars + prediction maps stay on the device: ONE read-back behind the last batch
+        orig_gt = []  # gripper mode: the unmodified labels of the kept samples (already on the host there: the filter has to look at them)
         with torch.no_grad():
             for _ in range(self.val_batches):
                 data, val_iterator = next_or_restart(val_iterator, val_dataloader)
                 pixel_values, labels, attention_mask, input_ids = to_dev(data, self.device)
-                if len(maskidx) == 1 and maskidx[0] == 6:  # keep only samples whose clean gripper prediction is right (TMA.py:222-248)
+                if gripper:  # keep only samples whose clean gripper prediction is right (TMA.py:222-248): the NEXT forward's batch depends
+                    # on this forward's predictions — the one read-back per batch that cannot be deferred
                     clean = self.randomPatchTransform.im_process(pixel_values, mean=self.mean, std=self.std)
                     _, _, pre = self.model_loss(input_ids, attention_mask, clean, labels, ops.LOSS_CE, need_grad=False)
                     pm = pre.cpu().numpy()
@@ -156,22 +160,26 @@ class OpenVLAAttacker(AttackBase):
                         continue
                     labels, attention_mask, input_ids = labels[ok], attention_mask[ok], input_ids[ok]
                     pixel_values = [pixel_values[b] for b in ok]
+                    orig_gt.append(gt[ok])
                 val_num_sample += labels.shape[0]
                 modified_images = self._images(pixel_values, patch.detach(), geometry, colorjitter)
                 newlabels = tma_target_labels(labels, target)
                 _, scalars, pred = self.model_loss(input_ids, attention_mask, modified_images, newlabels, ops.LOSS_CE, need_grad=False)
-                cont_pred, cont_gt = self.decode_pred_gt(pred, newlabels)
-                val_rel += float(self.calculate_relative_distance_target(cont_pred, cont_gt))
-                if len(maskidx) == 1 and maskidx[0] == 6:
-                    tm = (newlabels[:, 1:] > 31743).cpu().numpy()
-                    r = self.calculate_01_ASR(pred.cpu().numpy()[tm], labels[:, 1:].cpu().numpy()[tm])
-                    asr6 = [a + b for a, b in zip(asr6, r)]
-                avg_L1 += float(torch.nn.functional.l1_loss(cont_pred, cont_gt)) if cont_pred.numel() else 0.0
-                n = max(len(maskidx), 1)
-                if cont_pred.numel():
-                    eq = (cont_pred.view(-1, n) == cont_gt.view(-1, n)).all(dim=1)
-                    success += int(eq.sum())
-                avg_CE += float(scalars[1])
+                rb.add(scalars, pred, newlabels)
+        host, maps = rb.read()
+        n = max(len(maskidx), 1)
+        for k, (sc, (p_np, gt_np)) in enumerate(zip(host, maps)):  # the reference's per-batch bookkeeping (TMA.py:250-290), in batch order
+            cont_pred, cont_gt = self.decode_pred_gt_np(p_np, gt_np)
+            val_rel += float(self.calculate_relative_distance_target(cont_pred, cont_gt))
+            if gripper:
+                tm = gt_np > 31743
+                r = self.calculate_01_ASR(p_np[tm], orig_gt[k][tm])
+                asr6 = [a + b for a, b in zip(asr6, r)]
+            avg_L1 += float(torch.nn.functional.l1_loss(cont_pred, cont_gt)) if cont_pred.numel() else 0.0
+            if cont_pred.numel():
+                eq = (cont_pred.view(-1, n) == cont_gt.view(-1, n)).all(dim=1)
+                success += int(eq.sum())
+            avg_CE += float(np.float32(sc[1]))
         val_num_sample = max(val_num_sample, 1)
         avg_L1 /= val_num_sample
         avg_CE /= val_num_sample

@@ -12,7 +12,7 @@ import torch
 from .. import ops
 from ..labels import mask_labels as _mask_labels
 from ..optim import CosineWarmupSchedule, PatchOptimizer
-from .engine import AttackBase, next_or_restart, to_dev, wandb, wandb_enabled
+from .engine import AttackBase, ValReadback, next_or_restart, to_dev, wandb, wandb_enabled
 
 IGNORE_INDEX = -100
 
@@ -113,6 +113,7 @@ class OpenVLAAttacker(AttackBase):
         relative_distance = {f"{idx}": [] for idx in maskidx}
         modified_images = None
         val_UAD = 0.0
+        rb = ValReadback(self.val_batches, self.device)  # nothing is read back inside the loop: the host enqueues batch after batch
         with torch.no_grad():
             for _ in range(self.val_batches):
                 data, val_iterator = next_or_restart(val_iterator, val_dataloader)
@@ -123,13 +124,15 @@ class OpenVLAAttacker(AttackBase):
                 labels = self.mask_labels(labels, maskidx)
                 _, scalars, pred = self.model_loss(input_ids, attention_mask, modified_images, labels, ops.LOSS_UADA_DDP,
                                                    w=self.mse_weight, need_grad=False)
-                cont_pred, cont_gt = self.decode_pred_gt(pred, labels)
-                relative_distance = self.calculate_relative_distance(cont_pred, cont_gt, maskidx, relative_distance)
-                s = scalars.cpu().numpy()
-                avg_MSE_Distance += float(s[2])
-                val_UAD = float(s[7])
-                avg_UAD += val_UAD
-                avg_CE_loss += float(s[1])
+                rb.add(scalars, pred, labels)
+        host, maps = rb.read()
+        for s, (p_np, gt_np) in zip(host, maps):  # the reference's per-batch bookkeeping (UADA.py:229-246), in batch order
+            cont_pred, cont_gt = self.decode_pred_gt_np(p_np, gt_np)
+            relative_distance = self.calculate_relative_distance(cont_pred, cont_gt, maskidx, relative_distance)
+            avg_MSE_Distance += float(np.float32(s[2]))
+            val_UAD = float(np.float32(s[7]))
+            avg_UAD += val_UAD
+            avg_CE_loss += float(np.float32(s[1]))
         avg_MSE_Distance /= val_num_sample
         avg_UAD /= val_num_sample
         avg_CE_loss /= val_num_sample

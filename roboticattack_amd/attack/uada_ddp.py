@@ -14,13 +14,14 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
 import torch
 
 from .. import dist as vdist
 from .. import ops
 from ..labels import mask_labels as _mask_labels
 from ..optim import CosineWarmupSchedule, PatchOptimizer
-from .engine import AttackBase, to_dev, wandb, wandb_enabled
+from .engine import AttackBase, ValReadback, to_dev, wandb, wandb_enabled
 
 
 def default_model_factory(vla_path: str, device):
@@ -172,6 +173,7 @@ class OpenVLAAttacker(AttackBase):
         """UADA_ddp.py:233-324: 100 local val batches, 3 scalar all-reduces (C5), rank 0 writes the files."""
         avg_CE = avg_MSE = avg_UAD = 0.0
         modified_images = None
+        rb = ValReadback(self.val_batches, self.device)  # one read-back behind the last batch instead of one per batch
         with torch.no_grad():
             for j, data in enumerate(self.val_loader):
                 if j == self.val_batches:
@@ -182,10 +184,12 @@ class OpenVLAAttacker(AttackBase):
                 labels = self._prepare_labels(labels)
                 _, scalars, _ = self.model_loss(input_ids, attention_mask, modified_images, labels, self._loss_mode(),
                                                 w=float(self.MSE_weights), alpha=self.alpha, beta=self.belta, need_grad=False)
-                s = scalars.cpu().numpy()
-                avg_MSE += float(s[2] if self.attack_type == "UADA" else s[0])  # selection metric: MSE distance (UADA) or the attack loss
-                avg_UAD += float(s[7])
-                avg_CE += float(s[1])
+                rb.add(scalars)
+        host, _ = rb.read()
+        for s in host:
+            avg_MSE += float(np.float32(s[2] if self.attack_type == "UADA" else s[0]))  # selection metric: MSE distance (UADA) or the attack loss
+            avg_UAD += float(np.float32(s[7]))
+            avg_CE += float(np.float32(s[1]))
         avg_MSE /= self.val_batches
         avg_UAD /= self.val_batches
         avg_CE /= self.val_batches

@@ -14,7 +14,7 @@ import torch
 from .. import ops
 from ..labels import mask_labels as _mask_labels
 from ..optim import CosineWarmupSchedule, PatchOptimizer
-from .engine import AttackBase, next_or_restart, to_dev, wandb, wandb_enabled
+from .engine import AttackBase, ValReadback, next_or_restart, to_dev, wandb, wandb_enabled
 
 
 class OpenVLAAttacker(AttackBase):
@@ -113,6 +113,7 @@ class OpenVLAAttacker(AttackBase):
         avg_angle = avg_dist = avg_res = 0.0
         val_num_sample = 0
         modified_images = None
+        rb = ValReadback(self.val_batches, self.device)  # one read-back behind the last batch instead of one per batch
         with torch.no_grad():
             for _ in range(self.val_batches):
                 data, val_iterator = next_or_restart(val_iterator, val_dataloader)
@@ -124,10 +125,12 @@ class OpenVLAAttacker(AttackBase):
                     labels = self.mask_labels(labels, maskidx)
                 _, scalars, _ = self.model_loss(input_ids, attention_mask, modified_images, labels, mode, alpha=self.alpha,
                                                 beta=self.belta, scale=scale, need_grad=False, full_ce=False)
-                s = scalars.cpu().numpy()
-                avg_angle += float(s[3])
-                avg_dist += float(s[4])
-                avg_res += float(s[0])
+                rb.add(scalars)
+        host, _ = rb.read()
+        for s in host:
+            avg_angle += float(np.float32(s[3]))
+            avg_dist += float(np.float32(s[4]))
+            avg_res += float(np.float32(s[0]))
         avg_angle /= val_num_sample
         avg_dist /= val_num_sample
         avg_res /= val_num_sample

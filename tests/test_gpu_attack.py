@@ -759,6 +759,7 @@ def test_bench_line_with_every_block_is_compact(tmp_path):
     assert full["config_steps"]["cfg5"]["resize_patch"] and "K0" in full["config_steps"]["cfg5"]["hot_path_ops_us"]  # the per-image resize ran
     assert "K3" in full["config_steps"]["cfg4"]["hot_path_ops_us"] and "K3h" not in full["config_steps"]["cfg4"]["hot_path_ops_us"]  # CE gradient: GEMM head + K3
     assert c["bs4_images_per_s_vs_bs8"] > 0 and c["projected_strong_speedup_2_before_comm"] > 0 and full["per_rank_step"]["bs4"]["labelled_rows"] == 8
+    assert c["val_ms_per_batch_bs8"] > 0 and c["val_ms_per_batch_bs8_sync_every_batch"] > 0 and full["validation_pass"]["batches"] == 12  # the validation pass, A B A B
     assert len(c["k2_sweep_frac_B64_256_1024_4096"]) == 4 and all(0 < f < 1 for f in c["k2_sweep_frac_B64_256_1024_4096"])
     assert len(full["k2_sweep"]) == 4 and "K1t_patch_apply_fwd_tiles" in full["roofline_kernels_standalone"] and full["rank_shapes"]
     cb = d["cpu_baseline"]
