@@ -211,6 +211,12 @@ def kernel_suite(B=64, ph=50, pw=50, iters=50, device="cuda:0", maskidx=(0,), lo
                          "the 263 MB of weights partly stay in the 256 MB Infinity Cache between calls — the in-step figure is the bench line's `roofline`")
         rec("K3h_gemm_path_for_comparison", "K3h", lambda: ops.loss_rows_stats(torch.nn.functional.linear(hid, w_head), rowmap, ops.LOSS_UADA_DDP, 5.0, grad=gslice),
             nb, in_stream=True, rows=R, note="the same through the hipBLASLt LM-head GEMM + vaa_loss_rows_stats (what the step runs with VAA_FUSED_HEAD=0)")
+        if ops.head_slice_applies(R, Dh, 32064):
+            # K3s: the slice-only head — logits of the 256 action columns + statistics + gradient + head backward in ONE launch: hidden rows in, d hidden
+            # out, the 2.1 MB weight slice and its transposed copy
+            nbs = 2 * (2 * R * Dh) + 2 * (2 * 256 * Dh)
+            rec("K3s_head_slice_fwd_bwd", "K3s", lambda: ops.head_slice_fwd_bwd(hid, w_head, rowmap, ops.LOSS_UADA_DDP, 5.0, want_scalars=False), nbs, in_stream=True,
+                rows=R, note="what every inner step of the slice modes runs (K3h only behind it on the steps whose CE is read); back-to-back calls in a stream")
         del w_head, hid
     return res
 

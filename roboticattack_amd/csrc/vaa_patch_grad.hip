@@ -50,6 +50,8 @@ struct GradArgs {
     // scaled gradient of the tiles that carry kept pixels: geff[b][ty*16 + tx][c*196 + y*14 + x] (tiles without a kept pixel are not written)
     const float* geff;
     const float* geff2;      // non-null: the tile kernel ran one tower per workgroup and `geff` holds {tower 0, tower 1} PAIRS per element: the gather adds the two
+    int geff_bf16;           // geff / geff2 are the two towers' bf16-ROUNDED pixel gradients, one plane each, unscaled: the gather applies 1/std and adds — the
+                             // products and the sum the tile kernel would have formed, bit for bit, at half the bytes written and read back
     const uint16_t* keep_t;  // TILED only: K1's tile-major keep words [B,3,256,14] (vaa_patch_apply_fwd_tiles) instead of `keep`
 };
 
@@ -309,7 +311,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
                             for (int cc = 0; cc < NCH; ++cc) {
                                 const size_t ge = gel + (c_base + cc) * (kTilePx * kTilePx);  // even
-                                if (a.geff2) {  // {tower 0, tower 1} pairs, added here — the tile kernel's own fp32 sum
+                                if (a.geff2 && a.geff_bf16) {  // one bf16 PLANE per tower (geff, geff2): two adjacent pixels = 4 bytes of each; scaled and added here
+                                    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.geff) + ge);
+                                    const uint32_t w1 = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(a.geff2) + ge);
+                                    const float s0 = a.istd6[c_base + cc], s1 = a.istd6[c_base + cc + 3];
+                                    gt[k][0][cc] = bf16_bits_to_f32(w0 & 0xffffu) * s0 + bf16_bits_to_f32(w1 & 0xffffu) * s1;
+                                    gt[k][1][cc] = bf16_bits_to_f32(w0 >> 16) * s0 + bf16_bits_to_f32(w1 >> 16) * s1;
+                                } else if (a.geff2) {  // {tower 0, tower 1} pairs, added here — the tile kernel's own fp32 sum
                                     const float4 v4 = *reinterpret_cast<const float4*>(a.geff + 2 * ge);
                                     gt[k][0][cc] = v4.x + v4.y;
                                     gt[k][1][cc] = v4.z + v4.w;
@@ -611,7 +619,7 @@ extern "C" int vaa_patch_grad_gather(const uint16_t* gout_bf16, const float* pat
     a.g = gout_bf16; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode; a.band_rows = ph;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.geff_bf16 = 0; a.keep_t = nullptr;
     return launch_scatter_reduce<false>(a, gpatch, st, "vaa_patch_grad_gather");
 }
 
@@ -642,7 +650,7 @@ extern "C" int vaa_patch_grad_gather_multi(const uint16_t* gout_bf16, const floa
     a.g = gout_bf16; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = (float)(1.0 / (double)std6[q]);
-    a.geff = nullptr; a.geff2 = nullptr; a.keep_t = nullptr;
+    a.geff = nullptr; a.geff2 = nullptr; a.geff_bf16 = 0; a.keep_t = nullptr;
     return launch_scatter_multi<false>(a, max_h, max_w, (hipStream_t)stream, "vaa_patch_grad_gather_multi");
 }
 
@@ -666,6 +674,7 @@ struct EmbedArgs {
     float* geff2;               // non-null: room for the pair layout of tower_split ({tower 0, tower 1} per element, in geff)
     int B, D0, D1, round_bf16;
     int tower_split;            // one tower per workgroup: halves the per-workgroup chain while the launch is far from filling the chip
+    int pair_bf16;              // tower_split with round_bf16: geff / geff2 are bf16 planes of the towers' rounded values, unscaled (the gather scales and adds)
     int ny;                     // 64-tile row groups of an image that go to separate workgroups (1: a workgroup walks them in sequence)
     float istd6[6];
 };
@@ -916,9 +925,20 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
     // blockIdx.x % 8 = one XCD and one L2 (the rows are fetched from HBM once); different units touch disjoint rows and are dealt round-robin
     // over the 8 XCDs — unit = (tower * ny + mg0) * B + b, so that a full batch keeps image b on XCD b % 8 for both towers, while a small batch
     // with large per-image patches (resize_patch: 4 images x 4 row groups x 2 towers) still covers all 8 XCDs instead of B of them.
+    // SPLIT: a tower's units go to ONE half of the XCDs (tower 0: XCDs 0-3, tower 1: 4-7), so an L2 is filled with one tower's packed weights,
+    // not both (8 x 2.56 MB -> 4 x 1.21 + 4 x 1.36 MB of fills at the OpenVLA widths: profiles/traffic_r05.json had the kernel fetch 27.2 MB
+    // for 5.8 MB of dY rows)
     const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
-    const int unit = (slot_id / nch) * 8 + xcd, ch = slot_id % nch, ny = a.ny;
-    if (unit >= a.B * ny * (SPLIT ? 2 : 1)) return;
+    const int ch = slot_id % nch, ny = a.ny;
+    int unit;
+    if (SPLIT) {
+        const int per_tower = a.B * ny, v = (slot_id / nch) * 4 + (xcd & 3);
+        if (v >= per_tower) return;
+        unit = (xcd >> 2) * per_tower + v;
+    } else {
+        unit = (slot_id / nch) * 8 + xcd;
+        if (unit >= a.B * ny) return;
+    }
     const int b = unit % a.B, mg0 = (unit / a.B) % ny;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
 #ifdef VAA_K2_TIMING
@@ -1062,8 +1082,12 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float v = maybe_bf16(acc[j][q][r], a.round_bf16) * (tower ? s1[j] : s0[j]);
-                        res[j][q][r] = (tower != t_lo) ? res[j][q][r] + v : v;
+                        if (SPLIT && a.pair_bf16) {  // the rounded value itself (as a float): the gather scales and adds
+                            res[j][q][r] = bf16_bits_to_f32(f32_to_bf16_bits(acc[j][q][r]));
+                        } else {
+                            const float v = maybe_bf16(acc[j][q][r], a.round_bf16) * (tower ? s1[j] : s0[j]);
+                            res[j][q][r] = (tower != t_lo) ? res[j][q][r] + v : v;
+                        }
                     }
             K2_STAMP(2 + 2 * tower)
         }
@@ -1077,7 +1101,9 @@ __global__ __launch_bounds__(kEmbedFastThreads) void embed_dgrad_tiles_lds_kerne
                     const int sl = mg * 64 + q * 16 + g * 4 + r;
                     if (sl < M) {
                         const size_t el = ((size_t)b * 256 + tiles[sl]) * kTileElems + n[j];
-                        if (SPLIT) a.geff[el * 2 + t_lo] = res[j][q][r];  // {tower 0, tower 1} interleaved: ONE 8-byte load per element in the gather
+                        if (SPLIT && a.pair_bf16)  // a bf16 plane per tower (the towers run on different XCD halves: interleaved halves of one word were written back by both L2s)
+                            reinterpret_cast<uint16_t*>(t_lo ? a.geff2 : a.geff)[el] = (uint16_t)(__float_as_uint(res[j][q][r]) >> 16);  // (exact: rounded above)
+                        else if (SPLIT) a.geff[el * 2 + t_lo] = res[j][q][r];  // {tower 0, tower 1} interleaved: ONE 8-byte load per element in the gather
                         else a.geff[el] = res[j][q][r];
                     }
                 }
@@ -1103,6 +1129,7 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
     const unsigned ny = (unsigned)(tiles_bound <= 64 ? 1 : (tiles_bound <= 128 ? 2 : 4));
     const size_t lds_fast = (size_t)64 * (Dmax + 8) * sizeof(uint16_t);
     e.tower_split = 0;
+    e.pair_bf16 = 0;
     e.ny = (int)ny;
     if (lds_fast <= 150 * 1024 && (size_t)64 * (Dmax / 8) <= (size_t)kEmbedStageMax * kEmbedFastThreads) {
         // Workgroups per unit (image, row group). A workgroup's time is a chain — tile list, staging of a tower's rows, k-loop, (second tower), store —,
@@ -1126,8 +1153,11 @@ static int launch_embed_tiles(EmbedArgs& e, int ph, int pw, hipStream_t st, cons
             set_error("%s: hipFuncSetAttribute failed", who);
             return VAA_E_LAUNCH;
         }
-        const long units = (long)B * ny * (e.tower_split ? 2 : 1);
-        const dim3 grid((unsigned)((units + 7) / 8 * 8 * nch)), blk(kEmbedFastThreads);
+        const long units = (long)B * ny;
+        // SPLIT: every XCD takes ceil(units / 4) units of ITS tower; else 8 XCDs share the units
+        const long slots = e.tower_split ? (units + 3) / 4 : (units + 7) / 8;
+        e.pair_bf16 = (e.tower_split && e.round_bf16 && !getenv("VAA_K2E_F32_PAIRS")) ? 1 : 0;
+        const dim3 grid((unsigned)(slots * 8 * nch)), blk(kEmbedFastThreads);
         if (!e.tower_split) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<false, 2>), grid, blk, lds_fast, st, e, nch);
         else if (nbmax == 1) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 1>), grid, blk, lds_fast, st, e, nch);
         else if (nbmax == 2) VAA_LAUNCH((embed_dgrad_tiles_lds_kernel<true, 2>), grid, blk, lds_fast, st, e, nch);
@@ -1217,7 +1247,7 @@ static int embed_grad_gather_impl(const char* who, const uint16_t* dy0, int D0, 
     a.g = nullptr; a.patch = patch; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = (float*)ws; a.pdesc = nullptr;
     a.B = B; a.ph = ph; a.pw = pw; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles;
+    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.geff_bf16 = e.pair_bf16; a.keep_t = keep_tiles;
     if (keep_tiles) a.keep = reinterpret_cast<const uint8_t*>(keep_tiles);  // non-null selects the stored-mask instantiation
     return launch_scatter_reduce<true>(a, defer_reduce ? nullptr : gpatch, st, who);
 }
@@ -1289,7 +1319,7 @@ static int embed_grad_gather_multi_impl(const char* who, const uint16_t* dy0, in
     a.g = nullptr; a.patch = packed; a.xy = xy; a.theta = theta; a.keep = keep_bits; a.partial = gpacked; a.pdesc = pdesc;
     a.B = B; a.ph = max_h; a.pw = max_w; a.geometry = geometry ? 1 : 0; a.mask_mode = mask_mode;
     for (int q = 0; q < 6; ++q) a.istd6[q] = e.istd6[q];
-    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.keep_t = keep_tiles;
+    a.geff = e.geff; a.geff2 = e.tower_split ? e.geff2 : nullptr; a.geff_bf16 = e.pair_bf16; a.keep_t = keep_tiles;
     if (keep_tiles) a.keep = reinterpret_cast<const uint8_t*>(keep_tiles);  // non-null selects the stored-mask instantiation
     return launch_scatter_multi<true>(a, max_h, max_w, st, who);
 }

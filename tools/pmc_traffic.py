@@ -83,6 +83,7 @@ def main():
            "K3_full_one_launch_optin": ("rows_stats_kernel<unsigned short, 256, true>",),                          # UADA: full-row gradient in ONE launch (VAA_K3_ONE_PASS=1, rows read once)
            "K3_full_rows_fwd_bwd": ("rows_stats_kernel<unsigned short, 256, false>", "rows_finish_kernel<unsigned short, 256>|131072"),  # the default since round 4: two launches
            "K3h_head_loss_rows_stats": ("head_stats_kernel", "head_finish_kernel"),                                   # LM head fused with K3's statistics (weight stream)
+           "K3sl_head_slice_fwd_bwd": ("head_slice_kernel",),                                                        # K3s: slice-only head + statistics + gradient + head backward
            "EPI_step_epilogue": ("step_epilogue_kernel",),
            "K4_patch_update": ("patch_update_kernel",)}
     # a kernel that belongs to two ops (reduce: K2 and K2'; stats: both K3 modes) ran once per op call, so its per-launch mean is counted once in each
