@@ -264,17 +264,18 @@ class AttackBase:
         ops.step_epilogue(sink["partials"], msg, scalars, update=optimizer.fused_update_args())
 
     # ---- fail loud, never NaN: once per outer iteration, behind the read-back that synchronises anyway ----
-    def assert_finite_state(self, patch, optimizer, host_scalars, where: str, all_ranks: bool = False):
+    def assert_finite_state(self, patch, optimizer, host_scalars, where: str, all_ranks: bool = False, device_failure=None):
         """`host_scalars`: the loss scalars of the outer iteration's inner steps, already on the host (their read-back was the sync).
         AdamW's m / v are the sticky witnesses of any non-finite gradient of ANY inner step (a NaN that entered them never leaves, while the
         clamp turns the patch itself into a finite 0), the library's failure word covers kernels that had to give up (vaa_async_error: a
         per-PROCESS word). `all_ranks` (the data-parallel loop): the verdict is all-reduced (MIN) before anyone raises, so that every rank
         leaves the loop together instead of one rank raising while the others wait in the next all-reduce until the RCCL timeout."""
-        device_failure = None
+        # `device_failure`: a failure this rank's inner loop already caught (and polled) — the data-parallel loop keeps its collectives going and
+        # hands it over here, so that the verdict below is all-reduced instead of one rank raising alone
         try:
             ops.async_error_check()
         except _lib.VaaError as e:  # reported like every other non-finite state (and cleared: the poll is the consumer of the sticky word)
-            device_failure = str(e)
+            device_failure = device_failure or str(e)
         ok_dev = torch.isfinite(patch.detach()).all()
         if getattr(optimizer, "m", None) is not None:
             ok_dev = ok_dev & torch.isfinite(optimizer.m).all() & torch.isfinite(optimizer.v).all()

@@ -17,6 +17,7 @@ import os
 import numpy as np
 import torch
 
+from .. import _lib
 from .. import dist as vdist
 from .. import ops
 from ..labels import mask_labels as _mask_labels
@@ -93,6 +94,12 @@ class OpenVLAAttacker(AttackBase):
 
     def attack(self, rank, world_size):
         self.setup(rank, world_size)
+        try:
+            return self._attack(rank, world_size)
+        finally:  # also when the run ends with NonFiniteAttackState: a process that leaves its group open can block at exit
+            self.cleanup()
+
+    def _attack(self, rank, world_size):
         dev = self.device
         if rank == 0:
             patch = torch.rand(self.patch_size).to(dev)  # UADA_ddp.py:140-141
@@ -119,30 +126,50 @@ class OpenVLAAttacker(AttackBase):
                 break
             pixel_values, labels, attention_mask, input_ids = to_dev(data, dev)
             labels = self._prepare_labels(labels)
+            s_sum = sync.buf[sync.n_grad :]
+            device_failure = None  # a library call of THIS rank reported a device-side failure (the sticky word, e.g. a hand-over that timed out)
             for inner_loop in range(self.innerLoop):
-                optimizer.zero_grad()
-                # the loop reads the loss scalars of the LAST inner step only (UADA_ddp.py:214-221, below): the full-vocabulary CE is evaluated there
-                full_ce = inner_loop == self.innerLoop - 1 or os.environ.get("VAA_FULL_CE_EVERY_STEP", "0") == "1"  # (=1: K3h behind K3s on every step; same patch bits)
-                if fused and world_size == 1:  # nothing to exchange: K4 runs inside the epilogue launch (five launches per step)
-                    self.fused_ddp_step(pixel_values, patch, input_ids, attention_mask, labels, self.geometry, float(self.MSE_weights),
-                                        sync.buf, scalars, optimizer=optimizer, full_ce=full_ce)
-                    s_sum = sync.buf[sync.n_grad :]
-                    continue
-                if fused:
-                    self.fused_ddp_step(pixel_values, patch, input_ids, attention_mask, labels, self.geometry, float(self.MSE_weights),
-                                        sync.buf, scalars, full_ce=full_ce)
-                    g_sum, s_sum = sync.allreduce_packed()  # C3 + C4 in one message: [grad | CE, MSE, UAD, total]
-                else:
-                    pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
-                                                                              geometry=self.geometry)
-                    total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, self._loss_mode(), w=float(self.MSE_weights),
-                                                           alpha=self.alpha, beta=self.belta, full_ce=full_ce)
-                    total.backward()  # K2 inside
-                    g_sum, s_sum = sync.allreduce_step(patch.grad, scalars, pick)
-                optimizer.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4, DDP mean folded in
+                exchanged = False
+                if device_failure is None:
+                    try:
+                        optimizer.zero_grad()
+                        # the loop reads the loss scalars of the LAST inner step only (UADA_ddp.py:214-221, below): the full-vocabulary CE is evaluated there
+                        full_ce = inner_loop == self.innerLoop - 1 or os.environ.get("VAA_FULL_CE_EVERY_STEP", "0") == "1"  # (=1: K3h behind K3s on every step; same patch bits)
+                        if fused and world_size == 1:  # nothing to exchange: K4 runs inside the epilogue launch (five launches per step)
+                            self.fused_ddp_step(pixel_values, patch, input_ids, attention_mask, labels, self.geometry, float(self.MSE_weights),
+                                                sync.buf, scalars, optimizer=optimizer, full_ce=full_ce)
+                            s_sum = sync.buf[sync.n_grad :]
+                            continue
+                        if fused:
+                            self.fused_ddp_step(pixel_values, patch, input_ids, attention_mask, labels, self.geometry, float(self.MSE_weights),
+                                                sync.buf, scalars, full_ce=full_ce)
+                            exchanged = True
+                            g_sum, s_sum = sync.allreduce_packed()  # C3 + C4 in one message: [grad | CE, MSE, UAD, total]
+                        else:
+                            pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
+                                                                                      geometry=self.geometry)
+                            total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, self._loss_mode(), w=float(self.MSE_weights),
+                                                                   alpha=self.alpha, beta=self.belta, full_ce=full_ce)
+                            total.backward()  # K2 inside
+                            exchanged = True
+                            g_sum, s_sum = sync.allreduce_step(patch.grad, scalars, pick)
+                        optimizer.step(grad=g_sum.view_as(patch), grad_scale=inv_world)  # K4, DDP mean folded in
+                    except _lib.VaaError as e:
+                        # The failure word is sticky: every library call of this rank fails until it is polled. Raising here would leave the OTHER
+                        # ranks waiting in this step's all-reduce until the RCCL timeout: poll it now (the poll clears it), keep the
+                        # collective's cadence with a NaN message for the rest of the outer iteration, and let the all-reduced verdict below
+                        # take every rank out of the loop together.
+                        device_failure = str(e)
+                        try:
+                            ops.async_error_check()
+                        except _lib.VaaError:
+                            pass
+                if device_failure is not None and world_size > 1 and not exchanged:
+                    sync.buf.fill_(float("nan"))
+                    _, s_sum = sync.allreduce_packed()
             scheduler.step()
             s = (s_sum * inv_world).cpu().numpy()
-            self.assert_finite_state(patch, optimizer, s, f"{self.attack_type} (data parallel) outer iteration {i}", all_ranks=True)
+            self.assert_finite_state(patch, optimizer, s, f"{self.attack_type} (data parallel) outer iteration {i}", all_ranks=True, device_failure=device_failure)
             # UADA_ddp.py:207,216-217: `patch.grad.mean()` AFTER DistributedDataParallel averaged the gradient, i.e. the mean of the averaged
             # gradient (identical on every rank, so the reference's MAX all-reduce of it is the value itself): K4 reports it
             log_patch_grad = float(optimizer.last_stats[1].item())
@@ -154,7 +181,6 @@ class OpenVLAAttacker(AttackBase):
                 wandb.log(train_logdata, step=i)
             if i % self.val_every == 0:
                 self.validate(i, patch, rank)
-        self.cleanup()
         return patch
 
     def _loss_mode(self):

@@ -349,22 +349,11 @@ static size_t head_lds_bytes(int nrb) {
     return lds_h > lds_t ? lds_h : lds_t;
 }
 
-// the LDS a workgroup may ask for on the CURRENT device (gfx950: 160 KB), queried once per device
-static size_t device_lds_limit() {
-    static std::atomic<long> cached[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 64 * 1024; }
-    long v = cached[dev].load(std::memory_order_acquire);
-    if (v == 0) {
-        int per_block = 0, optin = 0;  // the larger of the default and the opt-in limit (runtimes differ in which of the two carries the 160 KB)
-        if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); per_block = 0; }
-        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess) { (void)hipGetLastError(); optin = 0; }
-        v = per_block > optin ? per_block : optin;
-        if (v <= 0) v = 64 * 1024;
-        cached[dev].store(v, std::memory_order_release);
-    }
-    return (size_t)v;
-}
+// the LDS a workgroup may ask for: 160 KB on gfx950, the only device this library runs on (vaa_device_check). Round 5 asked the runtime
+// (MaxSharedMemoryPerBlock / SharedMemPerBlockOptin) and fell back to 64 KB when the query failed or reported less: a runtime that reports 64 KB
+// would then have disabled K3h above 64 rows SILENTLY — and differently on different ranks. With the architectural constant a
+// runtime that really refuses the opt-in fails loudly at hipFuncSetAttribute instead.
+static size_t device_lds_limit() { return 160 * 1024; }
 
 }  // namespace vaa
 

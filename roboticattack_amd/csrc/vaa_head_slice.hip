@@ -361,8 +361,8 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     unsigned long long w0[NRB][4];
 #pragma unroll
     for (int u = 0; u < NRB; ++u) request(u, w0[u]);
-    bool own_gave_up = false;
-    {
+    bool own_gave_up = a.max_polls < 0;  // (test hook VAA_K3_HANDOVER_POLLS=-1: the failure path, deterministically)
+    if (!own_gave_up) {
         int polls = 0;
         for (;;) {
             bool ok = true;

@@ -115,13 +115,18 @@ extern "C" int vaa_patch_update(float* patch, const float* g, float* m, float* v
         set_error("vaa_patch_update: null pointer argument");
         return VAA_E_INVALID;
     }
-    if (g == patch || g == m || g == v) {
-        set_error("vaa_patch_update: the gradient must not alias the patch or a moment buffer");
-        return VAA_E_INVALID;
-    }
     if (n <= 0 || (mode != VAA_OPT_ADAMW_HF && mode != VAA_OPT_PGD_SIGN) || (mode == VAA_OPT_ADAMW_HF && step < 1)) {
         set_error("vaa_patch_update: bad sizes/mode (n=%d mode=%d step=%d)", n, mode, step);
         return VAA_E_INVALID;
+    }
+    {   // several workgroups read the WHOLE gradient while others already write their elements of patch / m / v: no byte of g may lie inside
+        // one of those buffers (a view into a shared flat buffer overlaps without being pointer-equal)
+        const uintptr_t g0 = (uintptr_t)g, g1 = g0 + (size_t)n * sizeof(float);
+        auto overlaps = [&](const float* p) { const uintptr_t p0 = (uintptr_t)p; return p && g0 < p0 + (size_t)n * sizeof(float) && p0 < g1; };
+        if (overlaps(patch) || (mode == VAA_OPT_ADAMW_HF && (overlaps(m) || overlaps(v)))) {
+            set_error("vaa_patch_update: the gradient must not overlap the patch or a moment buffer");
+            return VAA_E_INVALID;
+        }
     }
     UpdArgs a;
     a.patch = patch; a.g = g; a.m = m; a.v = v; a.stats = stats; a.n = n; a.mode = mode;

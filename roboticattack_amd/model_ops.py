@@ -94,13 +94,15 @@ class ScaleAddFn(torch.autograd.Function):
     def backward(ctx, g):
         (ls,) = ctx.saved_tensors
         g = g.contiguous()
-        return g, _scale_add(None, g, ls.contiguous()), None
+        da = _scale_add(None, g, ls.contiguous()) if ctx.needs_input_grad[1] else None
+        return (g if ctx.needs_input_grad[0] else None), da, None  # (ls is frozen: scale_add dispatches here only then)
 
 
 def scale_add(x: torch.Tensor, a: torch.Tensor, ls: torch.Tensor) -> torch.Tensor:
     """torch.addcmul(x, a, ls) for a LayerScale vector ls [D]; the fused kernel for bf16 ROCm tensors of equal shape, D % 8 == 0."""
     if (enabled(x) and a.dtype == x.dtype and ls.dtype == x.dtype and x.shape == a.shape and ls.dim() == 1 and ls.shape[0] == x.shape[-1]
-            and x.shape[-1] % 8 == 0 and os.environ.get("VAA_MODEL_SCALE_ADD", "1") != "0"):
+            and x.shape[-1] % 8 == 0 and a.device == x.device and ls.device == x.device and not ls.requires_grad  # (an unfrozen LayerScale needs addcmul's gradient)
+            and os.environ.get("VAA_MODEL_SCALE_ADD", "1") != "0"):
         return ScaleAddFn.apply(x, a, ls)
     return torch.addcmul(x, a, ls)
 

@@ -588,16 +588,65 @@ def build_openvla(cfg: OpenVLACfg | None = None, device="cuda", dtype=torch.bflo
     return m.eval()
 
 
+def check_hf_config(cfg: OpenVLACfg, ckpt_dir: str) -> list:
+    """The checkpoint's `config.json` (OpenVLAConfig: configuration_prismatic.py:83-123; `text_config` = the Llama config, :119-123) against the
+    constants this module tree is built with. Returns the list of disagreements (empty = the checkpoint fits): a checkpoint whose shapes or
+    numerical constants differ — RMSNorm epsilon, RoPE base, vocabulary / padding, image size, a single vision tower — must not be loaded
+    into a model that silently computes with other values. A checkpoint directory without config.json is refused as well."""
+    import json
+    import os
+
+    path = os.path.join(ckpt_dir, "config.json")
+    if not os.path.exists(path):
+        return [f"no config.json in {ckpt_dir}"]
+    with open(path) as f:
+        conf = json.load(f)
+    tc = conf.get("text_config") or {}
+    bad = []
+
+    def need(what, got, want, tol=0.0):
+        if got is None:
+            return
+        ok = abs(float(got) - float(want)) <= tol * abs(float(want)) if isinstance(want, float) else got == want
+        if not ok:
+            bad.append(f"{what} = {got!r}, model has {want!r}")
+
+    need("text_config.hidden_size", tc.get("hidden_size"), cfg.llm_dim)
+    need("text_config.num_hidden_layers", tc.get("num_hidden_layers"), cfg.llm_layers)
+    need("text_config.num_attention_heads", tc.get("num_attention_heads"), cfg.llm_heads)
+    need("text_config.num_key_value_heads", tc.get("num_key_value_heads"), cfg.llm_heads)  # no grouped-query attention in this module tree
+    need("text_config.intermediate_size", tc.get("intermediate_size"), cfg.llm_mlp)
+    need("text_config.vocab_size", tc.get("vocab_size"), cfg.vocab)
+    # transformers' LlamaConfig defaults when a key is absent from text_config: rms_norm_eps 1e-6, rope_theta 10000.0
+    need("text_config.rms_norm_eps", float(tc.get("rms_norm_eps", 1e-6)), float(cfg.rms_eps), 1e-9)
+    need("text_config.rope_theta", float(tc.get("rope_theta", 10000.0)), float(cfg.rope_theta), 1e-9)
+    if tc.get("rope_scaling") not in (None, {}):
+        bad.append(f"text_config.rope_scaling = {tc.get('rope_scaling')!r}: not supported")
+    need("pad_token_id", conf.get("pad_token_id"), 32000)          # configuration_prismatic.py:101; the loops pad with it (UADA.py:48)
+    need("text_config.pad_token_id", tc.get("pad_token_id"), 32000)
+    sizes = conf.get("image_sizes")
+    if sizes is not None and [int(v) for v in sizes] != [224, 224]:
+        bad.append(f"image_sizes = {sizes!r}, the patch transform and K1 are built for 224 x 224 frames")
+    if conf.get("use_fused_vision_backbone") is False:
+        bad.append("use_fused_vision_backbone = false: this module tree has the two fused towers (DINOv2 + SigLIP)")
+    return bad
+
+
 def load_hf_openvla(model: OpenVLAShaped, ckpt_dir: str) -> OpenVLAShaped:
     """Map a local HF `openvla/openvla-7b` safetensors checkpoint onto this module tree (names follow
     modeling_prismatic.py: vision_backbone.{featurizer,fused_featurizer}.*, projector.fc{1,2,3}, language_model.model.*).
-    The name mapping is exercised on a synthetic checkpoint written with the HF module names (tests/test_host_logic.py); the released
-    weights themselves are not in this image (no network), so no numerical check against them exists."""
+    `config.json` is read first (check_hf_config): a checkpoint whose shapes or constants (rms_norm_eps, rope_theta, pad_token_id, image size)
+    disagree with the model's OpenVLACfg is refused. The name mapping is exercised on a synthetic checkpoint written with the HF module names
+    (tests/test_host_logic.py); the released weights themselves are not in this image (no network), so no numerical check against them exists."""
     import glob
     import os
 
     from safetensors.torch import load_file
 
+    bad = check_hf_config(model.cfg, ckpt_dir)
+    if bad:
+        raise ValueError(f"load_hf_openvla: {ckpt_dir}/config.json disagrees with the model this loader builds ({'; '.join(bad)}) — build the "
+                         "model with an OpenVLACfg that carries the checkpoint's values")
     sd = {}
     for f in sorted(glob.glob(os.path.join(ckpt_dir, "*.safetensors"))):
         sd.update(load_file(f))

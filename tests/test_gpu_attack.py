@@ -300,6 +300,66 @@ def test_ddp_attacker_single_rank(tmp_path, attack, monkeypatch):
     assert os.path.exists(os.path.join(str(tmp_path), "0", "patch.pt"))
 
 
+def _failing_rank_worker(rank, world, port, out_dir):
+    """One rank of the product data-parallel attacker on the tiny OpenVLA-shaped model (K3s runs); rank 1's hand-overs give up at once."""
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VAA_DIST_BACKEND="gloo")
+    if rank == 1:
+        os.environ["VAA_K3_HANDOVER_POLLS"] = "-1"
+    from roboticattack_amd.attack.engine import NonFiniteAttackState
+    from roboticattack_amd.attack.uada_ddp import OpenVLAAttacker
+    from roboticattack_amd.synthetic import SyntheticLoader
+
+    _seed()
+    OpenVLAAttacker.val_batches = 1
+    params = dict(vla_path="random:tiny", dataset_name="synthetic", save_dir=os.path.join(out_dir, f"rank{rank}"), patch_size=[3, 50, 50], lr=0.03, bs=2, warmup=1,
+                  num_iter=2, maskidx=[0], innerLoop=3, geometry=True, use_wandb=False, MSE_weights=5, device=torch.device("cuda:0"),
+                  dataset_factory=lambda name, bs, r, w: (SyntheticLoader(bs, seed=1 + r, kind="smooth"), SyntheticLoader(bs, seed=2, kind="smooth", length=1)))
+    verdict = "finished"
+    try:
+        OpenVLAAttacker._attack_entry(rank, params, world)
+    except NonFiniteAttackState as e:
+        verdict = "NonFiniteAttackState: " + str(e)
+    except Exception as e:  # anything else (a VaaError escaping the loop, a collective timeout) is the bug this test is about
+        verdict = f"{type(e).__name__}: {e}"
+    with open(os.path.join(out_dir, f"verdict{rank}.txt"), "w") as f:
+        f.write(verdict)
+
+
+def test_ddp_device_failure_on_one_rank_takes_every_rank_out_together(tmp_path):
+    """the library's failure word is STICKY, so the failing rank's next library call inside the inner loop raises VaaError before the
+    per-iteration verdict runs — and the other rank would wait in the step's all-reduce until the collective times out. The loop now catches
+    it, polls the word, keeps the collective's cadence with a NaN message and hands the failure to the all-reduced verdict: BOTH ranks leave
+    with NonFiniteAttackState in the same outer iteration, nothing saved. Two ranks on one GPU over gloo; rank 1's K3s hand-overs give up."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    alive = [p.is_alive() for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    v = [open(os.path.join(str(tmp_path), f"verdict{r}.txt")).read() if os.path.exists(os.path.join(str(tmp_path), f"verdict{r}.txt")) else "<no verdict>" for r in range(2)]
+    assert not any(alive), f"a rank is still waiting (in a collective?): alive={alive} verdicts={v}"
+    assert all(x.startswith("NonFiniteAttackState") for x in v), v
+    assert "detected on THIS rank" in v[1] and "hand-over" in v[1] and "outer iteration 0" in v[0] and "outer iteration 0" in v[1]
+    assert not os.path.exists(os.path.join(str(tmp_path), "rank0", "last"))
+
+
 def test_ddp_attacker_slice_head_cadence(tmp_path, monkeypatch):
     """the data-parallel UADA loop runs K3s (slice-only head, ONE launch) on every inner step and K3h's full-vocabulary stream
     only on the LAST inner step of an outer iteration — the only one whose CE the loop reads (UADA_ddp.py:214-221). Against the same run with

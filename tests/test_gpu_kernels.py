@@ -1499,7 +1499,10 @@ def test_k3_one_pass_handover_timeout_fails_loudly(ops, monkeypatch):
     monkeypatch.setenv("VAA_K3_ONE_PASS", "1")
     monkeypatch.setenv("VAA_K3_HANDOVER_POLLS", "0")
     g = torch.zeros_like(logits)
-    ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=g)
+    try:  # with 0 polls the kernel may give up before the call's own launch check reads the (sticky) word: the call itself may then raise
+        ops.loss_rows_fwd_bwd(logits, rm, ops.LOSS_UADA, w=5.0, grad_kind=ops.GRAD_FULL, grad=g)
+    except _lib.VaaError as e:
+        assert "hand-over timed out" in str(e)
     torch.cuda.synchronize()
     assert torch.isnan(g.float()).any()  # poisoned, never stale or silently partial
     patch = torch.rand(3, 8, 8, device=DEV)

@@ -222,6 +222,26 @@ def test_hf_checkpoint_name_mapping_roundtrip(tmp_path):
                 n2 = n2.replace(f".{proj}.", f".mlp.{proj}.")
             hf[f"language_model.model.{n2}"] = p.detach().clone()
     save_file({k: v.contiguous() for k, v in hf.items()}, str(tmp_path / "model-00001-of-00001.safetensors"))
+    # the checkpoint's config.json is read and checked against the model's constants (configuration_prismatic.py:83-123)
+    import json
+
+    tc = tiny_cfg()
+    with pytest.raises(ValueError, match="no config.json"):
+        load_hf_openvla(OpenVLAShaped(tiny_cfg()).eval(), str(tmp_path))
+    conf = {"pad_token_id": 32000, "image_sizes": [224, 224], "use_fused_vision_backbone": True, "vision_backbone_id": "dinosiglip-vit-so-224px",
+            "text_config": {"hidden_size": tc.llm_dim, "num_hidden_layers": tc.llm_layers, "num_attention_heads": tc.llm_heads, "intermediate_size": tc.llm_mlp,
+                            "vocab_size": 32064, "rms_norm_eps": 1e-06, "pad_token_id": 32000}}
+    for key, val, where in (("rms_norm_eps", 1e-05, "rms_norm_eps"), ("rope_theta", 500000.0, "rope_theta"), ("hidden_size", 4096, "hidden_size"),
+                            ("pad_token_id", 0, "text_config.pad_token_id"), ("num_key_value_heads", 1, "num_key_value_heads")):
+        badc = json.loads(json.dumps(conf))
+        badc["text_config"][key] = val
+        (tmp_path / "config.json").write_text(json.dumps(badc))
+        with pytest.raises(ValueError, match=where):
+            load_hf_openvla(OpenVLAShaped(tiny_cfg()).eval(), str(tmp_path))
+    (tmp_path / "config.json").write_text(json.dumps(dict(conf, image_sizes=[384, 384])))
+    with pytest.raises(ValueError, match="image_sizes"):
+        load_hf_openvla(OpenVLAShaped(tiny_cfg()).eval(), str(tmp_path))
+    (tmp_path / "config.json").write_text(json.dumps(conf))
     dst = load_hf_openvla(OpenVLAShaped(tiny_cfg()).eval(), str(tmp_path))
     for (n1, p1), (n2, p2) in zip(src.named_parameters(), dst.named_parameters()):
         assert n1 == n2 and torch.equal(p1, p2), n1
