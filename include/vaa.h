@@ -65,8 +65,16 @@ extern "C" {
 const char* vaa_last_error(void);
 int vaa_version(void);
 /*
- * Device-side failures surface here and NEVER as a silent NaN: a kernel that has to give up (today only the opt-in one-launch K3, when its
- * grid-wide hand-over runs out of polls) NaN-poisons its outputs AND sets a bit in a pinned host word. The word is process-wide and STICKY:
+ * PROCESS-WIDE STATE — the two places where this library is NOT the stateless, per-stream re-entrant operator set SURVEY.md section 8b sketched
+ * (everything else is: caller-owned memory and streams, no allocation, no synchronisation, thread-local error text):
+ *   (1) the device-failure word behind vaa_async_error() below: one pinned host word per process, STICKY, not attributed to a stream;
+ *   (2) the per-dispatch profiler vaa_prof_*: one record table per process behind a mutex.
+ * Also per process, but invisible to callers: a launch-tag counter and "one stream at a time has a waiting grid in flight" bookkeeping for the
+ * launches whose workgroups wait for each other (vaa_head_slice_fwd_bwd; the opt-in one-launch form of vaa_loss_rows_fwd_bwd) — they only decide
+ * between the one-launch and the two-launch form of those calls, never their results.
+ *
+ * Device-side failures surface here and NEVER as a silent NaN: a kernel that has to give up (vaa_head_slice_fwd_bwd's one-launch form and the opt-in
+ * one-launch K3, when a hand-over runs out of polls) NaN-poisons its outputs AND sets a bit in a pinned host word. The word is process-wide and STICKY:
  * from then on EVERY library call on any stream or thread returns VAA_E_LAUNCH (reason in vaa_last_error()) — the failure is not attributed
  * to a stream, and no call consumes it — until vaa_async_error() is called: the explicit poll reports the failure (VAA_E_LAUNCH) and clears
  * the word. The attack loops poll it behind their once-per-outer-iteration read-back, before anything is written to disk (UADA.py:257-275).

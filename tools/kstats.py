@@ -7,7 +7,7 @@ path (calls, average us, us per step, algorithmic share) and the top framework k
 import csv
 import sys
 
-HAND = ("patch_apply", "embed_dgrad", "patch_grad_", "head_stats_kernel", "head_finish_kernel", "rows_stats_kernel", "rows_finish_kernel", "loss_stats_kernel",
+HAND = ("patch_apply", "embed_dgrad", "patch_grad_", "head_slice", "head_stats_kernel", "head_finish_kernel", "rows_stats_kernel", "rows_finish_kernel", "loss_stats_kernel",
         "loss_grad_kernel", "step_epilogue_kernel", "patch_update_kernel", "patch_resize", "loss_rowmap_kernel")
 
 

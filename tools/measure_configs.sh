@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5: BASELINE configs 2 / 4 / 5 end to end under rocprofv3 (the product loops' own inner_step through `bench.py --attack`), config 5's
 # backward A/B (K2'-MULTI against the ViT patch-embed conv backward in torch + K2-MULTI), and the in-step A/B of the fused LM head at bs=64.
-#   gpurun --timeout 2400 -- 'bash tools/measure_configs.sh [cfg] [cfg5ab] [head]'      (default: all three parts)
+#   gpurun --timeout 2400 -- 'bash tools/measure_configs.sh [cfg] [cfg5ab] [head] [k3s]'      (default: cfg cfg5ab head)
 # Outputs: gpurun_out/cfg/{cfgN_kernel_stats.csv, cfgN.json, cfgN_summary.txt, ...}; copy what is to be judged into profiles/r05_*.
 set -uo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
@@ -33,6 +33,12 @@ for p in ${parts}; do
     cfg5ab)  # the same UPA step with the pixel path: conv backward of both towers in torch + K2-MULTI on the bf16 pixel gradient
       run cfg5_pixel_path "VAA_FUSED_EMBED_GRAD=0" --attack upa --bs 4 --resize-patch --patch 3,100,100
       run cfg5_again "" --attack upa --bs 4 --resize-patch --patch 3,100,100
+      ;;
+    k3s)     # round 6: K3s on every step + K3h on 1 of 50 (the default) against K3h + finish + the 256-column GEMM on every step, inside the bs=64 step, A B B A
+      run k3s_cadence_1 ""
+      run k3h_every_1 "VAA_HEAD_EVERY_STEP=1"
+      run k3h_every_2 "VAA_HEAD_EVERY_STEP=1"
+      run k3s_cadence_2 ""
       ;;
     head)    # fused LM head (K3h) against hipBLASLt head + K3 statistics, inside the bs=64 step, A B B A
       run head_gemm_1 "VAA_FUSED_HEAD=0"
