@@ -45,6 +45,12 @@ def test_sizes_and_argument_errors_without_gpu():
     assert L.vaa_patch_embed_pack_weights(None, 1024, None, None) == -1 and b"null pointer" in L.vaa_last_error()
     assert L.vaa_patch_embed_grad_ws_bytes(64, 50, 50) == L.vaa_patch_grad_ws_bytes(64, 50, 50) + 2 * 64 * 256 * 588 * 4 + 256  # partials + a tile-gradient buffer per tower
     assert L.vaa_patch_embed_grad_multi_ws_bytes(4) == 2 * 4 * 256 * 588 * 4 + 256
+    # K3s: shapes it covers and its scratch (two logits + the launch tag per 64-bit word, whole row blocks)
+    assert L.vaa_head_slice_applies(128, 4096, 32064) == 1 and L.vaa_head_slice_applies(129, 4096, 32064) == 0 and L.vaa_head_slice_applies(16, 4160, 32064) == 0
+    assert L.vaa_head_slice_applies(16, 64, 32064) == 1 and L.vaa_head_slice_applies(16, 64, 40000) == 0 and L.vaa_head_slice_applies(0, 64, 32064) == 0
+    assert L.vaa_head_slice_ws_bytes(1) == 16 * 1024 and L.vaa_head_slice_ws_bytes(128) == 128 * 1024 and L.vaa_head_slice_ws_bytes(0) == 0
+    assert L.vaa_head_slice_pack(None, 4096, 32064, None, None) == -1 and b"null pointer" in L.vaa_last_error()
+    assert L.vaa_head_slice_fwd_bwd(None, None, None, 4096, None, 16, 8, 30, 32064, 1, _lib.f32x([5, .8, .2, 1]), None, None, None, 0, None, None, None, None, 0, None) == -1
     # empty batches return before anything is validated or launched
     assert L.vaa_patch_embed_grad_gather_multi(None, 64, None, 64, None, None, None, None, None, None, None, 0, 50, 50, 1, 0, _lib.f32x([1] * 6), 1, None, None, 0, None) == 0
     assert L.vaa_patch_grad_gather_multi(None, None, None, None, None, None, 0, 50, 50, 1, 0, _lib.f32x([1] * 6), None, None) == 0

@@ -10,7 +10,7 @@ the label-driven route (FULL layout).
 
     python tools/soak_loss.py --head --seconds 300 --seed 3
 
-K3h (`vaa_head_loss_rows_stats`, LM head fused with K3's statistics): every case draws a batch (1 ... 128 labelled rows, samples without
+K3h (`vaa_head_loss_rows_stats`, LM head fused with K3's statistics) and, on the same inputs, K3s (`vaa_head_slice_fwd_bwd`, bit for bit K3h's slice outputs): every case draws a batch (1 ... 128 labelled rows, samples without
 labels), a head width D (multiples of 64 up to 1024, or 4096), scales, ties (duplicated weight rows in different workgroups' column ranges,
 a dominant column) and checks the kernel's bf16 logits against a torch GEMM (single bf16 roundings), the ORACLE on those logits (scalars
 3e-5, gradient slice 1e-2 of its scale, both argmax maps with first-maximum-wins) and `vaa_loss_rows_stats` on those logits (bit for bit).
@@ -192,6 +192,33 @@ def one_head_case(seed):
     if not (torch.equal(gs2.view(torch.int16), gs.view(torch.int16)) and torch.equal(pred2, pred) and torch.equal(pred_full2, pred_full)
             and torch.equal(sc2[[2, 6, 7]], sc[[2, 6, 7]])):
         fails.append(f"head vs K3 statistics on the same logits {tag}")
+    # K3s (round 6; vaa_head_slice_fwd_bwd) on the same inputs: K3h's action logits / gradient slice / slice scalars BIT FOR BIT (one-launch, two-launch
+    # and grouped forms by the environment the soak is run with), dH against the exact products of the bf16 operands; UPA through the publishing form
+    if ops.head_slice_applies(R, D, V):
+        o = ops.head_slice_fwd_bwd(h, W, rm, ops.LOSS_UADA_DDP, w, want_dh=True, want_scalars=True, want_grad_slice=True)
+        words = o["zs"][: R * 1024].view(torch.int64).view(R, 128)
+        zs = (words & 0xFFFFFFFF).to(torch.int32).view(torch.bfloat16).view(R, 256)
+        if not torch.equal(zs.view(torch.int16), lg[:, 31744:32000].contiguous().view(torch.int16)):
+            fails.append(f"slice logits differ from K3h's {tag}")
+        if not torch.equal(o["grad_slice"].view(torch.int16), gs.view(torch.int16)):
+            fails.append(f"slice gradient differs from K3h's {tag}")
+        s2 = o["scalars"]
+        if not (torch.equal(s2[[0, 2, 5, 6, 7]], sc[[0, 2, 5, 6, 7]]) and float(s2[1]) == 0.0 and torch.equal(o["pred"], pred)):
+            fails.append(f"slice scalars {tag}: {s2.cpu().numpy()} vs {sc.cpu().numpy()}")
+        g64, w64 = gs.double(), W[31744:32000].double()
+        ref, rmag = g64 @ w64, g64.abs() @ w64.abs()
+        dh = o["dh"].double()
+        if not bool(((dh - ref).abs() <= 0.5 * torch.maximum(ref.abs(), dh.abs()) * 2.0 ** -7 + 2e-6 * rmag + 1e-30).all()):
+            fails.append(f"slice dH {tag}: worst |d| {float((dh - ref).abs().max()):.3e}")
+        if R % 8 == 0 and rs.rand() < 0.5:  # UPA needs whole samples of eight labelled rows: reuse the row count with an unmasked batch
+            _, lab8, _ = synthetic.synth_text_batch(seed % 9973 + 1, R // 8)
+            rm8 = ops.LossRowMap(lab8.to(DEV))
+            kw = dict(w=w, alpha=float(rs.uniform(0.1, 1.0)), beta=float(rs.uniform(0.1, 1.0)))
+            a_ = ops.head_loss_rows_fwd_bwd(h, W, rm8, ops.LOSS_UPA, want_grad=True, **kw)
+            b_ = ops.head_slice_fwd_bwd(h, W, rm8, ops.LOSS_UPA, want_dh=True, want_scalars=True, want_grad_slice=True, **kw)
+            if not (torch.equal(b_["grad_slice"].view(torch.int16), a_[3].view(torch.int16)) and torch.equal(b_["scalars"][[0, 2, 3, 4, 5, 6, 7]], a_[0][[0, 2, 3, 4, 5, 6, 7]])
+                    and torch.equal(b_["pred"], a_[1])):
+                fails.append(f"slice UPA differs from K3h + finish {tag}")
     return fails
 
 
