@@ -79,8 +79,14 @@ __device__ __forceinline__ int xor_lane_i(int v) {
 template <int O>
 __device__ __forceinline__ float xor_lane(float v) { return __int_as_float(xor_lane_i<O>(__float_as_int(v))); }
 
-template <int NR>
-__device__ __forceinline__ void slice_stats_half(const float (&x)[NR][8], int hl, float (&alse)[NR], float (&E)[NR], int (&pred)[NR]) {
+struct NoHook {
+    template <typename T>
+    __device__ __forceinline__ void operator()(T) const {}
+};
+// `between(stage)` (stage = std::integral_constant 1, 2, 3) runs behind the argmax butterflies, the exponentials and the sum butterflies, fenced for the
+// scheduler: the caller trickles independent memory requests in between instead of stalling the chain behind a burst of them
+template <int NR, typename F = NoHook>
+__device__ __forceinline__ void slice_stats_half(const float (&x)[NR][8], int hl, float (&alse)[NR], float (&E)[NR], int (&pred)[NR], F between = F()) {
     float bestv[NR], es[NR], ew[NR];
     int besti[NR];
 #pragma unroll
@@ -99,6 +105,9 @@ __device__ __forceinline__ void slice_stats_half(const float (&x)[NR][8], int hl
     }
     K3S_ARGMAX_STEP(16) K3S_ARGMAX_STEP(8) K3S_ARGMAX_STEP(4) K3S_ARGMAX_STEP(2) K3S_ARGMAX_STEP(1)
 #undef K3S_ARGMAX_STEP
+    __builtin_amdgcn_sched_barrier(0);
+    between(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < NR; ++n) {
         es[n] = 0.0f;
@@ -110,6 +119,9 @@ __device__ __forceinline__ void slice_stats_half(const float (&x)[NR][8], int hl
             ew[n] += ex * (float)(hl * 8 + e + 1);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    between(std::integral_constant<int, 2>{});
+    __builtin_amdgcn_sched_barrier(0);
 #define K3S_SUM_STEP(O)                                              \
     _Pragma("unroll") for (int n = 0; n < NR; ++n) {                    \
         es[n] += xor_lane<O>(es[n]);                                    \
@@ -117,6 +129,9 @@ __device__ __forceinline__ void slice_stats_half(const float (&x)[NR][8], int hl
     }
     K3S_SUM_STEP(16) K3S_SUM_STEP(8) K3S_SUM_STEP(4) K3S_SUM_STEP(2) K3S_SUM_STEP(1)
 #undef K3S_SUM_STEP
+    __builtin_amdgcn_sched_barrier(0);
+    between(std::integral_constant<int, 3>{});
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < NR; ++n) {
         E[n] = ew[n] / es[n];
@@ -340,29 +355,11 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     K3S_STAMP(3);
-    // ---- phase 3's B operand: fragments of the transposed slice, requested now: the fetch path is idle while the logits travel (about 1.9 us
-    //      from a producer's store to a consumer's load), and the poll's words queue behind these requests — they come back when both are
-    //      done. (Requested behind a successful poll they held the statistics back by their 2 us of issue; in front of phase 1 they delay the
-    //      logits.) The workgroup's 16 output tiles: NRB row tiles x kDW / 16 column tiles; a wave's two tiles share their column tile when
-    //      NRB > 1, so it fetches ONE tile's fragments ----
-    constexpr int kDT = kDW / 16;            // column tiles
-    constexpr int kNB = NRB == 1 ? 2 : 1;    // distinct column tiles of a wave's two output tiles
-    const int dbase = (mb * 16 + j) * kDW;
-    const int dt0 = NRB == 1 ? 2 * wv : wv % kDT, rt0 = NRB == 1 ? 0 : (wv / kDT) * 2;  // tiles (rt0, dt0), (rt0 + 1, dt0) — or (0, dt0), (0, dt0 + 1) at NRB = 1
-    v8s_s bfr[kNB][kNA / 32];
-    if (a.dh) {
-#pragma unroll
-        for (int t = 0; t < kNB; ++t) {
-            const int d = min(dbase + (dt0 + t) * 16 + c, D - 1);  // columns beyond D re-read the last one: never stored
-#pragma unroll
-            for (int ks = 0; ks < kNA / 32; ++ks) bfr[t][ks] = *reinterpret_cast<const v8s_s*>(a.wt + (size_t)d * kNA + ks * 32 + g * 8);
-        }
-    }
     unsigned long long w0[NRB][4];
 #pragma unroll
     for (int u = 0; u < NRB; ++u) request(u, w0[u]);
     bool own_gave_up = a.max_polls < 0;  // (test hook VAA_K3_HANDOVER_POLLS=-1: the failure path, deterministically)
-    if (!own_gave_up) {
+    if (!own_gave_up) {  // poll with NOTHING else in flight: loads return in order, a retry must not queue behind other requests
         int polls = 0;
         for (;;) {
             bool ok = true;
@@ -376,13 +373,33 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
         }
     }
     K3S_STAMP(4);
+    // ---- phase 3's B operand: fragments of the transposed slice (128 KB / NRB per workgroup), requested in QUARTERS between the stages of the
+    //      statistics below. All sixteen instructions per wave at once (128 KB per CU) stall the wave's issue behind the CU's fetch rate: behind
+    //      the poll they held the statistics back by 2 us, in front of it the poll's words came back 2.9 us late. The workgroup's 16 output tiles:
+    //      NRB row tiles x kDW / 16 column tiles; a wave's two tiles share their column tile when NRB > 1, so it fetches ONE tile's fragments ----
+    constexpr int kDT = kDW / 16;            // column tiles
+    constexpr int kNB = NRB == 1 ? 2 : 1;    // distinct column tiles of a wave's two output tiles
+    const int dbase = (mb * 16 + j) * kDW;
+    const int dt0 = NRB == 1 ? 2 * wv : wv % kDT, rt0 = NRB == 1 ? 0 : (wv / kDT) * 2;  // tiles (rt0, dt0), (rt0 + 1, dt0) — or (0, dt0), (0, dt0 + 1) at NRB = 1
+    v8s_s bfr[kNB][kNA / 32];
+    const uint16_t* bsrc[kNB];
+#pragma unroll
+    for (int t = 0; t < kNB; ++t) bsrc[t] = a.wt + (size_t)min(dbase + (dt0 + t) * 16 + c, D - 1) * kNA + g * 8;  // columns beyond D re-read the last one: never stored
+    auto issue_b = [&](auto qc) {
+        constexpr int kPerQ = kNB * (kNA / 32) / 4, q0 = decltype(qc)::value * kPerQ;
+        if (a.dh) {
+#pragma unroll
+            for (int i = q0; i < q0 + kPerQ; ++i) bfr[i / (kNA / 32)][i % (kNA / 32)] = *reinterpret_cast<const v8s_s*>(bsrc[i / (kNA / 32)] + (i % (kNA / 32)) * 32);
+        }
+    };
+    issue_b(std::integral_constant<int, 0>{});
     float xo[NRB][8], own_alse[NRB], own_E[NRB];
     {   // the own rows, their dependent shuffle chains side by side
         if (own_gave_up) give_up();
         int pred[NRB];
 #pragma unroll
         for (int u = 0; u < NRB; ++u) decode_logits8(w0[u], xo[u]);
-        slice_stats_half<NRB>(xo, hl, own_alse, own_E, pred);
+        slice_stats_half<NRB>(xo, hl, own_alse, own_E, pred, issue_b);  // (quarters 1, 2, 3 of the B fragments go out between its stages)
 #pragma unroll
         for (int u = 0; u < NRB; ++u) {
             if (own_gave_up) { own_alse[u] = __uint_as_float(0x7fc00000u); own_E[u] = own_alse[u]; }
