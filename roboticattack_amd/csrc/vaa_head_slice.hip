@@ -6,23 +6,27 @@
 // (UADA_ddp.py:214-221 logs `celoss` once per outer iteration) and never in UPA's reverse-direction mode — so the 263 MB weight stream of
 // vaa_head.hip (K3h) runs on those steps only, and every step runs this kernel: [R' <= 128, D] x W[31744:32000]^T, 2.1 MB of weights.
 //
-//   grid = ceil(R'/16) row blocks x 16 workgroups of 4 waves; workgroup (rb, j):
+//   grid = ceil(R'/16) row blocks x 16 workgroups of 8 waves; workgroup (rb, j):
 //     phase 1  logits tile [16 rows of block rb] x [16 action columns 16 j ..]: H and W rows go global -> LDS by LDS-DMA in full 128-byte lines
-//              (8 rows x 128 B per instruction, the slot image and XOR placement of head_stats_kernel), a ring of slot groups of four k-chunks,
-//              counted vmcnt waits and ONE raw s_barrier per group; wave 0 runs the single mfma_f32_16x16x32_bf16 accumulator chain over K in
-//              the k-chunk order of the K3h workgroup that owns these columns (start chunk (5 w) mod D/64): the SAME instruction sequence per
-//              output element, so the bf16-rounded logits are bit for bit K3h's. The tile goes to a [R',256] bf16 scratch by agent-scope stores.
-//     hand-over  two-level arrival count + a {generation} word (the scheme of rows_stats_kernel<.., ONEPASS>): the grid is <= 128 workgroups and
-//              admitted only when the device keeps twice that resident; otherwise the same kernel runs as two launches (phases 1, then 2).
+//              (8 rows x 128 B per instruction, the slot image and XOR placement of head_stats_kernel), a ring of groups of four k-chunks with
+//              EXACT request counts, counted vmcnt waits and ONE raw s_barrier per group; wave 0 reads a group's sixteen fragments, then runs the
+//              single mfma_f32_16x16x32_bf16 accumulator chain over K in the k-chunk order of the K3h workgroup that owns these columns (start
+//              chunk (5 w) mod D/64): the SAME instruction sequence per output element, so the bf16-rounded logits are bit for bit K3h's.
+//              A CU's fetch path moves 22-29 B/clk: ~4.4 us for the tile's 256 KB is this phase's floor.
+//     hand-over  the tile goes to a scratch of 64-bit words {launch tag : 32 | logit 2q+1 : 16 | logit 2q : 16} by agent-scope stores; a consumer
+//              polls the very words it is going to use — two memory round trips. The grid is <= 128 workgroups and admitted only when the
+//              device keeps twice that resident; otherwise the same kernel runs as two launches (phase 1, then phases 2 + 3).
 //     phase 2  every workgroup of row block rb reads the block's 16 x 256 logits and recomputes — with the arithmetic of head_finish_kernel /
-//              rows_stats_kernel, two rows per wave instruction — {alse, E, argmax} and the gradient slice
-//              g = kE p_a ((a+1) - E) (UADA_ddp.py:99-114; UPA: kE from the batch means, UPA.py:375-387, all rows folded in the fixed order
-//              of rows_fold) as a bf16 [16,256] MFMA operand in LDS. Workgroups j = 0 leave the SliceStats (and NEUTRAL full-vocabulary parts)
-//              in K3's workspace layout: vaa_step_epilogue folds them as ever; or workgroup 0 folds and publishes scalars + prediction maps itself.
+//              rows_stats_kernel, one row per HALF wave — {alse, E, argmax} and the gradient slice g = kE p_a ((a+1) - E) (UADA_ddp.py:99-114;
+//              UPA: kE from the batch means, UPA.py:375-387, all rows folded in the fixed order of rows_fold) as a bf16 [16,256] MFMA operand in
+//              LDS. Workgroups j = 0 leave the SliceStats (and NEUTRAL full-vocabulary parts) in K3's workspace layout: vaa_step_epilogue folds
+//              them as ever; or workgroup 0 folds and publishes scalars + prediction maps itself.
 //     phase 3  dH[16 rows, 256 j .. 256 j + 256) = g [16,256] x W[31744:32000, those columns]: the B fragments come from a [D,256] transposed copy
-//              of the slice (vaa_head_slice_pack, once per weight) and are requested BEFORE the hand-over wait, so the wait hides their latency.
+//              of the slice (vaa_head_slice_pack, once per weight), requested in quarters BETWEEN the stages of phase 2 (a burst of all of them
+//              stalls the statistics behind the CU's fetch rate).
 //   Bytes per launch at R' = 128, D = 4096: H 1.05 MB + W slice 2.10 MB + transposed slice 2.10 MB read, dH 1.05 MB written = 6.3 MB
-//   (K3h + finish + the 256-column GEMM: 263.7 + 1.05 + ~4.3 MB).
+//   (K3h + finish + the 256-column GEMM: 263.7 + 1.05 + ~4.3 MB). 11.9 us per dispatch warm, ~16 us in the bs=64 step: a latency chain
+//   (profiles/r06_k3s_stamps.txt).
 #include <stdlib.h>
 
 #include <atomic>
@@ -393,6 +397,11 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
         }
     };
     issue_b(std::integral_constant<int, 0>{});
+    unsigned long long wpre[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}};
+    if (all_rows && NRB < nit) {  // UPA / the publishing workgroup: the next two blocks' words travel while the own rows are reduced
+        request(NRB, wpre[0]);
+        request(NRB + 1, wpre[1]);
+    }
     float xo[NRB][8], own_alse[NRB], own_E[NRB];
     {   // the own rows, their dependent shuffle chains side by side
         if (own_gave_up) give_up();
@@ -419,8 +428,13 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     if (all_rows) {
         for (int i0 = NRB; i0 < nit; i0 += 2) {  // the other rows (UPA's batch means, the publishing workgroup's fold): two blocks side by side
             unsigned long long wq[2][4];
-            request(i0, wq[0]);
-            request(i0 + 1, wq[1]);
+            if (i0 == NRB) {  // the first pair was requested in front of the own rows' statistics (below the own poll): its round trip is over
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { wq[0][q] = wpre[0][q]; wq[1][q] = wpre[1][q]; }
+            } else {
+                request(i0, wq[0]);
+                request(i0 + 1, wq[1]);
+            }
             int polls = 0;
             bool gave_up = false;
             while (!__all(valid(wq[0]) && valid(wq[1]))) {
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
         // the fold in rows_fold's order (thread t takes row t; lanes by xor-shuffle, then waves in order): rows_fold<256> has thread t of 256 take
         // rows t, t + 256, ...; R' <= 128 leaves the upper waves empty, so the first four waves' sums in wave order are its bits (adding the
         // other waves' exact zeros changes nothing)
-        double accd[7] = {0, 0, 0, 0, 0, 0, 0};
+        double accd[2] = {0, 0};  // rows_fold's acc[5], acc[6]: each sum is reduced on its own there, so two of its seven give the same bits
         for (int rr = tid; rr < Rn; rr += kST) {
             const RowMap m = rm[rr];
             if (m.ord == 0 && rr + 2 < Rn) {
@@ -464,12 +478,12 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
                 }
                 double c1, nd;
                 u3.terms(c1, nd);
-                accd[5] += c1;
-                accd[6] += nd;
+                accd[0] += c1;
+                accd[1] += nd;
             }
         }
-        block_sums<7, kST>(accd, shf);
-        const double aux1 = 1.0 / (accd[6] / a.ra.B + 1e-3);  // UPA.py:384
+        block_sums<2, kST>(accd, reinterpret_cast<double (*)[2]>(&shf[0][0]));
+        const double aux1 = 1.0 / (accd[1] / a.ra.B + 1e-3);  // UPA.py:384
         if (a.dh || a.gs) {
 #pragma unroll
             for (int u = 0; u < NRB; ++u) {
