@@ -374,6 +374,9 @@ class LoopRunner:
         self.scal10 = torch.zeros((1, 10), dtype=torch.float32, device=dev)
         self.R = int((self.labels[:, 1:] != -100).sum())
         self.sync = None
+        self.k = 0
+        self.read_every = 100  # UPA_wrapper.py:119 (--innerLoop): the loop reads the loss terms of the LAST inner step of an outer iteration (UPA.py:171-186)
+        self.force_ce = None   # True / False pins the step kind (profiled blocks, the finite-state check); None = the cadence
 
     @property
     def scal(self):
@@ -381,12 +384,14 @@ class LoopRunner:
 
     def step(self):
         a = self.att
+        self.k += 1
         if self.name == "uada":
             a.inner_step(self.patch, self.opt, self.img, self.input_ids, self.attn, self.labels, self.geometry, self.scal10, 0)
         elif self.name == "tma":
             a.inner_step(self.patch, self.opt, self.img, self.input_ids, self.attn, self.labels, self.geometry, False, self.scal10, 0)
         else:
-            a.inner_step(self.patch, self.opt, self.img, self.input_ids, self.attn, self.labels, self.geometry, self.mode, self.scale, self.scal10, 0)
+            read = (self.k % self.read_every == 0) if self.force_ce is None else bool(self.force_ce)
+            a.inner_step(self.patch, self.opt, self.img, self.input_ids, self.attn, self.labels, self.geometry, self.mode, self.scale, self.scal10, 0, read_scalars=read)
 
 
 def make_runner(kind, model, dev, B, patch_shape, rank, world, geometry=True, maskidx=None, resize_patch=False):
@@ -606,6 +611,9 @@ def config_block(model, dev, steps):
         n_p = 5
         _, _, _, recs, _ = timed_steps(r, n_p, 0, 1, dev, profile=True)
         kern, op_us = kernel_table(recs, n_p)
+        r.force_ce = True
+        r.step()  # a step that reads its scalars (UPA folds them on the last inner step of an outer iteration only)
+        r.force_ce = None
         e = {"what": what, "loop": kind, "bs": b, "patch": pshape, "geometry": geo, "resize_patch": resize, "labelled_rows": r.R,
              "ms_per_step": dt / n * 1e3, "steps_per_s": n / dt, "images_per_s": b * n / dt, "host_cpu_ms_per_step": cpu * 1e3,
              "hot_path_us_per_step": sum(op_us.values()), "hot_path_launches_per_step": sum(k["launches_per_step"] for k in kern.values()),
@@ -728,7 +736,6 @@ def main():
     if run_weak:
         dt, host_enqueue, host_cpu, _, crecs = timed_steps(runner, args.steps, args.warmup, world, dev, comm=True)
         comm_w = comm_summary(crecs, world, args.steps, dt, dev)
-        finite = bool(torch.isfinite(runner.scal).all())
         # ---- the same steps once more, SEPARATELY, with the library's per-dispatch timer armed: the in-step kernel durations, per step KIND
         #      (slice-only steps, then steps that also evaluate the full-vocabulary CE: 1 of INNER_LOOP in the loop) ----
         if psteps > 0:
@@ -740,6 +747,14 @@ def main():
                 runner.force_ce = True
                 _, _, _, recs_ce, _ = timed_steps(runner, min(psteps, 4), 1, world, dev, profile=True)
                 runner.force_ce = None
+        # the loss scalars of a step that READS them (the loop folds them on the last inner step of an outer iteration only): finite?
+        if hasattr(runner, "force_ce"):
+            runner.force_ce = True
+        runner.step()
+        if hasattr(runner, "force_ce"):
+            runner.force_ce = None
+        torch.cuda.synchronize()
+        finite = bool(torch.isfinite(runner.scal).all()) and bool(torch.isfinite(runner.patch.detach()).all())
     t_region = time.perf_counter() - t_main - t_setup
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2**30
     b2b = allreduce_back_to_back(runner.sync, world) if world > 1 else None
@@ -752,6 +767,9 @@ def main():
         r_s = StepRunner(model, dev, bs_s, patch_shape, rank, world, geometry=geometry)
         dt_s, enq_s, cpu_s, _, crecs_s = timed_steps(r_s, args.steps, args.warmup, world, dev, comm=True)
         comm_s = comm_summary(crecs_s, world, args.steps, dt_s, dev)
+        r_s.force_ce = True
+        r_s.step()
+        r_s.force_ce = None
         fin_s = torch.tensor([1.0 if bool(torch.isfinite(r_s.scal).all()) else 0.0], device=dev)
         dist.all_reduce(fin_s, op=dist.ReduceOp.MIN)
         mem_s = torch.tensor([torch.cuda.max_memory_allocated(dev) / 2**30], dtype=torch.float64, device=dev)

@@ -103,13 +103,16 @@ class AttackBase:
         self.n_img_tokens = vla.vision_backbone.featurizer.patch_embed.num_patches
 
     # ---- the model + loss leg of a step ----
-    def model_loss(self, input_ids, attention_mask, pix, labels, mode, w=5.0, alpha=0.8, beta=0.2, scale=1.0, need_grad=True, full_ce=True):
+    def model_loss(self, input_ids, attention_mask, pix, labels, mode, w=5.0, alpha=0.8, beta=0.2, scale=1.0, need_grad=True, full_ce=True, read_scalars=True):
         """Returns (total [autograd scalar or None], scalars f32[8] device, pred i32 [B,L-1] device).
 
         `full_ce=False` (slice modes — UADA_DDP, UPA — on a model that exposes its hidden rows): the caller will not read this step's
         full-vocabulary CE (scalars[1]) nor the full argmax (`pred`): the reference reads them on the LAST inner step of an outer iteration
         only (UADA_ddp.py:214-221) and never in UPA's reverse-direction mode (UPA.py:145-186). The step then runs K3s alone — 2.1 MB of head
         weights instead of the 263 MB stream; scalars[1] = 0, pred = -1. The gradient path is the same on every step either way.
+        `read_scalars=False` (same models and modes, training steps): the caller reads NONE of this step's loss scalars — the loops read the
+        scalars of the last inner step of an outer iteration only (UADA_ddp.py:214-221, UPA.py:171-186) — so not even the slice statistics are
+        folded: scalars = 0 (implies full_ce=False).
 
         `pred` is the argmax over the WHOLE vocabulary at every labelled position (-1 elsewhere), i.e. the reference's
         `action_logits.argmax(dim=2)` (UADA.py:165-167, TMA.py:148-149) that its relative-distance / L1 / ASR metrics and the
@@ -127,7 +130,7 @@ class AttackBase:
                 if mode in ops.SLICE_MODES and self._slice_head(int(h.shape[0]), h, W):
                     # K3s: slice-only head + statistics + gradient + head backward in ONE launch, on every step; K3h's 263 MB stream only
                     # behind it on the steps whose CE / full argmax is read
-                    total, scalars, _, pred_full = ops.HeadSliceLoss.apply(h, W, self._row_map, mode, w, alpha, beta, scale, bool(full_ce))
+                    total, scalars, _, pred_full = ops.HeadSliceLoss.apply(h, W, self._row_map, mode, w, alpha, beta, scale, bool(full_ce), bool(read_scalars))
                     return total, scalars, pred_full
                 head = ops.HeadLossRowsFused if (mode in ops.SLICE_MODES and self._fused_head(int(h.shape[0]), h, W)) else ops.HeadLossRows
                 total, scalars, _, pred_full = head.apply(h, W, self._row_map, mode, w, alpha, beta, scale)
@@ -209,7 +212,8 @@ class AttackBase:
         """The UADA_ddp inner step (UADA_ddp.py:189-206) up to the gradient exchange, six hand-written launches around the model:
         K1 -> [ViTs, Llama, LM head on the labelled rows] -> K3 statistics + gradient slice -> [head / model backward] -> K2' tile GEMM ->
         scatter -> epilogue. On return `msg` (f32 [3*ph*pw + 4]) holds [patch gradient | CE, w^2*MSE, UAD, total] of THIS rank, ready for
-        one all-reduce, and `scalars` (f32[8]) the loss scalars; returns the full-vocabulary predictions [B,L-1] (i32, device).
+        one all-reduce, and `scalars` (f32[8]) the loss scalars; returns the full-vocabulary predictions [B,L-1] (i32, device) — all three only on
+        the steps the caller marks `full_ce` (the steps whose scalars are read; else the tail / `scalars` are left as they were and None is returned).
         Nothing is synchronised; patch.grad is not touched. `optimizer` (single-GPU run, no L1 clip): K4 is applied by the epilogue launch
         itself — five launches per step, the caller then calls neither the all-reduce nor optimizer.step()."""
         pack = self._rows_cache(labels, attention_mask)
@@ -227,9 +231,14 @@ class AttackBase:
             o = ops.head_slice_fwd_bwd(hd, W, self._row_map, ops.LOSS_UADA_DDP, w, want_dh=True, want_scalars=False)
             ws = ops.head_loss_rows_stats(hd, W, self._row_map, ops.LOSS_UADA_DDP, w) if full_ce else o["ws"]
             h.backward(o["dh"])
+            upd = optimizer.fused_update_args() if optimizer is not None else None
+            if not full_ce:
+                # nobody reads this step's loss scalars (the loop reads those of the LAST inner step of an outer iteration: UADA_ddp.py:214-221):
+                # the epilogue in its pass-through form — K2's final sum (+ K4), no fold; `scalars` / the message tail keep the last read step's values
+                ops.step_epilogue(sink["partials"], msg, scalars, update=upd)
+                return None
             _, pred_full = ops.step_epilogue(sink["partials"], msg, scalars, rowmap=self._row_map, R=R, V=int(W.shape[0]),
-                                             mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws,
-                                             update=optimizer.fused_update_args() if optimizer is not None else None)
+                                             mode=ops.LOSS_UADA_DDP, w=w, loss_ws=ws, update=upd)
             return pred_full
         gsl = torch.empty((R, ops.N_ACTION), dtype=h.dtype, device=h.device)
         if self._fused_head(R, h, W):

@@ -149,7 +149,7 @@ class OpenVLAAttacker(AttackBase):
                             pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std,
                                                                                       geometry=self.geometry)
                             total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, self._loss_mode(), w=float(self.MSE_weights),
-                                                                   alpha=self.alpha, beta=self.belta, full_ce=full_ce)
+                                                                   alpha=self.alpha, beta=self.belta, full_ce=full_ce, read_scalars=full_ce)
                             total.backward()  # K2 inside
                             exchanged = True
                             g_sum, s_sum = sync.allreduce_step(patch.grad, scalars, pick)

@@ -8,6 +8,8 @@ before AdamW (UPA.py:157) — fused into K4. Validation: 100 batches, best patch
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -51,17 +53,22 @@ class OpenVLAAttacker(AttackBase):
             return ops.LOSS_UPA, 1.0
         return ops.LOSS_CE, -1.0  # loss = -output.loss (UPA.py:150)
 
-    def inner_step(self, patch, optimizer, pixel_values, input_ids, attention_mask, labels, geometry, mode, scale, scalars_out, k, do_step=True):
+    def inner_step(self, patch, optimizer, pixel_values, input_ids, attention_mask, labels, geometry, mode, scale, scalars_out, k, do_step=True, read_scalars=True):
         """One iteration of the hot inner loop (UPA.py:127-159): [K0 per-image patch resize ->] K1 -> model -> K3 (K3h when the loss lives in the
         action slice) -> backward -> K2 / K2' (MULTI forms with resize_patch) -> K4 with the L1 clip (UPA.py:157) in front of AdamW."""
         pix = self.randomPatchTransform.apply_random_patch_batch(pixel_values, patch, mean=self.mean, std=self.std, geometry=geometry)
         # the reverse-direction loop never reads output.loss nor a full-vocabulary argmax (UPA.py:145-150,171-186): slice-only head (K3s)
-        total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, mode, alpha=self.alpha, beta=self.belta, scale=scale, full_ce=False)
+        # (`read_scalars`: the loop prints / logs the loss terms of the LAST inner step of an outer iteration only, UPA.py:171-186: the others skip the fold)
+        total, scalars, pred = self.model_loss(input_ids, attention_mask, pix, labels, mode, alpha=self.alpha, beta=self.belta, scale=scale, full_ce=False,
+                                               read_scalars=read_scalars)
         total.backward()
         if do_step:
-            scalars_out[k, 8:10] = optimizer.step()  # K4: L1 clip 1e-3 -> AdamW -> clamp
+            stats = optimizer.step()  # K4: L1 clip 1e-3 -> AdamW -> clamp
+            if read_scalars:
+                scalars_out[k, 8:10] = stats
             optimizer.zero_grad()
-        scalars_out[k, :8] = scalars
+        if read_scalars:
+            scalars_out[k, :8] = scalars
         return pred
 
     def patchattack_unconstrained(self, train_dataloader, val_dataloader, num_iter=5000, target_action=np.zeros(7),
@@ -90,8 +97,10 @@ class OpenVLAAttacker(AttackBase):
             if guide:
                 labels = self.change_target(labels)
             do_step = (i + 1) % accumulate_steps == 0 or (i + 1) == len(train_dataloader)
+            every = os.environ.get("VAA_FULL_CE_EVERY_STEP", "0") == "1"  # (=1: every step folds its scalars; same patch bits)
             for inner_loop in range(innerLoop):
-                self.inner_step(patch, optimizer, pixel_values, input_ids, attention_mask, labels, geometry, mode, scale, scal, inner_loop, do_step=do_step)
+                self.inner_step(patch, optimizer, pixel_values, input_ids, attention_mask, labels, geometry, mode, scale, scal, inner_loop, do_step=do_step,
+                                read_scalars=every or inner_loop == innerLoop - 1)
             if scheduler is not None and do_step:
                 scheduler.step()
             host = scal[:innerLoop].cpu().numpy()

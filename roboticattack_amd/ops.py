@@ -880,21 +880,40 @@ class HeadLossRowsFused(torch.autograd.Function):
         return dh, None, None, None, None, None, None, None
 
 
+_silent_cache = {}
+
+
+def _silent_outputs(device, B: int, L: int):
+    """What a step whose loss scalars nobody reads hands back: zeros[8] and -1 maps (allocated once per device and shape; never written)."""
+    key = (device.index, B, L)
+    hit = _silent_cache.get(key)
+    if hit is None:
+        hit = (torch.zeros(8, dtype=torch.float32, device=device), torch.full((B, L - 1), -1, dtype=torch.int32, device=device))
+        _silent_cache[key] = hit
+    return hit
+
+
 class HeadSliceLoss(torch.autograd.Function):
     """The slice modes' head + loss + head backward as K3s (head_slice_fwd_bwd: ONE launch; d total / d hidden is produced in the forward and
-    handed back by the backward). `full_ce` — a step whose full-vocabulary CE / argmax is READ (the last inner step of an outer iteration,
-    UADA_ddp.py:214-221; validation passes that log CE) — adds K3h's statistics pass + fold for the scalars and prediction maps: the
-    gradient path is K3s's on every step, so the patch trajectory does not depend on which steps evaluate CE.
-    Returns (total, scalars f32[8], pred_slice, pred_full); scalars[1] (CE) = 0 and pred_full = -1 on slice-only steps."""
+    handed back by the backward). `read_scalars=False` — a step whose loss scalars the loop never reads (every inner step but the last of an
+    outer iteration: UADA_ddp.py:214-221, UPA.py:171-186) — runs the launch without its fold: scalars = 0, maps = -1. `full_ce` — a step whose
+    full-vocabulary CE / argmax is READ (the last inner step of the data-parallel UADA loop; validation passes that log CE) — adds K3h's
+    statistics pass + fold for the scalars and prediction maps. The gradient path is K3s's on every step, so the patch trajectory does not
+    depend on which steps evaluate what.
+    Returns (total, scalars f32[8], pred_slice, pred_full); scalars[1] (CE) = 0 and pred_full = -1 unless full_ce."""
 
     @staticmethod
-    def forward(ctx, hidden, weight, rowmap, mode, w, alpha, beta, scale, full_ce):
+    def forward(ctx, hidden, weight, rowmap, mode, w, alpha, beta, scale, full_ce, read_scalars=True):
         h = hidden.detach().contiguous()
-        o = head_slice_fwd_bwd(h, weight, rowmap, mode, w, alpha, beta, scale, want_dh=True, want_scalars=not full_ce)
+        full_ce = bool(full_ce and read_scalars)
+        o = head_slice_fwd_bwd(h, weight, rowmap, mode, w, alpha, beta, scale, want_dh=True, want_scalars=bool(read_scalars and not full_ce))
         if full_ce:  # K3s left the SliceStats + neutral parts; K3h now writes the real parts (and the same SliceStat bits) into the same workspace
             scalars, pred, pred_full, _ = head_loss_rows_fwd_bwd(h, weight, rowmap, mode, w, alpha, beta, scale, want_grad=False)
-        else:
+        elif read_scalars:
             scalars, pred, pred_full = o["scalars"], o["pred"], o["pred_full"]
+        else:
+            scalars, pred = _silent_outputs(h.device, rowmap.B, rowmap.L)
+            pred_full = pred
         ctx.save_for_backward(o["dh"])
         ctx.mark_non_differentiable(scalars, pred, pred_full)
         return scalars[0].clone(), scalars, pred, pred_full
@@ -902,7 +921,7 @@ class HeadSliceLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtotal, _gs, _gp, _gf):
         (dh,) = ctx.saved_tensors
-        return dh * gtotal.to(dh.dtype), None, None, None, None, None, None, None, None
+        return dh * gtotal.to(dh.dtype), None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------

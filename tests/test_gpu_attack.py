@@ -394,9 +394,9 @@ def test_ddp_attacker_slice_head_cadence(tmp_path, monkeypatch):
         class Att(uada_ddp.OpenVLAAttacker):
             val_every = 10 ** 9
 
-            def assert_finite_state(self, patch, optimizer, host, where, all_ranks=False):
+            def assert_finite_state(self, patch, optimizer, host, where, **kw):
                 snaps.append(patch.detach().cpu().numpy().copy())
-                return super().assert_finite_state(patch, optimizer, host, where, all_ranks=all_ranks)
+                return super().assert_finite_state(patch, optimizer, host, where, **kw)
 
         att = Att(vla_path="x", dataset_name="synthetic", save_dir=str(tmp_path / tag), patch_size=[3, 50, 50], lr=0.02, bs=3, warmup=1, num_iter=iters, maskidx=[0],
                   innerLoop=inner, geometry=True, use_wandb=False, MSE_weights=5,
@@ -422,6 +422,59 @@ def test_ddp_attacker_slice_head_cadence(tmp_path, monkeypatch):
     assert np.abs(runs["cadence"][3] - runs["r5"][3]).max() <= 2e-5 and np.abs(runs["cadence"][3] - runs["cadence"][0][0]).max() > 1e-3  # (it moved)
     for k in ("TRAIN_attack_loss(CE)", "TRAIN_attack_loss (MSE_Distance)", "TRAIN_UAD"):
         assert runs["cadence"][1][k] == pytest.approx(runs["r5"][1][k], rel=2e-3, abs=1e-5)
+
+
+def test_upa_loop_slice_head_silent_steps(tmp_path, monkeypatch):
+    """UPA's reverse-direction loop on a model that exposes its hidden rows: K3s alone on every inner step (the loop never reads CE, UPA.py:145-186), and
+    the loss terms are folded only on the LAST inner step of an outer iteration — the only ones the loop prints / logs (UPA.py:171-186). Against the
+    same run folding on every step (VAA_FULL_CE_EVERY_STEP=1): patch after every optimiser step and the logged terms bit for bit. Against the round-5
+    path (VAA_HEAD_EVERY_STEP=1: K3h + finish + the 256-column GEMM): patches to 2e-5, logged terms to 2e-3."""
+    import types
+
+    from roboticattack_amd import ops
+    from roboticattack_amd.attack.upa import OpenVLAAttacker
+    from roboticattack_amd.openvla_model import OpenVLACfg, VitCfg, build_openvla
+    from roboticattack_amd.optim import PatchOptimizer
+
+    cfg = OpenVLACfg(dino=VitCfg(128, 3, 2, 256, 5, False, True), siglip=VitCfg(192, 3, 2, 384, 0, False, False), llm_dim=256, llm_layers=2, llm_heads=2, llm_mlp=512)
+    vla = build_openvla(cfg, device=DEV, dtype=torch.bfloat16, seed=17)
+    args = types.SimpleNamespace(wandb_project="false")
+    inner, n_it, bs = 3, 3, 2
+    runs = {}
+    orig_step = PatchOptimizer.step
+    for tag, env in (("default", {}), ("every", {"VAA_FULL_CE_EVERY_STEP": "1"}), ("r5", {"VAA_HEAD_EVERY_STEP": "1"})):
+        for k in ("VAA_FULL_CE_EVERY_STEP", "VAA_HEAD_EVERY_STEP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _seed()
+        snaps, logs = [], []
+
+        def rec(self, *a, **k):
+            r = orig_step(self, *a, **k)
+            snaps.append(self.patch.detach().cpu().numpy().copy())
+            return r
+
+        monkeypatch.setattr(PatchOptimizer, "step", rec)
+        att = OpenVLAAttacker(vla, None, str(tmp_path / tag), optimizer="adamW", resize_patch=False, alpha=0.8, belta=0.2)
+        att.val_batches = 1
+        train, val = _Fresh([31 + i for i in range(n_it)], bs), _Fresh([77], 1)
+        ops.prof_start(4096)
+        att.patchattack_unconstrained(train, val, num_iter=n_it, patch_size=[3, 50, 50], lr=0.03, accumulate_steps=1, maskidx=[0, 1, 2], warmup=1, geometry=True,
+                                      innerLoop=inner, guide=False, reverse_direction=True, args=args)
+        names = [n for n, _ in ops.prof_collect()]
+        runs[tag] = (snaps, dict(att.last_train_log), list(att.train_CE_loss), names)
+        monkeypatch.setattr(PatchOptimizer, "step", orig_step)
+    nm = runs["default"][3]
+    assert sum("head_slice_kernel" in n for n in nm) >= inner * n_it and not any("head_stats_kernel" in n for n in nm)  # K3s only, training and validation
+    assert any("head_stats_kernel" in n for n in runs["r5"][3]) and not any("head_slice_kernel" in n for n in runs["r5"][3])
+    assert len(runs["default"][0]) == inner * n_it
+    for a, b in zip(runs["default"][0], runs["every"][0]):
+        assert np.array_equal(a, b)
+    assert runs["default"][1] == runs["every"][1] and runs["default"][2] == runs["every"][2] and runs["default"][1]["TRAIN_ANGLE_LOSS"] > 0
+    assert np.abs(runs["default"][0][-1] - runs["r5"][0][-1]).max() <= 2e-5 and np.abs(runs["default"][0][-1] - runs["default"][0][0]).max() > 1e-3
+    for k in ("TRAIN_attack_loss(CE)", "TRAIN_ANGLE_LOSS", "TRAIN_DISTANCE_LOSS"):
+        assert runs["default"][1][k] == pytest.approx(runs["r5"][1][k], rel=2e-3, abs=1e-5)
 
 
 def _two_rank_worker(rank, world, port, out_dir, attack, num_iter, inner, bs, resize=False, psize=50):

@@ -693,8 +693,14 @@ def test_k4_every_form_vs_oracle(ops, shape, mode):
         s = st.cpu().numpy()
         scale = 0.5 if mode != "pgd" else 1.0
         assert abs(s[0] - l1) <= 1e-5 * l1 and abs(s[1] - scale * g.mean()) <= 1e-6 * abs(g).mean() + 1e-9
-    with pytest.raises(Exception, match="alias"):
+    with pytest.raises(Exception, match="overlap"):
         ops.patch_update(p, p, m, v, ops.OPT_ADAMW_HF, 1e-3, 1)
+    # ... and a gradient that only PARTLY overlaps a buffer it is not pointer-equal to (views into one flat buffer: ADVICE r5)
+    flat = torch.zeros(2 * n, device=DEV)
+    pv, gv = flat[:n].view(shape), flat[n // 2 : n // 2 + n].view(shape)
+    with pytest.raises(Exception, match="overlap"):
+        ops.patch_update(pv, gv, m, v, ops.OPT_ADAMW_HF if mode != "pgd" else ops.OPT_PGD_SIGN, 1e-3, 1)
+    ops.patch_update(pv, flat[n:].view(shape), m, v, ops.OPT_ADAMW_HF if mode != "pgd" else ops.OPT_PGD_SIGN, 1e-3, 1)  # adjacent, not overlapping: fine
 
 
 @pytest.mark.parametrize("mode,maskidx,dtype", [("UADA_DDP", [0], torch.bfloat16), ("UADA_DDP", [0, 1, 2], torch.float32), ("UADA", [0], torch.float32),
