@@ -108,15 +108,17 @@ class SurrogateEmbedVLA(nn.Module):
         x = pixel_values.to(torch.bfloat16)
         return F.linear(self._tiles(x[:, :3]), self.w0, self.b0), F.linear(self._tiles(x[:, 3:]), self.w1, self.b1)
 
-    def _logits(self, input_ids, e0, e1):
+    def _hidden(self, input_ids, e0, e1):
         x = torch.cat([e0, e1], dim=2).float() @ self.proj  # [B,256,d] fp32 from here on
         te = self.tok[input_ids]
         h = torch.cat([te[:, :1], x, te[:, 1:]], dim=1)
         S = h.shape[1]
         denom = torch.arange(1, S + 1, device=h.device, dtype=h.dtype)[None, :, None]
         c = torch.cumsum(h, dim=1) / denom
-        h2 = torch.tanh(c @ self.mix) + 0.25 * h
-        return h2 @ self.head
+        return torch.tanh(c @ self.mix) + 0.25 * h
+
+    def _logits(self, input_ids, e0, e1):
+        return self._hidden(input_ids, e0, e1) @ self.head
 
     def forward(self, input_ids, attention_mask=None, pixel_values=None, labels=None, **_):
         logits = self._logits(input_ids, *self.embeds(pixel_values))
@@ -145,3 +147,27 @@ class SurrogateEmbedVLA(nn.Module):
         if row_index is None:
             row_index = self.label_row_index(labels)
         return logits.reshape(-1, logits.shape[-1]).index_select(0, row_index)
+
+
+class SurrogateHeadVLA(SurrogateEmbedVLA):
+    """SurrogateEmbedVLA with a bf16 LM head over bf16 hidden states — `lm_head.weight` [vocab, d] as LlamaForCausalLM holds it, logits upcast to
+    fp32 ([3p transformers 4.40.1 modeling_llama.py]: `logits = logits.float()`) — and the hidden-rows interface of OpenVLAShaped
+    (`hidden_rows`, `lm_head`): the smallest model on which the slice-only head K3s (vaa_head_slice_fwd_bwd) runs inside an attack loop, so that
+    K3s, K2' and the fused update sit together on a REFERENCE-LOOP trajectory (tools/gen_golden.py:gen_trajectory_upa_k3s drives the
+    reference's own UPA loop over this module on the CPU: bf16 matmul head, torch autograd through it).  d = 192: three of K3s's 64-wide
+    k-chunks, so its chunk rotation is exercised."""
+
+    def __init__(self, d: int = 192, D0: int = 64, D1: int = 128, vocab: int = MODEL_VOCAB, seed: int = 0):
+        super().__init__(d=d, D0=D0, D1=D1, vocab=vocab, seed=seed)
+        g = torch.Generator().manual_seed(seed + 7919)
+        self.lm_head = nn.Linear(d, vocab, bias=False)
+        self.lm_head.weight = nn.Parameter((torch.randn(vocab, d, generator=g) * (16.0 / math.sqrt(d))).to(torch.bfloat16), requires_grad=False)
+        self.head = None  # the fp32 head of the parent is not part of this model
+
+    def _logits(self, input_ids, e0, e1):
+        return self.lm_head(self._hidden(input_ids, e0, e1).to(torch.bfloat16)).float()
+
+    def hidden_rows(self, input_ids, pixel_values, row_index, patch_embeds=None, pack=None):
+        e0, e1 = (patch_embeds[0], patch_embeds[1]) if patch_embeds is not None else self.embeds(pixel_values)
+        h = self._hidden(input_ids, e0, e1)
+        return h.reshape(-1, h.shape[-1]).index_select(0, row_index).to(torch.bfloat16)

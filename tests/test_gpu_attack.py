@@ -1190,6 +1190,84 @@ def test_uada_trajectory_k2e_vs_reference_loop(tmp_path, monkeypatch):
     np.testing.assert_allclose(att.train_UAD, d["train_uad"], atol=1e-4)
 
 
+def test_upa_trajectory_k3s_vs_reference_loop(tmp_path, monkeypatch):
+    """The slice-only head K3s on a reference-loop trajectory: tools/gen_golden.py:gen_trajectory_upa_k3s drove the reference's own
+    `UPA.patchattack_unconstrained` (reverse_direction loss, geometry=True, L1 clip + HF AdamW) over SurrogateHeadVLA on the CPU — bf16
+    patch-embed towers, fp32 body, bf16 hidden states into a bf16 LM head through torch's bf16 matmul and its autograd — and recorded the patch
+    after every optimiser step. Here the same module sits on the GPU and exposes its hidden rows, LM head and patch-embed weights, so every
+    training step is K1 tile-major -> model body -> K3s (vaa_head_slice_fwd_bwd: slice logits, statistics, gradient slice and d loss / d hidden in
+    one launch; no full-vocabulary logits anywhere) -> K2' -> L1 clip + AdamW: the patch after EVERY step, `last/patch.pt` and the logged losses
+    agree within the north-star tolerance 1e-4, and K3s is the kernel that ran (profiled), never K3h or the [R,V] statistics."""
+    import types
+
+    from roboticattack_amd import ops
+    from roboticattack_amd.attack.upa import OpenVLAAttacker
+    from roboticattack_amd.surrogate import SurrogateHeadVLA
+
+    d = np.load(os.path.join(GOLDEN, "traj_upa_k3s.npz"))
+    n_it, inner, bs = int(d["num_iter"]), int(d["inner"]), int(d["bs"])
+    vla = SurrogateHeadVLA(seed=int(d["model_seed"])).to(DEV)
+    att = OpenVLAAttacker(vla, None, str(tmp_path), optimizer="adamW", resize_patch=False, alpha=float(d["alpha"]), belta=float(d["belta"]))
+    assert att.randomPatchTransform.embed_with is vla and att.use_rows
+    att.val_batches = 2
+    calls = {"k3s_train": 0, "k3s_eval": 0, "k2e": 0, "other_heads": 0}
+    o_k3s, o_k2e = ops.head_slice_fwd_bwd, ops.patch_embed_grad_gather_tiles
+
+    def c_k3s(*a, **k):
+        calls["k3s_train" if k.get("want_dh", True) else "k3s_eval"] += 1
+        return o_k3s(*a, **k)
+
+    def c_k2e(*a, **k):
+        calls["k2e"] += 1
+        return o_k2e(*a, **k)
+
+    def other(name):
+        orig = getattr(ops, name)
+
+        def f(*a, **k):
+            calls["other_heads"] += 1
+            return orig(*a, **k)
+
+        return f
+
+    monkeypatch.setattr(ops, "head_slice_fwd_bwd", c_k3s)
+    monkeypatch.setattr(ops, "patch_embed_grad_gather_tiles", c_k2e)
+    for name in ("head_loss_rows_stats", "head_loss_rows_fwd_bwd", "loss_rows_fwd_bwd"):
+        monkeypatch.setattr(ops, name, other(name))
+    snaps = []
+    orig = att.inner_step
+
+    def rec(patch, *a, **k):
+        r = orig(patch, *a, **k)
+        snaps.append(patch.detach().cpu().numpy().copy())
+        return r
+
+    att.inner_step = rec
+    _seed()
+    train = _Fresh([int(d["train_seed0"]) + i for i in range(n_it)], bs)
+    val = _Fresh([int(d["val_seed"])], 1)
+    ops.prof_start(4096)
+    att.patchattack_unconstrained(train, val, num_iter=n_it, patch_size=[3, 50, 50], lr=float(d["lr"]), accumulate_steps=1, maskidx=list(d["maskidx"]),
+                                  warmup=int(d["warmup"]), geometry=True, innerLoop=inner, guide=False, reverse_direction=True,
+                                  args=types.SimpleNamespace(wandb_project="false"))
+    kernels = [n for n, _ in ops.prof_collect()]
+    n_slice = sum("head_slice_kernel" in n for n in kernels)
+    assert calls["k3s_train"] == n_it * inner and calls["k2e"] == n_it * inner and calls["other_heads"] == 0, calls
+    assert calls["k3s_eval"] == att.val_batches  # one validation pass (i = 0), also slice-only
+    assert n_slice >= n_it * inner + att.val_batches and not any(k in n for n in kernels for k in ("head_stats_kernel", "loss_stats_kernel", "loss_grad_kernel", "rows_stats_kernel")), sorted(set(kernels))
+    ref = d["patches"]
+    assert len(snaps) == len(ref) == n_it * inner
+    err = [float(np.abs(s - r).max()) for s, r in zip(snaps, ref)]
+    print("per-step max |patch - reference|:", ["%.2e" % e for e in err], "movement", float(np.abs(ref[-1] - ref[0]).max()))
+    assert max(err) <= 1e-4, err  # the north-star tolerance ...
+    assert max(err) <= 2e-5, err  # ... and what this loop actually holds: 4.9e-6 after 9 moving steps, 0.25 % of the distance travelled
+    # it moves (the L1 clip to 1e-3 in front of HF AdamW's eps = 1e-6 makes UPA's steps ~0.1 * lr: UPA.py:157); lr = 0 during outer iteration 0
+    assert np.abs(ref[-1] - ref[0]).max() > 1e-3 and np.array_equal(snaps[0], snaps[inner - 1])
+    last = torch.load(os.path.join(str(tmp_path), "last", "patch.pt"))
+    assert np.abs(last.numpy() - d["last_saved"]).max() <= 1e-4
+    np.testing.assert_allclose(att.train_CE_loss, d["train_ce"], rtol=3e-4)
+
+
 def test_fused_head_step_vs_gemm_head_step(monkeypatch):
     """The data-parallel UADA step with the LM head FUSED into K3's statistics (vaa_head_loss_rows_stats: what `fused_ddp_step` runs up to 128
     labelled rows, i.e. at every batch size of BASELINE's configs) against the same step with the head as a hipBLASLt GEMM +
