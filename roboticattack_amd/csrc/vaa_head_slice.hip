@@ -6,27 +6,30 @@
 // (UADA_ddp.py:214-221 logs `celoss` once per outer iteration) and never in UPA's reverse-direction mode — so the 263 MB weight stream of
 // vaa_head.hip (K3h) runs on those steps only, and every step runs this kernel: [R' <= 128, D] x W[31744:32000]^T, 2.1 MB of weights.
 //
-//   grid = ceil(R'/16) row blocks x 16 workgroups of 8 waves; workgroup (rb, j):
-//     phase 1  logits tile [16 rows of block rb] x [16 action columns 16 j ..]: H and W rows go global -> LDS by LDS-DMA in full 128-byte lines
-//              (8 rows x 128 B per instruction, the slot image and XOR placement of head_stats_kernel), a ring of groups of four k-chunks with
-//              EXACT request counts, counted vmcnt waits and ONE raw s_barrier per group; wave 0 reads a group's sixteen fragments, then runs the
-//              single mfma_f32_16x16x32_bf16 accumulator chain over K in the k-chunk order of the K3h workgroup that owns these columns (start
+//   grid = ceil(R'/16) row blocks x 32 workgroups of 8 waves (8-column form, the default; 16 workgroups in the 16-column form); workgroup (rb, j):
+//     phase 1  logits tile [16 rows of block rb] x [8 action columns 8 j ..] (the 16 x 16 MFMA tile carries its eight columns twice): H and W rows go
+//              global -> LDS by LDS-DMA in full 128-byte lines (8 rows x 128 B per instruction, the slot image and XOR placement of
+//              head_stats_kernel), a ring of groups of four k-chunks with EXACT request counts, counted vmcnt waits and ONE raw s_barrier per group;
+//              wave 0 keeps two half groups of fragments — the reads of one half travel while the four dependent MFMAs of the other run — and runs
+//              the single mfma_f32_16x16x32_bf16 accumulator chain over K in the k-chunk order of the K3h workgroup that owns these columns (start
 //              chunk (5 w) mod D/64): the SAME instruction sequence per output element, so the bf16-rounded logits are bit for bit K3h's.
-//              A CU's fetch path moves 22-29 B/clk: ~4.4 us for the tile's 256 KB is this phase's floor.
+//              What bounds the kernel is what ONE CU has to fetch (its fetch path moves 22-29 B/clk): 128 KB of hidden rows + 8 KB per action
+//              column + (phase 3) 512 B per column of dH — 256 KB per CU on 256 CUs in this form, 384 KB per CU on 128 CUs in the 16-column form.
 //     hand-over  the tile goes to a scratch of 64-bit words {launch tag : 32 | logit 2q+1 : 16 | logit 2q : 16} by agent-scope stores; a consumer
-//              polls the very words it is going to use — two memory round trips. The grid is <= 128 workgroups and admitted only when the
-//              device keeps twice that resident; otherwise the same kernel runs as two launches (phase 1, then phases 2 + 3).
+//              polls the very words it is going to use — two memory round trips. The grid is <= 256 workgroups of 72 KB LDS and 122 VGPRs (two per
+//              CU) and admitted only when the device keeps twice that resident; otherwise the same kernel runs as two launches (phase 1, then
+//              phases 2 + 3).
 //     phase 2  every workgroup of row block rb reads the block's 16 x 256 logits and recomputes — with the arithmetic of head_finish_kernel /
 //              rows_stats_kernel, one row per HALF wave — {alse, E, argmax} and the gradient slice g = kE p_a ((a+1) - E) (UADA_ddp.py:99-114;
 //              UPA: kE from the batch means, UPA.py:375-387, all rows folded in the fixed order of rows_fold) as a bf16 [16,256] MFMA operand in
 //              LDS. Workgroups j = 0 leave the SliceStats (and NEUTRAL full-vocabulary parts) in K3's workspace layout: vaa_step_epilogue folds
 //              them as ever; or workgroup 0 folds and publishes scalars + prediction maps itself.
-//     phase 3  dH[16 rows, 256 j .. 256 j + 256) = g [16,256] x W[31744:32000, those columns]: the B fragments come from a [D,256] transposed copy
+//     phase 3  dH[16 rows, 128 j .. 128 j + 128) = g [16,256] x W[31744:32000, those columns]: the B fragments come from a [D,256] transposed copy
 //              of the slice (vaa_head_slice_pack, once per weight), requested in quarters BETWEEN the stages of phase 2 (a burst of all of them
-//              stalls the statistics behind the CU's fetch rate).
+//              stalls the statistics behind the CU's fetch rate; all of them in front of the poll: no better, 10.8 against 9.7 us at 16 rows).
 //   Bytes per launch at R' = 128, D = 4096: H 1.05 MB + W slice 2.10 MB + transposed slice 2.10 MB read, dH 1.05 MB written = 6.3 MB
-//   (K3h + finish + the 256-column GEMM: 263.7 + 1.05 + ~4.3 MB). 11.9 us per dispatch warm, ~16 us in the bs=64 step: a latency chain
-//   (profiles/r06_k3s_stamps.txt).
+//   (K3h + finish + the 256-column GEMM: 263.7 + 1.05 + ~4.3 MB). 10.4 us per dispatch warm (16-column form: 11.7; round 6's first form 12.1),
+//   13.5-13.7 us in the bs=64 step (15.2-15.4; 15.6-15.7): a latency chain (profiles/r06_k3s_stamps.txt).
 #include <stdlib.h>
 
 #include <atomic>
@@ -49,11 +52,14 @@ constexpr int kSGroups = 16;                // D = 4096: 64 k-chunks
 #define VAA_SLICE_RING 8
 #endif
 constexpr int kSRing = VAA_SLICE_RING;      // groups of 16 KB in LDS: kSRing - 1 in flight (two 1 KB instructions per wave and group)
-constexpr int kSRows = 32;                  // rows per slot: 16 hidden + 16 weight
-constexpr int kSSlot = kSRows * kSK;        // elements per chunk image
+#ifndef VAA_SLICE_RING8
+#define VAA_SLICE_RING8 6
+#endif
+constexpr int kSRing8 = VAA_SLICE_RING8;    // ... of the 8-column form (groups of 12 KB): 72 KB, so that TWO workgroups fit a CU (its grid is up to 256)
+constexpr int kSDMax = 4096;                // D covered: workgroups per row block x columns of dH per workgroup
 constexpr int kSGS = kNA + 8;               // row stride (bf16) of the gradient / output tiles in LDS
 constexpr int kSRowsMax = 128;
-constexpr int kSTPW = 2;                    // 16-column output tiles per wave in phase 3: 16 workgroups x 8 waves x 2 tiles x 16 = D <= 4096
+
 
 struct SliceHeadArgs {
     const uint16_t* h;   // [R, D] bf16 hidden rows (final norm applied)
@@ -176,20 +182,29 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #define K3S_STAMP(i) do { } while (0)
 #endif
 
-template <int NRB>
-__global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
-    extern __shared__ __align__(16) uint16_t smem[];  // phase 1: the ring [kSRing][4 chunks][32 rows][64]; afterwards the gradient and output tiles
+// CT = action columns per workgroup in phase 1: 16 (16 workgroups per row block) or 8 (32 workgroups per row block: the 16 x 16 MFMA tile carries
+// its eight columns twice; what bounds this kernel is what ONE CU has to fetch — 128 KB of hidden rows + CT x 8 KB of weight rows + 4096 / (256 / CT)
+// x 512 B of the transposed slice — so half the columns per workgroup on twice the CUs: 256 instead of 384 KB per CU)
+template <int NRB, int CT>
+__global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(CT == 8 ? 4 : 2, CT == 8 ? 4 : 2))) void head_slice_kernel(SliceHeadArgs a) {
+    static_assert(CT == 16 || (CT == 8 && NRB == 1), "row-block groups exist in the 16-column form only");
+    constexpr int kJ = kNA / CT;            // workgroups per row block
+    constexpr int kRS = 16 + CT;            // rows of a chunk image: 16 hidden + CT weight rows
+    [[maybe_unused]] constexpr int kSSlot = kRS * kSK;       // elements per chunk image
+    [[maybe_unused]] constexpr int kOct = kRS / 8;           // LDS-DMA instructions (8 rows x 128 B) per chunk image
+    [[maybe_unused]] constexpr int kRing = CT == 16 ? kSRing : kSRing8;
+    extern __shared__ __align__(16) uint16_t smem[];  // phase 1: the ring [kRing][4 chunks][kRS rows][64]; afterwards the gradient and output tiles
     __shared__ float sAlse[kSRowsMax], sE[kSRowsMax];
     __shared__ double shf[kST / 64][7];
     __shared__ int bar_ok;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int rb = blockIdx.x >> 4, j = blockIdx.x & 15;
+    const int rb = blockIdx.x / kJ, j = blockIdx.x % kJ;
     const int R = a.ra.R, D = a.D;
     const int nchunks = D / kSK;
     // phases 2 and 3 work on a GROUP of NRB consecutive row blocks: workgroup (rb, j) of group rg = rb / NRB computes the gradient rows of all
     // 16 NRB rows and the dH tile [those rows] x [256 / NRB columns of D]: the B operand of phase 3 is 128 KB / NRB per workgroup instead of 128 KB
     // (a CU's fetch path moves ~56 GB/s: the 128 KB stalled the statistics behind their issue for 2 us and skewed the waves by 1.8 us at NRB = 1)
-    constexpr int kDW = kNA / NRB;          // columns of D per workgroup
+    constexpr int kDW = kSDMax / kJ / NRB;  // columns of D per workgroup
     constexpr int kOS = kDW + 8;            // row stride (bf16) of the output tile
     uint16_t* gt = smem;                    // gradient tile [16 NRB][kSGS] ...
     uint16_t* ot = gt + 16 * NRB * kSGS;    // ... and output tile [16 NRB][kOS]
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
 
     if (a.phases & 1) {
         // ---- phase 1: 16 x 16 logits over all of K, in the k-chunk order of the K3h workgroup that owns columns 16 j .. (vaa_head.hip) ----
-        const int k3h_wg = kA0 / kHeadCols + (j * 16) / kHeadCols;
+        const int k3h_wg = kA0 / kHeadCols + (j * CT) / kHeadCols;
         const int kstart = (int)(((unsigned)k3h_wg * 5u) % (unsigned)nchunks);
         auto kchunk = [&](int ch) { const int cc = ch + kstart; return cc >= nchunks ? cc - nchunks : cc; };
         auto lds_off = [](int row, int piece) { return row * kSK + ((piece ^ (row & 7)) << 3); };
@@ -225,58 +240,85 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
             // per k-step: 9.4 against 7.0 us for the phase). The fetch path of a CU moves 22-29 B/clk of L2 hits with eight waves issuing
             // (tools/probe/cu_fetch_probe.hip): ~4.5 us for the workgroup's 256 KB is this phase's floor.
             const int wvu = __builtin_amdgcn_readfirstlane(wv);  // the DMA destination (M0) is per wave
-            const int cw = wvu >> 2, r8 = (wvu & 3) * 8;         // this wave's chunk parity within a pair and its row octet of the slot
+            // (8-column form: three instructions per chunk image, waves 0 .. 5 request, waves 6 and 7 only keep the barriers)
+            const int cw = wvu / kOct, r8 = (wvu % kOct) * 8;    // this wave's chunk parity within a pair and its row octet of the slot
+            const bool dma = wvu < 2 * kOct;
             const int lrow = lane >> 3, lpiece = (lane & 7) ^ lrow;
             const uint16_t* src = r8 < 16 ? a.h + (size_t)min(rb * 16 + r8 + lrow, R - 1) * D + lpiece * 8
-                                          : a.w + (size_t)(kA0 + j * 16 + (r8 - 16) + lrow) * D + lpiece * 8;
+                                          : a.w + (size_t)(kA0 + j * CT + (r8 - 16) + lrow) * D + lpiece * 8;
             auto request_group = [&](int gi) {
-                uint16_t* grp = smem + (size_t)(gi % kSRing) * (kSGrp * kSSlot);
+                uint16_t* grp = smem + (size_t)(gi % kRing) * (kSGrp * kSSlot);
+                if (dma) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int q = 2 * h + cw;
-                    auto* dst = (__attribute__((address_space(3))) void*)(grp + q * kSSlot + r8 * kSK);
-                    __builtin_amdgcn_global_load_lds(src + kchunk(gi * kSGrp + q) * kSK, dst, 16, 0, 0);
+                    for (int h = 0; h < 2; ++h) {
+                        const int q = 2 * h + cw;
+                        auto* dst = (__attribute__((address_space(3))) void*)(grp + q * kSSlot + r8 * kSK);
+                        __builtin_amdgcn_global_load_lds(src + kchunk(gi * kSGrp + q) * kSK, dst, 16, 0, 0);
+                    }
                 }
             };
 #pragma unroll
-            for (int gi = 0; gi < kSRing - 1; ++gi) request_group(gi);
+            for (int gi = 0; gi < kRing - 1; ++gi) request_group(gi);
+            // wave 0 keeps TWO half groups of fragments (two k-chunks = eight 16-byte reads per operand pair each): the reads of one half travel
+            // while the four dependent MFMAs of the other run — read all sixteen, wait, eight MFMAs per group was 650 clocks per group, as long as
+            // the group's 16 KB take through the CU's fetch path; with 12 KB per group (8-column form) the chain was what bounded the phase
+            v8s_s fa[2][kSGrp], fb[2][kSGrp];
+            auto read_half = [&](int gi, int half) {
+                const uint16_t* grp = smem + (size_t)(gi % kRing) * (kSGrp * kSSlot) + half * 2 * kSSlot;
 #pragma unroll
-            for (int gi = 0; gi < kSGroups; ++gi) {
-                wait_vmcnt(2 * (kSGroups - 1 - gi < kSRing - 2 ? kSGroups - 1 - gi : kSRing - 2));  // this wave's share of group gi has landed
-                __builtin_amdgcn_s_barrier();                                                        // ... everybody's; wave 0 is done with group gi - 1
-                if (gi + kSRing - 1 < kSGroups) request_group(gi + kSRing - 1);                      // into the slots of group gi - 1
-                if (wv == 0) {
-                    const uint16_t* grp = smem + (size_t)(gi % kSRing) * (kSGrp * kSSlot);
-                    v8s_s af[kSGrp * 2], bf[kSGrp * 2];
+                for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
-                    for (int qq = 0; qq < kSGrp; ++qq)
+                    for (int jj = 0; jj < 2; ++jj) {
+                        fa[half][qq * 2 + jj] = *reinterpret_cast<const v8s_s*>(grp + qq * kSSlot + lds_off(c, jj * 4 + g));
+                        fb[half][qq * 2 + jj] = *reinterpret_cast<const v8s_s*>(grp + qq * kSSlot + lds_off(16 + c % CT, jj * 4 + g));
+                    }
+            };
+            auto mfma_half = [&](int half) {
 #pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            af[qq * 2 + jj] = *reinterpret_cast<const v8s_s*>(grp + qq * kSSlot + lds_off(c, jj * 4 + g));
-                            bf[qq * 2 + jj] = *reinterpret_cast<const v8s_s*>(grp + qq * kSSlot + lds_off(16 + c, jj * 4 + g));
-                        }
+                for (int s4 = 0; s4 < kSGrp; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[half][s4], fb[half][s4], acc, 0, 0, 0);
+            };
+            if (wv == 0) {  // (a requester itself: wave 0 takes chunk parity 0, row octet 0)
+#pragma unroll
+                for (int gi = 0; gi < kSGroups; ++gi) {
+                    wait_vmcnt(2 * (kSGroups - 1 - gi < kRing - 2 ? kSGroups - 1 - gi : kRing - 2));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // its reads of group gi - 1 are in registers
+                    __builtin_amdgcn_s_barrier();
+                    if (gi + kRing - 1 < kSGroups) request_group(gi + kRing - 1);
+                    read_half(gi, 0);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int s8 = 0; s8 < kSGrp * 2; ++s8) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s8], bf[s8], acc, 0, 0, 0);
+                    if (gi > 0) mfma_half(1);  // the second half of group gi - 1
                     __builtin_amdgcn_sched_barrier(0);
+                    read_half(gi, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_half(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfma_half(1);
+            } else {
+#pragma unroll
+                for (int gi = 0; gi < kSGroups; ++gi) {
+                    wait_vmcnt(2 * (kSGroups - 1 - gi < kRing - 2 ? kSGroups - 1 - gi : kRing - 2));    // this wave's share of group gi has landed
+                    __builtin_amdgcn_s_barrier();                                                        // ... everybody's; wave 0 is done with group gi - 1's slots
+                    if (gi + kRing - 1 < kSGroups) request_group(gi + kRing - 1);                        // into the slots of group gi - 1
                 }
             }
 #endif
         } else {  // any other D (a multiple of 64): one chunk (4 KB = a 16-byte piece for each of 256 threads) per barrier pair
             const int cw = tid >> 8, lr = (tid & 255) >> 3, lp = tid & 7;
-            const uint16_t* src = lr < 16 ? a.h + (size_t)min(rb * 16 + lr, R - 1) * D + lp * 8 : a.w + (size_t)(kA0 + j * 16 + (lr - 16)) * D + lp * 8;
+            const bool ld = cw == 0 && lr < kRS;
+            const uint16_t* src = lr < 16 ? a.h + (size_t)min(rb * 16 + lr, R - 1) * D + lp * 8 : a.w + (size_t)(kA0 + j * CT + (lr - 16) % CT) * D + lp * 8;
             const int my_off = lds_off(lr, lp);
             for (int ch = 0; ch < nchunks; ++ch) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (cw == 0) v = *reinterpret_cast<const uint4*>(src + kchunk(ch) * kSK);
+                if (ld) v = *reinterpret_cast<const uint4*>(src + kchunk(ch) * kSK);
                 __syncthreads();
-                if (cw == 0) *reinterpret_cast<uint4*>(smem + my_off) = v;
+                if (ld) *reinterpret_cast<uint4*>(smem + my_off) = v;
                 __syncthreads();
                 if (wv == 0) {
 #pragma unroll
                     for (int jj = 0; jj < kSK / 32; ++jj) {
                         const v8s_s af1 = *reinterpret_cast<const v8s_s*>(smem + lds_off(c, jj * 4 + g));
-                        const v8s_s bf1 = *reinterpret_cast<const v8s_s*>(smem + lds_off(16 + c, jj * 4 + g));
+                        const v8s_s bf1 = *reinterpret_cast<const v8s_s*>(smem + lds_off(16 + c % CT, jj * 4 + g));
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc, 0, 0, 0);
                     }
                 }
@@ -288,8 +330,8 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const unsigned z = f32_to_bf16_bits(acc[r]);
                 const unsigned zn = (unsigned)__shfl_xor((int)z, 1, 64);
-                if (!(c & 1))
-                    __hip_atomic_store(a.zs + (size_t)(rb * 16 + g * 4 + r) * (kNA / 2) + ((j * 16 + c) >> 1), ((unsigned long long)a.tag << 32) | z | (zn << 16),
+                if (!(c & 1) && c < CT)
+                    __hip_atomic_store(a.zs + (size_t)(rb * 16 + g * 4 + r) * (kNA / 2) + ((j * CT + c) >> 1), ((unsigned long long)a.tag << 32) | z | (zn << 16),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -359,6 +401,27 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     K3S_STAMP(3);
+    // ---- phase 3's B operand: fragments of the transposed slice (128 KB / NRB per workgroup), requested in QUARTERS between the stages of the
+    //      statistics below. All sixteen instructions per wave at once (128 KB per CU) stall the wave's issue behind the CU's fetch rate: behind
+    //      the poll they held the statistics back by 2 us, in front of it the poll's words came back 2.9 us late. The workgroup's 16 output tiles:
+    //      NRB row tiles x kDW / 16 column tiles; a wave's two tiles share their column tile when NRB > 1, so it fetches ONE tile's fragments ----
+    constexpr int kDT = kDW / 16;                   // column tiles
+    constexpr int kTPW = NRB * kDT / (kST / 64);    // output tiles per wave: 2 (one in the 8-column form)
+    constexpr int kNB = NRB == 1 ? kTPW : 1;        // distinct column tiles among them
+    static_assert(kTPW == 1 || kTPW == 2, "");
+    const int dbase = (mb * kJ + j) * kDW;
+    const int dt0 = NRB == 1 ? kTPW * wv : wv % kDT, rt0 = NRB == 1 ? 0 : (wv / kDT) * 2;  // tiles (rt0, dt0), (rt0 + 1, dt0) — or (0, dt0) [, (0, dt0 + 1)] at NRB = 1
+    v8s_s bfr[kNB][kNA / 32];
+    const uint16_t* bsrc[kNB];
+#pragma unroll
+    for (int t = 0; t < kNB; ++t) bsrc[t] = a.wt + (size_t)min(dbase + (dt0 + t) * 16 + c, D - 1) * kNA + g * 8;  // columns beyond D re-read the last one: never stored
+    auto issue_b = [&](auto qc) {
+        constexpr int kPerQ = kNB * (kNA / 32) / 4, q0 = decltype(qc)::value * kPerQ;
+        if (a.dh) {
+#pragma unroll
+            for (int i = q0; i < q0 + kPerQ; ++i) bfr[i / (kNA / 32)][i % (kNA / 32)] = *reinterpret_cast<const v8s_s*>(bsrc[i / (kNA / 32)] + (i % (kNA / 32)) * 32);
+        }
+    };
     unsigned long long w0[NRB][4];
 #pragma unroll
     for (int u = 0; u < NRB; ++u) request(u, w0[u]);
@@ -377,30 +440,16 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
         }
     }
     K3S_STAMP(4);
-    // ---- phase 3's B operand: fragments of the transposed slice (128 KB / NRB per workgroup), requested in QUARTERS between the stages of the
-    //      statistics below. All sixteen instructions per wave at once (128 KB per CU) stall the wave's issue behind the CU's fetch rate: behind
-    //      the poll they held the statistics back by 2 us, in front of it the poll's words came back 2.9 us late. The workgroup's 16 output tiles:
-    //      NRB row tiles x kDW / 16 column tiles; a wave's two tiles share their column tile when NRB > 1, so it fetches ONE tile's fragments ----
-    constexpr int kDT = kDW / 16;            // column tiles
-    constexpr int kNB = NRB == 1 ? 2 : 1;    // distinct column tiles of a wave's two output tiles
-    const int dbase = (mb * 16 + j) * kDW;
-    const int dt0 = NRB == 1 ? 2 * wv : wv % kDT, rt0 = NRB == 1 ? 0 : (wv / kDT) * 2;  // tiles (rt0, dt0), (rt0 + 1, dt0) — or (0, dt0), (0, dt0 + 1) at NRB = 1
-    v8s_s bfr[kNB][kNA / 32];
-    const uint16_t* bsrc[kNB];
-#pragma unroll
-    for (int t = 0; t < kNB; ++t) bsrc[t] = a.wt + (size_t)min(dbase + (dt0 + t) * 16 + c, D - 1) * kNA + g * 8;  // columns beyond D re-read the last one: never stored
-    auto issue_b = [&](auto qc) {
-        constexpr int kPerQ = kNB * (kNA / 32) / 4, q0 = decltype(qc)::value * kPerQ;
-        if (a.dh) {
-#pragma unroll
-            for (int i = q0; i < q0 + kPerQ; ++i) bfr[i / (kNA / 32)][i % (kNA / 32)] = *reinterpret_cast<const v8s_s*>(bsrc[i / (kNA / 32)] + (i % (kNA / 32)) * 32);
-        }
-    };
     issue_b(std::integral_constant<int, 0>{});
-    unsigned long long wpre[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}};
-    if (all_rows && NRB < nit) {  // UPA / the publishing workgroup: the next two blocks' words travel while the own rows are reduced
-        request(NRB, wpre[0]);
-        request(NRB + 1, wpre[1]);
+    constexpr int kPair = CT == 8 ? 1 : 2;  // row blocks of the other rows reduced side by side (one in the 8-column form: registers for two workgroups per CU)
+    unsigned long long wpre[kPair][4];
+#pragma unroll
+    for (int u = 0; u < kPair; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wpre[u][q] = 0ull;
+    if (all_rows && NRB < nit) {  // UPA / the publishing workgroup: the next blocks' words travel while the own rows are reduced
+#pragma unroll
+        for (int u = 0; u < kPair; ++u) request(NRB + u, wpre[u]);
     }
     float xo[NRB][8], own_alse[NRB], own_E[NRB];
     {   // the own rows, their dependent shuffle chains side by side
@@ -426,31 +475,37 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
     }
     K3S_STAMP(5);
     if (all_rows) {
-        for (int i0 = NRB; i0 < nit; i0 += 2) {  // the other rows (UPA's batch means, the publishing workgroup's fold): two blocks side by side
-            unsigned long long wq[2][4];
-            if (i0 == NRB) {  // the first pair was requested in front of the own rows' statistics (below the own poll): its round trip is over
+        for (int i0 = NRB; i0 < nit; i0 += kPair) {  // the other rows (UPA's batch means, the publishing workgroup's fold): kPair blocks side by side
+            unsigned long long wq[kPair][4];
+            if (i0 == NRB) {  // the first ones were requested in front of the own rows' statistics (below the own poll): their round trip is over
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { wq[0][q] = wpre[0][q]; wq[1][q] = wpre[1][q]; }
+                for (int u = 0; u < kPair; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wq[u][q] = wpre[u][q];
             } else {
-                request(i0, wq[0]);
-                request(i0 + 1, wq[1]);
+#pragma unroll
+                for (int u = 0; u < kPair; ++u) request(i0 + u, wq[u]);
             }
             int polls = 0;
             bool gave_up = false;
-            while (!__all(valid(wq[0]) && valid(wq[1]))) {
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < kPair; ++u) ok = ok && valid(wq[u]);
+                if (__all(ok)) break;
                 if (++polls > a.max_polls) { gave_up = true; break; }
                 __builtin_amdgcn_s_sleep(1);
-                request(i0, wq[0]);
-                request(i0 + 1, wq[1]);
+#pragma unroll
+                for (int u = 0; u < kPair; ++u) request(i0 + u, wq[u]);
             }
             if (gave_up) give_up();
-            float x[2][8], alse[2], E[2];
-            int pred[2];
-            decode_logits8(wq[0], x[0]);
-            decode_logits8(wq[1], x[1]);
-            slice_stats_half<2>(x, hl, alse, E, pred);
+            float x[kPair][8], alse[kPair], E[kPair];
+            int pred[kPair];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < kPair; ++u) decode_logits8(wq[u], x[u]);
+            slice_stats_half<kPair>(x, hl, alse, E, pred);
+#pragma unroll
+            for (int u = 0; u < kPair; ++u) {
                 if (i0 + u >= nit) continue;
                 if (gave_up) { alse[u] = __uint_as_float(0x7fc00000u); E[u] = alse[u]; }
                 leave(it_of(i0 + u), alse[u], E[u], pred[u]);
@@ -512,28 +567,30 @@ __global__ __launch_bounds__(kST) void head_slice_kernel(SliceHeadArgs a) {
 
     // ---- phase 3: dH tile = g [16 NRB, 256] x slice [256, these kDW columns of D] ----
     if (a.dh) {
-        v4f_s acc3[2];
-        acc3[0] = (v4f_s){0.f, 0.f, 0.f, 0.f};
-        acc3[1] = (v4f_s){0.f, 0.f, 0.f, 0.f};
+        v4f_s acc3[kTPW];
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t) acc3[t] = (v4f_s){0.f, 0.f, 0.f, 0.f};
         const int rt1 = NRB == 1 ? 0 : rt0 + 1;
 #pragma unroll
         for (int ks = 0; ks < kNA / 32; ++ks) {
             const v8s_s af0 = *reinterpret_cast<const v8s_s*>(gt + (rt0 * 16 + c) * kSGS + ks * 32 + g * 8);
-            const v8s_s af1 = NRB == 1 ? af0 : *reinterpret_cast<const v8s_s*>(gt + (rt1 * 16 + c) * kSGS + ks * 32 + g * 8);
             acc3[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bfr[0][ks], acc3[0], 0, 0, 0);
-            acc3[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bfr[kNB - 1][ks], acc3[1], 0, 0, 0);
+            if (kTPW == 2) {
+                const v8s_s af1 = NRB == 1 ? af0 : *reinterpret_cast<const v8s_s*>(gt + (rt1 * 16 + c) * kSGS + ks * 32 + g * 8);
+                acc3[kTPW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bfr[kNB - 1][ks], acc3[kTPW - 1], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < kTPW; ++t) {
             const int rt = NRB == 1 ? 0 : rt0 + t, dt = NRB == 1 ? dt0 + t : dt0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) ot[(rt * 16 + g * 4 + r) * kOS + dt * 16 + c] = (uint16_t)f32_to_bf16_bits(acc3[t][r]);
         }
         K3S_STAMP(8);
         __syncthreads();
-        // 16 NRB rows x kDW columns = 4096 elements = one 16-byte piece per thread
+        // 16 NRB rows x kDW columns = 4096 elements (2048 in the 8-column form) = one 16-byte piece per thread
         const int orow = tid / (kDW / 8), col = (tid % (kDW / 8)) * 8, d = dbase + col, grow = rg * NRB * 16 + orow;
-        if (grow < R && d < D) *reinterpret_cast<uint4*>(a.dh + (size_t)grow * D + d) = *reinterpret_cast<const uint4*>(ot + orow * kOS + col);
+        if (orow < 16 * NRB && grow < R && d < D) *reinterpret_cast<uint4*>(a.dh + (size_t)grow * D + d) = *reinterpret_cast<const uint4*>(ot + orow * kOS + col);
     }
     K3S_STAMP(9);
     // ---- publication (callers without a step epilogue): workgroup 0 folds the rows it has just written into scalars[8] + the prediction maps ----
@@ -558,26 +615,34 @@ __global__ __launch_bounds__(256) void head_slice_pack_kernel(const uint16_t* __
     }
 }
 
-static size_t slice_lds_bytes() { return (size_t)kSRing * kSGrp * kSSlot * sizeof(uint16_t); }  // the ring (the gradient / output tiles reuse it)
+// the ring (the gradient / output tiles reuse it): 128 KB, or 72 KB in the 8-column form
+static size_t slice_lds_bytes(int ct) { return (size_t)(ct == 16 ? kSRing : kSRing8) * kSGrp * (16 + ct) * kSK * sizeof(uint16_t); }
 
-static const void* slice_kernel_fn(int nrb_group) {
-    return nrb_group == 1 ? (const void*)head_slice_kernel<1> : (nrb_group == 2 ? (const void*)head_slice_kernel<2> : (const void*)head_slice_kernel<4>);
+// instantiations: row-block groups of 1 / 2 / 4 in the 16-column form, and the 8-column form
+static int slice_inst(int nrb_group, int ct) { return ct == 8 ? 3 : (nrb_group == 1 ? 0 : (nrb_group == 2 ? 1 : 2)); }
+static const void* slice_kernel_fn(int inst) {
+    switch (inst) {
+        case 0: return (const void*)head_slice_kernel<1, 16>;
+        case 1: return (const void*)head_slice_kernel<2, 16>;
+        case 2: return (const void*)head_slice_kernel<4, 16>;
+        default: return (const void*)head_slice_kernel<1, 8>;
+    }
 }
 
 // resident workgroups of head_slice_kernel<NRB> on the current device (occupancy x CUs), queried once per device and instantiation; 0 = unknown
-static long slice_resident_slots(int nrb_group) {
-    static std::atomic<long> slots[3][16];
+static long slice_resident_slots(int inst) {
+    static std::atomic<long> slots[4][16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 0; }
-    const int inst = nrb_group == 1 ? 0 : (nrb_group == 2 ? 1 : 2);
     long have = slots[inst][dev].load(std::memory_order_relaxed);
     if (have == 0) {
         int cus = 0, per_cu = 0;
         hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess) {
-            if (nrb_group == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<1>, kST, slice_lds_bytes());
-            else if (nrb_group == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<2>, kST, slice_lds_bytes());
-            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<4>, kST, slice_lds_bytes());
+            if (inst == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<1, 16>, kST, slice_lds_bytes(16));
+            else if (inst == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<2, 16>, kST, slice_lds_bytes(16));
+            else if (inst == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<4, 16>, kST, slice_lds_bytes(16));
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_slice_kernel<1, 8>, kST, slice_lds_bytes(8));
         }
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -590,10 +655,11 @@ static long slice_resident_slots(int nrb_group) {
     return have > 0 ? have : 0;
 }
 
-static void slice_launch(int nrb_group, unsigned grid, size_t lds, hipStream_t st, const SliceHeadArgs& a) {
-    if (nrb_group == 1) VAA_LAUNCH(head_slice_kernel<1>, dim3(grid), dim3(kST), lds, st, a);
-    else if (nrb_group == 2) VAA_LAUNCH(head_slice_kernel<2>, dim3(grid), dim3(kST), lds, st, a);
-    else VAA_LAUNCH(head_slice_kernel<4>, dim3(grid), dim3(kST), lds, st, a);
+static void slice_launch(int inst, unsigned grid, size_t lds, hipStream_t st, const SliceHeadArgs& a) {
+    if (inst == 0) launch_k("head_slice_kernel<1>", head_slice_kernel<1, 16>, dim3(grid), dim3(kST), lds, st, a);
+    else if (inst == 1) launch_k("head_slice_kernel<2>", head_slice_kernel<2, 16>, dim3(grid), dim3(kST), lds, st, a);
+    else if (inst == 2) launch_k("head_slice_kernel<4>", head_slice_kernel<4, 16>, dim3(grid), dim3(kST), lds, st, a);
+    else launch_k("head_slice_kernel<1,8>", head_slice_kernel<1, 8>, dim3(grid), dim3(kST), lds, st, a);
 }
 
 }  // namespace vaa
@@ -602,7 +668,7 @@ extern "C" size_t vaa_loss_rows_ws_bytes(int R);
 
 extern "C" int vaa_head_slice_applies(int R, int D, int V) {
     // V <= 32,768: the fold arithmetic this kernel shares with rows_finish_kernel is its 256-thread form
-    return (R > 0 && R <= vaa::kSRowsMax && D >= vaa::kSK && (D % vaa::kSK) == 0 && D <= 16 * (vaa::kST / 64) * vaa::kSTPW * 16 && V >= vaa::kA0 + vaa::kNA && (V % 8) == 0 &&
+    return (R > 0 && R <= vaa::kSRowsMax && D >= vaa::kSK && (D % vaa::kSK) == 0 && D <= vaa::kSDMax && V >= vaa::kA0 + vaa::kNA && (V % 8) == 0 &&
             V <= 32768) ? 1 : 0;
 }
 
@@ -617,6 +683,11 @@ static void slice_groups(int R, int& nrb_group, int& nblk_pad) {
     if (ev && (ev[0] == '2' || ev[0] == '4')) nrb_group = (ev[0] - '0') <= nblk || nblk >= 3 ? (ev[0] - '0') : nblk;
     if (nrb_group == 4 && nblk < 3) nrb_group = nblk >= 2 ? 2 : 1;
     nblk_pad = (nblk + nrb_group - 1) / nrb_group * nrb_group;
+}
+// action columns per workgroup in phase 1: 8 (32 workgroups per row block) unless VAA_K3S_COLS=16 or a row-block group asks for the 16-column form
+static int slice_cols(int nrb_group) {
+    const char* ev = getenv("VAA_K3S_COLS");
+    return (nrb_group > 1 || (ev && ev[0] == '1' && ev[1] == '6')) ? 16 : 8;
 }
 }  // namespace vaa
 
@@ -658,7 +729,7 @@ extern "C" int vaa_head_slice_fwd_bwd(const uint16_t* hidden, const uint16_t* w_
     }
     if (!vaa_head_slice_applies(R, D, V) || B <= 0 || L <= 1 || (long)R > (long)B * (L - 1)) {
         set_error("%s: shape not covered (R=%d <= %d rows, D=%d a multiple of %d up to %d, V=%d <= 32768; B=%d L=%d)", who, R, kSRowsMax, D, kSK,
-                  16 * (kST / 64) * kSTPW * 16, V, B, L);
+                  kSDMax, V, B, L);
         return VAA_E_UNSUPPORTED;
     }
     if ((((uintptr_t)hidden) | ((uintptr_t)w_head) | ((uintptr_t)w_slice_t) | ((uintptr_t)dhidden) | ((uintptr_t)grad_slice) | ((uintptr_t)ws)) & 15u) {
@@ -681,23 +752,24 @@ extern "C" int vaa_head_slice_fwd_bwd(const uint16_t* hidden, const uint16_t* w_
     a.ra.ldz = kNA; a.ra.zcol0 = kA0;
     a.ra.w = params[0]; a.ra.alpha = params[1]; a.ra.beta = params[2]; a.ra.scale = params[3];
     a.D = D; a.publish = scalars ? 1 : 0;
-    const size_t lds = slice_lds_bytes();
-    static_assert(16 * 4 * kSGS + 16 * 4 * (kNA / 4 + 8) <= kSRing * kSGrp * kSSlot && 2 * 16 * kSGS <= kSRing * kSGrp * kSSlot, "the tiles reuse the ring");
+    static_assert(16 * 4 * kSGS + 16 * 4 * (kNA / 4 + 8) <= kSRing * kSGrp * 32 * kSK && 16 * kSGS + 16 * (kSDMax / 32 + 8) <= kSRing8 * kSGrp * 24 * kSK,
+                  "the tiles reuse the ring");
     int nrb_group = 1, nblk_pad = 1;
     slice_groups(R, nrb_group, nblk_pad);
-    static std::atomic<unsigned long long> attr_done[3];  // [instantiation] bit = device ordinal: the dynamic-LDS opt-in (128 KB) is set once per device
+    const int ct = slice_cols(nrb_group), inst = slice_inst(nrb_group, ct);
+    const size_t lds = slice_lds_bytes(ct);
+    static std::atomic<unsigned long long> attr_done[4];  // [instantiation] bit = device ordinal: the dynamic-LDS opt-in (128 / 72 KB) is set once per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
-    const int inst = nrb_group == 1 ? 0 : (nrb_group == 2 ? 1 : 2);
     if (lds > 64 * 1024 && !(attr_done[inst].load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute(slice_kernel_fn(nrb_group), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(slice_kernel_fn(inst), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             set_error("%s: hipFuncSetAttribute failed", who);
             return VAA_E_LAUNCH;
         }
         attr_done[inst].fetch_or(bit, std::memory_order_acq_rel);
     }
-    const unsigned grid = (unsigned)nblk_pad * 16u;
+    const unsigned grid = (unsigned)nblk_pad * (unsigned)(kNA / ct);
     // the launch's tag: unique in the process (one counter for all streams and devices), scrambled so that no plausible stale content of the
     // scratch (small integers, bf16 pairs, an old launch's tag) equals it
     static std::atomic<unsigned> tag_counter{0u};
@@ -716,7 +788,7 @@ extern "C" int vaa_head_slice_fwd_bwd(const uint16_t* hidden, const uint16_t* w_
         const hipError_t ce = hipStreamIsCapturing(st, &cs);
         if (ce != hipSuccess) (void)hipGetLastError();
         const bool capturing = ce != hipSuccess || cs != hipStreamCaptureStatusNone;
-        one = !capturing && 2l * grid <= slice_resident_slots(nrb_group) && rows_one_pass_stream_ok(st);
+        one = !capturing && 2l * grid <= slice_resident_slots(inst) && rows_one_pass_stream_ok(st);
     }
     const char* dbg = getenv("VAA_K3S_DEBUG_PHASES");  // measurement hook (tools/k3s_bench.py): run phase 1 or phases 2 + 3 alone
     if (dbg && (dbg[0] == '1' || dbg[0] == '2')) {
@@ -724,19 +796,19 @@ extern "C" int vaa_head_slice_fwd_bwd(const uint16_t* hidden, const uint16_t* w_
         if (dbg[0] == '2') a.tag = last_tag;
         last_tag = a.tag;
         a.phases = dbg[0] - '0';
-        slice_launch(nrb_group, grid, lds, st, a);
+        slice_launch(inst, grid, lds, st, a);
         return check_launch(who);
     }
     if (one) {
         a.phases = 3;
-        slice_launch(nrb_group, grid, lds, st, a);
+        slice_launch(inst, grid, lds, st, a);
         return check_launch(who);
     }
     a.phases = 1;
-    slice_launch(nrb_group, grid, lds, st, a);
+    slice_launch(inst, grid, lds, st, a);
     int rc = check_launch("vaa_head_slice_fwd_bwd(logits)");
     if (rc != VAA_OK) return rc;
     a.phases = 2;
-    slice_launch(nrb_group, grid, lds, st, a);
+    slice_launch(inst, grid, lds, st, a);
     return check_launch("vaa_head_slice_fwd_bwd(gradient)");
 }

@@ -456,6 +456,7 @@ def test_upa_loop_slice_head_silent_steps(tmp_path, monkeypatch):
             return r
 
         monkeypatch.setattr(PatchOptimizer, "step", rec)
+        os.makedirs(tmp_path / tag, exist_ok=True)  # the caller owns the run directory (UPA_wrapper.py creates it)
         att = OpenVLAAttacker(vla, None, str(tmp_path / tag), optimizer="adamW", resize_patch=False, alpha=0.8, belta=0.2)
         att.val_batches = 1
         train, val = _Fresh([31 + i for i in range(n_it)], bs), _Fresh([77], 1)

@@ -117,6 +117,38 @@ def test_head_slice_two_launches_equal_one(ops, monkeypatch, mode_name, B, maski
     assert torch.equal(a["scalars"], b["scalars"]) and torch.equal(a["pred"], b["pred"])
 
 
+@pytest.mark.parametrize("mode_name,B,maskidx,D", [("UADA_DDP", 64, [0], 4096), ("UADA_DDP", 8, [0], 4096), ("UADA_DDP", 13, [0, 1, 2], 4096), ("UPA", 16, [0, 1, 2], 4096),
+                                                   ("UPA", 4, [0, 1, 2], 4096), ("UADA_DDP", 5, [0, 3], 192), ("UPA", 7, [0, 1, 2], 320)])
+def test_head_slice_forms_agree_bit_for_bit(ops, monkeypatch, mode_name, B, maskidx, D):
+    """The kernel's forms — 8 action columns per workgroup (32 workgroups per row block: the default), 16 columns (VAA_K3S_COLS=16), and 16 columns with
+    row-block groups of 2 / 4 (VAA_K3S_GROUP) — are the same arithmetic on a different decomposition: every output bit for bit, one launch or two."""
+    upa = mode_name == "UPA"
+    mode = ops.LOSS_UPA if upa else ops.LOSS_UADA_DDP
+    labels, W, h, rm, R = _case(ops, B, maskidx, D, 4400 + B, upa)
+
+    def run():
+        o = ops.head_slice_fwd_bwd(h, W, rm, mode, want_grad_slice=True)
+        torch.cuda.synchronize()
+        return {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in o.items()}
+
+    ops.prof_start(64)
+    a = run()
+    names = [n for n, _ in ops.prof_collect()]
+    assert any("head_slice_kernel<1,8>" in n for n in names), names  # the default IS the 8-column form
+    for env in ({"VAA_K3S_COLS": "16"}, {"VAA_K3S_COLS": "16", "VAA_K3S_ONE_LAUNCH": "0"}, {"VAA_K3S_ONE_LAUNCH": "0"}, {"VAA_K3S_GROUP": "2"}, {"VAA_K3S_GROUP": "4"}):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            ops.prof_start(64)
+            b = run()
+            names = [n for n, _ in ops.prof_collect()]
+        if "VAA_K3S_COLS" in env:
+            assert any("head_slice_kernel<1>" in n for n in names) and not any("<1,8>" in n for n in names), names
+        for k in ("dh", "grad_slice"):
+            assert torch.equal(_bits(a[k]), _bits(b[k])), (env, k)
+        assert torch.equal(a["scalars"], b["scalars"]) and torch.equal(a["pred"], b["pred"]) and torch.equal(a["pred_full"], b["pred_full"]), env
+
+
 @pytest.mark.parametrize("B,maskidx", [(64, [0]), (8, [0]), (5, [0, 1, 2])])
 def test_head_slice_with_step_epilogue_and_ce_steps(ops, B, maskidx):
     """The data-parallel step's cadence: K3s every step (its SliceStats + neutral parts folded by vaa_step_epilogue: CE = 0, pred_full = -1), and on the

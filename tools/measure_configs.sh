@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5: BASELINE configs 2 / 4 / 5 end to end under rocprofv3 (the product loops' own inner_step through `bench.py --attack`), config 5's
 # backward A/B (K2'-MULTI against the ViT patch-embed conv backward in torch + K2-MULTI), and the in-step A/B of the fused LM head at bs=64.
-#   gpurun --timeout 2400 -- 'bash tools/measure_configs.sh [cfg] [cfg5ab] [head] [k3s]'      (default: cfg cfg5ab head)
+#   gpurun --timeout 2400 -- 'bash tools/measure_configs.sh [cfg] [cfg5ab] [head] [k3s] [k3scols]'      (default: cfg cfg5ab head)
 # Outputs: gpurun_out/cfg/{cfgN_kernel_stats.csv, cfgN.json, cfgN_summary.txt, ...}; copy what is to be judged into profiles/r05_*.
 set -uo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
@@ -39,6 +39,12 @@ for p in ${parts}; do
       run k3h_every_1 "VAA_HEAD_EVERY_STEP=1"
       run k3h_every_2 "VAA_HEAD_EVERY_STEP=1"
       run k3s_cadence_2 ""
+      ;;
+    k3scols) # round 6: K3s with 8 action columns per workgroup (32 workgroups per row block, the default) against 16, inside the bs=64 step, A B B A
+      run k3s_cols8_1 ""
+      run k3s_cols16_1 "VAA_K3S_COLS=16"
+      run k3s_cols16_2 "VAA_K3S_COLS=16"
+      run k3s_cols8_2 ""
       ;;
     head)    # fused LM head (K3h) against hipBLASLt head + K3 statistics, inside the bs=64 step, A B B A
       run head_gemm_1 "VAA_FUSED_HEAD=0"

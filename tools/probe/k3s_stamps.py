@@ -20,7 +20,7 @@ for R in (128, 16):
         o = ops.head_slice_fwd_bwd(h, W, rm, ops.LOSS_UADA_DDP, 5.0, want_scalars=False)
     torch.cuda.synchronize()
     del scratch
-    nwg = (R+15)//16*16
+    nwg = (R+15)//16*(16 if os.environ.get('VAA_K3S_COLS') == '16' else 32)
     st = o["zs"][512<<10:(512<<10)+nwg*16*8].view(torch.int64).view(nwg,16).cpu().numpy().astype(np.int64)
     t0 = st[:,0].min()
     rel = (st[:, :10]-t0)*0.01  # us
