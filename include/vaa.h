@@ -310,7 +310,8 @@ int vaa_head_loss_rows_finish(const void* rowmap, int R, int B, int L, int V, in
  *   ws        dev >= vaa_head_slice_ws_bytes(R): the [ceil16(R),128] action logits as 64-bit words {launch tag, logit 2q+1, logit 2q} (bf16) — the
  *             SAME MFMA sequence per element as vaa_head_loss_rows_stats (same k order), hence bit for bit its slice logits, statistics and
  *             gradient slice
- * One launch needs workgroups that wait for each other (<= 128; they poll the tagged words they are going to use): admitted when the device keeps twice the grid resident, the stream is not being
+ * One launch needs workgroups that wait for each other (<= 256 — 32 per block of 16 rows, 8 action columns each; VAA_K3S_COLS=16: 16 per block —; they
+ * poll the tagged words they are going to use): admitted when the device keeps twice the grid resident, the stream is not being
  * captured and no other stream of the process has a waiting grid in flight; otherwise (or VAA_K3S_ONE_LAUNCH=0) the same kernel runs as two
  * launches with the same bits. A hand-over that times out NaN-poisons dhidden / the statistics AND raises vaa_async_error().
  * Covers vaa_head_slice_applies(R, D, V) == 1: R <= 128, D a multiple of 64 up to 4096, V <= 32768.

@@ -36,9 +36,9 @@ timeout 900 python bench.py --gpus 2 --steps 4 --warmup 1 --full-out gpurun_out/
 VAA_NO_TN_DGRAD=1 timeout 1500 python bench.py --gpus 8 --steps 3 --warmup 1 --regions strong --full-out gpurun_out/measure/bench_8ranks_one_gpu_full.json > "${out}/bench_8ranks_one_gpu.json" 2> "${out}/bench_8ranks_one_gpu.err"
 timeout 200 python tools/k3_onepass_check.py > "${out}/k3_onepass.txt" 2>&1
 # K3s: the slice-only head against K3h + finish + the 256-column GEMM (per dispatch, in a stream, cold), and where its time goes (timing build)
-timeout 300 python tools/k3s_bench.py 128 64 32 16 > "${out}/k3s_bench.txt" 2>&1
+{ timeout 300 python tools/k3s_bench.py 128 64 32 16; echo "== VAA_K3S_COLS=16 (16 action columns per workgroup, 16 workgroups per row block)"; VAA_K3S_COLS=16 timeout 300 python tools/k3s_bench.py 128 16; } > "${out}/k3s_bench.txt" 2>&1
 sed -e 's#^out=.*#out="${here}/../libvaa_hip_timing.so"#' -e "s#^here=.*#here=${root}/roboticattack_amd/csrc#" roboticattack_amd/csrc/build.sh > /tmp/build_timing.sh && bash /tmp/build_timing.sh -DVAA_K3S_TIMING > /dev/null 2>&1
-{ VAA_LIB_PATH="${root}/roboticattack_amd/libvaa_hip_timing.so" timeout 200 python tools/probe/k3s_stamps.py; VAA_LIB_PATH="${root}/roboticattack_amd/libvaa_hip_timing.so" timeout 200 python tools/probe/k3s_stamps.py cold; } > "${out}/k3s_stamps.txt" 2>&1
+{ for c in 8 16; do echo "== ${c} action columns per workgroup, warm then behind a 1 GiB copy"; VAA_K3S_COLS=${c} VAA_LIB_PATH="${root}/roboticattack_amd/libvaa_hip_timing.so" timeout 200 python tools/probe/k3s_stamps.py; VAA_K3S_COLS=${c} VAA_LIB_PATH="${root}/roboticattack_amd/libvaa_hip_timing.so" timeout 200 python tools/probe/k3s_stamps.py cold; done; } > "${out}/k3s_stamps.txt" 2>&1
 rm -f roboticattack_amd/libvaa_hip_timing.so
 # the validation pass of the data-parallel loop (bs = 8, 12 batches, A B A B against the per-batch read-back), alone and under rocprofv3
 timeout 600 python tools/val_bench.py openvla-7b 12 > "${out}/val_bench.json" 2> "${out}/val_bench.err"
