@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(CT == 8 ? 4
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned z = f32_to_bf16_bits(acc[r]);
-                const unsigned zn = (unsigned)__shfl_xor((int)z, 1, 64);
+                const unsigned zn = (unsigned)xor_lane_i<1>((int)z);  // the neighbouring column: a DPP quad permute (ds_bpermute's round trip, four times, sat on the critical path)
                 if (!(c & 1) && c < CT)
                     __hip_atomic_store(a.zs + (size_t)(rb * 16 + g * 4 + r) * (kNA / 2) + ((j * CT + c) >> 1), ((unsigned long long)a.tag << 32) | z | (zn << 16),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

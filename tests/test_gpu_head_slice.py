@@ -125,6 +125,8 @@ def test_head_slice_forms_agree_bit_for_bit(ops, monkeypatch, mode_name, B, mask
     upa = mode_name == "UPA"
     mode = ops.LOSS_UPA if upa else ops.LOSS_UADA_DDP
     labels, W, h, rm, R = _case(ops, B, maskidx, D, 4400 + B, upa)
+    for k in ("VAA_K3S_COLS", "VAA_K3S_GROUP", "VAA_K3S_ONE_LAUNCH"):  # (a run of the whole file under one of the switches)
+        monkeypatch.delenv(k, raising=False)
 
     def run():
         o = ops.head_slice_fwd_bwd(h, W, rm, mode, want_grad_slice=True)
