@@ -43,6 +43,15 @@ namespace vaa {
 
 typedef short v8s_s __attribute__((ext_vector_type(8)));
 typedef float v4f_s __attribute__((ext_vector_type(4)));
+typedef float v2f_s __attribute__((ext_vector_type(2)));
+typedef __bf16 v2bf_s __attribute__((ext_vector_type(2)));
+
+// {bf16(hi) : 16 | bf16(lo) : 16} in ONE instruction (v_cvt_pk_bf16_f32, round to nearest even): the bits f32_to_bf16_bits computes in seven for every
+// value that is not a NaN (a NaN stays a NaN) — on this kernel's critical path (logits -> tagged words) and in its VALU-bound part (the gradient tile)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const v2f_s v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2bf_s));
+}
 
 constexpr int kST = 512;                    // 8 waves: 2 half waves x 8 = the 16 rows of a block in phase 2, 16 output tiles of 16 columns in phase 3
 constexpr int kSK = 64;                     // k-chunk: one 128-byte line per row (head_stats_kernel's)
@@ -100,12 +109,17 @@ __device__ __forceinline__ void slice_stats_half(const float (&x)[NR][8], int hl
     float bestv[NR], es[NR], ew[NR];
     int besti[NR];
 #pragma unroll
-    for (int n = 0; n < NR; ++n) {
-        int ai = 0;
+    for (int n = 0; n < NR; ++n) {  // first maximum of the lane's eight logits, value and index carried together (an index into x[] costs a select chain per step)
+        float bv = x[n][0];
+        int bi = 0;
 #pragma unroll
-        for (int e = 1; e < 8; ++e) if (x[n][e] > x[n][ai]) ai = e;
-        bestv[n] = x[n][ai];
-        besti[n] = hl * 8 + ai;
+        for (int e = 1; e < 8; ++e) {
+            const bool gt = x[n][e] > bv;
+            bv = gt ? x[n][e] : bv;
+            bi = gt ? e : bi;
+        }
+        bestv[n] = bv;
+        besti[n] = hl * 8 + bi;
     }
 #define K3S_ARGMAX_STEP(O)                                                                                   \
     _Pragma("unroll") for (int n = 0; n < NR; ++n) {                                                        \
@@ -326,10 +340,13 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(CT == 8 ? 4
         }
         K3S_STAMP(1);
         if (wv == 0) {  // C/D layout: column = lane & 15, row = 4 (lane >> 4) + r; two columns + the tag per 64-bit agent-scope store
+            // rows r, r + 1 packed; the neighbouring column's pair by a DPP quad permute (four ds_bpermute round trips sat on the critical path here)
+            const unsigned z01 = pack_bf16x2(acc[0], acc[1]), z23 = pack_bf16x2(acc[2], acc[3]);
+            const unsigned n01 = (unsigned)xor_lane_i<1>((int)z01), n23 = (unsigned)xor_lane_i<1>((int)z23);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned z = f32_to_bf16_bits(acc[r]);
-                const unsigned zn = (unsigned)xor_lane_i<1>((int)z);  // the neighbouring column: a DPP quad permute (ds_bpermute's round trip, four times, sat on the critical path)
+                const unsigned z = (((r & 2) ? z23 : z01) >> ((r & 1) * 16)) & 0xffffu;
+                const unsigned zn = (((r & 2) ? n23 : n01) >> ((r & 1) * 16)) & 0xffffu;
                 if (!(c & 1) && c < CT)
                     __hip_atomic_store(a.zs + (size_t)(rb * 16 + g * 4 + r) * (kNA / 2) + ((j * CT + c) >> 1), ((unsigned long long)a.tag << 32) | z | (zn << 16),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -388,10 +405,10 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(CT == 8 ? 4
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = row < Rn ? kE * expf(x[e] - alse) * ((float)(hl * 8 + e + 1) - E) : 0.0f;
         uint4 pk;
-        pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
-        pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
-        pk.z = f32_to_bf16_bits(o[4]) | (f32_to_bf16_bits(o[5]) << 16);
-        pk.w = f32_to_bf16_bits(o[6]) | (f32_to_bf16_bits(o[7]) << 16);
+        pk.x = pack_bf16x2(o[0], o[1]);
+        pk.y = pack_bf16x2(o[2], o[3]);
+        pk.z = pack_bf16x2(o[4], o[5]);
+        pk.w = pack_bf16x2(o[6], o[7]);
         *reinterpret_cast<uint4*>(gt + (u * 16 + own_lr) * kSGS + hl * 8) = pk;
         if (a.gs && j == 0 && u == mb && row < R) *reinterpret_cast<uint4*>(a.gs + (size_t)row * kNA + hl * 8) = pk;
     };
@@ -584,7 +601,11 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(CT == 8 ? 4
         for (int t = 0; t < kTPW; ++t) {
             const int rt = NRB == 1 ? 0 : rt0 + t, dt = NRB == 1 ? dt0 + t : dt0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[(rt * 16 + g * 4 + r) * kOS + dt * 16 + c] = (uint16_t)f32_to_bf16_bits(acc3[t][r]);
+            for (int r = 0; r < 4; r += 2) {
+                const unsigned pr = pack_bf16x2(acc3[t][r], acc3[t][r + 1]);
+                ot[(rt * 16 + g * 4 + r) * kOS + dt * 16 + c] = (uint16_t)(pr & 0xffffu);
+                ot[(rt * 16 + g * 4 + r + 1) * kOS + dt * 16 + c] = (uint16_t)(pr >> 16);
+            }
         }
         K3S_STAMP(8);
         __syncthreads();
