@@ -87,12 +87,13 @@ struct SliceHeadArgs {
 // the slice statistics of NR rows, each held by a HALF wave (32 lanes x 8 logits), the rows' dependent shuffle chains side by side: the arithmetic of
 // head_finish_kernel / rows_stats_kernel — whose 64-lane butterflies start at offset 32 against neutral upper lanes (-inf, 0), and whose separate
 // wave_max of the lane maxima IS the value the argmax butterfly ends with (max is exact) — hence the same bits
-// lane ^ O within a half wave: DPP quad permutes (O = 1, 2) and ds_swizzle's bit-mask mode (O = 4, 8, 16; it works on 32-lane halves) — no
+// lane ^ O within a half wave: DPP quad permutes (O = 1, 2), a DPP row rotate (O = 8) and ds_swizzle's bit-mask mode (O = 4, 16; it works on 32-lane halves) — no
 // address register and a shorter round trip than __shfl_xor's ds_bpermute; pure data movement, the same bits
 template <int O>
 __device__ __forceinline__ int xor_lane_i(int v) {
     if (O == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
     if (O == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    if (O == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false); // row_ror:8 — within a row of 16 lanes, lane + 8 mod 16 IS lane ^ 8
     return __builtin_amdgcn_ds_swizzle(v, (O << 10) | 0x1F);                       // {xor = O, or = 0, and = 0x1f}
 }
 template <int O>
@@ -439,7 +440,11 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(CT == 8 ? 4
             for (int i = q0; i < q0 + kPerQ; ++i) bfr[i / (kNA / 32)][i % (kNA / 32)] = *reinterpret_cast<const v8s_s*>(bsrc[i / (kNA / 32)] + (i % (kNA / 32)) * 32);
         }
     };
+    // (the first poll in front of the barrier above — its round trip under the wait for wave 0 — is WORSE: 12.5 against 9.6 us at 128 rows; seven waves per
+    //  workgroup poll early, miss, and their uncached re-reads delay the producers' stores;
     unsigned long long w0[NRB][4];
+    //  a pause of 0.2-0.3 us in front of it instead — so that it does not come back empty — : 10.1 against 10.9 us behind a 1 GiB copy, nothing warm,
+    //  12.6 against 12.8 us in the bs=64 step (A B B A, within the noise): not kept)
 #pragma unroll
     for (int u = 0; u < NRB; ++u) request(u, w0[u]);
     bool own_gave_up = a.max_polls < 0;  // (test hook VAA_K3_HANDOVER_POLLS=-1: the failure path, deterministically)
