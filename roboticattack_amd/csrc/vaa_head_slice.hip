@@ -440,9 +440,9 @@ __global__ __launch_bounds__(kST) __attribute__((amdgpu_waves_per_eu(CT == 8 ? 4
             for (int i = q0; i < q0 + kPerQ; ++i) bfr[i / (kNA / 32)][i % (kNA / 32)] = *reinterpret_cast<const v8s_s*>(bsrc[i / (kNA / 32)] + (i % (kNA / 32)) * 32);
         }
     };
+    unsigned long long w0[NRB][4];
     // (the first poll in front of the barrier above — its round trip under the wait for wave 0 — is WORSE: 12.5 against 9.6 us at 128 rows; seven waves per
     //  workgroup poll early, miss, and their uncached re-reads delay the producers' stores;
-    unsigned long long w0[NRB][4];
     //  a pause of 0.2-0.3 us in front of it instead — so that it does not come back empty — : 10.1 against 10.9 us behind a 1 GiB copy, nothing warm,
     //  12.6 against 12.8 us in the bs=64 step (A B B A, within the noise): not kept)
 #pragma unroll
