@@ -28,8 +28,8 @@
 //              of the slice (vaa_head_slice_pack, once per weight), requested in quarters BETWEEN the stages of phase 2 (a burst of all of them
 //              stalls the statistics behind the CU's fetch rate; all of them in front of the poll: no better, 10.8 against 9.7 us at 16 rows).
 //   Bytes per launch at R' = 128, D = 4096: H 1.05 MB + W slice 2.10 MB + transposed slice 2.10 MB read, dH 1.05 MB written = 6.3 MB
-//   (K3h + finish + the 256-column GEMM: 263.7 + 1.05 + ~4.3 MB). 10.4 us per dispatch warm (16-column form: 11.7; round 6's first form 12.1),
-//   13.5-13.7 us in the bs=64 step (15.2-15.4; 15.6-15.7): a latency chain (profiles/r06_k3s_stamps.txt).
+//   (K3h + finish + the 256-column GEMM: 263.7 + 1.05 + ~4.3 MB). 9.5 us per dispatch warm (16-column form: 10.7; round 6's first form 12.1),
+//   12.6-12.7 us in the bs=64 step (14.1-14.2; 15.6-15.7): a latency chain (profiles/r06_k3s_stamps.txt).
 #include <stdlib.h>
 
 #include <atomic>
