@@ -13,10 +13,20 @@ for R in (128, 16):
     rm = ops.LossRowMap(labels)
     h = torch.randn(R, D, device=DEV, generator=g).to(torch.bfloat16)
     cold = len(sys.argv) > 1 and sys.argv[1] == "cold"
+    gemms = len(sys.argv) > 1 and sys.argv[1] == "gemms"  # behind ~100 ms of bf16 GEMMs over 3 GB of weights: caches AND clocks as inside a model step
     scratch = (torch.empty(1 << 30, dtype=torch.uint8, device=DEV), torch.empty(1 << 30, dtype=torch.uint8, device=DEV)) if cold else None
+    if gemms:
+        ws_ = [torch.randn(4096, 11008, device=DEV, dtype=torch.bfloat16) * 0.01 for _ in range(32)]
+        xs_ = torch.randn(16384, 4096, device=DEV, dtype=torch.bfloat16)
     for _ in range(5):
         if cold:  # a 1 GiB device copy replaces every L2 and the Infinity Cache: what the call sees inside a model step
             scratch[1].copy_(scratch[0])
+        if gemms:
+            for w_ in ws_:
+                y_ = xs_ @ w_
+            hh = h + 0  # the hidden rows are fresh, as the final norm leaves them
+            o = ops.head_slice_fwd_bwd(hh, W, rm, ops.LOSS_UADA_DDP, 5.0, want_scalars=False)
+            continue
         o = ops.head_slice_fwd_bwd(h, W, rm, ops.LOSS_UADA_DDP, 5.0, want_scalars=False)
     torch.cuda.synchronize()
     del scratch
