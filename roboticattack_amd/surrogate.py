@@ -149,6 +149,17 @@ class SurrogateEmbedVLA(nn.Module):
         return logits.reshape(-1, logits.shape[-1]).index_select(0, row_index)
 
 
+class _BiaslessHead(nn.Module):
+    """`lm_head`: F.linear with a frozen [vocab, d] weight (built from the given tensor: nn.Linear's constructor would draw from the global RNG)."""
+
+    def __init__(self, weight: torch.Tensor):
+        super().__init__()
+        self.weight = nn.Parameter(weight, requires_grad=False)
+
+    def forward(self, x):
+        return F.linear(x, self.weight)
+
+
 class SurrogateHeadVLA(SurrogateEmbedVLA):
     """SurrogateEmbedVLA with a bf16 LM head over bf16 hidden states — `lm_head.weight` [vocab, d] as LlamaForCausalLM holds it, logits upcast to
     fp32 ([3p transformers 4.40.1 modeling_llama.py]: `logits = logits.float()`) — and the hidden-rows interface of OpenVLAShaped
@@ -160,8 +171,7 @@ class SurrogateHeadVLA(SurrogateEmbedVLA):
     def __init__(self, d: int = 192, D0: int = 64, D1: int = 128, vocab: int = MODEL_VOCAB, seed: int = 0):
         super().__init__(d=d, D0=D0, D1=D1, vocab=vocab, seed=seed)
         g = torch.Generator().manual_seed(seed + 7919)
-        self.lm_head = nn.Linear(d, vocab, bias=False)
-        self.lm_head.weight = nn.Parameter((torch.randn(vocab, d, generator=g) * (16.0 / math.sqrt(d))).to(torch.bfloat16), requires_grad=False)
+        self.lm_head = _BiaslessHead((torch.randn(vocab, d, generator=g) * (16.0 / math.sqrt(d))).to(torch.bfloat16))
         self.head = None  # the fp32 head of the parent is not part of this model
 
     def _logits(self, input_ids, e0, e1):

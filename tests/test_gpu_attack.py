@@ -1269,6 +1269,76 @@ def test_upa_trajectory_k3s_vs_reference_loop(tmp_path, monkeypatch):
     np.testing.assert_allclose(att.train_CE_loss, d["train_ce"], rtol=3e-4)
 
 
+def test_ddp_trajectory_k3s_vs_reference_loop(tmp_path, monkeypatch):
+    """The HEADLINE loop on a reference-loop trajectory: tools/gen_golden.py:gen_trajectory_ddp_k3s drove the reference's own
+    `UADA_ddp.OpenVLAAttacker.attack(rank 0, world 1)` (UADA_ddp.py:138-324: patch init, inner loop with the MSE-only weighted_loss, HF AdamW + clamp,
+    the schedule stepped per outer iteration, the validation pass at i = 0 drawing its placements from the same RNG stream) over SurrogateHeadVLA on
+    the CPU (device / DDP / collective calls of one rank redirected, nothing else), recording the patch after every optimiser step and the train
+    log of every outer iteration. Here `attack/uada_ddp.py` runs the same module on the GPU, where every training step is `fused_ddp_step`:
+    K1 tile-major -> body -> K3s (UADA_DDP; K3h behind it on the last inner step of an outer iteration) -> K2' -> step epilogue with AdamW inside.
+    Patch after EVERY step, `last/patch.pt`, the logged CE / MSE / UAD and the validation averages within the north-star tolerance."""
+    import socket
+
+    from roboticattack_amd import ops
+    from roboticattack_amd.attack import uada_ddp
+    from roboticattack_amd.surrogate import SurrogateHeadVLA
+
+    d = np.load(os.path.join(GOLDEN, "traj_ddp_k3s.npz"))
+    n_it, inner, bs = int(d["num_iter"]), int(d["inner"]), int(d["bs"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    for k, v in dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+    for k in ("VAA_FULL_CE_EVERY_STEP", "VAA_HEAD_EVERY_STEP"):
+        monkeypatch.delenv(k, raising=False)
+    snaps, logs = [], []
+
+    class Att(uada_ddp.OpenVLAAttacker):
+        val_batches = 100  # UADA_ddp.py:240 (the loader below holds two batches: the pass ends with it, the averages still divide by 100)
+
+        def fused_ddp_step(self, pixel_values, patch, *a, **k):
+            r = super().fused_ddp_step(pixel_values, patch, *a, **k)
+            snaps.append(patch.detach().cpu().numpy().copy())
+            return r
+
+        def assert_finite_state(self, patch, optimizer, host, where, **kw):
+            logs.append(np.array(host, dtype=np.float64).copy())
+            return super().assert_finite_state(patch, optimizer, host, where, **kw)
+
+    att = Att(vla_path="x", dataset_name="synthetic", save_dir=str(tmp_path), patch_size=[3, 50, 50], lr=float(d["lr"]), bs=bs, warmup=int(d["warmup"]),
+              num_iter=n_it, maskidx=[int(v) for v in d["maskidx"]], innerLoop=inner, geometry=True, use_wandb=False, MSE_weights=int(d["MSE_weights"]),
+              model_factory=lambda path, dev: SurrogateHeadVLA(seed=int(d["model_seed"])).to(dev),
+              dataset_factory=lambda name, b, rank, world: (_Fresh([int(d["train_seed0"]) + i for i in range(n_it)], bs),
+                                                            _Fresh([int(d["val_seed0"]) + i for i in range(int(d["val_batches"]))], bs)))
+    assert att.fused_ddp_available()
+    _seed()  # random / numpy / torch = 42 right in front of the loop, as the generator did
+    ops.prof_start(4096)
+    patch = att.attack(0, 1)
+    names = [n for n, _ in ops.prof_collect()]
+    # K3s on every training step, K3h behind it once per outer iteration; K2' every step; the validation pass (CE is logged there) is K3h's
+    assert sum("head_slice_kernel" in n for n in names) == n_it * inner and sum("embed_dgrad" in n for n in names) == n_it * inner
+    assert sum("head_stats_kernel" in n for n in names) == n_it + int(d["val_batches"]), sorted(set(names))
+    ref = d["patches"]
+    assert len(snaps) == len(ref) == n_it * inner
+    err = [float(np.abs(a - b).max()) for a, b in zip(snaps, ref)]
+    print("per-step max |patch - reference|:", ["%.2e" % e for e in err], "movement", float(np.abs(ref[-1] - ref[0]).max()))
+    assert max(err) <= 1e-4, err
+    assert np.abs(ref[-1] - ref[0]).max() > 5e-3 and np.array_equal(snaps[0], snaps[inner - 1])  # it moves; lr = 0 during outer iteration 0
+    last = torch.load(os.path.join(str(tmp_path), "last", "patch.pt")).numpy()
+    assert np.abs(last - d["last_saved"]).max() <= 1e-4  # the patch the i = 0 validation pass saved
+    assert np.abs(patch.detach().cpu().numpy() - ref[-1]).max() <= 1e-4
+    logs = np.stack(logs)  # [CE, w^2 MSE, UAD, total] of the last inner step of every outer iteration
+    np.testing.assert_allclose(logs[:, 0], d["train_ce"], rtol=3e-4)
+    # (the MSE term is a mean over six rows of a soft-argmax through bf16 hidden states: one flipped bf16 rounding of a hidden element shows at 1e-3)
+    np.testing.assert_allclose(logs[:, 1], d["train_mse"], rtol=2e-3)
+    np.testing.assert_allclose(logs[:, 2], d["train_uad"], atol=2e-4)
+    np.testing.assert_allclose([float(att.val_MSE_Distance[0])], d["val_mse"], rtol=2e-3)
+    np.testing.assert_allclose([float(att.val_UAD[0])], d["val_uad"], atol=2e-5)
+    np.testing.assert_allclose([float(att.val_CE_loss[0])], d["val_ce"], rtol=3e-4)
+
+
 def test_fused_head_step_vs_gemm_head_step(monkeypatch):
     """The data-parallel UADA step with the LM head FUSED into K3's statistics (vaa_head_loss_rows_stats: what `fused_ddp_step` runs up to 128
     labelled rows, i.e. at every batch size of BASELINE's configs) against the same step with the head as a hipBLASLt GEMM +

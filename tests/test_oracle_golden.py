@@ -275,7 +275,7 @@ def test_c_oracle_eval_paste_byte_exact():
 def test_committed_fixtures_are_what_the_reference_produces_here(tmp_path):
     """Oracle pinning, re-checked wherever /root/reference is present: tools/gen_golden.py drives the reference's own functions again (the quick
     parts: RNG parameter stream, mask_labels / tokenizer pairs, scheduler table, K3 losses, the eval-time paste, the K1/K2 cases) and every array it
-    writes equals the committed fixture bit for bit. (The trajectory parts replay whole loops: `python tools/gen_golden.py traj traj2 trajk2e traj3 traj4 trajk3s`.)"""
+    writes equals the committed fixture bit for bit. (The trajectory parts replay whole loops: `python tools/gen_golden.py traj traj2 trajk2e traj3 traj4 trajk3s trajddp`.)"""
     import subprocess
     import sys
 

@@ -746,6 +746,136 @@ def gen_trajectory_upa_k3s():
         vla=SurrogateHeadVLA(seed=seed), model_seed=seed)
 
 
+def gen_trajectory_ddp_k3s():
+    """The HEADLINE loop on a reference loop: the reference's own `UADA_ddp.OpenVLAAttacker.attack(rank = 0, world_size = 1)` (UADA_ddp.py:138-324:
+    patch init + broadcast, the inner loop with the MSE-only `weighted_loss`, HF AdamW + clamp, the cosine schedule stepped per outer iteration, the
+    i % 200 validation pass with its placements drawn from the same RNG stream) over SurrogateHeadVLA on the CPU.
+    The loop is written for CUDA devices and a NCCL group: `.to('cuda')`, `.to(rank)`, `device=rank`, `DDP(model, device_ids=[rank])`,
+    `dist.all_reduce(op=AVG)`. None of that is arithmetic at world size 1, so for THIS run the module sees: a `torch` whose `tensor(...)` drops
+    `device=`, `Tensor.to` that ignores 'cuda' / an integer rank, a `DDP` that calls the module, a `dist` whose collectives over one rank are the
+    identity. `__init__` (HF model + RLDS dataset loading) is bypassed: its attributes are set by hand to what it would have set.
+    The product replays it with `attack/uada_ddp.py` on the GPU: K1 tile-major -> K3s (UADA_DDP) -> K2' -> step epilogue with AdamW inside
+    (tests/test_gpu_attack.py:test_ddp_trajectory_k3s_vs_reference_loop)."""
+    import transformers
+
+    from oracle.ref_port import HFAdamW
+    from roboticattack_amd.surrogate import SurrogateHeadVLA
+
+    D = ref.UADA_ddp
+    transformers.AdamW = HFAdamW
+    D.transformers.AdamW = HFAdamW
+    n_it, inner, bs, seed, lr, warm, wts = 4, 3, 3, 9, 2e-3, 1, 5
+    save_dir = "/tmp/vaa_golden_traj_ddp"
+    shutil.rmtree(save_dir, ignore_errors=True)
+    os.makedirs(save_dir)
+
+    class _Vla(SurrogateHeadVLA):
+        def to(self, *a, **k):  # `.to(rank)`
+            return self
+
+    class _Batches(list):  # a "dataset" whose items are whole batches (bs = 1 + a collator that unwraps): `.shard()` of one shard is itself
+        def shard(self, num_shards, index):
+            assert num_shards == 1 and index == 0
+            return self
+
+    att = object.__new__(D.OpenVLAAttacker)
+    att.processor = None
+    att.vla = _Vla(seed=seed)
+    att.action_tokenizer = ref.action_tokenizer.ActionTokenizer(ref_import.FakeTokenizer())
+    att.save_dir = save_dir
+    att.randomPatchTransform = ref.transform.RandomPatchTransform(att.vla.device, False)
+    att.mean = [torch.tensor([0.484375, 0.455078125, 0.40625]), torch.tensor([0.5, 0.5, 0.5])]
+    att.std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
+    att.MSE_Distance_best = 1000000
+    att.collator = lambda items: items[0]
+    att.bs, att.lr, att.warmup, att.num_iter, att.maskidx, att.innerLoop = 1, lr, warm, n_it, [0, 1], inner
+    att.geometry, att.use_wandb, att.patch_size, att.MSE_weights = True, True, [3, 50, 50], wts  # (use_wandb: the train log goes to the recorder below)
+    att.val_CE_loss, att.val_MSE_Distance, att.val_UAD = [], [], []
+    att.train_dataset = _Batches(synthetic.synth_batch(9300 + i, bs, "smooth") for i in range(n_it))
+    att.val_dataset = _Batches(synthetic.synth_batch(9400 + i, bs, "smooth") for i in range(2))
+    att.setup = lambda rank, world_size: None
+    att.cleanup = lambda: None
+
+    class _Torch:  # `torch.tensor([x], dtype=..., device=rank)`; everything else is torch
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def tensor(*a, device=None, **k):
+            return torch.tensor(*a, **k)
+
+    class _DDP:
+        def __init__(self, module, **_):
+            self.module = module
+
+        def __call__(self, *a, **k):
+            return self.module(*a, **k)
+
+    class _Dist:
+        ReduceOp = torch.distributed.ReduceOp
+        broadcast = staticmethod(lambda t, src=0: None)
+        all_reduce = staticmethod(lambda t, op=None: None)
+        is_initialized = staticmethod(lambda: True)
+
+    snaps = []
+    orig_step, orig_to = HFAdamW.step, torch.Tensor.to
+
+    def rec_step(self, closure=None):
+        orig_step(self)
+        snaps.append(self.param_groups[0]["params"][0].detach().clone().clamp(0, 1).numpy())
+
+    def to(self, *a, **k):
+        if a and (a[0] == "cuda" or (isinstance(a[0], int) and not isinstance(a[0], bool))):
+            a = a[1:]
+            if not a and not k:
+                return self
+        return orig_to(self, *a, **k)
+
+    logs = []
+    saved = (D.torch, D.DDP, D.dist, D.tqdm, D.wandb)
+    D.torch, D.DDP, D.dist = _Torch(), _DDP, _Dist
+    D.wandb = types.SimpleNamespace(log=lambda d, step=None: logs.append((step, {k: float(v) for k, v in d.items() if k.startswith("TRAIN")})),
+                                    Image=lambda *a, **k: None)
+
+    class _Bar:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def update(self, n):
+            pass
+
+    D.tqdm = _Bar
+    HFAdamW.step = rec_step
+    torch.Tensor.to = to
+    os.environ["RANK"] = "0"
+    random.seed(42)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    try:
+        att.attack(0, 1)
+    finally:
+        HFAdamW.step, torch.Tensor.to = orig_step, orig_to
+        D.torch, D.DDP, D.dist, D.tqdm, D.wandb = saved
+    last = torch.load(os.path.join(save_dir, "last", "patch.pt")).numpy()
+    tl = [(st, d) for st, d in logs if d]
+    assert len(tl) == n_it, logs
+    np.savez_compressed(os.path.join(GOLD, "traj_ddp_k3s.npz"), num_iter=n_it, inner=inner, bs=bs, warmup=warm, lr=lr, MSE_weights=wts,
+                        maskidx=np.array([0, 1]), model_seed=seed, train_seed0=9300, val_seed0=9400, val_batches=2,
+                        patches=np.stack(snaps).astype(np.float32), last_saved=last,
+                        train_ce=np.array([d["TRAIN_attack_loss(CE)"] for _, d in tl]), train_mse=np.array([d["TRAIN_attack_loss (MSE_Distance)"] for _, d in tl]),
+                        train_uad=np.array([d["TRAIN_UAD"] for _, d in tl]), train_patch_grad=np.array([d["TRAIN_patch_gradient"] for _, d in tl]),
+                        val_mse=np.array([float(v) for v in att.val_MSE_Distance]), val_uad=np.array([float(v) for v in att.val_UAD]),
+                        val_ce=np.array([float(v) for v in att.val_CE_loss]))
+    print("traj_ddp_k3s: steps", len(snaps), "train", tl, "movement", np.abs(snaps[-1] - snaps[0]).max(), "val", att.val_MSE_Distance, att.val_UAD, att.val_CE_loss,
+          sorted(os.listdir(save_dir)))
+
+
 # ------------------------------------------------------------------------------------------------
 # eval-time paste: RandomPatchTransform.simulation_random_patch (appply_random_transform.py:43-78)
 # ------------------------------------------------------------------------------------------------
@@ -770,8 +900,8 @@ def gen_sim():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1k2", "resize", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "trajk2e", "traj3", "traj4", "trajk3s", "sim"]
+    which = sys.argv[1:] or ["k1k2", "resize", "rng", "labels", "k3", "sched", "fmt", "traj", "traj2", "trajk2e", "traj3", "traj4", "trajk3s", "trajddp", "sim"]
     fns = dict(k1k2=gen_k1k2, resize=gen_resize, rng=gen_rng_stream, labels=gen_labels_tokenizer, k3=gen_k3, sched=gen_sched, fmt=gen_patch_format,
-               traj=gen_trajectory, traj2=gen_trajectory_tma_upa, trajk2e=gen_trajectory_k2e, traj3=gen_trajectory_upa_resize, traj4=gen_trajectory_tma_geo7, trajk3s=gen_trajectory_upa_k3s, sim=gen_sim)
+               traj=gen_trajectory, traj2=gen_trajectory_tma_upa, trajk2e=gen_trajectory_k2e, traj3=gen_trajectory_upa_resize, traj4=gen_trajectory_tma_geo7, trajk3s=gen_trajectory_upa_k3s, trajddp=gen_trajectory_ddp_k3s, sim=gen_sim)
     for w in which:
         fns[w]()
