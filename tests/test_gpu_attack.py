@@ -1339,6 +1339,96 @@ def test_ddp_trajectory_k3s_vs_reference_loop(tmp_path, monkeypatch):
     np.testing.assert_allclose([float(att.val_CE_loss[0])], d["val_ce"], rtol=3e-4)
 
 
+def _ddp_traj_worker(rank, world, port, out_dir, golden_path):
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VAA_DIST_BACKEND="gloo")
+    for k in ("VAA_FULL_CE_EVERY_STEP", "VAA_HEAD_EVERY_STEP"):
+        os.environ.pop(k, None)
+    from roboticattack_amd import ops, optim
+    from roboticattack_amd.attack import uada_ddp
+    from roboticattack_amd.surrogate import SurrogateHeadVLA
+
+    d = np.load(golden_path)
+    n_it, inner, bs, nval = int(d["num_iter"]), int(d["inner"]), int(d["bs"]), int(d["val_batches"])
+    snaps, logs = [], []
+    orig = optim.PatchOptimizer.step
+
+    def rec(self, *a, **k):
+        r = orig(self, *a, **k)
+        snaps.append(self.patch.detach().cpu().numpy().copy())
+        return r
+
+    optim.PatchOptimizer.step = rec
+
+    class Att(uada_ddp.OpenVLAAttacker):
+        val_batches = 100  # UADA_ddp.py:240
+
+        def assert_finite_state(self, patch, optimizer, host, where, **kw):
+            logs.append(np.array(host, dtype=np.float64).copy())
+            return super().assert_finite_state(patch, optimizer, host, where, **kw)
+
+    att = Att(vla_path="x", dataset_name="synthetic", save_dir=os.path.join(out_dir, f"rank{rank}"), patch_size=[3, 50, 50], lr=float(d["lr"]), bs=bs,
+              warmup=int(d["warmup"]), num_iter=n_it, maskidx=[int(v) for v in d["maskidx"]], innerLoop=inner, geometry=True, use_wandb=False,
+              MSE_weights=int(d["MSE_weights"]), device=torch.device("cuda:0"),
+              model_factory=lambda path, dev: SurrogateHeadVLA(seed=int(d["model_seed"])).to(dev),
+              # rank r's shard: the batches seeded seed0 + world * i + r (the generator's `.shard(num_shards=world, index=rank)`)
+              dataset_factory=lambda name, b, r, w: (_Fresh([int(d["train_seed0"]) + w * i + r for i in range(n_it)], bs),
+                                                     _Fresh([int(d["val_seed0"]) + w * i + r for i in range(nval)], bs)))
+    assert att.fused_ddp_available()
+    _seed()  # UADA_wrapper_ddp.py:53: every rank seeds 42
+    ops.prof_start(4096)
+    patch = att.attack(rank, world)
+    names = [n for n, _ in ops.prof_collect()]
+    np.savez(os.path.join(out_dir, f"traj_r{rank}.npz"), snaps=np.stack(snaps), final=patch.detach().cpu().numpy(), logs=np.stack(logs),
+             n_slice=sum("head_slice_kernel" in n for n in names), n_k2e=sum("embed_dgrad" in n for n in names), n_k3h=sum("head_stats_kernel" in n for n in names),
+             val=np.array([float(att.val_MSE_Distance[0]), float(att.val_UAD[0]), float(att.val_CE_loss[0])] if rank == 0 else [0.0, 0.0, 0.0]))
+
+
+def test_ddp_two_rank_trajectory_k3s_vs_reference_loop(tmp_path):
+    """TWO ranks of the headline loop against TWO ranks of the reference's: tools/gen_golden.py:gen_trajectory_ddp_k3s ran the reference's own
+    `UADA_ddp.OpenVLAAttacker.attack(rank, 2)` in two CPU processes over a gloo group — torch's own DistributedDataParallel averaging the patch gradient,
+    each rank on its shard of the batches, every rank seeded 42 — and recorded the patch after every optimiser step. Here two processes share the one GPU
+    (VAA_DIST_BACKEND=gloo): every step is K1 tile-major -> K3s -> K2' -> step epilogue -> ONE packed all-reduce [gradient | CE, MSE, UAD, total] -> K4 with
+    the 1 / world mean folded in. Both ranks bit-identical after every step; the trajectory, the all-reduced train log and rank 0's validation averages
+    within the north-star tolerance of the reference's."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    golden = os.path.join(GOLDEN, "traj_ddp2_k3s.npz")
+    d = np.load(golden)
+    n_it, inner, world = int(d["num_iter"]), int(d["inner"]), int(d["world"])
+    assert world == 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_ddp_traj_worker, args=(world, port, str(tmp_path), golden), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "traj_r0.npz"), np.load(tmp_path / "traj_r1.npz")
+    assert np.array_equal(r0["snaps"], r1["snaps"]) and np.array_equal(r0["final"], r1["final"]) and np.array_equal(r0["logs"], r1["logs"])
+    for r in (r0, r1):  # K3s + K2' on every step of every rank; K3h once per outer iteration + the validation batches
+        assert int(r["n_slice"]) == n_it * inner and int(r["n_k2e"]) == n_it * inner and int(r["n_k3h"]) == n_it + int(d["val_batches"])
+    ref = d["patches"]
+    assert r0["snaps"].shape == ref.shape
+    err = np.abs(r0["snaps"] - ref).reshape(len(ref), -1).max(1)
+    print("per-step max |patch - reference|:", ["%.2e" % e for e in err], "movement", float(np.abs(ref[-1] - ref[0]).max()))
+    assert err.max() <= 1e-4, err
+    assert np.abs(ref[-1] - ref[0]).max() > 5e-3 and np.array_equal(r0["snaps"][0], r0["snaps"][inner - 1])
+    assert np.abs(r0["final"] - ref[-1]).max() <= 1e-4
+    last = torch.load(tmp_path / "rank0" / "last" / "patch.pt").numpy()
+    assert np.abs(last - d["last_saved"]).max() <= 1e-4 and not os.path.exists(tmp_path / "rank1" / "last")
+    np.testing.assert_allclose(r0["logs"][:, 0], d["train_ce"], rtol=3e-4)   # the AVG all-reduce of the ranks' last-inner-step values
+    np.testing.assert_allclose(r0["logs"][:, 1], d["train_mse"], rtol=2e-3)
+    np.testing.assert_allclose(r0["logs"][:, 2], d["train_uad"], atol=2e-4)
+    np.testing.assert_allclose(r0["val"][0], d["val_mse"][0], rtol=2e-3)
+    np.testing.assert_allclose(r0["val"][1], d["val_uad"][0], atol=2e-5)
+    np.testing.assert_allclose(r0["val"][2], d["val_ce"][0], rtol=3e-4)
+
+
 def test_fused_head_step_vs_gemm_head_step(monkeypatch):
     """The data-parallel UADA step with the LM head FUSED into K3's statistics (vaa_head_loss_rows_stats: what `fused_ddp_step` runs up to 128
     labelled rows, i.e. at every batch size of BASELINE's configs) against the same step with the head as a hipBLASLt GEMM +

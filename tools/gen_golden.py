@@ -746,16 +746,17 @@ def gen_trajectory_upa_k3s():
         vla=SurrogateHeadVLA(seed=seed), model_seed=seed)
 
 
-def gen_trajectory_ddp_k3s():
-    """The HEADLINE loop on a reference loop: the reference's own `UADA_ddp.OpenVLAAttacker.attack(rank = 0, world_size = 1)` (UADA_ddp.py:138-324:
-    patch init + broadcast, the inner loop with the MSE-only `weighted_loss`, HF AdamW + clamp, the cosine schedule stepped per outer iteration, the
-    i % 200 validation pass with its placements drawn from the same RNG stream) over SurrogateHeadVLA on the CPU.
+def _ref_ddp_worker(rank, world, port, cfg, out_path):
+    """One rank of the reference's own `UADA_ddp.OpenVLAAttacker.attack(rank, world)` (UADA_ddp.py:138-324) over SurrogateHeadVLA on the CPU.
     The loop is written for CUDA devices and a NCCL group: `.to('cuda')`, `.to(rank)`, `device=rank`, `DDP(model, device_ids=[rank])`,
-    `dist.all_reduce(op=AVG)`. None of that is arithmetic at world size 1, so for THIS run the module sees: a `torch` whose `tensor(...)` drops
-    `device=`, `Tensor.to` that ignores 'cuda' / an integer rank, a `DDP` that calls the module, a `dist` whose collectives over one rank are the
-    identity. `__init__` (HF model + RLDS dataset loading) is bypassed: its attributes are set by hand to what it would have set.
-    The product replays it with `attack/uada_ddp.py` on the GPU: K1 tile-major -> K3s (UADA_DDP) -> K2' -> step epilogue with AdamW inside
-    (tests/test_gpu_attack.py:test_ddp_trajectory_k3s_vs_reference_loop)."""
+    `dist.all_reduce(op=AVG)`. For THIS run the module sees: a `torch` whose `tensor(...)` drops `device=`, a `Tensor.to` that ignores 'cuda' /
+    an integer rank, and
+      world 1: a `DDP` that calls the module and a `dist` whose collectives over one rank are the identity;
+      world 2: torch's own DistributedDataParallel on a gloo group (without `device_ids`) — the gradient averaging is ITS arithmetic — and torch's
+               own `dist`, with AVG (which gloo lacks) as SUM / world.
+    `__init__` (HF model + RLDS dataset loading) is bypassed: its attributes are set by hand to what it would have set. The loop's own statements run
+    unmodified. Rank r's shard of the data = the batches seeded train_seed0 + world * i + r (a `.shard()` of a dataset of whole batches)."""
+    import torch.distributed as tdist
     import transformers
 
     from oracle.ref_port import HFAdamW
@@ -764,23 +765,33 @@ def gen_trajectory_ddp_k3s():
     D = ref.UADA_ddp
     transformers.AdamW = HFAdamW
     D.transformers.AdamW = HFAdamW
-    n_it, inner, bs, seed, lr, warm, wts = 4, 3, 3, 9, 2e-3, 1, 5
-    save_dir = "/tmp/vaa_golden_traj_ddp"
+    n_it, inner, bs = cfg["num_iter"], cfg["inner"], cfg["bs"]
+    save_dir = f"/tmp/vaa_golden_traj_ddp_w{world}_r{rank}"
     shutil.rmtree(save_dir, ignore_errors=True)
     os.makedirs(save_dir)
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        tdist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class _Out(dict):  # like transformers' ModelOutput: a mapping (DistributedDataParallel looks for the output tensors in it) with attribute access
+        __getattr__ = dict.__getitem__
 
     class _Vla(SurrogateHeadVLA):
         def to(self, *a, **k):  # `.to(rank)`
             return self
 
-    class _Batches(list):  # a "dataset" whose items are whole batches (bs = 1 + a collator that unwraps): `.shard()` of one shard is itself
+        def forward(self, *a, **k):
+            o = super().forward(*a, **k)
+            return _Out(loss=o.loss, logits=o.logits)
+
+    class _Batches(list):  # a "dataset" whose items are whole batches (bs = 1 + a collator that unwraps)
         def shard(self, num_shards, index):
-            assert num_shards == 1 and index == 0
-            return self
+            assert num_shards == world and index == rank
+            return _Batches(self[index::num_shards])
 
     att = object.__new__(D.OpenVLAAttacker)
     att.processor = None
-    att.vla = _Vla(seed=seed)
+    att.vla = _Vla(seed=cfg["model_seed"])
     att.action_tokenizer = ref.action_tokenizer.ActionTokenizer(ref_import.FakeTokenizer())
     att.save_dir = save_dir
     att.randomPatchTransform = ref.transform.RandomPatchTransform(att.vla.device, False)
@@ -788,12 +799,12 @@ def gen_trajectory_ddp_k3s():
     att.std = [torch.tensor([0.228515625, 0.2236328125, 0.224609375]), torch.tensor([0.5, 0.5, 0.5])]
     att.MSE_Distance_best = 1000000
     att.collator = lambda items: items[0]
-    att.bs, att.lr, att.warmup, att.num_iter, att.maskidx, att.innerLoop = 1, lr, warm, n_it, [0, 1], inner
-    att.geometry, att.use_wandb, att.patch_size, att.MSE_weights = True, True, [3, 50, 50], wts  # (use_wandb: the train log goes to the recorder below)
+    att.bs, att.lr, att.warmup, att.num_iter, att.maskidx, att.innerLoop = 1, cfg["lr"], cfg["warmup"], n_it, list(cfg["maskidx"]), inner
+    att.geometry, att.use_wandb, att.patch_size, att.MSE_weights = True, True, [3, 50, 50], cfg["MSE_weights"]  # (use_wandb: the train log goes to the recorder below)
     att.val_CE_loss, att.val_MSE_Distance, att.val_UAD = [], [], []
-    att.train_dataset = _Batches(synthetic.synth_batch(9300 + i, bs, "smooth") for i in range(n_it))
-    att.val_dataset = _Batches(synthetic.synth_batch(9400 + i, bs, "smooth") for i in range(2))
-    att.setup = lambda rank, world_size: None
+    att.train_dataset = _Batches(synthetic.synth_batch(cfg["train_seed0"] + i, bs, "smooth") for i in range(n_it * world))
+    att.val_dataset = _Batches(synthetic.synth_batch(cfg["val_seed0"] + i, bs, "smooth") for i in range(cfg["val_batches"] * world))
+    att.setup = lambda rank_, world_size: None
     att.cleanup = lambda: None
 
     class _Torch:  # `torch.tensor([x], dtype=..., device=rank)`; everything else is torch
@@ -804,38 +815,34 @@ def gen_trajectory_ddp_k3s():
         def tensor(*a, device=None, **k):
             return torch.tensor(*a, **k)
 
-    class _DDP:
+    class _DDP1:
         def __init__(self, module, **_):
             self.module = module
 
         def __call__(self, *a, **k):
             return self.module(*a, **k)
 
-    class _Dist:
-        ReduceOp = torch.distributed.ReduceOp
+    class _Dist1:
+        ReduceOp = tdist.ReduceOp
         broadcast = staticmethod(lambda t, src=0: None)
         all_reduce = staticmethod(lambda t, op=None: None)
         is_initialized = staticmethod(lambda: True)
 
-    snaps = []
-    orig_step, orig_to = HFAdamW.step, torch.Tensor.to
+    class _DistN:
+        ReduceOp = tdist.ReduceOp
+        broadcast = staticmethod(tdist.broadcast)
+        is_initialized = staticmethod(tdist.is_initialized)
 
-    def rec_step(self, closure=None):
-        orig_step(self)
-        snaps.append(self.param_groups[0]["params"][0].detach().clone().clamp(0, 1).numpy())
+        @staticmethod
+        def all_reduce(t, op=None):
+            if op == tdist.ReduceOp.AVG:  # gloo has no AVG
+                tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+                t /= world
+            else:
+                tdist.all_reduce(t, op=op)
 
-    def to(self, *a, **k):
-        if a and (a[0] == "cuda" or (isinstance(a[0], int) and not isinstance(a[0], bool))):
-            a = a[1:]
-            if not a and not k:
-                return self
-        return orig_to(self, *a, **k)
-
-    logs = []
-    saved = (D.torch, D.DDP, D.dist, D.tqdm, D.wandb)
-    D.torch, D.DDP, D.dist = _Torch(), _DDP, _Dist
-    D.wandb = types.SimpleNamespace(log=lambda d, step=None: logs.append((step, {k: float(v) for k, v in d.items() if k.startswith("TRAIN")})),
-                                    Image=lambda *a, **k: None)
+    def _ddp_n(module, device_ids=None, **k):
+        return torch.nn.parallel.DistributedDataParallel(module, **k)
 
     class _Bar:
         def __init__(self, *a, **k):
@@ -850,30 +857,79 @@ def gen_trajectory_ddp_k3s():
         def update(self, n):
             pass
 
-    D.tqdm = _Bar
+    snaps, logs = [], []
+    orig_step, orig_to = HFAdamW.step, torch.Tensor.to
+
+    def rec_step(self, closure=None):
+        orig_step(self)
+        snaps.append(self.param_groups[0]["params"][0].detach().clone().clamp(0, 1).numpy())
+
+    def to(self, *a, **k):
+        if a and (a[0] == "cuda" or (isinstance(a[0], int) and not isinstance(a[0], bool))):
+            a = a[1:]
+            if not a and not k:
+                return self
+        return orig_to(self, *a, **k)
+
+    saved = (D.torch, D.DDP, D.dist, D.tqdm, D.wandb)
+    D.torch, D.DDP, D.dist, D.tqdm = _Torch(), (_DDP1 if world == 1 else _ddp_n), (_Dist1 if world == 1 else _DistN), _Bar
+    D.wandb = types.SimpleNamespace(log=lambda d, step=None: logs.append((step, {k: float(v) for k, v in d.items() if k.startswith("TRAIN")})),
+                                    Image=lambda *a, **k: None)
     HFAdamW.step = rec_step
     torch.Tensor.to = to
-    os.environ["RANK"] = "0"
-    random.seed(42)
+    os.environ["RANK"] = str(rank)
+    random.seed(42)  # UADA_wrapper_ddp.py:53: every rank seeds 42
     np.random.seed(42)
     torch.manual_seed(42)
     try:
-        att.attack(0, 1)
+        att.attack(rank, world)
     finally:
         HFAdamW.step, torch.Tensor.to = orig_step, orig_to
         D.torch, D.DDP, D.dist, D.tqdm, D.wandb = saved
-    last = torch.load(os.path.join(save_dir, "last", "patch.pt")).numpy()
-    tl = [(st, d) for st, d in logs if d]
-    assert len(tl) == n_it, logs
-    np.savez_compressed(os.path.join(GOLD, "traj_ddp_k3s.npz"), num_iter=n_it, inner=inner, bs=bs, warmup=warm, lr=lr, MSE_weights=wts,
-                        maskidx=np.array([0, 1]), model_seed=seed, train_seed0=9300, val_seed0=9400, val_batches=2,
-                        patches=np.stack(snaps).astype(np.float32), last_saved=last,
-                        train_ce=np.array([d["TRAIN_attack_loss(CE)"] for _, d in tl]), train_mse=np.array([d["TRAIN_attack_loss (MSE_Distance)"] for _, d in tl]),
-                        train_uad=np.array([d["TRAIN_UAD"] for _, d in tl]), train_patch_grad=np.array([d["TRAIN_patch_gradient"] for _, d in tl]),
-                        val_mse=np.array([float(v) for v in att.val_MSE_Distance]), val_uad=np.array([float(v) for v in att.val_UAD]),
-                        val_ce=np.array([float(v) for v in att.val_CE_loss]))
-    print("traj_ddp_k3s: steps", len(snaps), "train", tl, "movement", np.abs(snaps[-1] - snaps[0]).max(), "val", att.val_MSE_Distance, att.val_UAD, att.val_CE_loss,
-          sorted(os.listdir(save_dir)))
+    tl = [d for _, d in logs if d]  # (rank 0 logs)
+    out = dict(patches=np.stack(snaps).astype(np.float32))
+    if rank == 0:
+        assert len(tl) == n_it, logs
+        out.update(last_saved=torch.load(os.path.join(save_dir, "last", "patch.pt")).numpy(),
+                   train_ce=np.array([d["TRAIN_attack_loss(CE)"] for d in tl]), train_mse=np.array([d["TRAIN_attack_loss (MSE_Distance)"] for d in tl]),
+                   train_uad=np.array([d["TRAIN_UAD"] for d in tl]), train_patch_grad=np.array([d["TRAIN_patch_gradient"] for d in tl]),
+                   val_mse=np.array([float(v) for v in att.val_MSE_Distance]), val_uad=np.array([float(v) for v in att.val_UAD]),
+                   val_ce=np.array([float(v) for v in att.val_CE_loss]))
+    np.savez(out_path % rank, **out)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+def gen_trajectory_ddp_k3s():
+    """The HEADLINE loop on a reference loop (see _ref_ddp_worker): world size 1 -> traj_ddp_k3s.npz, and TWO ranks (two CPU processes, gloo, torch's
+    own DistributedDataParallel averaging the patch gradient) -> traj_ddp2_k3s.npz. The product replays them with `attack/uada_ddp.py` on the GPU:
+    K1 tile-major -> K3s (UADA_DDP) -> K2' -> step epilogue (+ AdamW inside at one rank; the packed all-reduce + K4 at two)
+    (tests/test_gpu_attack.py:test_ddp_trajectory_k3s_vs_reference_loop, test_ddp_two_rank_trajectory_k3s_vs_reference_loop)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    base = dict(num_iter=4, inner=3, bs=3, lr=2e-3, warmup=1, MSE_weights=5, maskidx=[0, 1], val_batches=2)
+    for world, tag, extra in ((1, "traj_ddp_k3s", dict(model_seed=9, train_seed0=9300, val_seed0=9400)),
+                              (2, "traj_ddp2_k3s", dict(model_seed=10, train_seed0=9500, val_seed0=9600))):
+        cfg = dict(base, **extra)
+        out_path = f"/tmp/vaa_golden_{tag}_r%d.npz"
+        if world == 1:
+            _ref_ddp_worker(0, 1, 0, cfg, out_path)
+        else:
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+            s_.close()
+            mp.spawn(_ref_ddp_worker, args=(world, port, cfg, out_path), nprocs=world, join=True)
+        r = [dict(np.load(out_path % k)) for k in range(world)]
+        for k in range(1, world):
+            assert np.array_equal(r[0]["patches"], r[k]["patches"]), "the reference's ranks hold the same patch after every step"
+        d = dict(r[0], world=world, **{k: (np.array(v) if isinstance(v, list) else v) for k, v in cfg.items()})
+        np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **d)
+        print(f"{tag}: world {world} steps", len(d["patches"]), "movement", float(np.abs(d["patches"][-1] - d["patches"][0]).max()), "train ce", d["train_ce"],
+              "mse", d["train_mse"], "val", d["val_mse"], d["val_uad"], d["val_ce"])
 
 
 # ------------------------------------------------------------------------------------------------
