@@ -12,7 +12,8 @@ stable across machines), so each fixture stays small.
 Defect handling: D1 repaired in memory by ref_import; D2 (resize_patch=True: every image scales the BASE patch) by
 ref_import.load_transform_d2_repaired for the `resize` and `traj3` fixtures; D3 (TMA passes `colorjitter=` to a function that does not take it)
 by dropping the argument on the one transform instance of `traj4`; everything else is exercised only through code paths that run as shipped.
-Parts: k1k2 resize rng labels k3 sched fmt traj traj2 trajk2e traj3 (UPA + resize_patch loop, config 5) traj4 (TMA 7-DoF + geometry loop, config 4) sim.
+Parts: k1k2 resize rng labels k3 sched fmt traj traj2 trajk2e traj3 (UPA + resize_patch loop, config 5) traj4 (TMA 7-DoF + geometry loop, config 4) trajk3s (UPA loop over a surrogate with a bf16 LM head: K3s) trajddp (the data-parallel
+UADA_ddp.attack() loop at world sizes 1 and 2) sim.
 """
 from __future__ import annotations
 
